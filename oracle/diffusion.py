@@ -1,0 +1,133 @@
+"""fp32 CPU restatement of the diffusion schedule and the DDIM / DDPM sampling loops
+(oracle — test infrastructure only).
+
+Follows:
+  rdm/models/diffusion/ddim.py:27-56    make_schedule
+  rdm/models/diffusion/ddim.py:142-215  ddim_sampling (loop order, intermediates rule)
+  rdm/models/diffusion/ddim.py:217-268  p_sample_ddim (CFG batch doubling, update)
+  [ldm, un-vendored, parity unpinned — SURVEY.md appendix A.2]
+      DDPM.register_schedule, make_ddim_timesteps, make_ddim_sampling_parameters,
+      LatentDiffusion.p_sample / p_sample_loop
+Known-answer constants: SURVEY.md appendix C (checked in tests/test_oracle_schedule.py).
+"""
+import numpy as np
+import torch
+
+
+class Schedule:
+    """[ldm] DDPM.register_schedule with beta_schedule='linear' (A.2). fp32 buffers."""
+
+    def __init__(self, timesteps=1000, linear_start=0.0015, linear_end=0.0195, v_posterior=0.0):
+        betas = np.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=np.float64) ** 2
+        alphas = 1.0 - betas
+        ac = np.cumprod(alphas, axis=0)
+        ac_prev = np.append(1.0, ac[:-1])
+        f32 = lambda a: torch.tensor(a, dtype=torch.float32)
+        self.num_timesteps = timesteps
+        self.betas = f32(betas)
+        self.alphas_cumprod = f32(ac)
+        self.alphas_cumprod_prev = f32(ac_prev)
+        self.sqrt_alphas_cumprod = f32(np.sqrt(ac))
+        self.sqrt_one_minus_alphas_cumprod = f32(np.sqrt(1.0 - ac))
+        self.sqrt_recip_alphas_cumprod = f32(np.sqrt(1.0 / ac))
+        self.sqrt_recipm1_alphas_cumprod = f32(np.sqrt(1.0 / ac - 1))
+        pv = (1 - v_posterior) * betas * (1.0 - ac_prev) / (1.0 - ac) + v_posterior * betas
+        self.posterior_variance = f32(pv)
+        self.posterior_log_variance_clipped = f32(np.log(np.maximum(pv, 1e-20)))
+        self.posterior_mean_coef1 = f32(betas * np.sqrt(ac_prev) / (1.0 - ac))
+        self.posterior_mean_coef2 = f32((1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac))
+
+
+def make_ddim_timesteps(S, T=1000):
+    """[ldm] make_ddim_timesteps('uniform'): arange(0,T,T//S)+1."""
+    c = T // S
+    return np.asarray(list(range(0, T, c))) + 1
+
+
+def make_ddim_sampling_parameters(alphacums: torch.Tensor, ddim_timesteps, eta):
+    """[ldm] make_ddim_sampling_parameters; alphacums is the model's fp32 buffer
+    (ddim.py:44-46 passes alphas_cumprod.cpu()).  Returns torch fp32 alphas / sigmas and a
+    numpy alphas_prev, mirroring ldm's mixed types (SURVEY A.2 'Precision')."""
+    alphas = alphacums[ddim_timesteps]
+    alphas_prev = np.asarray([alphacums[0]] + alphacums[ddim_timesteps[:-1]].tolist())
+    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+    return sigmas, alphas, alphas_prev
+
+
+def ddim_schedule(sched: Schedule, S, eta):
+    ts = make_ddim_timesteps(S, sched.num_timesteps)
+    sigmas, alphas, alphas_prev = make_ddim_sampling_parameters(sched.alphas_cumprod, ts, eta)
+    # per-step fp32 scalars as materialised by torch.full_like(e_t, value) (ddim.py:253-256)
+    f = lambda v: torch.as_tensor(np.asarray(v), dtype=torch.float32).reshape(-1)
+    a_t = f(alphas)
+    a_prev = f(alphas_prev)
+    sigma = f(sigmas)
+    sqrt_1m = f(np.sqrt(1.0 - np.asarray(alphas, dtype=np.float32)))  # ddim.py:52 np.sqrt(1-ddim_alphas)
+    return ts, a_t, a_prev, sigma, sqrt_1m
+
+
+def p_sample_ddim(apply_model, x, c, t, index, sch, *, scale=1.0, uc=None, noise=None, temperature=1.0):
+    """ddim.py:217-268 with the options the native path supports."""
+    ts, a_t, a_prev, sigma, sqrt_1m = sch
+    b = x.shape[0]
+    assert scale >= 1.0
+    if noise is None:
+        noise = torch.zeros_like(x)
+    if scale > 1.0:
+        out = apply_model(torch.cat([x] * 2), torch.cat([t] * 2), torch.cat([c, uc]))
+        e_t, e_u = out[:b], out[b:]
+        e_t = e_u + scale * (e_t - e_u)
+    else:
+        e_t = apply_model(x, t, c)
+    at = torch.full_like(e_t, float(a_t[index]))
+    ap = torch.full_like(e_t, float(a_prev[index]))
+    sg = torch.full_like(e_t, float(sigma[index]))
+    s1m = torch.full_like(e_t, float(sqrt_1m[index]))
+    pred_x0 = (x - s1m * e_t) / at.sqrt()
+    dir_xt = (1.0 - ap - sg ** 2).sqrt() * e_t
+    nz = sg * noise * temperature
+    x_prev = ap.sqrt() * pred_x0 + dir_xt + nz
+    return x_prev, pred_x0
+
+
+def ddim_sample(apply_model, sched: Schedule, S, x_T, cond, *, eta=0.0, scale=1.0, uncond=None,
+                noise=None, log_every_t=100, temperature=1.0):
+    """ddim.py:142-215. `noise` is an optional [S,B,...] stack consumed in loop order."""
+    sch = ddim_schedule(sched, S, eta)
+    ts = sch[0]
+    img = x_T
+    inter = {"x_inter": [img], "pred_x0": [img]}
+    total = ts.shape[0]
+    for i, step in enumerate(np.flip(ts)):
+        index = total - i - 1
+        t = torch.full((x_T.shape[0],), int(step), dtype=torch.long)
+        nz = None if noise is None else noise[i]
+        img, pred_x0 = p_sample_ddim(apply_model, img, cond, t, index, sch, scale=scale, uc=uncond,
+                                     noise=nz, temperature=temperature)
+        if index % log_every_t == 0 or index == total - 1:
+            inter["x_inter"].append(img)
+            inter["pred_x0"].append(pred_x0)
+    return img, inter
+
+
+def p_sample_ddpm(apply_model, sched: Schedule, x, c, t, noise, clip_denoised=True, temperature=1.0):
+    """[ldm] LatentDiffusion.p_sample / p_mean_variance / q_posterior (A.2)."""
+    ti = int(t[0])
+    eps = apply_model(x, t, c)
+    x0 = sched.sqrt_recip_alphas_cumprod[ti] * x - sched.sqrt_recipm1_alphas_cumprod[ti] * eps
+    if clip_denoised:
+        x0 = x0.clamp(-1.0, 1.0)
+    mean = sched.posterior_mean_coef1[ti] * x0 + sched.posterior_mean_coef2[ti] * x
+    logvar = sched.posterior_log_variance_clipped[ti]
+    nonzero = 0.0 if ti == 0 else 1.0
+    return mean + nonzero * (0.5 * logvar).exp() * noise * temperature
+
+
+def ddpm_sample(apply_model, sched: Schedule, x_T, cond, noise, timesteps=None, clip_denoised=True):
+    """[ldm] p_sample_loop: for i in reversed(range(timesteps or T)). noise [T',B,...]."""
+    T = timesteps or sched.num_timesteps
+    img = x_T
+    for n, i in enumerate(reversed(range(T))):
+        t = torch.full((x_T.shape[0],), i, dtype=torch.long)
+        img = p_sample_ddpm(apply_model, sched, img, cond, t, noise[n], clip_denoised)
+    return img

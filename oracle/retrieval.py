@@ -1,0 +1,115 @@
+"""CPU restatement of the retrieval step and conditioning glue
+(oracle — test infrastructure only).
+
+Follows:
+  rdm/data/retrieval_dataset/dsetbuilder.py:478-518  search_k_nearest (query normalisation,
+        search_batched -> (uint32 idx [B,k] by descending score, f32 dist), gathers)
+  rdm/data/retrieval_dataset/dsetbuilder.py:574       searcher built on embedding/||embedding||
+  rdm/models/diffusion/ddpm.py:760-777                retro_cond assembly (query first, k-1 nbrs)
+  rdm/models/diffusion/ddpm.py:662-686                unconditional conditioning
+  rdm/models/diffusion/ddpm.py:847-875                get_qids
+  scripts/rdm_sample.py:203-214                       custom_to_np uint8 conversion (truncation)
+
+PARITY UNPINNED w.r.t. the deployed reference: the reference's searcher is ScaNN 1.2.4
+(un-vendored, approximate tree+AH for N >= 2e4).  This oracle is the EXACT maximum-inner-
+product search that ScaNN approximates (and equals ScaNN's own brute-force mode for N < 2e4,
+dsetbuilder.py:590-592).  Definition used by oracle and HIP path alike:
+  * database rows  d_i = fp16( x_i / ||x_i|| )   (fp32 norm, rounded once to fp16)
+  * query          q^  = q / ||q||               (fp32)
+  * score          s_i = sum_j q^_j * d_ij       (exact products, fp64 accumulation)
+  * result         top-k by (score descending, index ascending)
+"""
+import numpy as np
+
+
+def normalize_db(emb: np.ndarray) -> np.ndarray:
+    """Rows -> unit norm in fp32, stored fp16 (what the searcher is built on)."""
+    x = emb.astype(np.float32)
+    n = np.sqrt((x * x).sum(axis=1, keepdims=True, dtype=np.float32))
+    return (x / n).astype(np.float16)
+
+
+def normalize_queries(q: np.ndarray) -> np.ndarray:
+    q = q.astype(np.float32)
+    return q / np.linalg.norm(q, axis=1)[:, np.newaxis]
+
+
+def exact_topk(dbn: np.ndarray, qn: np.ndarray, k: int, chunk: int = 262144):
+    """Exact MIPS top-k. dbn fp16 [N,D] (normalised), qn f32 [B,D] (normalised).
+    Returns (idx uint32 [B,k], score f32 [B,k]); ties -> lower index."""
+    B = qn.shape[0]
+    q64 = qn.astype(np.float64)
+    best_s = np.full((B, 0), 0.0)
+    best_i = np.zeros((B, 0), dtype=np.int64)
+    for s0 in range(0, dbn.shape[0], chunk):
+        blk = dbn[s0:s0 + chunk].astype(np.float64)
+        sc = q64 @ blk.T                                        # [B, n]
+        ids = np.arange(s0, s0 + blk.shape[0], dtype=np.int64)[None].repeat(B, 0)
+        cs = np.concatenate([best_s, sc], axis=1)
+        ci = np.concatenate([best_i, ids], axis=1)
+        order = np.lexsort((ci, -cs), axis=1)[:, :k]            # score desc, then index asc
+        best_s = np.take_along_axis(cs, order, 1)
+        best_i = np.take_along_axis(ci, order, 1)
+    return best_i.astype(np.uint32), best_s.astype(np.float32)
+
+
+def search_k_nearest(data_pool: dict, dbn: np.ndarray, queries: np.ndarray, k: int):
+    """dsetbuilder.py:478-518 with query_embedded=True."""
+    qn = normalize_queries(queries)
+    nns, dist = exact_topk(dbn, qn, k)
+    return {
+        "embeddings": data_pool["embedding"][nns],
+        "img_ids": data_pool["img_id"][nns],
+        "patch_coords": data_pool["patch_coords"][nns],
+        "queries": queries,
+        "nns": nns,
+        "distances": dist,
+        "q_embeddings": queries,
+    }
+
+
+def assemble_retro_cond(q_emb: np.ndarray, r_emb: np.ndarray, k_nn: int, omit_query=False, normalize=False,
+                        n_reps=None) -> np.ndarray:
+    """ddpm.py:760-777 (nn_encoder is None branch, example_maps None). f32 [B,k,512]."""
+    q = q_emb.astype(np.float32)
+    r = r_emb.astype(np.float32)
+    if normalize:
+        q = q / np.linalg.norm(q, axis=-1, keepdims=True)
+        r = r / np.linalg.norm(r, axis=-1, keepdims=True)
+    if omit_query:
+        rc = r
+    else:
+        rc = np.concatenate([q[:, None], r[:, :k_nn - 1]], axis=1)
+    if n_reps is not None:
+        rc = np.concatenate([rc] * n_reps, axis=1)
+    return rc
+
+
+def unconditional_conditioning(vex: np.ndarray, shape, label, k_nn: int) -> np.ndarray:
+    """ddpm.py:662-686 with a label: stack(stack(vex/||vex|| * label, k), bs)."""
+    bs = shape[0]
+    sig = vex / np.linalg.norm(vex.reshape(-1)) * label
+    sig = np.stack([sig] * k_nn, axis=0)
+    return np.stack([sig] * bs, axis=0).astype(np.float32)
+
+
+def get_qids(nn_memory: np.ndarray, memsize, N: int, id_count: dict = None, use_weights=False, rng=np.random):
+    """ddpm.py:847-875 (use_memory=True branch)."""
+    if isinstance(memsize, float):
+        assert 0 < memsize <= 1.0
+        memsize = int(memsize * nn_memory.shape[0])
+    memsize = min(memsize, nn_memory.shape[0])
+    mem = nn_memory[:memsize]
+    ps = None
+    if use_weights:
+        freqs = np.asarray([id_count[int(i)] for i in mem])
+        ps = freqs / freqs.sum(keepdims=True)
+    return rng.choice(mem, size=N, p=ps)
+
+
+def custom_to_np_uint8(x: np.ndarray) -> np.ndarray:
+    """scripts/rdm_sample.py:203-214: clamp(-1,1) -> (x+1)/2 -> CHW->HWC -> *255 -> astype(uint8)."""
+    x = np.clip(x.astype(np.float32), -1.0, 1.0)
+    x = (x + np.float32(1.0)) / np.float32(2.0)
+    x = np.transpose(x, (0, 2, 3, 1))
+    return (np.float32(255.0) * x).astype(np.uint8)

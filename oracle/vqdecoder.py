@@ -1,0 +1,144 @@
+"""fp32 CPU restatement of the VQ-f4 first-stage decode (oracle — test infrastructure only).
+
+PARITY UNPINNED: the source (ldm VQModelInterface / Decoder / ResnetBlock / AttnBlock,
+taming VectorQuantizer2) is not vendored in the reference; restated from SURVEY.md
+appendix A.3.  Call sites in the reference: rdm/models/diffusion/ddpm.py:840, 981;
+configuration models/rdm/imagenet/config.yaml:60-80.
+"""
+import math
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class VQSpec:
+    embed_dim: int = 3
+    n_embed: int = 8192
+    z_channels: int = 3
+    ch: int = 128
+    ch_mult: Tuple[int, ...] = (1, 2, 4)
+    num_res_blocks: int = 2
+    out_ch: int = 3
+    resolution: int = 256
+    mid_attn: bool = True
+
+    @property
+    def z_res(self):
+        return self.resolution // 2 ** (len(self.ch_mult) - 1)
+
+
+def shipped_vq_spec():
+    return VQSpec()
+
+
+def tiny_vq_spec():
+    return VQSpec(n_embed=512, ch=32, ch_mult=(1, 2, 4), num_res_blocks=1, resolution=64)
+
+
+def _res_shapes(p, pre, cin, cout):
+    p[pre + ".norm1.weight"] = (cin,); p[pre + ".norm1.bias"] = (cin,)
+    p[pre + ".conv1.weight"] = (cout, cin, 3, 3); p[pre + ".conv1.bias"] = (cout,)
+    p[pre + ".norm2.weight"] = (cout,); p[pre + ".norm2.bias"] = (cout,)
+    p[pre + ".conv2.weight"] = (cout, cout, 3, 3); p[pre + ".conv2.bias"] = (cout,)
+    if cin != cout:
+        p[pre + ".nin_shortcut.weight"] = (cout, cin, 1, 1); p[pre + ".nin_shortcut.bias"] = (cout,)
+
+
+def vq_param_shapes(s: VQSpec) -> Dict[str, tuple]:
+    """State-dict names per SURVEY A.3 (prefix `first_stage_model.` stripped)."""
+    p: Dict[str, tuple] = {}
+    p["quantize.embedding.weight"] = (s.n_embed, s.embed_dim)
+    p["post_quant_conv.weight"] = (s.z_channels, s.embed_dim, 1, 1); p["post_quant_conv.bias"] = (s.z_channels,)
+    nl = len(s.ch_mult)
+    block_in = s.ch * s.ch_mult[-1]
+    p["decoder.conv_in.weight"] = (block_in, s.z_channels, 3, 3); p["decoder.conv_in.bias"] = (block_in,)
+    _res_shapes(p, "decoder.mid.block_1", block_in, block_in)
+    if s.mid_attn:
+        a = "decoder.mid.attn_1"
+        p[a + ".norm.weight"] = (block_in,); p[a + ".norm.bias"] = (block_in,)
+        for n in ("q", "k", "v", "proj_out"):
+            p[f"{a}.{n}.weight"] = (block_in, block_in, 1, 1); p[f"{a}.{n}.bias"] = (block_in,)
+    _res_shapes(p, "decoder.mid.block_2", block_in, block_in)
+    for lvl in reversed(range(nl)):
+        block_out = s.ch * s.ch_mult[lvl]
+        for i in range(s.num_res_blocks + 1):
+            _res_shapes(p, f"decoder.up.{lvl}.block.{i}", block_in, block_out)
+            block_in = block_out
+        if lvl != 0:
+            p[f"decoder.up.{lvl}.upsample.conv.weight"] = (block_in, block_in, 3, 3)
+            p[f"decoder.up.{lvl}.upsample.conv.bias"] = (block_in,)
+    p["decoder.norm_out.weight"] = (block_in,); p["decoder.norm_out.bias"] = (block_in,)
+    p["decoder.conv_out.weight"] = (s.out_ch, block_in, 3, 3); p["decoder.conv_out.bias"] = (s.out_ch,)
+    return p
+
+
+def _gn(x, sd, pre):
+    return F.group_norm(x, 32, sd[pre + ".weight"], sd[pre + ".bias"], 1e-6)
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)
+
+
+def _resnet(sd, pre, x):
+    h = F.conv2d(_swish(_gn(x, sd, pre + ".norm1")), sd[pre + ".conv1.weight"], sd[pre + ".conv1.bias"], padding=1)
+    h = F.conv2d(_swish(_gn(h, sd, pre + ".norm2")), sd[pre + ".conv2.weight"], sd[pre + ".conv2.bias"], padding=1)
+    if (pre + ".nin_shortcut.weight") in sd:
+        x = F.conv2d(x, sd[pre + ".nin_shortcut.weight"], sd[pre + ".nin_shortcut.bias"])
+    return x + h
+
+
+def _attn(sd, pre, x):
+    """[ldm] AttnBlock: single head over h*w tokens, scale C^-0.5."""
+    h_ = _gn(x, sd, pre + ".norm")
+    q = F.conv2d(h_, sd[pre + ".q.weight"], sd[pre + ".q.bias"])
+    k = F.conv2d(h_, sd[pre + ".k.weight"], sd[pre + ".k.bias"])
+    v = F.conv2d(h_, sd[pre + ".v.weight"], sd[pre + ".v.bias"])
+    b, c, h, w = q.shape
+    q = q.reshape(b, c, h * w).permute(0, 2, 1)
+    k = k.reshape(b, c, h * w)
+    w_ = torch.bmm(q, k) * (int(c) ** -0.5)
+    w_ = F.softmax(w_, dim=2)
+    v = v.reshape(b, c, h * w)
+    h_ = torch.bmm(v, w_.permute(0, 2, 1)).reshape(b, c, h, w)
+    h_ = F.conv2d(h_, sd[pre + ".proj_out.weight"], sd[pre + ".proj_out.bias"])
+    return x + h_
+
+
+def vq_quantize(sd, z):
+    """[taming] VectorQuantizer2.forward (legacy ordering irrelevant for inference):
+    argmin of ||z||^2 + ||e||^2 - 2 z.e ; first minimum on ties. Returns (z_q, indices)."""
+    e = sd["quantize.embedding.weight"]
+    zf = z.permute(0, 2, 3, 1).contiguous()
+    flat = zf.reshape(-1, e.shape[1])
+    d = (flat ** 2).sum(1, keepdim=True) + (e ** 2).sum(1) - 2 * flat @ e.t()
+    idx = torch.argmin(d, dim=1)
+    zq = e[idx].reshape(zf.shape)
+    zq = zf + (zq - zf)  # straight-through form, reproduced literally (A.3)
+    return zq.permute(0, 3, 1, 2).contiguous(), idx
+
+
+def vq_decode(sd, spec: VQSpec, z, scale_factor=1.0, force_not_quantize=False, return_indices=False):
+    """decode_first_stage -> VQModelInterface.decode (A.3)."""
+    z = z / scale_factor
+    idx = None
+    if not force_not_quantize:
+        z, idx = vq_quantize(sd, z)
+    h = F.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
+    h = F.conv2d(h, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"], padding=1)
+    h = _resnet(sd, "decoder.mid.block_1", h)
+    if spec.mid_attn:
+        h = _attn(sd, "decoder.mid.attn_1", h)
+    h = _resnet(sd, "decoder.mid.block_2", h)
+    for lvl in reversed(range(len(spec.ch_mult))):
+        for i in range(spec.num_res_blocks + 1):
+            h = _resnet(sd, f"decoder.up.{lvl}.block.{i}", h)
+        if lvl != 0:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = F.conv2d(h, sd[f"decoder.up.{lvl}.upsample.conv.weight"], sd[f"decoder.up.{lvl}.upsample.conv.bias"], padding=1)
+    h = _swish(_gn(h, sd, "decoder.norm_out"))
+    out = F.conv2d(h, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
+    return (out, idx) if return_indices else out
