@@ -1,0 +1,166 @@
+/* librdm_hip.so — C ABI of the MI355X-native retrieval-augmented diffusion sampling path.
+ *
+ * The reference (CompVis/retrieval-augmented-diffusion-models) is pure Python and has no FFI
+ * boundary; each entry point below names the reference call it replaces (file:line relative to
+ * the reference tree).  INTEGRATION.md shows the ctypes binding a maintainer adds on the
+ * reference side.
+ *
+ * Conventions
+ *   - return 0 on success, negative on error; rdm_last_error(ctx) gives the message.
+ *   - no exceptions cross the ABI; no torch types; plain pointers and sizes.
+ *   - pointers marked [dev] are device pointers on the context's HIP device (e.g.
+ *     torch.Tensor.data_ptr()); [host] are host pointers.  The caller owns every buffer; the
+ *     library keeps no reference to caller memory after a call returns, except rdm_db_load with
+ *     copy = 0, which is documented there.
+ *   - work is enqueued on the context's stream (rdm_set_stream; default = the null stream, which is
+ *     also torch's default current stream) and calls return after enqueue unless noted.
+ *   - a context is bound to one device and is not thread-safe.
+ *   - layouts at the boundary are the reference's: NCHW fp32 images/latents, [B,k,512] fp32
+ *     conditioning, int64 timesteps/tokens.  Internal layout (NHWC bf16) is private.
+ */
+#ifndef RDM_HIP_H
+#define RDM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rdm_ctx rdm_ctx;
+
+#define RDM_MAX_LEVELS 8
+
+/* UNetModel constructor arguments that shape the sampling graph
+ * (rdm/modules/diffusionmodules/openaimodel.py:66-129; models/rdm/imagenet/config.yaml:36-59). */
+typedef struct {
+    int in_channels, out_channels, model_channels, num_res_blocks;
+    int n_attention_resolutions, attention_resolutions[RDM_MAX_LEVELS];
+    int n_channel_mult, channel_mult[RDM_MAX_LEVELS];
+    int num_head_channels, context_dim;
+} rdm_unet_cfg;
+
+/* ldm VQModelInterface ddconfig (models/rdm/imagenet/config.yaml:60-80). */
+typedef struct {
+    int embed_dim, n_embed, z_channels, ch, n_ch_mult, ch_mult[RDM_MAX_LEVELS];
+    int num_res_blocks, out_ch, resolution, mid_attn, kl; /* kl=1: AutoencoderKL decode (no quantiser) */
+} rdm_vq_cfg;
+
+/* CLIP constructor arguments (rdm/modules/custom_clip/model.py:238-252). */
+typedef struct {
+    int embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size;
+    int context_length, vocab_size, transformer_width, transformer_heads, transformer_layers;
+} rdm_clip_cfg;
+
+/* DDIMSampler.sample arguments the native loop implements (rdm/models/diffusion/ddim.py:58-140). */
+typedef struct {
+    int S;                 /* number of DDIM steps */
+    int batch;             /* B */
+    int k;                 /* neighbours in the conditioning [B,k,context_dim] */
+    int channels, height, width;      /* latent shape (3,64,64) */
+    float eta, temperature;
+    float unconditional_guidance_scale;   /* >= 1; > 1 enables CFG batch doubling (ddim.py:229-238) */
+    int log_every_t;       /* intermediates rule, ddim.py:207 */
+    /* schedule: the model's fp32 alphas_cumprod buffer [T] (ddim.py:30) */
+    int T; const float* alphas_cumprod; /* [host] */
+} rdm_ddim_args;
+
+/* ldm LatentDiffusion.p_sample_loop arguments (reached from rdm/models/diffusion/ddpm.py:1008). */
+typedef struct {
+    int timesteps;         /* loop runs reversed(range(timesteps)) */
+    int batch, k, channels, height, width;
+    int clip_denoised; float temperature;
+    int T;                 /* schedule length; arrays below are fp32 [T], [host] */
+    const float* sqrt_recip_alphas_cumprod; const float* sqrt_recipm1_alphas_cumprod;
+    const float* posterior_mean_coef1; const float* posterior_mean_coef2;
+    const float* posterior_log_variance_clipped;
+} rdm_ddpm_args;
+
+/* ---- context -------------------------------------------------------------------------------- */
+int rdm_ctx_create(int device_id, rdm_ctx** out);
+void rdm_ctx_destroy(rdm_ctx* ctx);
+const char* rdm_last_error(rdm_ctx* ctx);
+int rdm_set_stream(rdm_ctx* ctx, void* hip_stream);
+const char* rdm_version(void);
+
+/* ---- weights --------------------------------------------------------------------------------
+ * The library defines the packed-blob layout; rdm_*_manifest writes it as text, one line per entry:
+ *     <offset> <nbytes> <kind> <src>[,<src>...]
+ * where <src> are the reference's own state_dict keys and <kind> is one of
+ *   f32 | bf16 | bf16_t | conv3 | geglu_w | geglu_b   (see DESIGN.md "Weight blob").
+ * The caller fills a host blob accordingly and hands it to rdm_load_*, which copies it to HBM.
+ * Returns the number of bytes needed for the text (excluding NUL) if buf is too small. */
+long long rdm_unet_manifest(const rdm_unet_cfg* cfg, char* buf, size_t buflen, size_t* blob_bytes);
+long long rdm_vq_manifest(const rdm_vq_cfg* cfg, char* buf, size_t buflen, size_t* blob_bytes);
+long long rdm_clip_manifest(const rdm_clip_cfg* cfg, char* buf, size_t buflen, size_t* blob_bytes);
+/* replaces torch.load + load_state_dict for model.diffusion_model / first_stage_model / CLIP
+ * (scripts/rdm_sample.py:163-170, rdm/modules/retrievers.py:76). packed [host]. */
+int rdm_load_unet(rdm_ctx* ctx, const rdm_unet_cfg* cfg, const void* packed, size_t nbytes);
+int rdm_load_vq(rdm_ctx* ctx, const rdm_vq_cfg* cfg, const void* packed, size_t nbytes);
+int rdm_load_clip(rdm_ctx* ctx, const rdm_clip_cfg* cfg, const void* packed, size_t nbytes);
+
+/* ---- UNet: UNetModel.forward(x, timesteps, context) (openaimodel.py:335-371) via
+ *      MinimalRETRODiffusion.apply_model (rdm/models/diffusion/ddpm.py:445-458).
+ * x [dev] f32 [b,Cin,H,W]; t [dev] int64 [b]; ctx [dev] f32 [b,k,context_dim]; eps_out [dev] f32 [b,Cout,H,W]. */
+int rdm_unet_forward(rdm_ctx* ctx, const float* x, const int64_t* t, const float* context, int b, int k, int H, int W,
+                     float* eps_out);
+
+/* ---- samplers -------------------------------------------------------------------------------
+ * DDIMSampler.sample / ddim_sampling / p_sample_ddim (rdm/models/diffusion/ddim.py:58-268).
+ * x_T [dev] f32 [B,C,H,W]; cond, uncond [dev] f32 [B,k,ctx_dim] (uncond may be NULL when scale == 1);
+ * noise [dev] f32 [S,B,C,H,W] or NULL (required when eta > 0; consumed in loop order);
+ * z_out [dev] f32 [B,C,H,W]; x_inter / pred_x0_inter [dev] f32 [n_inter,B,C,H,W] or NULL, filled for the
+ * steps ddim.py:207 logs (n_inter = rdm_ddim_num_intermediates). */
+int rdm_ddim_num_intermediates(int S, int log_every_t);
+int rdm_ddim_sample(rdm_ctx* ctx, const rdm_ddim_args* args, const float* x_T, const float* cond, const float* uncond,
+                    const float* noise, float* z_out, float* x_inter, float* pred_x0_inter);
+/* ldm LatentDiffusion.p_sample_loop / p_sample (no CFG on this path).
+ * noise [dev] f32 [timesteps,B,C,H,W], consumed in loop order. */
+int rdm_ddpm_sample(rdm_ctx* ctx, const rdm_ddpm_args* args, const float* x_T, const float* cond, const float* noise,
+                    float* z_out);
+
+/* ---- first stage: LatentDiffusion.decode_first_stage -> VQModelInterface.decode
+ *      (called at rdm/models/diffusion/ddpm.py:840, 981). z [dev] f32 [b,3,h,w] -> img [dev] f32 [b,3,H,W];
+ * indices_out [dev] int32 [b*h*w] or NULL. */
+int rdm_vq_decode(rdm_ctx* ctx, const float* z, int b, int force_not_quantize, float* img_out, int32_t* indices_out);
+/* scripts/rdm_sample.py:203-214 custom_to_np/custom_to_pil: f32 NCHW [-1,1] -> uint8 NHWC (truncating). */
+int rdm_to_uint8(rdm_ctx* ctx, const float* img, int b, int c, int h, int w, uint8_t* out);
+
+/* ---- CLIP: CLIP.encode_text / encode_image (rdm/modules/custom_clip/model.py:304-320), used by
+ *      ClipImageRetriever / CLIPTextEmbedder (rdm/modules/retrievers.py:67-117).
+ * tokens [dev] int64 [b,context_length]; image [dev] f32 [b,3,R,R] already CLIP-normalised; out [dev] f32 [b,embed]. */
+int rdm_clip_encode_text(rdm_ctx* ctx, const int64_t* tokens, int b, float* out);
+int rdm_clip_encode_image(rdm_ctx* ctx, const float* image, int b, float* out);
+
+/* ---- retrieval: DatasetBuilder.train_searcher + searcher.search_batched
+ *      (rdm/data/retrieval_dataset/dsetbuilder.py:534-619, 490; call sites ddpm.py:298,734,906).
+ * rdm_db_load: emb [host or dev] fp16 or fp32 [n,dim] raw embeddings; the searcher's dataset is
+ *   fp16(x/||x||) held in HBM (dsetbuilder.py:574).  dtype: 0 = fp16, 1 = fp32. is_device: 1 if emb is [dev].
+ * rdm_knn: q [dev] f32 [b,dim] raw queries (normalised internally, dsetbuilder.py:487);
+ *   idx_out [dev] uint32 [b,k] by descending score, ties -> lower index; score_out [dev] f32 [b,k] (or NULL). */
+int rdm_db_load(rdm_ctx* ctx, const void* emb, long long n, int dim, int dtype, int is_device);
+long long rdm_db_size(rdm_ctx* ctx);
+int rdm_knn(rdm_ctx* ctx, const float* q, int b, int k, uint32_t* idx_out, float* score_out);
+/* data_pool['embedding'][nns] gather (dsetbuilder.py:493): idx [dev] uint32 [n_idx] -> out [dev] f32 [n_idx,dim]
+ * of the RAW (un-normalised) embeddings (rdm_db_load keeps a raw copy in HBM next to the normalised one). */
+int rdm_db_gather(rdm_ctx* ctx, const uint32_t* idx, long long n_idx, float* out);
+
+/* ---- operator-level entry points (used by the parity tests; thin wrappers over the kernels) ---- */
+int rdm_op_linear(rdm_ctx* ctx, const void* a_bf16, const void* w_bf16, const float* bias, const void* residual_bf16,
+                  void* out_bf16, float* out_f32, int M, int N, int K, int act, float alpha);
+int rdm_op_conv3x3(rdm_ctx* ctx, const void* x0_bf16, const void* x1_bf16, int C0, int C1, const void* w_bf16,
+                   const float* bias, const float* rowvec, int rowvec_ld, const void* residual_bf16, void* out_bf16,
+                   int B, int Hin, int Win, int N, int stride, int ups);
+int rdm_op_groupnorm(rdm_ctx* ctx, const void* x0_bf16, const void* x1_bf16, int C0, int C1, int B, int HW,
+                     const float* gamma, const float* beta, float eps, int silu, void* out_bf16);
+int rdm_op_layernorm(rdm_ctx* ctx, const void* x, int in_is_f32, const float* gamma, const float* beta, int M, int C,
+                     float eps, void* out_bf16);
+int rdm_op_self_attention(rdm_ctx* ctx, const void* qk_bf16, const void* vt_bf16, int B, int n, int heads,
+                          void* out_bf16);
+int rdm_op_small_attention(rdm_ctx* ctx, const void* q_bf16, int ldq, const void* k_bf16, const void* v_bf16, int ldkv,
+                           int B, int nq, int nkv, int heads, int D, int causal, float scale, void* out_bf16, int ldo);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -50,7 +50,8 @@ def make_ddim_sampling_parameters(alphacums: torch.Tensor, ddim_timesteps, eta):
     numpy alphas_prev, mirroring ldm's mixed types (SURVEY A.2 'Precision')."""
     alphas = alphacums[ddim_timesteps]
     alphas_prev = np.asarray([alphacums[0]] + alphacums[ddim_timesteps[:-1]].tolist())
-    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+    a32 = alphas.numpy()            # fp32 values promoted to float64 by the float64 alphas_prev array, as in ldm
+    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - a32) * (1 - a32 / alphas_prev))
     return sigmas, alphas, alphas_prev
 
 

@@ -14,8 +14,9 @@ PARITY UNPINNED w.r.t. the deployed reference: the reference's searcher is ScaNN
 (un-vendored, approximate tree+AH for N >= 2e4).  This oracle is the EXACT maximum-inner-
 product search that ScaNN approximates (and equals ScaNN's own brute-force mode for N < 2e4,
 dsetbuilder.py:590-592).  Definition used by oracle and HIP path alike:
-  * database rows  d_i = fp16( x_i / ||x_i|| )   (fp32 norm, rounded once to fp16)
-  * query          q^  = q / ||q||               (fp32)
+  * database rows  d_i = fp16( x_i / n_i ),  n_i = fp32( sqrt( sum_j x_ij^2 ) ) with the sum in fp64
+                   (division in fp32, one RNE rounding to fp16)
+  * query          q^  = q / fp32( sqrt( sum_j q_j^2 in fp64 ) )   (division in fp32)
   * score          s_i = sum_j q^_j * d_ij       (exact products, fp64 accumulation)
   * result         top-k by (score descending, index ascending)
 """
@@ -25,13 +26,14 @@ import numpy as np
 def normalize_db(emb: np.ndarray) -> np.ndarray:
     """Rows -> unit norm in fp32, stored fp16 (what the searcher is built on)."""
     x = emb.astype(np.float32)
-    n = np.sqrt((x * x).sum(axis=1, keepdims=True, dtype=np.float32))
+    n = np.sqrt((x.astype(np.float64) ** 2).sum(axis=1, keepdims=True)).astype(np.float32)
     return (x / n).astype(np.float16)
 
 
 def normalize_queries(q: np.ndarray) -> np.ndarray:
     q = q.astype(np.float32)
-    return q / np.linalg.norm(q, axis=1)[:, np.newaxis]
+    n = np.sqrt((q.astype(np.float64) ** 2).sum(axis=1, keepdims=True)).astype(np.float32)
+    return q / n
 
 
 def exact_topk(dbn: np.ndarray, qn: np.ndarray, k: int, chunk: int = 262144):

@@ -1,0 +1,366 @@
+"""ctypes binding of librdm_hip.so (include/rdm_hip.h) + a thin torch-tensor convenience layer.
+
+There is deliberately NO fallback: if the shared library is missing this module raises at import,
+and `Context()` raises when no HIP device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librdm_hip.so")
+
+RDM_MAX_LEVELS = 8
+ACT_NONE, ACT_GEGLU, ACT_QUICKGELU, ACT_SILU = 0, 1, 2, 3
+
+
+class UNetCfg(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("model_channels", C.c_int),
+                ("num_res_blocks", C.c_int), ("n_attention_resolutions", C.c_int),
+                ("attention_resolutions", C.c_int * RDM_MAX_LEVELS), ("n_channel_mult", C.c_int),
+                ("channel_mult", C.c_int * RDM_MAX_LEVELS), ("num_head_channels", C.c_int), ("context_dim", C.c_int)]
+
+
+class VqCfg(C.Structure):
+    _fields_ = [("embed_dim", C.c_int), ("n_embed", C.c_int), ("z_channels", C.c_int), ("ch", C.c_int),
+                ("n_ch_mult", C.c_int), ("ch_mult", C.c_int * RDM_MAX_LEVELS), ("num_res_blocks", C.c_int),
+                ("out_ch", C.c_int), ("resolution", C.c_int), ("mid_attn", C.c_int), ("kl", C.c_int)]
+
+
+class ClipCfg(C.Structure):
+    _fields_ = [("embed_dim", C.c_int), ("image_resolution", C.c_int), ("vision_layers", C.c_int),
+                ("vision_width", C.c_int), ("vision_patch_size", C.c_int), ("context_length", C.c_int),
+                ("vocab_size", C.c_int), ("transformer_width", C.c_int), ("transformer_heads", C.c_int),
+                ("transformer_layers", C.c_int)]
+
+
+class DdimArgs(C.Structure):
+    _fields_ = [("S", C.c_int), ("batch", C.c_int), ("k", C.c_int), ("channels", C.c_int), ("height", C.c_int),
+                ("width", C.c_int), ("eta", C.c_float), ("temperature", C.c_float),
+                ("unconditional_guidance_scale", C.c_float), ("log_every_t", C.c_int), ("T", C.c_int),
+                ("alphas_cumprod", C.POINTER(C.c_float))]
+
+
+class DdpmArgs(C.Structure):
+    _fields_ = [("timesteps", C.c_int), ("batch", C.c_int), ("k", C.c_int), ("channels", C.c_int), ("height", C.c_int),
+                ("width", C.c_int), ("clip_denoised", C.c_int), ("temperature", C.c_float), ("T", C.c_int),
+                ("sqrt_recip_alphas_cumprod", C.POINTER(C.c_float)), ("sqrt_recipm1_alphas_cumprod", C.POINTER(C.c_float)),
+                ("posterior_mean_coef1", C.POINTER(C.c_float)), ("posterior_mean_coef2", C.POINTER(C.c_float)),
+                ("posterior_log_variance_clipped", C.POINTER(C.c_float))]
+
+
+_P = C.c_void_p
+# name -> (restype, argtypes); exactly the symbols include/rdm_hip.h declares
+SIGNATURES = {
+    "rdm_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "rdm_ctx_destroy": (None, [_P]),
+    "rdm_last_error": (C.c_char_p, [_P]),
+    "rdm_set_stream": (C.c_int, [_P, _P]),
+    "rdm_version": (C.c_char_p, []),
+    "rdm_unet_manifest": (C.c_longlong, [C.POINTER(UNetCfg), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rdm_vq_manifest": (C.c_longlong, [C.POINTER(VqCfg), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rdm_clip_manifest": (C.c_longlong, [C.POINTER(ClipCfg), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rdm_load_unet": (C.c_int, [_P, C.POINTER(UNetCfg), _P, C.c_size_t]),
+    "rdm_load_vq": (C.c_int, [_P, C.POINTER(VqCfg), _P, C.c_size_t]),
+    "rdm_load_clip": (C.c_int, [_P, C.POINTER(ClipCfg), _P, C.c_size_t]),
+    "rdm_unet_forward": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "rdm_ddim_num_intermediates": (C.c_int, [C.c_int, C.c_int]),
+    "rdm_ddim_sample": (C.c_int, [_P, C.POINTER(DdimArgs), _P, _P, _P, _P, _P, _P, _P]),
+    "rdm_ddpm_sample": (C.c_int, [_P, C.POINTER(DdpmArgs), _P, _P, _P, _P]),
+    "rdm_vq_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "rdm_to_uint8": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "rdm_clip_encode_text": (C.c_int, [_P, _P, C.c_int, _P]),
+    "rdm_clip_encode_image": (C.c_int, [_P, _P, C.c_int, _P]),
+    "rdm_db_load": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, C.c_int]),
+    "rdm_db_size": (C.c_longlong, [_P]),
+    "rdm_knn": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "rdm_db_gather": (C.c_int, [_P, _P, C.c_longlong, _P]),
+    "rdm_op_linear": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "rdm_op_conv3x3": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int]),
+    "rdm_op_groupnorm": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_float, C.c_int, _P]),
+    "rdm_op_layernorm": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
+    "rdm_op_self_attention": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "rdm_op_small_attention": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_float, _P, C.c_int]),
+}
+
+
+def load_library(path: str = LIB_PATH):
+    if not os.path.exists(path):
+        raise ImportError(
+            f"librdm_hip.so not found at {path}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C retrieval-augmented-diffusion-models_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = load_library()
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        assert t.is_contiguous(), "tensor must be contiguous"
+        return C.c_void_p(t.data_ptr())
+    raise TypeError(type(t))
+
+
+def make_unet_cfg(in_channels=3, out_channels=3, model_channels=192, num_res_blocks=2, attention_resolutions=(8, 4, 2),
+                  channel_mult=(1, 2, 3, 5), num_head_channels=32, context_dim=512, **_ignored) -> UNetCfg:
+    c = UNetCfg()
+    c.in_channels, c.out_channels, c.model_channels, c.num_res_blocks = in_channels, out_channels, model_channels, num_res_blocks
+    c.n_attention_resolutions = len(attention_resolutions)
+    for i, v in enumerate(attention_resolutions):
+        c.attention_resolutions[i] = int(v)
+    c.n_channel_mult = len(channel_mult)
+    for i, v in enumerate(channel_mult):
+        c.channel_mult[i] = int(v)
+    c.num_head_channels, c.context_dim = num_head_channels, context_dim
+    return c
+
+
+def make_vq_cfg(embed_dim=3, n_embed=8192, z_channels=3, ch=128, ch_mult=(1, 2, 4), num_res_blocks=2, out_ch=3,
+                resolution=256, mid_attn=True, kl=False, **_ignored) -> VqCfg:
+    c = VqCfg()
+    c.embed_dim, c.n_embed, c.z_channels, c.ch = embed_dim, n_embed, z_channels, ch
+    c.n_ch_mult = len(ch_mult)
+    for i, v in enumerate(ch_mult):
+        c.ch_mult[i] = int(v)
+    c.num_res_blocks, c.out_ch, c.resolution, c.mid_attn, c.kl = num_res_blocks, out_ch, resolution, int(mid_attn), int(kl)
+    return c
+
+
+def make_clip_cfg(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=32,
+                  context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8,
+                  transformer_layers=12, **_ignored) -> ClipCfg:
+    c = ClipCfg()
+    (c.embed_dim, c.image_resolution, c.vision_layers, c.vision_width, c.vision_patch_size, c.context_length,
+     c.vocab_size, c.transformer_width, c.transformer_heads, c.transformer_layers) = (
+        embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size, context_length, vocab_size,
+        transformer_width, transformer_heads, transformer_layers)
+    return c
+
+
+def manifest(kind: str, cfg):
+    """-> (list of (offset, nbytes, kind, [src...]), blob_bytes)"""
+    fn = {"unet": lib.rdm_unet_manifest, "vq": lib.rdm_vq_manifest, "clip": lib.rdm_clip_manifest}[kind]
+    blob = C.c_size_t(0)
+    n = fn(C.byref(cfg), None, 0, C.byref(blob))
+    if n < 0:
+        raise ValueError(f"unsupported {kind} config")
+    buf = C.create_string_buffer(int(n) + 1)
+    fn(C.byref(cfg), buf, int(n) + 1, C.byref(blob))
+    out = []
+    for line in buf.value.decode().splitlines():
+        off, nb, kd, srcs = line.split(" ")
+        out.append((int(off), int(nb), kd, srcs.split(",")))
+    return out, int(blob.value)
+
+
+class RdmError(RuntimeError):
+    pass
+
+
+class Context:
+    """One library context per HIP device (include/rdm_hip.h: rdm_ctx)."""
+
+    def __init__(self, device: int = 0):
+        if not torch.cuda.is_available():
+            raise RdmError("rdm_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+        h = _P()
+        rc = lib.rdm_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise RdmError(f"rdm_ctx_create failed ({rc}); no usable HIP device {device}")
+        self._h = h
+        self.device = torch.device("cuda", device)
+        self.unet_cfg = self.vq_cfg = self.clip_cfg = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.rdm_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RdmError(f"librdm_hip error {rc}: {lib.rdm_last_error(self._h).decode()}")
+
+    def use_current_stream(self):
+        self._check(lib.rdm_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    # ---- weights
+    def load_unet(self, cfg: UNetCfg, blob: np.ndarray):
+        self._check(lib.rdm_load_unet(self._h, C.byref(cfg), blob.ctypes.data_as(_P), blob.nbytes)); self.unet_cfg = cfg
+
+    def load_vq(self, cfg: VqCfg, blob: np.ndarray):
+        self._check(lib.rdm_load_vq(self._h, C.byref(cfg), blob.ctypes.data_as(_P), blob.nbytes)); self.vq_cfg = cfg
+
+    def load_clip(self, cfg: ClipCfg, blob: np.ndarray):
+        self._check(lib.rdm_load_clip(self._h, C.byref(cfg), blob.ctypes.data_as(_P), blob.nbytes)); self.clip_cfg = cfg
+
+    # ---- model calls (torch CUDA tensors in / out)
+    def _dev(self, t, dtype):
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def unet_forward(self, x, t, context):
+        x = self._dev(x, torch.float32); t = self._dev(t, torch.int64); context = self._dev(context, torch.float32)
+        b, _, H, W = x.shape
+        out = torch.empty((b, self.unet_cfg.out_channels, H, W), device=self.device, dtype=torch.float32)
+        self._check(lib.rdm_unet_forward(self._h, _ptr(x), _ptr(t), _ptr(context), b, context.shape[1], H, W, _ptr(out)))
+        return out
+
+    def ddim_sample(self, S, x_T, cond, uncond, alphas_cumprod, eta=0.0, scale=1.0, noise=None, log_every_t=100,
+                    temperature=1.0, want_intermediates=False):
+        x_T = self._dev(x_T, torch.float32); cond = self._dev(cond, torch.float32)
+        uncond = None if uncond is None else self._dev(uncond, torch.float32)
+        noise = None if noise is None else self._dev(noise, torch.float32)
+        ac = np.ascontiguousarray(alphas_cumprod.detach().cpu().numpy() if isinstance(alphas_cumprod, torch.Tensor)
+                                  else alphas_cumprod, dtype=np.float32)
+        B, Cc, H, W = x_T.shape
+        a = DdimArgs(S=S, batch=B, k=cond.shape[1], channels=Cc, height=H, width=W, eta=eta, temperature=temperature,
+                     unconditional_guidance_scale=scale, log_every_t=log_every_t, T=ac.shape[0],
+                     alphas_cumprod=ac.ctypes.data_as(C.POINTER(C.c_float)))
+        z = torch.empty_like(x_T)
+        xi = pi = None
+        if want_intermediates:
+            T_ = ac.shape[0]; c_ = T_ // S
+            total = len(range(0, T_, c_))
+            n = lib.rdm_ddim_num_intermediates(total, log_every_t)
+            xi = torch.empty((n,) + tuple(x_T.shape), device=self.device, dtype=torch.float32)
+            pi = torch.empty_like(xi)
+        self._check(lib.rdm_ddim_sample(self._h, C.byref(a), _ptr(x_T), _ptr(cond), _ptr(uncond), _ptr(noise), _ptr(z),
+                                        _ptr(xi), _ptr(pi)))
+        return z, xi, pi
+
+    def ddpm_sample(self, timesteps, x_T, cond, noise, sched, clip_denoised=True, temperature=1.0):
+        x_T = self._dev(x_T, torch.float32); cond = self._dev(cond, torch.float32); noise = self._dev(noise, torch.float32)
+        arrs = {k: np.ascontiguousarray(np.asarray(v, dtype=np.float32)) for k, v in sched.items()}
+        fp = lambda k: arrs[k].ctypes.data_as(C.POINTER(C.c_float))
+        B, Cc, H, W = x_T.shape
+        a = DdpmArgs(timesteps=timesteps, batch=B, k=cond.shape[1], channels=Cc, height=H, width=W,
+                     clip_denoised=int(clip_denoised), temperature=temperature, T=arrs["posterior_mean_coef1"].shape[0],
+                     sqrt_recip_alphas_cumprod=fp("sqrt_recip_alphas_cumprod"),
+                     sqrt_recipm1_alphas_cumprod=fp("sqrt_recipm1_alphas_cumprod"),
+                     posterior_mean_coef1=fp("posterior_mean_coef1"), posterior_mean_coef2=fp("posterior_mean_coef2"),
+                     posterior_log_variance_clipped=fp("posterior_log_variance_clipped"))
+        z = torch.empty_like(x_T)
+        self._check(lib.rdm_ddpm_sample(self._h, C.byref(a), _ptr(x_T), _ptr(cond), _ptr(noise), _ptr(z)))
+        return z
+
+    def vq_decode(self, z, force_not_quantize=False, return_indices=False):
+        z = self._dev(z, torch.float32)
+        b = z.shape[0]; r = self.vq_cfg.resolution
+        img = torch.empty((b, self.vq_cfg.out_ch, r, r), device=self.device, dtype=torch.float32)
+        idx = torch.empty((b * z.shape[2] * z.shape[3],), device=self.device, dtype=torch.int32) if return_indices else None
+        self._check(lib.rdm_vq_decode(self._h, _ptr(z), b, int(force_not_quantize), _ptr(img), _ptr(idx)))
+        return (img, idx) if return_indices else img
+
+    def to_uint8(self, img):
+        img = self._dev(img, torch.float32)
+        b, c, h, w = img.shape
+        out = torch.empty((b, h, w, c), device=self.device, dtype=torch.uint8)
+        self._check(lib.rdm_to_uint8(self._h, _ptr(img), b, c, h, w, _ptr(out)))
+        return out
+
+    def clip_encode_text(self, tokens):
+        tokens = self._dev(tokens, torch.int64)
+        out = torch.empty((tokens.shape[0], self.clip_cfg.embed_dim), device=self.device, dtype=torch.float32)
+        self._check(lib.rdm_clip_encode_text(self._h, _ptr(tokens), tokens.shape[0], _ptr(out)))
+        return out
+
+    def clip_encode_image(self, image):
+        image = self._dev(image, torch.float32)
+        out = torch.empty((image.shape[0], self.clip_cfg.embed_dim), device=self.device, dtype=torch.float32)
+        self._check(lib.rdm_clip_encode_image(self._h, _ptr(image), image.shape[0], _ptr(out)))
+        return out
+
+    # ---- retrieval
+    def db_load(self, emb):
+        """emb: numpy fp16/fp32 [n,dim] (host) or torch CUDA tensor (device)."""
+        if isinstance(emb, torch.Tensor) and emb.is_cuda:
+            emb = emb.contiguous()
+            dt = {torch.float16: 0, torch.float32: 1}[emb.dtype]
+            self._check(lib.rdm_db_load(self._h, _ptr(emb), emb.shape[0], emb.shape[1], dt, 1))
+        else:
+            emb = np.ascontiguousarray(emb.numpy() if isinstance(emb, torch.Tensor) else emb)
+            dt = {np.dtype(np.float16): 0, np.dtype(np.float32): 1}[emb.dtype]
+            self._check(lib.rdm_db_load(self._h, emb.ctypes.data_as(_P), emb.shape[0], emb.shape[1], dt, 0))
+
+    def db_size(self):
+        return int(lib.rdm_db_size(self._h))
+
+    def knn(self, q, k):
+        q = self._dev(q, torch.float32)
+        idx = torch.empty((q.shape[0], k), device=self.device, dtype=torch.int32)   # uint32 bits
+        sc = torch.empty((q.shape[0], k), device=self.device, dtype=torch.float32)
+        self._check(lib.rdm_knn(self._h, _ptr(q), q.shape[0], k, _ptr(idx), _ptr(sc)))
+        return idx, sc
+
+    def db_gather(self, idx, dim):
+        idx = idx.contiguous()
+        out = torch.empty((idx.numel(), dim), device=self.device, dtype=torch.float32)
+        self._check(lib.rdm_db_gather(self._h, _ptr(idx), idx.numel(), _ptr(out)))
+        return out.reshape(tuple(idx.shape) + (dim,))
+
+    # ---- operator-level (parity tests)
+    def op_linear(self, a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out_f32=False):
+        M, K = a.shape; N = w.shape[0]
+        No = N // 2 if act == ACT_GEGLU else N
+        ob = None if out_f32 else torch.empty((M, No), device=self.device, dtype=torch.bfloat16)
+        of = torch.empty((M, No), device=self.device, dtype=torch.float32) if out_f32 else None
+        self._check(lib.rdm_op_linear(self._h, _ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(ob), _ptr(of), M, N, K,
+                                      act, float(alpha)))
+        return of if out_f32 else ob
+
+    def op_conv3x3(self, x0, w, bias, x1=None, rowvec=None, residual=None, stride=1, ups=0):
+        B, Hin, Win, C0 = x0.shape
+        C1 = 0 if x1 is None else x1.shape[3]
+        N = w.shape[0]
+        Ho = Hin * 2 if ups else (Hin // 2 if stride == 2 else Hin)
+        Wo = Win * 2 if ups else (Win // 2 if stride == 2 else Win)
+        out = torch.empty((B, Ho, Wo, N), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_conv3x3(self._h, _ptr(x0), _ptr(x1), C0, C1, _ptr(w), _ptr(bias), _ptr(rowvec),
+                                       0 if rowvec is None else rowvec.shape[1], _ptr(residual), _ptr(out), B, Hin, Win, N,
+                                       stride, ups))
+        return out
+
+    def op_groupnorm(self, x0, gamma, beta, eps, silu, x1=None):
+        B, HW, C0 = x0.shape
+        C1 = 0 if x1 is None else x1.shape[2]
+        out = torch.empty((B, HW, C0 + C1), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_groupnorm(self._h, _ptr(x0), _ptr(x1), C0, C1, B, HW, _ptr(gamma), _ptr(beta), float(eps),
+                                         int(silu), _ptr(out)))
+        return out
+
+    def op_layernorm(self, x, gamma, beta, eps=1e-5):
+        M, Cc = x.shape
+        out = torch.empty((M, Cc), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_layernorm(self._h, _ptr(x), int(x.dtype == torch.float32), _ptr(gamma), _ptr(beta), M, Cc,
+                                         float(eps), _ptr(out)))
+        return out
+
+    def op_self_attention(self, qk, vt, heads):
+        B, n, C2 = qk.shape
+        out = torch.empty((B, n, C2 // 2), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_self_attention(self._h, _ptr(qk), _ptr(vt), B, n, heads, _ptr(out)))
+        return out
+
+    def op_small_attention(self, q, k, v, heads, D, causal, scale):
+        B, nq, Cc = q.shape
+        assert k.stride(-2) == v.stride(-2)
+        out = torch.empty((B, nq, heads * D), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_small_attention(self._h, _ptr(q), Cc, _ptr(k), _ptr(v), k.shape[2], B, nq, k.shape[1], heads,
+                                               D, int(causal), float(scale), _ptr(out), heads * D))
+        return out

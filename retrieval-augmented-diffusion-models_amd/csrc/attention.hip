@@ -1,0 +1,161 @@
+// Attention kernels (gfx950).
+// Replaces rdm/modules/attention.py:42-74 (CrossAttention.forward: einsum QK^T * scale -> softmax ->
+// einsum AV, d_head = 32) for both uses in BasicTransformerBlock (attention.py:92-96), and
+// nn.MultiheadAttention inside CLIP's ResidualAttentionBlock (custom_clip/model.py:166-187).
+//
+// 1) flash_d32: self-attention, d_head = 32, n % 32 == 0.  Never materialises the n x n scores
+//    (the reference moves 475 M score elements per sample per forward).  One wave owns 32 query rows.
+//    Both contractions run on 32x32x16 bf16 MFMA in the *swapped* form:
+//        S^T[kv][q] = K . Q^T      (A = K rows, B = Q rows)       -> a lane holds 16 scores of ONE query
+//        O^T[d][q]  = V^T . P^T    (A = V^T rows, B = P^T = the lane's own exp'd scores)
+//    so softmax statistics are lane-local (one cross-half shuffle per tile), the rescale of O is a
+//    per-lane scalar, and P never leaves registers.  The K rows of a tile are loaded in a permuted
+//    order (bits 2,3 of the in-tile index swapped) so that the 8 scores a lane holds per MFMA k-step
+//    are 8 CONSECUTIVE keys: the V^T operand is then one 16-byte load per lane and no LDS, no
+//    transpose and no cross-lane permute is needed.  V^T ([B, C, n]) is produced directly by the
+//    projection GEMM (swapped operands), K/V tiles are L2-resident (<= 64 KB per head).
+// 2) small_attention<D>: generic VALU kernel for short key sequences (cross-attention over the k
+//    retrieved neighbours, n_kv = k <= 16; CLIP n = 77/50 with optional causal mask; odd sizes).
+#include "kernels.h"
+
+
+__global__ __launch_bounds__(256) void flash_d32_kernel(FlashParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;
+    const int q0 = (blockIdx.x * nw + wave) * 32;
+    if (q0 >= p.n) return;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int l31 = lane & 31, hf = lane >> 5;
+    const long long tok0 = (long long)b * p.n;
+
+    // Q as the B operand of S^T = K.Q^T : lane (q = l31) holds d = ks*16 + hf*8 .. +8
+    bf16x8 qf[2];
+    {
+        const bf16_t* qp = p.q + (tok0 + q0 + l31) * p.ldq + h * 32 + hf * 8;
+        qf[0] = *(const bf16x8*)(qp);
+        qf[1] = *(const bf16x8*)(qp + 16);
+    }
+    // in-tile key permutation: position p holds key pi(p) = p with bits 2 and 3 swapped
+    const int pos = l31;
+    const int pi = (pos & ~0xc) | ((pos & 4) << 1) | ((pos & 8) >> 1);
+    const bf16_t* kbase = p.k + (tok0 + pi) * p.ldk + h * 32 + hf * 8;
+    const bf16_t* vbase = p.vt + ((long long)b * p.C + h * 32 + l31) * p.n + hf * 8;
+
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    for (int kv0 = 0; kv0 < p.n; kv0 += 32) {
+        const bf16_t* kp = kbase + (long long)kv0 * p.ldk;
+        const bf16x8 k0 = *(const bf16x8*)(kp);
+        const bf16x8 k1 = *(const bf16x8*)(kp + 16);
+        const bf16x8 v0 = *(const bf16x8*)(vbase + kv0);
+        const bf16x8 v1 = *(const bf16x8*)(vbase + kv0 + 16);
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[r] = 0.f;
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1], s, 0, 0, 0);
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; r++) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mnew = fmaxf(m, mx * p.scale_log2e);
+        const float alpha = exp2f(m - mnew);
+        float ps = 0.f;
+        float pr[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) { pr[r] = exp2f(s[r] * p.scale_log2e - mnew); ps += pr[r]; }
+        l = l * alpha + ps;
+        m = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] *= alpha;
+        union { bf16x8 v; uint32_t u[4]; } pb0, pb1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            pb0.u[i] = pack2bf(pr[2 * i], pr[2 * i + 1]);
+            pb1.u[i] = pack2bf(pr[8 + 2 * i], pr[8 + 2 * i + 1]);
+        }
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb0.v, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb1.v, o, 0, 0, 0);
+    }
+    l += __shfl_xor(l, 32);
+    const float inv = 1.f / l;
+    bf16_t* op = p.out + (tok0 + q0 + l31) * p.ldo + h * 32 + 4 * hf;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        uint2 w;
+        w.x = pack2bf(o[g * 4 + 0] * inv, o[g * 4 + 1] * inv);
+        w.y = pack2bf(o[g * 4 + 2] * inv, o[g * 4 + 3] * inv);
+        *(uint2*)(op + 8 * g) = w;
+    }
+}
+
+hipError_t launch_flash_d32(const FlashParams& p, int heads, int batch, hipStream_t st) {
+    if (p.n % 32 != 0 || p.C != heads * 32) return hipErrorInvalidValue;
+    int nw = p.n / 32; if (nw > 4) nw = 4;
+    dim3 grid((p.n / 32 + nw - 1) / nw, heads, batch);
+    flash_d32_kernel<<<grid, nw * 64, 0, st>>>(p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ small attention
+
+template <int D>
+__global__ __launch_bounds__(256) void small_attention_kernel(SmallAttnParams p) {
+    extern __shared__ float kv[];            // K [nkv][D] then V [nkv][D]  (f32)
+    const int h = blockIdx.y, b = blockIdx.z;
+    float* Ks = kv; float* Vs = kv + p.nkv * D;
+    for (int i = threadIdx.x; i < p.nkv * (D / 8); i += blockDim.x) {
+        const int j = i / (D / 8), c = (i % (D / 8)) * 8;
+        const bf16x8 kk = *(const bf16x8*)(p.k + ((long long)b * p.nkv + j) * p.ldk + h * D + c);
+        const bf16x8 vv = *(const bf16x8*)(p.v + ((long long)b * p.nkv + j) * p.ldv + h * D + c);
+#pragma unroll
+        for (int e = 0; e < 8; e++) { Ks[j * D + c + e] = bf2f((bf16_t)kk[e]); Vs[j * D + c + e] = bf2f((bf16_t)vv[e]); }
+    }
+    __syncthreads();
+    for (int qi = blockIdx.x * blockDim.x + threadIdx.x; qi < p.nq; qi += gridDim.x * blockDim.x) {
+        float qr[D], acc[D];
+        const bf16_t* qp = p.q + ((long long)b * p.nq + qi) * p.ldq + h * D;
+#pragma unroll
+        for (int c = 0; c < D; c += 8) {
+            const bf16x8 t = *(const bf16x8*)(qp + c);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { qr[c + e] = bf2f((bf16_t)t[e]) * p.scale; acc[c + e] = 0.f; }
+        }
+        float m = -INFINITY, l = 0.f;
+        const int jend = p.causal ? min(p.nkv, qi + 1) : p.nkv;
+        for (int j = 0; j < jend; j++) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; d++) s += qr[d] * Ks[j * D + d];
+            const float mn = fmaxf(m, s);
+            const float a = __expf(m - mn), pj = __expf(s - mn);
+            l = l * a + pj; m = mn;
+#pragma unroll
+            for (int d = 0; d < D; d++) acc[d] = acc[d] * a + pj * Vs[j * D + d];
+        }
+        const float inv = 1.f / l;
+        bf16_t* op = p.out + ((long long)b * p.nq + qi) * p.ldo + h * D;
+#pragma unroll
+        for (int c = 0; c < D; c += 8) {
+            uint4 w;
+            w.x = pack2bf(acc[c] * inv, acc[c + 1] * inv); w.y = pack2bf(acc[c + 2] * inv, acc[c + 3] * inv);
+            w.z = pack2bf(acc[c + 4] * inv, acc[c + 5] * inv); w.w = pack2bf(acc[c + 6] * inv, acc[c + 7] * inv);
+            *(uint4*)(op + c) = w;
+        }
+    }
+}
+
+hipError_t launch_small_attention(const SmallAttnParams& p, int D, int heads, int batch, hipStream_t st) {
+    const size_t sm = (size_t)p.nkv * D * 2 * sizeof(float);
+    if (sm > 64 * 1024) return hipErrorInvalidValue;
+    int threads = p.nq >= 256 ? 256 : ((p.nq + 63) / 64) * 64;
+    int gx = (p.nq + threads - 1) / threads;
+    dim3 grid(gx, heads, batch);
+    if (D == 32) small_attention_kernel<32><<<grid, threads, sm, st>>>(p);
+    else if (D == 64) small_attention_kernel<64><<<grid, threads, sm, st>>>(p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}

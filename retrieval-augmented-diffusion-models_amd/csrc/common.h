@@ -1,0 +1,59 @@
+// Shared device/host helpers for librdm_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, same as torch's float->bfloat16 for finite values
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float quickgelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
+// 16-byte async global->LDS copy: LDS address = wave-uniform `lds_wave_base` + lane*16.
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gptr, (LDS_AS void*)lds_wave_base, 16, 0, 0);
+}
+
+// epilogue activation ids (igemm)
+enum { ACT_NONE = 0, ACT_GEGLU = 1, ACT_QUICKGELU = 2, ACT_SILU = 3 };
+
+struct IgemmParams {
+    // A operand: logical [M, K].  Two channel-concatenated sources (A1 may be null, C1 = 0).
+    const bf16_t* A0; const bf16_t* A1;
+    int C0, C1;                 // channels (row length) of each source; linear: K = C0 + C1
+    const bf16_t* W;            // [N][K] bf16, K contiguous
+    int M, N, K;
+    // conv3x3 geometry (conv mode): input [B, Hin, Win, C0(+C1)], output [B, Hout, Wout, N]
+    int Hin, Win, Hout, Wout, stride, ups;
+    // epilogue
+    float alpha;                // acc scale
+    const float* bias;          // [N] (permuted for GEGLU) or null
+    const float* rowvec;        // [B, rowvec_ld] per-sample per-column add (time embedding) or null
+    int rowvec_ld, rows_per_sample;
+    const bf16_t* res_bf16;     // [M, ldo] residual or null
+    const float* res_f32;       // [M, ldo] residual or null
+    bf16_t* out_bf16; float* out_f32;   // either / both
+    int ldo;                    // output row stride (elements)
+    int act;
+    // batching over blockIdx.z (element strides)
+    long long sA, sW, sO;
+    const void* zero_page;      // >= 16 B of zeros
+};

@@ -1,0 +1,69 @@
+// Internal kernel-launch interface of librdm_hip (host side). All launches are asynchronous on `st`.
+#pragma once
+#include "common.h"
+
+struct GnParams {
+    const bf16_t* x0; const bf16_t* x1;   // [B, HW, C0], [B, HW, C1] (x1 may be null)
+    int C0, C1, HW, B, groups;
+    int nchunk;                           // pixel chunks per sample
+    float* partial;                       // [B, nchunk, groups, 2] (sum, sumsq)
+    const float* gamma; const float* beta;
+    float eps; int silu;
+    bf16_t* out;                          // [B, HW, C0+C1]
+};
+
+struct FlashParams {
+    const bf16_t* q; int ldq;        // q[(b*n + i)*ldq + h*32 + d]
+    const bf16_t* k; int ldk;        // k[(b*n + j)*ldk + h*32 + d]
+    const bf16_t* vt;                // vt[((b*C) + h*32 + d)*n + j]
+    bf16_t* out; int ldo;            // out[(b*n + i)*ldo + h*32 + d]
+    int n, C;                        // tokens, channels (= heads*32)
+    float scale_log2e;               // d^-0.5 * log2(e)
+};
+
+struct SmallAttnParams {
+    const bf16_t* q; int ldq;        // q[(b*nq + i)*ldq + h*D + d]
+    const bf16_t* k; int ldk; const bf16_t* v; int ldv;   // k[(b*nkv + j)*ldk + h*D + d]
+    bf16_t* out; int ldo;
+    int nq, nkv, causal;
+    float scale;
+};
+
+struct DdimStepParams {
+    const float* x; const float* eps; const float* noise;   // noise may be null (eta == 0)
+    float* x_prev; float* pred_x0;                           // pred_x0 may be null
+    long long n_per_batch;                                   // B*C*H*W
+    float a_t, a_prev, sigma_t, sqrt_one_minus_at, scale, temperature;
+    int cfg;
+};
+
+struct DdpmStepParams {
+    const float* x; const float* eps; const float* noise; float* x_prev; long long n;
+    float sqrt_recip, sqrt_recipm1, coef1, coef2, log_var; int clip, nonzero; float temperature;
+};
+
+hipError_t launch_igemm(const IgemmParams& p, bool conv, int batch, hipStream_t st);
+hipError_t launch_groupnorm(GnParams p, hipStream_t st);
+hipError_t launch_layernorm(const void* x, int in_is_f32, const float* gamma, const float* beta, void* out, int out_is_f32,
+                            int M, int C, float eps, hipStream_t st);
+hipError_t launch_flash_d32(const FlashParams& p, int heads, int batch, hipStream_t st);
+hipError_t launch_small_attention(const SmallAttnParams& p, int D, int heads, int batch, hipStream_t st);
+hipError_t launch_conv_in(const float* x, const float* w, const float* bias, bf16_t* out, int B, int Cin, int H, int W,
+                          int Cout, hipStream_t st);
+hipError_t launch_conv_out(const bf16_t* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin,
+                           int Cout, hipStream_t st);
+hipError_t launch_timestep_embedding(const long long* t, bf16_t* out, int B, int dim, hipStream_t st);
+hipError_t launch_cast_f32_bf16(const float* x, bf16_t* y, long long n, hipStream_t st);
+hipError_t launch_ddim_step(const DdimStepParams& p, hipStream_t st);
+hipError_t launch_ddpm_step(const DdpmStepParams& p, hipStream_t st);
+hipError_t launch_vq_quantize(const float* z, const float* codebook, int n_embed, const float* pq_w, const float* pq_b,
+                              float* out, int* idx_out, int B, int HW, int quantize, hipStream_t st);
+hipError_t launch_softmax_rows(const float* s, bf16_t* p, long long rows, int n, hipStream_t st);
+hipError_t launch_clip_embed(const long long* tokens, const float* tok_emb, const float* pos_emb, float* out, int B, int L,
+                             int Wd, hipStream_t st);
+hipError_t launch_clip_gather_eot(const long long* tokens, const float* x, float* out, int B, int L, int Wd, hipStream_t st);
+hipError_t launch_clip_patchify(const float* img, bf16_t* out, int B, int R, int P, hipStream_t st);
+hipError_t launch_clip_vit_assemble(const float* patch, const float* cls, const float* pos, float* out, int B, int GG, int Wd,
+                                    hipStream_t st);
+hipError_t launch_gather_rows_f32(const float* x, float* out, int B, long long row_stride, int Wd, hipStream_t st);
+hipError_t launch_to_uint8_hwc(const float* x, unsigned char* out, int B, int C, int H, int W, hipStream_t st);

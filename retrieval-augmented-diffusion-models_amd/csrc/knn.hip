@@ -1,0 +1,362 @@
+// Exact brute-force cosine top-k over the CLIP-embedding database resident in HBM (gfx950).
+// Replaces scann's searcher.search_batched (rdm/data/retrieval_dataset/dsetbuilder.py:490) and the
+// numpy normalisation around it (:487, :574); the gather replaces data_pool['embedding'][nns] (:493).
+//
+// HBM-bound for <= 64 queries: the fp16 database is streamed once per group of 64 queries.
+//   scan kernel   persistent blocks (one per CU) walk 256-row tiles; the tile's K-slices and the
+//                 matching query slices are staged by 16-byte LDS-DMA into a double-buffered LDS ring
+//                 (same source-swizzled layout as the GEMM), scored with 32x32x16 f16 MFMA.  The
+//                 query is split q^ = q_hi + q_lo (two fp16 words) so the approximate score is
+//                 fp32-accurate.  A lane holds 16 rows' scores of ONE query (MFMA D layout), so it
+//                 keeps a private sorted top-KSEL list in registers (threshold test + unrolled
+//                 insertion under a strict total order (score desc, index asc)).
+//   merge kernel  per query: thread-local top-KSEL over all lane lists -> LDS bitonic sort ->
+//                 the best 2*KSEL candidates are re-scored EXACTLY (fp64 accumulation of exact
+//                 products, the oracle's definition) and sorted by (score desc, index asc).
+// Any element of the true top-k survives every list level because every list keeps KSEL >= k + 4
+// entries of its subset; index ties resolve identically to the oracle.
+#include <string.h>
+
+#include "kernels.h"
+#include "knn.h"
+
+#define KNN_ROWS 256           // rows per tile
+#define KNN_Q 64               // queries per pass
+#define KNN_BK 64              // K slice per stage
+
+struct Cand { float s; uint32_t i; };
+__device__ __forceinline__ bool better(float s, uint32_t i, float ts, uint32_t ti) { return s > ts || (s == ts && i < ti); }
+
+template <int KSEL>
+__device__ __forceinline__ void list_insert(float (&ls)[KSEL], uint32_t (&li)[KSEL], float s, uint32_t i) {
+    if (!better(s, i, ls[KSEL - 1], li[KSEL - 1])) return;
+#pragma unroll
+    for (int j = 0; j < KSEL; j++) {
+        if (better(s, i, ls[j], li[j])) { const float ts = ls[j]; const uint32_t ti = li[j]; ls[j] = s; li[j] = i; s = ts; i = ti; }
+    }
+}
+
+// ---------------------------------------------------------------- database / query preparation
+// one wave per row: n = fp32(sqrt(sum x^2 in fp64)); out = fp16(x / n)
+template <typename TIN>
+__global__ __launch_bounds__(256) void knn_normalize_rows_kernel(const TIN* x, _Float16* out, long long n, int dim) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    double acc = 0.0;
+    for (int c = lane; c < dim; c += 64) { const double v = (double)(float)x[row * dim + c]; acc += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    const float nrm = (float)sqrt(acc);
+    for (int c = lane; c < dim; c += 64) {
+        const float v = (float)x[row * dim + c];
+        out[row * dim + c] = (_Float16)(nrm > 0.f ? v / nrm : 0.f);
+    }
+}
+
+// q f32 [b, dim] -> qn f32 [64, dim] (normalised, zero padded), qh / ql fp16 [64, dim]
+__global__ void knn_prep_queries_kernel(const float* q, int b, int dim, float* qn, _Float16* qh, _Float16* ql) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    double acc = 0.0;
+    if (row < b) for (int c = lane; c < dim; c += 64) { const double v = (double)q[(long long)row * dim + c]; acc += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    const float nrm = (float)sqrt(acc);
+    for (int c = lane; c < dim; c += 64) {
+        float v = 0.f;
+        if (row < b) v = q[(long long)row * dim + c] / nrm;
+        const _Float16 h = (_Float16)v;
+        qn[(long long)row * dim + c] = v;
+        qh[(long long)row * dim + c] = h;
+        ql[(long long)row * dim + c] = (_Float16)(v - (float)h);
+    }
+}
+
+// ---------------------------------------------------------------- scan
+struct ScanParams {
+    const _Float16* dbn; long long n; int dim; long long ntiles;
+    const _Float16* qh; const _Float16* ql;
+    float* cand_s; uint32_t* cand_i;      // [64][nlists][KSEL]
+    int nlists; const void* zero_page;
+};
+
+template <int KSEL>
+__global__ __launch_bounds__(256) void knn_scan_kernel(ScanParams p) {
+    constexpr int DB_BYTES = KNN_ROWS * 128, Q_BYTES = KNN_Q * 128, STAGE = DB_BYTES + 2 * Q_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = tid >> 3, pchunk = tid & 7;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int nkc = p.dim / KNN_BK;
+    const char* zero = (const char*)p.zero_page;
+
+    float ls[2][KSEL]; uint32_t li[2][KSEL];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int j = 0; j < KSEL; j++) { ls[t][j] = -INFINITY; li[t][j] = 0xffffffffu; }
+
+    // my tiles: blockIdx.x, +gridDim.x, ...
+    const long long my_tiles = (p.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const long long iters = my_tiles * nkc;
+
+    auto stage = [&](long long it, int buf) {
+        const long long tl = it / nkc; const int kc = (int)(it - tl * nkc);
+        const long long tile = blockIdx.x + tl * gridDim.x;
+        char* Ds = smem + buf * STAGE; char* Qh = Ds + DB_BYTES; char* Ql = Qh + Q_BYTES;
+#pragma unroll
+        for (int i = 0; i < KNN_ROWS / 32; i++) {
+            const int r = i * 32 + lrow;
+            const long long row = tile * KNN_ROWS + r;
+            const int c = pchunk ^ ((r >> 1) & 7);
+            const void* g = (row < p.n) ? (const void*)(p.dbn + row * p.dim + kc * KNN_BK + c * 8) : (const void*)zero;
+            glds16(g, Ds + (i * 32 + wave * 8) * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < KNN_Q / 32; i++) {
+            const int r = i * 32 + lrow;
+            const int c = pchunk ^ ((r >> 1) & 7);
+            glds16(p.qh + (long long)r * p.dim + kc * KNN_BK + c * 8, Qh + (i * 32 + wave * 8) * 128);
+            glds16(p.ql + (long long)r * p.dim + kc * KNN_BK + c * 8, Ql + (i * 32 + wave * 8) * 128);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    if (iters > 0) stage(0, 0);
+    for (long long it = 0; it < iters; it++) {
+        const int cur = (int)(it & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it + 1 < iters) stage(it + 1, cur ^ 1);
+        const char* Ds = smem + cur * STAGE; const char* Qh = Ds + DB_BYTES; const char* Ql = Qh + Q_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int chunk = kk * 2 + fhalf;
+            f16x8 a[2], bh[2], bl[2];
+#pragma unroll
+            for (int rf = 0; rf < 2; rf++) {
+                const int row = wave * 64 + rf * 32 + frow;
+                a[rf] = *(const f16x8*)(Ds + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int qt = 0; qt < 2; qt++) {
+                const int row = qt * 32 + frow;
+                const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+                bh[qt] = *(const f16x8*)(Qh + off);
+                bl[qt] = *(const f16x8*)(Ql + off);
+            }
+#pragma unroll
+            for (int rf = 0; rf < 2; rf++)
+#pragma unroll
+                for (int qt = 0; qt < 2; qt++) {
+                    acc[rf][qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rf], bl[qt], acc[rf][qt], 0, 0, 0);
+                    acc[rf][qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rf], bh[qt], acc[rf][qt], 0, 0, 0);
+                }
+        }
+        const long long tl = it / nkc; const int kc = (int)(it - tl * nkc);
+        if (kc == nkc - 1) {
+            const long long tile = blockIdx.x + tl * gridDim.x;
+            const long long rbase = tile * KNN_ROWS + wave * 64 + 4 * fhalf;
+#pragma unroll
+            for (int rf = 0; rf < 2; rf++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const long long row = rbase + rf * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < p.n) {
+                        list_insert<KSEL>(ls[0], li[0], acc[rf][0][r], (uint32_t)row);
+                        list_insert<KSEL>(ls[1], li[1], acc[rf][1][r], (uint32_t)row);
+                    }
+                    acc[rf][0][r] = 0.f; acc[rf][1][r] = 0.f;
+                }
+        }
+    }
+    const int list_id = blockIdx.x * 8 + wave * 2 + fhalf;
+#pragma unroll
+    for (int qt = 0; qt < 2; qt++) {
+        const long long base = ((long long)(qt * 32 + frow) * p.nlists + list_id) * KSEL;
+#pragma unroll
+        for (int j = 0; j < KSEL; j++) { p.cand_s[base + j] = ls[qt][j]; p.cand_i[base + j] = li[qt][j]; }
+    }
+}
+
+// ---------------------------------------------------------------- merge + exact re-score
+struct MergeParams {
+    const float* cand_s; const uint32_t* cand_i; int nlists;
+    const _Float16* dbn; const float* qn; int dim; long long n;
+    int k; uint32_t* idx_out; float* score_out; int qbase;   // output row = qbase + blockIdx.x
+};
+
+template <int KSEL>
+__global__ __launch_bounds__(256) void knn_merge_kernel(MergeParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NS = 256 * KSEL;
+    float* ss = (float*)smem; uint32_t* si = (uint32_t*)(smem + NS * 4);
+    const int q = blockIdx.x, tid = threadIdx.x;
+    float ls[KSEL]; uint32_t li[KSEL];
+#pragma unroll
+    for (int j = 0; j < KSEL; j++) { ls[j] = -INFINITY; li[j] = 0xffffffffu; }
+    const long long total = (long long)p.nlists * KSEL, base = (long long)q * total;
+    for (long long c = tid; c < total; c += 256) list_insert<KSEL>(ls, li, p.cand_s[base + c], p.cand_i[base + c]);
+#pragma unroll
+    for (int j = 0; j < KSEL; j++) { ss[tid * KSEL + j] = ls[j]; si[tid * KSEL + j] = li[j]; }
+    __syncthreads();
+    // bitonic sort, best first
+    for (int size = 2; size <= NS; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < NS / 2; t += 256) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = ((lo & size) == 0);       // ascending block => best first
+                const float a = ss[lo], b = ss[hi]; const uint32_t ai = si[lo], bi = si[hi];
+                const bool b_better = better(b, bi, a, ai);
+                if (b_better == up) { ss[lo] = b; si[lo] = bi; ss[hi] = a; si[hi] = ai; }
+            }
+            __syncthreads();
+        }
+    }
+    // exact re-score of the best R candidates: fp64 accumulation of exact products
+    constexpr int R = (2 * KSEL > 64) ? 64 : 2 * KSEL;
+    __shared__ double ex[R]; __shared__ uint32_t exi[R];
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int r = wave; r < R; r += 4) {
+        const uint32_t id = si[r];
+        double acc = 0.0;
+        if (id != 0xffffffffu && (long long)id < p.n) {
+            for (int c = lane; c < p.dim; c += 64)
+                acc += (double)p.qn[(long long)q * p.dim + c] * (double)(float)p.dbn[(long long)id * p.dim + c];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) { ex[r] = (id != 0xffffffffu) ? acc : -INFINITY; exi[r] = id; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int a = 1; a < R; a++) {       // insertion sort by (score desc, index asc)
+            const double s = ex[a]; const uint32_t id = exi[a]; int b = a - 1;
+            while (b >= 0 && (ex[b] < s || (ex[b] == s && exi[b] > id))) { ex[b + 1] = ex[b]; exi[b + 1] = exi[b]; b--; }
+            ex[b + 1] = s; exi[b + 1] = id;
+        }
+        for (int j = 0; j < p.k; j++) {
+            p.idx_out[(long long)(p.qbase + q) * p.k + j] = exi[j];
+            if (p.score_out) p.score_out[(long long)(p.qbase + q) * p.k + j] = (float)ex[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- gather
+template <typename TIN>
+__global__ void knn_gather_kernel(const TIN* raw, const uint32_t* idx, long long n_idx, int dim, float* out) {
+    const long long total = n_idx * dim;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / dim; const int c = (int)(i - r * dim);
+        out[i] = (float)raw[(long long)idx[r] * dim + c];
+    }
+}
+
+// ---------------------------------------------------------------- host
+static const char* hiperr(hipError_t e) { return e == hipSuccess ? nullptr : hipGetErrorString(e); }
+#define KNN_TRY(x) do { const char* _m = hiperr(x); if (_m) return _m; } while (0)
+
+void knn_free(KnnDb& db) {
+    if (db.dbn) hipFree(db.dbn);
+    if (db.raw) hipFree(db.raw);
+    if (db.scratch) hipFree(db.scratch);
+    db = KnnDb();
+}
+
+const char* knn_load(KnnDb& db, const void* emb, long long n, int dim, int dtype, int is_device, hipStream_t st) {
+    if (n <= 0 || dim <= 0 || dim % 64 != 0 || dim > 4096) return "dim must be a positive multiple of 64";
+    if (n >= 0xffffffffLL) return "database too large for uint32 indices";
+    if (dtype != 0 && dtype != 1) return "dtype must be 0 (fp16) or 1 (fp32)";
+    knn_free(db);
+    const size_t es = dtype == 0 ? 2 : 4;
+    const long long n_pad = (n + KNN_ROWS - 1) / KNN_ROWS * KNN_ROWS;
+    KNN_TRY(hipMalloc(&db.dbn, (size_t)n_pad * dim * 2));
+    KNN_TRY(hipMemsetAsync(db.dbn, 0, (size_t)n_pad * dim * 2, st));
+    KNN_TRY(hipMalloc(&db.raw, (size_t)n * dim * es));
+    // chunked upload keeps pinned/pageable staging bounded
+    const long long chunk = 1 << 20;
+    for (long long r0 = 0; r0 < n; r0 += chunk) {
+        const long long rows = (n - r0 < chunk) ? n - r0 : chunk;
+        char* dst = (char*)db.raw + (size_t)r0 * dim * es;
+        KNN_TRY(hipMemcpyAsync(dst, (const char*)emb + (size_t)r0 * dim * es, (size_t)rows * dim * es,
+                               is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        const int grid = (int)((rows + 3) / 4);
+        _Float16* out = (_Float16*)db.dbn + (size_t)r0 * dim;
+        if (dtype == 0) knn_normalize_rows_kernel<_Float16><<<grid, 256, 0, st>>>((const _Float16*)dst, out, rows, dim);
+        else knn_normalize_rows_kernel<float><<<grid, 256, 0, st>>>((const float*)dst, out, rows, dim);
+        KNN_TRY(hipGetLastError());
+    }
+    KNN_TRY(hipStreamSynchronize(st));
+    db.n = n; db.dim = dim; db.raw_dtype = dtype;
+    return nullptr;
+}
+
+template <int KSEL>
+static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t* idx_out, float* score_out, hipStream_t st) {
+    int dev = 0, ncu = 256;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const long long ntiles = (db.n + KNN_ROWS - 1) / KNN_ROWS;
+    int grid = (int)(ntiles < ncu ? ntiles : ncu);
+    const int nlists = grid * 8;
+    const size_t qn_b = (size_t)KNN_Q * db.dim * 4, qh_b = (size_t)KNN_Q * db.dim * 2;
+    const size_t cand_b = (size_t)KNN_Q * nlists * KSEL * 4;
+    const size_t need = qn_b + 2 * qh_b + 2 * cand_b + 1024;
+    if (db.scratch_bytes < need) {
+        if (db.scratch) { KNN_TRY(hipStreamSynchronize(st)); KNN_TRY(hipFree(db.scratch)); db.scratch = nullptr; db.scratch_bytes = 0; }
+        KNN_TRY(hipMalloc(&db.scratch, need)); db.scratch_bytes = need;
+    }
+    char* s = (char*)db.scratch;
+    float* qn = (float*)s; _Float16* qh = (_Float16*)(s + qn_b); _Float16* ql = (_Float16*)(s + qn_b + qh_b);
+    float* cs = (float*)(s + qn_b + 2 * qh_b); uint32_t* ci = (uint32_t*)(s + qn_b + 2 * qh_b + cand_b);
+    static void* zero_page = nullptr;
+    if (!zero_page) { KNN_TRY(hipMalloc(&zero_page, 256)); KNN_TRY(hipMemset(zero_page, 0, 256)); }
+    constexpr int scan_smem = 2 * (KNN_ROWS * 128 + 2 * KNN_Q * 128);
+    constexpr int merge_smem = 256 * KSEL * 8;
+    static bool attr = false;
+    if (!attr) {
+        KNN_TRY(hipFuncSetAttribute((const void*)knn_scan_kernel<KSEL>, hipFuncAttributeMaxDynamicSharedMemorySize, scan_smem));
+        KNN_TRY(hipFuncSetAttribute((const void*)knn_merge_kernel<KSEL>, hipFuncAttributeMaxDynamicSharedMemorySize, merge_smem));
+        attr = true;
+    }
+    for (int q0 = 0; q0 < b; q0 += KNN_Q) {
+        const int bq = (b - q0 < KNN_Q) ? b - q0 : KNN_Q;
+        knn_prep_queries_kernel<<<KNN_Q, 64, 0, st>>>(q + (size_t)q0 * db.dim, bq, db.dim, qn, qh, ql);
+        KNN_TRY(hipGetLastError());
+        ScanParams sp{}; sp.dbn = (const _Float16*)db.dbn; sp.n = db.n; sp.dim = db.dim; sp.ntiles = ntiles; sp.qh = qh; sp.ql = ql;
+        sp.cand_s = cs; sp.cand_i = ci; sp.nlists = nlists; sp.zero_page = zero_page;
+        knn_scan_kernel<KSEL><<<grid, 256, scan_smem, st>>>(sp);
+        KNN_TRY(hipGetLastError());
+        MergeParams mp{}; mp.cand_s = cs; mp.cand_i = ci; mp.nlists = nlists; mp.dbn = (const _Float16*)db.dbn; mp.qn = qn;
+        mp.dim = db.dim; mp.n = db.n; mp.k = k; mp.idx_out = idx_out; mp.score_out = score_out; mp.qbase = q0;
+        knn_merge_kernel<KSEL><<<bq, 256, merge_smem, st>>>(mp);
+        KNN_TRY(hipGetLastError());
+    }
+    return nullptr;
+}
+
+const char* knn_search(KnnDb& db, const float* q, int b, int k, uint32_t* idx_out, float* score_out, hipStream_t st) {
+    if (!db.dbn) return "no database loaded (rdm_db_load)";
+    if (b < 1 || k < 1) return "b and k must be positive";
+    if (k > db.n) return "k exceeds database size";
+    if (k + 4 <= 8) return search_impl<8>(db, q, b, k, idx_out, score_out, st);
+    if (k + 4 <= 16) return search_impl<16>(db, q, b, k, idx_out, score_out, st);
+    if (k + 4 <= 32) return search_impl<32>(db, q, b, k, idx_out, score_out, st);
+    return "k > 28 is not supported by the register top-k lists";
+}
+
+const char* knn_gather(KnnDb& db, const uint32_t* idx, long long n_idx, float* out, hipStream_t st) {
+    if (!db.raw) return "no database loaded (rdm_db_load)";
+    const long long total = n_idx * db.dim;
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+    if (db.raw_dtype == 0) knn_gather_kernel<_Float16><<<grid, 256, 0, st>>>((const _Float16*)db.raw, idx, n_idx, db.dim, out);
+    else knn_gather_kernel<float><<<grid, 256, 0, st>>>((const float*)db.raw, idx, n_idx, db.dim, out);
+    return hiperr(hipGetLastError());
+}

@@ -1,0 +1,381 @@
+// Small / bandwidth-bound kernels around the GEMM core (gfx950).
+#include "kernels.h"
+
+// ------------------------------------------------------------------ stem conv: few input channels
+// 3x3 pad-1 conv, input NCHW f32 [B,Cin,H,W] (Cin <= 4), output NHWC bf16 [B,H,W,Cout].
+// Replaces input_blocks.0 conv (openaimodel.py:149) and the VQ decoder conv_in.  K = 9*Cin = 27 is
+// far too small for MFMA: VALU, weights in LDS as [tap*Cin][Cout].
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* x, const float* w /*[Cout][Cin][3][3]*/,
+                                                      const float* bias, bf16_t* out, int B, int Cin, int H, int W,
+                                                      int Cout) {
+    extern __shared__ float ws[];   // [Cin*9][Cout] + bias[Cout]
+    const int K = Cin * 9;
+    for (int i = threadIdx.x; i < K * Cout; i += 256) {
+        const int co = i / K, k = i % K;              // w index = co*K + (ci*9 + tap)
+        ws[k * Cout + co] = w[i];
+    }
+    for (int i = threadIdx.x; i < Cout; i += 256) ws[K * Cout + i] = bias[i];
+    __syncthreads();
+    const int VC = Cout / 8;
+    const long long total = (long long)B * H * W * VC;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int v = (int)(i % VC);
+        const long long pix = i / VC;
+        const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = ws[K * Cout + v * 8 + e];
+        for (int ci = 0; ci < Cin; ci++) {
+            const float* xp = x + ((long long)(b * Cin + ci) * H) * W;
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int iy = yh + t / 3 - 1, ix = xw + t % 3 - 1;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                const float xv = xp[iy * W + ix];
+                const float* wr = ws + (ci * 9 + t) * Cout + v * 8;
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[e] += xv * wr[e];
+            }
+        }
+        uint4 o;
+        o.x = pack2bf(acc[0], acc[1]); o.y = pack2bf(acc[2], acc[3]);
+        o.z = pack2bf(acc[4], acc[5]); o.w = pack2bf(acc[6], acc[7]);
+        *(uint4*)(out + pix * Cout + v * 8) = o;
+    }
+}
+
+hipError_t launch_conv_in(const float* x, const float* w, const float* bias, bf16_t* out, int B, int Cin, int H, int W,
+                          int Cout, hipStream_t st) {
+    if (Cout % 8) return hipErrorInvalidValue;
+    const size_t sm = (size_t)(Cin * 9 + 1) * Cout * sizeof(float);
+    if (sm > 64 * 1024) return hipErrorInvalidValue;
+    const long long total = (long long)B * H * W * (Cout / 8);
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    conv_in_kernel<<<grid, 256, sm, st>>>(x, w, bias, out, B, Cin, H, W, Cout);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ head conv: few output channels
+// 3x3 pad-1 conv, input NHWC bf16 [B,H,W,Cin], output NCHW f32 [B,Cout,H,W], Cout <= 4.
+// Replaces UNet `out` conv (openaimodel.py:310) and the VQ decoder conv_out. One wave per pixel:
+// lanes split the (tap, 8-channel vector) items, butterfly-reduce, lane 0 stores.
+__global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* x, const float* w /*[Cout][Cin][3][3]*/,
+                                                       const float* bias, float* out, int B, int H, int W, int Cin,
+                                                       int Cout) {
+    extern __shared__ float ws[];   // [Cout][9][Cin]
+    for (int i = threadIdx.x; i < Cout * Cin * 9; i += 256) {
+        const int co = i / (Cin * 9), r = i % (Cin * 9), ci = r / 9, t = r % 9;
+        ws[(co * 9 + t) * Cin + ci] = w[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int VC = Cin / 8, items = 9 * VC;
+    const long long npix = (long long)B * H * W;
+    for (long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (long long)gridDim.x * 4) {
+        const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int it = lane; it < items; it += 64) {
+            const int t = it / VC, v = it - t * VC;
+            const int iy = yh + t / 3 - 1, ix = xw + t % 3 - 1;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            const bf16x8 d = *(const bf16x8*)(x + (((long long)b * H + iy) * W + ix) * Cin + v * 8);
+#pragma unroll
+            for (int co = 0; co < 4; co++) {
+                if (co < Cout) {
+                    const float* wr = ws + (co * 9 + t) * Cin + v * 8;
+                    float s = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) s += bf2f((bf16_t)d[e]) * wr[e];
+                    acc[co] += s;
+                }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < 4; co++)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc[co] += __shfl_xor(acc[co], o);
+        if (lane == 0) {
+#pragma unroll
+            for (int co = 0; co < 4; co++)
+                if (co < Cout) out[((long long)(b * Cout + co) * H + yh) * W + xw] = acc[co] + bias[co];
+        }
+    }
+}
+
+hipError_t launch_conv_out(const bf16_t* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin,
+                           int Cout, hipStream_t st) {
+    if (Cin % 8 || Cout > 4) return hipErrorInvalidValue;
+    const size_t sm = (size_t)Cout * 9 * Cin * sizeof(float);
+    if (sm > 64 * 1024) return hipErrorInvalidValue;
+    const long long npix = (long long)B * H * W;
+    int grid = (int)((npix + 3) / 4); if (grid > 16384) grid = 16384;
+    conv_out_kernel<<<grid, 256, sm, st>>>(x, w, bias, out, B, H, W, Cin, Cout);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ timestep embedding
+// ldm timestep_embedding: [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(1e4) * i / half). bf16 out.
+__global__ void timestep_embedding_kernel(const long long* t, bf16_t* out, int B, int dim) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, j = i % half;
+    const float freq = expf(-9.210340371976184f * (float)j / (float)half);
+    const float arg = (float)t[b] * freq;
+    out[(long long)b * dim + j] = f2bf(cosf(arg));
+    out[(long long)b * dim + half + j] = f2bf(sinf(arg));
+}
+hipError_t launch_timestep_embedding(const long long* t, bf16_t* out, int B, int dim, hipStream_t st) {
+    const int n = B * (dim / 2);
+    timestep_embedding_kernel<<<(n + 255) / 256, 256, 0, st>>>(t, out, B, dim);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ casts
+__global__ void cast_f32_bf16_kernel(const float* x, bf16_t* y, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = f2bf(x[i]);
+}
+hipError_t launch_cast_f32_bf16(const float* x, bf16_t* y, long long n, hipStream_t st) {
+    int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+    cast_f32_bf16_kernel<<<grid, 256, 0, st>>>(x, y, n);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ DDIM / DDPM updates (fp32)
+// rdm/models/diffusion/ddim.py:229-238 (CFG combine) + :253-267 (update), fused into one pass.
+// eps holds [B] rows (scale == 1) or [2B] rows (cond | uncond). Scalars are the fp32 values the
+// reference materialises with torch.full_like; sqrt taken in fp32 on device like a_t.sqrt().
+__global__ void ddim_step_kernel(DdimStepParams p) {
+    const float sa = sqrtf(p.a_t), sap = sqrtf(p.a_prev);
+    const float dirc = sqrtf(1.0f - p.a_prev - p.sigma_t * p.sigma_t);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n_per_batch;
+         i += (long long)gridDim.x * blockDim.x) {
+        float e = p.eps[i];
+        if (p.cfg) { const float eu = p.eps[p.n_per_batch + i]; e = eu + p.scale * (e - eu); }
+        const float x = p.x[i];
+        const float x0 = (x - p.sqrt_one_minus_at * e) / sa;
+        const float dir = dirc * e;
+        const float nz = p.noise ? p.sigma_t * p.noise[i] * p.temperature : 0.f;
+        p.x_prev[i] = sap * x0 + dir + nz;
+        if (p.pred_x0) p.pred_x0[i] = x0;
+    }
+}
+hipError_t launch_ddim_step(const DdimStepParams& p, hipStream_t st) {
+    int grid = (int)((p.n_per_batch + 255) / 256); if (grid > 2048) grid = 2048;
+    ddim_step_kernel<<<grid, 256, 0, st>>>(p);
+    return hipGetLastError();
+}
+
+// ldm LatentDiffusion.p_sample: x0 = c_recip*x - c_recipm1*eps; clamp; mean; + sigma*z
+__global__ void ddpm_step_kernel(DdpmStepParams p) {
+    const float sd = p.nonzero ? expf(0.5f * p.log_var) : 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long long)gridDim.x * blockDim.x) {
+        const float x = p.x[i];
+        float x0 = p.sqrt_recip * x - p.sqrt_recipm1 * p.eps[i];
+        if (p.clip) x0 = fminf(1.f, fmaxf(-1.f, x0));
+        const float mean = p.coef1 * x0 + p.coef2 * x;
+        p.x_prev[i] = mean + (p.nonzero ? sd * p.noise[i] * p.temperature : 0.f);
+    }
+}
+hipError_t launch_ddpm_step(const DdpmStepParams& p, hipStream_t st) {
+    int grid = (int)((p.n + 255) / 256); if (grid > 2048) grid = 2048;
+    ddpm_step_kernel<<<grid, 256, 0, st>>>(p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ VQ quantise + post_quant_conv
+// taming VectorQuantizer2: argmin_j |z|^2 + |e_j|^2 - 2 z.e_j (first minimum), z_q = e[idx],
+// then ldm post_quant_conv (1x1, embed_dim -> z_channels). embed_dim == z_channels == 3 in every shipped
+// config. z NCHW f32 -> out NCHW f32 [B,3,H,W]; idx int32 [B*H*W] optional. Codebook (+|e|^2) lives in
+// LDS as float4; every lane scans all codes (LDS broadcast reads).
+__global__ __launch_bounds__(256) void vq_quantize_kernel(const float* z, const float* codebook, int n_embed,
+                                                          const float* pq_w /*[3][3]*/, const float* pq_b,
+                                                          float* out, int* idx_out, int B, int HW, int quantize) {
+    extern __shared__ float4 cb[];
+    for (int j = threadIdx.x; j < n_embed; j += 256) {
+        const float e0 = codebook[j * 3], e1 = codebook[j * 3 + 1], e2 = codebook[j * 3 + 2];
+        cb[j] = make_float4(e0, e1, e2, (e0 * e0 + e1 * e1) + e2 * e2);
+    }
+    __syncthreads();
+    const long long npix = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / HW), r = (int)(i % HW);
+        const float* zp = z + (long long)b * 3 * HW + r;
+        float z0 = zp[0], z1 = zp[HW], z2 = zp[2 * HW];
+        int best = 0;
+        if (quantize) {
+            const float zz = (z0 * z0 + z1 * z1) + z2 * z2;
+            float bd = INFINITY;
+            for (int j = 0; j < n_embed; j++) {
+                const float4 e = cb[j];
+                const float dot = (z0 * e.x + z1 * e.y) + z2 * e.z;
+                const float d = (zz + e.w) - 2.f * dot;
+                if (d < bd) { bd = d; best = j; }
+            }
+            const float4 e = cb[best];
+            // straight-through form reproduced literally: z + (e - z)
+            z0 = z0 + (e.x - z0); z1 = z1 + (e.y - z1); z2 = z2 + (e.z - z2);
+        }
+        if (idx_out) idx_out[i] = best;
+        float* op = out + (long long)b * 3 * HW + r;
+#pragma unroll
+        for (int co = 0; co < 3; co++)
+            op[co * HW] = pq_b[co] + pq_w[co * 3] * z0 + pq_w[co * 3 + 1] * z1 + pq_w[co * 3 + 2] * z2;
+    }
+}
+hipError_t launch_vq_quantize(const float* z, const float* codebook, int n_embed, const float* pq_w, const float* pq_b,
+                              float* out, int* idx_out, int B, int HW, int quantize, hipStream_t st) {
+    const size_t sm = (size_t)n_embed * sizeof(float4);
+    if (sm > 160 * 1024 - 256) return hipErrorInvalidValue;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)vq_quantize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 256);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    const long long npix = (long long)B * HW;
+    int grid = (int)((npix + 255) / 256); if (grid > 1024) grid = 1024;
+    vq_quantize_kernel<<<grid, 256, sm, st>>>(z, codebook, n_embed, pq_w, pq_b, out, idx_out, B, HW, quantize);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ row softmax f32 -> bf16
+// VQ decoder AttnBlock (single head, 4096 tokens): softmax over the key axis of the f32 score matrix.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, bf16_t* p, long long rows, int n) {
+    const int lane = threadIdx.x & 63;
+    for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+        const float* sr = s + row * n;
+        float mx = -INFINITY;
+        for (int i = lane * 4; i < n; i += 256) {
+            const float4 v = *(const float4*)(sr + i);
+            mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int i = lane * 4; i < n; i += 256) {
+            const float4 v = *(const float4*)(sr + i);
+            sum += (__expf(v.x - mx) + __expf(v.y - mx)) + (__expf(v.z - mx) + __expf(v.w - mx));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.f / sum;
+        for (int i = lane * 4; i < n; i += 256) {
+            const float4 v = *(const float4*)(sr + i);
+            uint2 w;
+            w.x = pack2bf(__expf(v.x - mx) * inv, __expf(v.y - mx) * inv);
+            w.y = pack2bf(__expf(v.z - mx) * inv, __expf(v.w - mx) * inv);
+            *(uint2*)(p + row * n + i) = w;
+        }
+    }
+}
+hipError_t launch_softmax_rows(const float* s, bf16_t* p, long long rows, int n, hipStream_t st) {
+    if (n % 4) return hipErrorInvalidValue;
+    int grid = (int)((rows + 3) / 4); if (grid > 8192) grid = 8192;
+    softmax_rows_kernel<<<grid, 256, 0, st>>>(s, p, rows, n);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ CLIP helpers
+// token + positional embedding -> f32 residual stream [B, L, W] (custom_clip/model.py:308-310)
+__global__ void clip_embed_kernel(const long long* tokens, const float* tok_emb, const float* pos_emb, float* out, int B,
+                                  int L, int Wd) {
+    const long long n = (long long)B * L * Wd;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Wd); const long long r = i / Wd; const int l = (int)(r % L);
+        out[i] = tok_emb[tokens[r] * Wd + c] + pos_emb[l * Wd + c];
+    }
+}
+hipError_t launch_clip_embed(const long long* tokens, const float* tok_emb, const float* pos_emb, float* out, int B, int L,
+                             int Wd, hipStream_t st) {
+    const long long n = (long long)B * L * Wd;
+    int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
+    clip_embed_kernel<<<grid, 256, 0, st>>>(tokens, tok_emb, pos_emb, out, B, L, Wd);
+    return hipGetLastError();
+}
+// gather the EOT row (argmax of token ids, first max) of each sequence: [B,L,W] f32 -> [B,W] f32 (model.py:318)
+__global__ void clip_gather_eot_kernel(const long long* tokens, const float* x, float* out, int L, int Wd) {
+    const int b = blockIdx.x;
+    __shared__ int pos;
+    if (threadIdx.x == 0) {
+        long long best = tokens[(long long)b * L]; int bi = 0;
+        for (int l = 1; l < L; l++) { const long long t = tokens[(long long)b * L + l]; if (t > best) { best = t; bi = l; } }
+        pos = bi;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Wd; c += blockDim.x) out[(long long)b * Wd + c] = x[((long long)b * L + pos) * Wd + c];
+}
+hipError_t launch_clip_gather_eot(const long long* tokens, const float* x, float* out, int B, int L, int Wd, hipStream_t st) {
+    clip_gather_eot_kernel<<<B, 256, 0, st>>>(tokens, x, out, L, Wd);
+    return hipGetLastError();
+}
+// ViT patchify: image NCHW f32 [B,3,R,R] -> bf16 [B*G*G, 3*P*P] rows in (c, py, px) order == conv1 weight flattening
+__global__ void clip_patchify_kernel(const float* img, bf16_t* out, int B, int R, int P) {
+    const int G = R / P, K = 3 * P * P;
+    const long long n = (long long)B * G * G * K;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K); const long long r = i / K;
+        const int gx = (int)(r % G), gy = (int)((r / G) % G), b = (int)(r / (G * G));
+        const int c = k / (P * P), py = (k / P) % P, px = k % P;
+        out[i] = f2bf(img[(((long long)b * 3 + c) * R + gy * P + py) * R + gx * P + px]);
+    }
+}
+hipError_t launch_clip_patchify(const float* img, bf16_t* out, int B, int R, int P, hipStream_t st) {
+    const long long n = (long long)B * (R / P) * (R / P) * 3 * P * P;
+    int grid = (int)((n + 255) / 256); if (grid > 8192) grid = 8192;
+    clip_patchify_kernel<<<grid, 256, 0, st>>>(img, out, B, R, P);
+    return hipGetLastError();
+}
+// x[b, 0, :] = cls + pos[0]; x[b, 1+i, :] = patch[b*GG+i, :] + pos[1+i]  (model.py:221-222), f32
+__global__ void clip_vit_assemble_kernel(const float* patch, const float* cls, const float* pos, float* out, int B, int GG,
+                                         int Wd) {
+    const long long n = (long long)B * (GG + 1) * Wd;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Wd); const long long r = i / Wd; const int l = (int)(r % (GG + 1)); const int b = (int)(r / (GG + 1));
+        const float v = (l == 0) ? cls[c] : patch[((long long)b * GG + (l - 1)) * Wd + c];
+        out[i] = v + pos[l * Wd + c];
+    }
+}
+hipError_t launch_clip_vit_assemble(const float* patch, const float* cls, const float* pos, float* out, int B, int GG, int Wd,
+                                    hipStream_t st) {
+    const long long n = (long long)B * (GG + 1) * Wd;
+    int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
+    clip_vit_assemble_kernel<<<grid, 256, 0, st>>>(patch, cls, pos, out, B, GG, Wd);
+    return hipGetLastError();
+}
+// strided row gather f32: out[b,:] = x[(b*stride_rows), :]
+__global__ void gather_rows_f32_kernel(const float* x, float* out, int B, long long row_stride, int Wd) {
+    const long long n = (long long)B * Wd;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Wd); const int b = (int)(i / Wd);
+        out[i] = x[(long long)b * row_stride * Wd + c];
+    }
+}
+hipError_t launch_gather_rows_f32(const float* x, float* out, int B, long long row_stride, int Wd, hipStream_t st) {
+    const long long n = (long long)B * Wd;
+    int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
+    gather_rows_f32_kernel<<<grid, 256, 0, st>>>(x, out, B, row_stride, Wd);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ image conversion
+// scripts/rdm_sample.py:203-214: clamp(-1,1) -> (x+1)/2 -> CHW->HWC -> *255 -> uint8 (truncation)
+__global__ void to_uint8_hwc_kernel(const float* x, unsigned char* out, int B, int C, int H, int W) {
+    const long long n = (long long)B * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); const long long r = i / C;
+        const int xw = (int)(r % W), yh = (int)((r / W) % H), b = (int)(r / ((long long)W * H));
+        float v = x[(((long long)b * C + c) * H + yh) * W + xw];
+        v = fminf(1.f, fmaxf(-1.f, v));
+        v = (v + 1.0f) / 2.0f;
+        out[i] = (unsigned char)(255.0f * v);
+    }
+}
+hipError_t launch_to_uint8_hwc(const float* x, unsigned char* out, int B, int C, int H, int W, hipStream_t st) {
+    const long long n = (long long)B * H * W * C;
+    int grid = (int)((n + 255) / 256); if (grid > 8192) grid = 8192;
+    to_uint8_hwc_kernel<<<grid, 256, 0, st>>>(x, out, B, C, H, W);
+    return hipGetLastError();
+}

@@ -1,0 +1,196 @@
+// GroupNorm(32) [+SiLU] and LayerNorm for NHWC / token-major bf16 activations (gfx950).
+// Replaces: ldm `normalization` (GroupNorm32, eps 1e-5) + nn.SiLU in ResBlock in/out_layers and the
+// UNet `out` head (rdm/modules/diffusionmodules/openaimodel.py:307-309), `Normalize` (eps 1e-6) in
+// SpatialTransformer (rdm/modules/attention.py:16-17,147,183) and the VQ decoder, nn.LayerNorm x3 in
+// BasicTransformerBlock (attention.py:84-86) and CLIP's LayerNorm (custom_clip/model.py:152-158).
+//
+// HBM-bound.  GroupNorm is two streaming passes: (1) per-(sample, pixel-chunk) partial sums with
+// 16-byte coalesced row reads, reduced deterministically (fixed order, no atomics: results do not
+// depend on scheduling, so batch sharding over GPUs is bit-reproducible); (2) an elementwise
+// normalise+affine(+SiLU) pass that folds (mean, rstd, gamma, beta) into one per-channel FMA held in
+// LDS.  Both passes read the decoder's skip-concat as two source tensors (never materialised).
+#include "kernels.h"
+
+
+__device__ __forceinline__ const bf16_t* gn_src(const GnParams& p, int b, int row, int c) {
+    return (c < p.C0) ? p.x0 + ((long long)(b * p.HW + row) * p.C0 + c)
+                      : p.x1 + ((long long)(b * p.HW + row) * p.C1 + (c - p.C0));
+}
+
+// grid (nchunk, B); block = VC * R threads where VC = C/8 (16-byte vectors per row)
+__global__ void gn_stats_kernel(GnParams p) {
+    extern __shared__ float sm[];          // [R][C][2] then [C][2]
+    const int C = p.C0 + p.C1, VC = C >> 3;
+    const int R = blockDim.x / VC;
+    const int v = threadIdx.x % VC, rr = threadIdx.x / VC;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int rows_per = (p.HW + p.nchunk - 1) / p.nchunk;
+    const int r0 = chunk * rows_per, r1 = min(p.HW, r0 + rows_per);
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { s[i] = 0.f; q[i] = 0.f; }
+    if (rr < R) {
+        for (int row = r0 + rr; row < r1; row += R) {
+            const bf16x8 d = *(const bf16x8*)gn_src(p, b, row, v * 8);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const float f = bf2f((bf16_t)d[i]); s[i] += f; q[i] += f * f; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            sm[((rr * C) + v * 8 + i) * 2 + 0] = s[i];
+            sm[((rr * C) + v * 8 + i) * 2 + 1] = q[i];
+        }
+    }
+    __syncthreads();
+    // per-channel reduce over R (fixed order)
+    float* ch = sm + R * C * 2;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = 0.f, bq = 0.f;
+        for (int r = 0; r < R; r++) { a += sm[(r * C + c) * 2]; bq += sm[(r * C + c) * 2 + 1]; }
+        ch[c * 2] = a; ch[c * 2 + 1] = bq;
+    }
+    __syncthreads();
+    const int cg = C / p.groups;
+    if (threadIdx.x < p.groups) {
+        float a = 0.f, bq = 0.f;
+        for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; c++) { a += ch[c * 2]; bq += ch[c * 2 + 1]; }
+        float* o = p.partial + (((long long)b * p.nchunk + chunk) * p.groups + threadIdx.x) * 2;
+        o[0] = a; o[1] = bq;
+    }
+}
+
+// grid (nblk, B); block 256. Each block first folds the partials of its sample into per-channel (a, b).
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
+    extern __shared__ float sm[];          // [C][2]
+    const int C = p.C0 + p.C1, VC = C >> 3, cg = C / p.groups;
+    const int b = blockIdx.y;
+    __shared__ float gstat[64][2];
+    if (threadIdx.x < p.groups) {
+        double a = 0.0, q = 0.0;
+        const float* pp = p.partial + ((long long)b * p.nchunk * p.groups + threadIdx.x) * 2;
+        for (int k = 0; k < p.nchunk; k++) { a += pp[(long long)k * p.groups * 2]; q += pp[(long long)k * p.groups * 2 + 1]; }
+        const double n = (double)cg * p.HW;
+        const double mean = a / n;
+        double var = q / n - mean * mean;
+        if (var < 0) var = 0;
+        gstat[threadIdx.x][0] = (float)mean;
+        gstat[threadIdx.x][1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / cg;
+        const float a = gstat[g][1] * p.gamma[c];
+        sm[c * 2] = a; sm[c * 2 + 1] = p.beta[c] - gstat[g][0] * a;
+    }
+    __syncthreads();
+    const long long total = (long long)p.HW * VC;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int row = (int)(i / VC), v = (int)(i - (long long)row * VC);
+        const bf16x8 d = *(const bf16x8*)gn_src(p, b, row, v * 8);
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int c = v * 8 + j * 2;
+            float y0 = bf2f((bf16_t)d[j * 2]) * sm[c * 2] + sm[c * 2 + 1];
+            float y1 = bf2f((bf16_t)d[j * 2 + 1]) * sm[c * 2 + 2] + sm[c * 2 + 3];
+            if (p.silu) { y0 = silu_f(y0); y1 = silu_f(y1); }
+            o[j] = pack2bf(y0, y1);
+        }
+        *(uint4*)(p.out + ((long long)(b * p.HW + row) * C + v * 8)) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+hipError_t launch_groupnorm(GnParams p, hipStream_t st) {
+    const int C = p.C0 + p.C1;
+    if (C % 8 || C % p.groups || p.groups > 64 || (p.C0 % 8) || (p.C1 % 8)) return hipErrorInvalidValue;
+    const int VC = C / 8;
+    if (VC > 1024) return hipErrorInvalidValue;
+    int R = 256 / VC; if (R < 1) R = 1;
+    const int threads = ((VC * R + 63) / 64) * 64;
+    const size_t sm1 = (size_t)(R + 1) * C * 2 * sizeof(float);
+    gn_stats_kernel<<<dim3(p.nchunk, p.B), threads, sm1, st>>>(p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const long long total = (long long)p.HW * VC;
+    int nblk = (int)((total + 256 * 4 - 1) / (256 * 4));
+    if (nblk < 1) nblk = 1;
+    if (nblk > 2048) nblk = 2048;
+    gn_apply_kernel<<<dim3(nblk, p.B), 256, (size_t)C * 2 * sizeof(float), st>>>(p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ LayerNorm
+// one wave per row; input bf16 or f32, output bf16. C even, C <= 128*NP. Row cached in registers
+// (compile-time indexed so nothing goes to scratch), exact two-pass variance.
+template <typename TIN, typename TOUT, int NP>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TIN* x, const float* gamma, const float* beta,
+                                                        TOUT* out, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const TIN* xr = x + row * C;
+    float v[NP * 2];
+    const int npair = C >> 1;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        const int pi = lane + j * 64;
+        float a = 0.f, b = 0.f;
+        if (pi < npair) {
+            if constexpr (sizeof(TIN) == 2) {
+                const uint32_t u = *(const uint32_t*)(xr + pi * 2);
+                a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xffff0000u);
+            } else {
+                const float2 f = *(const float2*)(xr + pi * 2);
+                a = f.x; b = f.y;
+            }
+        }
+        v[j * 2] = a; v[j * 2 + 1] = b; s += a + b;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        if (lane + j * 64 < npair) {
+            const float d0 = v[j * 2] - mean, d1 = v[j * 2 + 1] - mean;
+            q += d0 * d0 + d1 * d1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / C + eps);
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        const int pi = lane + j * 64;
+        if (pi < npair) {
+            const int c = pi * 2;
+            const float y0 = (v[j * 2] - mean) * rstd * gamma[c] + beta[c];
+            const float y1 = (v[j * 2 + 1] - mean) * rstd * gamma[c + 1] + beta[c + 1];
+            if constexpr (sizeof(TOUT) == 2) *(uint32_t*)(out + row * C + c) = pack2bf(y0, y1);
+            else *(float2*)(out + row * C + c) = make_float2(y0, y1);
+        }
+    }
+}
+
+template <int NP>
+static void ln_dispatch(const void* x, int in_is_f32, const float* g, const float* b, void* out, int out_is_f32, int M, int C,
+                        float eps, hipStream_t st) {
+    const int grid = (M + 3) / 4;
+    if (in_is_f32) {
+        if (out_is_f32) layernorm_kernel<float, float, NP><<<grid, 256, 0, st>>>((const float*)x, g, b, (float*)out, M, C, eps);
+        else layernorm_kernel<float, bf16_t, NP><<<grid, 256, 0, st>>>((const float*)x, g, b, (bf16_t*)out, M, C, eps);
+    } else {
+        if (out_is_f32) layernorm_kernel<bf16_t, float, NP><<<grid, 256, 0, st>>>((const bf16_t*)x, g, b, (float*)out, M, C, eps);
+        else layernorm_kernel<bf16_t, bf16_t, NP><<<grid, 256, 0, st>>>((const bf16_t*)x, g, b, (bf16_t*)out, M, C, eps);
+    }
+}
+
+hipError_t launch_layernorm(const void* x, int in_is_f32, const float* gamma, const float* beta, void* out, int out_is_f32,
+                            int M, int C, float eps, hipStream_t st) {
+    if (C % 2 || C > 4096) return hipErrorInvalidValue;
+    if (C <= 1024) ln_dispatch<8>(x, in_is_f32, gamma, beta, out, out_is_f32, M, C, eps, st);
+    else ln_dispatch<32>(x, in_is_f32, gamma, beta, out, out_is_f32, M, C, eps, st);
+    return hipGetLastError();
+}

@@ -1,0 +1,164 @@
+"""GPU parity of the individual HIP kernels (called through the C ABI) against plain PyTorch fp32
+references of the same op on the same bf16-rounded inputs.
+
+Tolerance (bf16 storage, fp32 accumulation): |out - ref| <= 2^-7 * max|ref| elementwise — one bf16
+output rounding (2^-9 relative) plus accumulation-order noise; stated per test.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import bf16_round
+
+pytestmark = pytest.mark.gpu
+TOL = 2.0 ** -7
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+def _close(out, ref, tol=TOL, what=""):
+    out, ref = out.float().cpu(), ref.float().cpu()
+    err = (out - ref).abs().max().item()
+    bound = tol * ref.abs().max().item() + 1e-6
+    assert err <= bound, f"{what}: max err {err:.4e} > {bound:.4e}"
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 192, 192), (128, 384, 768), (1000, 128, 64), (2, 768, 192), (257, 960, 576),
+                                   (512, 64, 128)])
+def test_linear(ctx, M, N, K):
+    a, w, b = bf16_round(_rand((M, K), 1)), bf16_round(_rand((N, K), 2, K ** -0.5)), _rand((N,), 3, 0.1)
+    ref = a @ w.t() + b
+    d = ctx.device
+    out = ctx.op_linear(a.to(d, torch.bfloat16), w.to(d, torch.bfloat16), b.to(d))
+    _close(out, ref, what="linear")
+    outf = ctx.op_linear(a.to(d, torch.bfloat16), w.to(d, torch.bfloat16), b.to(d), out_f32=True)
+    _close(outf, ref, tol=2 ** -10, what="linear f32 out")
+
+
+def test_linear_residual_act_alpha(ctx):
+    from rdm_amd import _lib
+    M, N, K = 384, 192, 256
+    d = ctx.device
+    a, w, b, r = bf16_round(_rand((M, K), 4)), bf16_round(_rand((N, K), 5, K ** -0.5)), _rand((N,), 6, 0.1), bf16_round(_rand((M, N), 7))
+    ab, wb = a.to(d, torch.bfloat16), w.to(d, torch.bfloat16)
+    _close(ctx.op_linear(ab, wb, b.to(d), residual=r.to(d, torch.bfloat16)), a @ w.t() + b + r, what="residual")
+    _close(ctx.op_linear(ab, wb, b.to(d), act=_lib.ACT_SILU), F.silu(a @ w.t() + b), what="silu")
+    y = a @ w.t() + b
+    _close(ctx.op_linear(ab, wb, b.to(d), act=_lib.ACT_QUICKGELU), y * torch.sigmoid(1.702 * y), what="quickgelu")
+    _close(ctx.op_linear(ab, wb, None, alpha=0.125, out_f32=True), 0.125 * (a @ w.t()), tol=2 ** -10, what="alpha")
+
+
+def test_linear_geglu(ctx):
+    from rdm_amd import _lib
+    from rdm_amd.packing import _geglu_perm
+    M, C = 200, 128
+    d = ctx.device
+    a, w, b = bf16_round(_rand((M, C), 8)), bf16_round(_rand((8 * C, C), 9, C ** -0.5)), _rand((8 * C,), 10, 0.1)
+    p = a @ w.t() + b
+    x, g = p.chunk(2, dim=-1)
+    ref = x * F.gelu(g)
+    perm = _geglu_perm(8 * C)
+    out = ctx.op_linear(a.to(d, torch.bfloat16), w[perm].contiguous().to(d, torch.bfloat16), b[perm].contiguous().to(d), act=_lib.ACT_GEGLU)
+    assert out.shape == (M, 4 * C)
+    _close(out, ref, what="geglu")
+
+
+def _conv_ref(x_nhwc, w, b, stride=1, ups=False):
+    x = x_nhwc.permute(0, 3, 1, 2)
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    y = F.conv2d(x, w, b, stride=stride, padding=1)
+    return y.permute(0, 2, 3, 1)
+
+
+def _pack_conv(w):
+    return w.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,C,N,stride,ups", [(2, 8, 8, 64, 192, 1, 0), (3, 16, 16, 128, 128, 1, 0), (2, 16, 16, 64, 64, 2, 0),
+                                                  (2, 8, 8, 192, 192, 1, 1), (1, 32, 32, 64, 384, 1, 0), (5, 4, 4, 64, 64, 1, 0)])
+def test_conv3x3(ctx, B, H, W, C, N, stride, ups):
+    d = ctx.device
+    x, w, b = bf16_round(_rand((B, H, W, C), 11)), bf16_round(_rand((N, C, 3, 3), 12, (9 * C) ** -0.5)), _rand((N,), 13, 0.1)
+    ref = _conv_ref(x, w, b, stride, bool(ups))
+    out = ctx.op_conv3x3(x.to(d, torch.bfloat16), _pack_conv(w).to(d, torch.bfloat16), b.to(d), stride=stride, ups=ups)
+    assert tuple(out.shape) == tuple(ref.shape)
+    _close(out, ref, what="conv3x3")
+
+
+def test_conv3x3_dual_source_rowvec_residual(ctx):
+    d = ctx.device
+    B, H, W, C0, C1, N = 2, 8, 8, 128, 64, 192
+    x0, x1 = bf16_round(_rand((B, H, W, C0), 14)), bf16_round(_rand((B, H, W, C1), 15))
+    w, b = bf16_round(_rand((N, C0 + C1, 3, 3), 16, (9 * (C0 + C1)) ** -0.5)), _rand((N,), 17, 0.1)
+    temb, res = _rand((B, N + 7), 18), bf16_round(_rand((B, H, W, N), 19))
+    ref = _conv_ref(torch.cat([x0, x1], -1), w, b) + temb[:, None, None, 3:3 + N] + res
+    rowvec = temb.to(d)
+    out = ctx.op_conv3x3(x0.to(d, torch.bfloat16), _pack_conv(w).to(d, torch.bfloat16), b.to(d), x1=x1.to(d, torch.bfloat16),
+                         rowvec=rowvec, residual=res.to(d, torch.bfloat16))
+    # rowvec pointer is offset by 3 columns inside the library in real use; here test ld handling with a view
+    ref0 = _conv_ref(torch.cat([x0, x1], -1), w, b) + temb[:, None, None, :N] + res
+    _close(out, ref0, what="conv dual+rowvec+res")
+
+
+@pytest.mark.parametrize("B,HW,C0,C1,silu,eps", [(2, 64, 192, 0, 1, 1e-5), (3, 256, 128, 64, 1, 1e-5), (2, 16, 960, 0, 0, 1e-6),
+                                                 (1, 1024, 576, 384, 1, 1e-5), (2, 4096, 64, 0, 1, 1e-6)])
+def test_groupnorm(ctx, B, HW, C0, C1, silu, eps):
+    d = ctx.device
+    C = C0 + C1
+    x0 = bf16_round(_rand((B, HW, C0), 20) * 2 + 0.5)
+    x1 = bf16_round(_rand((B, HW, C1), 21)) if C1 else None
+    g, b = 1 + 0.1 * _rand((C,), 22), 0.1 * _rand((C,), 23)
+    xc = x0 if x1 is None else torch.cat([x0, x1], -1)
+    ref = F.group_norm(xc.permute(0, 2, 1), 32, g, b, eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    out = ctx.op_groupnorm(x0.to(d, torch.bfloat16), g.to(d), b.to(d), eps, silu, None if x1 is None else x1.to(d, torch.bfloat16))
+    _close(out, ref, what="groupnorm")
+
+
+@pytest.mark.parametrize("M,C,f32", [(100, 384, False), (77, 512, True), (513, 960, False), (9, 768, True), (4, 128, False)])
+def test_layernorm(ctx, M, C, f32):
+    d = ctx.device
+    x = _rand((M, C), 24) * 1.5 + 0.3
+    if not f32:
+        x = bf16_round(x)
+    g, b = 1 + 0.1 * _rand((C,), 25), 0.1 * _rand((C,), 26)
+    ref = F.layer_norm(x, (C,), g, b, 1e-5)
+    out = ctx.op_layernorm(x.to(d) if f32 else x.to(d, torch.bfloat16), g.to(d), b.to(d))
+    _close(out, ref, what="layernorm")
+
+
+@pytest.mark.parametrize("B,n,heads", [(2, 64, 2), (1, 256, 6), (2, 1024, 3), (3, 32, 4)])
+def test_flash_self_attention(ctx, B, n, heads):
+    d = ctx.device
+    C = heads * 32
+    q, k, v = (bf16_round(_rand((B, n, C), s)) for s in (27, 28, 29))
+    k = k * 2.0   # wider logits
+    sp = lambda t: t.reshape(B, n, heads, 32).permute(0, 2, 1, 3)
+    att = (sp(q) @ sp(k).transpose(-1, -2) * 32 ** -0.5).softmax(-1)
+    ref = (att @ sp(v)).permute(0, 2, 1, 3).reshape(B, n, C)
+    qk = torch.cat([q, k], -1).contiguous()
+    vt = v.permute(0, 2, 1).contiguous()                     # [B, C, n]
+    out = ctx.op_self_attention(qk.to(d, torch.bfloat16), vt.to(d, torch.bfloat16), heads)
+    _close(out, ref, tol=2 ** -6, what="flash attention")    # P is rounded to bf16 before the PV MFMA
+
+
+@pytest.mark.parametrize("B,nq,nkv,heads,D,causal", [(2, 64, 4, 4, 32, 0), (2, 77, 77, 2, 64, 1), (1, 50, 50, 3, 64, 0),
+                                                     (2, 16, 16, 2, 32, 0), (1, 1024, 16, 12, 32, 0)])
+def test_small_attention(ctx, B, nq, nkv, heads, D, causal):
+    d = ctx.device
+    C = heads * D
+    q, k, v = bf16_round(_rand((B, nq, C), 30)), bf16_round(_rand((B, nkv, C), 31)), bf16_round(_rand((B, nkv, C), 32))
+    sp = lambda t: t.reshape(B, t.shape[1], heads, D).permute(0, 2, 1, 3)
+    s = sp(q) @ sp(k).transpose(-1, -2) * D ** -0.5
+    if causal:
+        s = s + torch.full((nq, nkv), float("-inf")).triu_(1)
+    ref = (s.softmax(-1) @ sp(v)).permute(0, 2, 1, 3).reshape(B, nq, C)
+    out = ctx.op_small_attention(q.to(d, torch.bfloat16), k.to(d, torch.bfloat16), v.to(d, torch.bfloat16), heads, D, causal, D ** -0.5)
+    _close(out, ref, what="small attention")

@@ -1,0 +1,87 @@
+"""CPU suite: the C-ABI library loads, exports every symbol include/rdm_hip.h declares, refuses to run
+without a GPU (no fallback), and its weight manifests agree with the reference's state_dict layout."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip as oclip
+from oracle import unet as ounet
+from oracle import vqdecoder as ovq
+
+from _util import spec_to_clip_cfg, spec_to_unet_cfg, spec_to_vq_cfg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "rdm_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rdm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import rdm_amd  # noqa: F401
+    from rdm_amd import _lib
+    syms = _header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(_lib.lib, s), f"librdm_hip.so does not export {s}"
+    assert set(_lib.SIGNATURES) == set(syms), set(_lib.SIGNATURES) ^ set(syms)
+    assert b"gfx950" in _lib.lib.rdm_version()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback():
+    import rdm_amd  # noqa: F401
+    from rdm_amd import _lib
+    with pytest.raises(_lib.RdmError):
+        _lib.Context(0)
+
+
+def _check_manifest(kind, cfg, shapes):
+    import rdm_amd  # noqa: F401
+    from rdm_amd import _lib, packing
+    entries, blob_bytes = _lib.manifest(kind, cfg)
+    used = [s for e in entries for s in e[3]]
+    assert sorted(used) == sorted(shapes), set(used) ^ set(shapes)      # every reference key exactly once
+    ends = [off + nb for off, nb, _, _ in entries]
+    offs = [off for off, _, _, _ in entries]
+    assert all(o % 256 == 0 for o in offs) and all(a <= b for a, b in zip(ends[:-1], offs[1:])) and ends[-1] <= blob_bytes
+    sd = ounet.synth_state_dict(shapes, seed=1)
+    blob = packing.pack(kind, cfg, sd)
+    assert blob.nbytes == blob_bytes
+    return entries, blob, sd
+
+
+def test_unet_manifest_matches_reference_state_dict():
+    spec = ounet.tiny_spec()
+    entries, blob, sd = _check_manifest("unet", spec_to_unet_cfg(spec), ounet.param_shapes(spec))
+    # spot-check the conv3 layout: [N][ky][kx][C]
+    off, nb, kd, srcs = next(e for e in entries if e[2] == "conv3")
+    w = sd[srcs[0]]
+    got = torch.from_numpy(blob[off:off + nb].view(np.int16).copy()).view(torch.bfloat16).float().reshape(w.shape[0], 3, 3, w.shape[1])
+    assert torch.equal(got, w.permute(0, 2, 3, 1).to(torch.bfloat16).float())
+    # the shipped config's manifest covers all 688 tensors
+    full = ounet.shipped_spec()
+    import rdm_amd  # noqa: F401
+    from rdm_amd import _lib
+    e2, nbytes = _lib.manifest("unet", spec_to_unet_cfg(full))
+    assert sorted(s for e in e2 for s in e[3]) == sorted(ounet.param_shapes(full))
+    assert 0.79e9 < nbytes < 0.83e9          # ~0.80 GB bf16
+
+
+def test_vq_and_clip_manifests():
+    _check_manifest("vq", spec_to_vq_cfg(ovq.tiny_vq_spec()), ovq.vq_param_shapes(ovq.tiny_vq_spec()))
+    _check_manifest("clip", spec_to_clip_cfg(oclip.tiny_clip_spec()), oclip.clip_param_shapes(oclip.tiny_clip_spec()))
+
+
+def test_ema_key_mapping():
+    import rdm_amd  # noqa: F401
+    from rdm_amd import packing
+    ck = {"model.diffusion_model.out.2.weight": torch.zeros(1), "model_ema.diffusion_modelout2weight": torch.ones(1),
+          "model.diffusion_model.out.2.bias": torch.zeros(1), "first_stage_model.x": torch.zeros(1)}
+    sd = packing.ema_unet_state_dict(ck)
+    assert sd["out.2.weight"].item() == 1.0 and sd["out.2.bias"].item() == 0.0 and len(sd) == 2

@@ -1,0 +1,130 @@
+"""CPU suite: the oracle against the golden vectors generated from the reference's in-tree classes
+(tools/gen_golden.py) and against the known-answer schedule constants of SURVEY.md appendix C."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip as oclip
+from oracle import diffusion as odiff
+from oracle import retrieval as oret
+from oracle import unet as ounet
+from oracle import vqdecoder as ovq
+
+from _util import golden
+
+torch.set_grad_enabled(False)
+
+
+def test_unet_tiny_matches_reference_golden():
+    g = golden("unet_tiny.npz")
+    spec = ounet.tiny_spec()
+    sd = ounet.synth_state_dict(ounet.param_shapes(spec), seed=int(g["seed"]))
+    y = ounet.unet_forward(sd, spec, torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["ctx"]))
+    assert np.abs(y.numpy() - g["eps"]).max() <= 5e-5
+
+
+def test_unet_shipped_param_count_and_blocks():
+    spec = ounet.shipped_spec()
+    shapes = ounet.param_shapes(spec)
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 400_920_579
+    assert len(shapes) == 688
+    n_res = sum(1 for _, ls in spec.blocks for l in ls if l[0] == "res")
+    n_st = sum(1 for _, ls in spec.blocks for l in ls if l[0] == "st")
+    assert (n_res, n_st) == (22, 16)
+    heads = [l[2] for _, ls in spec.blocks for l in ls if l[0] == "st"]
+    assert heads == [12, 12, 18, 18, 30, 30, 30, 30, 30, 30, 18, 18, 18, 12, 12, 12]   # demo_rdm.ipynb:112-127
+
+
+def test_attention_golden():
+    g = golden("attention.npz")
+    C, heads = 128, 4
+    shapes_st = {"st.norm.weight": (C,), "st.norm.bias": (C,)}
+    # rebuild the exact shapes dict the generator used (names from the reference module)
+    tb = "transformer_blocks.0"
+    names = {f"norm.weight": (C,), "norm.bias": (C,), "proj_in.weight": (C, C, 1, 1), "proj_in.bias": (C,),
+             f"{tb}.attn1.to_q.weight": (C, C), f"{tb}.attn1.to_k.weight": (C, C), f"{tb}.attn1.to_v.weight": (C, C),
+             f"{tb}.attn1.to_out.0.weight": (C, C), f"{tb}.attn1.to_out.0.bias": (C,),
+             f"{tb}.ff.net.0.proj.weight": (8 * C, C), f"{tb}.ff.net.0.proj.bias": (8 * C,),
+             f"{tb}.ff.net.2.weight": (C, 4 * C), f"{tb}.ff.net.2.bias": (C,),
+             f"{tb}.attn2.to_q.weight": (C, C), f"{tb}.attn2.to_k.weight": (C, 512), f"{tb}.attn2.to_v.weight": (C, 512),
+             f"{tb}.attn2.to_out.0.weight": (C, C), f"{tb}.attn2.to_out.0.bias": (C,),
+             f"{tb}.norm1.weight": (C,), f"{tb}.norm1.bias": (C,), f"{tb}.norm2.weight": (C,), f"{tb}.norm2.bias": (C,),
+             f"{tb}.norm3.weight": (C,), f"{tb}.norm3.bias": (C,), "proj_out.weight": (C, C, 1, 1), "proj_out.bias": (C,)}
+    sd = ounet.synth_state_dict(names, seed=int(g["seed"]))
+    y = ounet.spatial_transformer({"st." + k: v for k, v in sd.items()}, "st", torch.from_numpy(g["st_x"]),
+                                  torch.from_numpy(g["st_ctx"]), heads)
+    assert np.abs(y.numpy() - g["st_y"]).max() <= 2e-5 * max(1.0, np.abs(g["st_y"]).max())
+
+
+def test_clip_tiny_golden():
+    g = golden("clip_tiny.npz")
+    spec = oclip.tiny_clip_spec()
+    sd = ounet.synth_state_dict(oclip.clip_param_shapes(spec), seed=int(g["seed"]))
+    sd["positional_embedding"] = sd["positional_embedding"] * 0.1
+    t = oclip.encode_text(sd, spec, torch.from_numpy(g["tokens"]))
+    i = oclip.encode_image(sd, spec, torch.from_numpy(g["image"]))
+    assert np.abs(t.numpy() - g["text_out"]).max() <= 5e-5
+    assert np.abs(i.numpy() - g["image_out"]).max() <= 5e-5
+
+
+def test_schedule_known_answers():
+    """SURVEY.md appendix C."""
+    s = odiff.Schedule()
+    ac = s.alphas_cumprod.double().numpy()
+    for idx, val in ((0, 0.9985), (1, 0.996994427069975), (21, 0.9657320290842367), (500, 0.11492200085532281),
+                     (981, 2.0195601706088703e-4), (999, 1.4230397519201791e-4)):
+        assert abs(ac[idx] - val) <= 2e-7 * max(val, 1e-3)
+    ts, a_t, a_prev, sigma, s1m = odiff.ddim_schedule(s, 50, 0.0)
+    assert ts[0] == 1 and ts[-1] == 981 and len(ts) == 50 and ts[1] == 21
+    assert odiff.make_ddim_timesteps(100)[-1] == 991 and odiff.make_ddim_timesteps(250)[-1] == 997
+    assert abs(float(a_prev[0]) - 0.9985) < 1e-6 and abs(float(a_prev[49]) - 2.9478561805828586e-4) < 1e-9
+    assert float(sigma.abs().max()) == 0.0
+    _, _, _, sig1, _ = odiff.ddim_schedule(s, 50, 1.0)
+    assert abs(float(sig1[0]) - 0.02743208756763818) < 1e-6 and abs(float(sig1[49]) - 0.5611383276027714) < 1e-5
+    assert abs(float(s.posterior_variance[1]) - 7.525194283185552e-4) < 1e-9
+    assert abs(float(s.posterior_log_variance_clipped[0]) + 46.051701859880914) < 1e-4
+    # one DDIM step, index 49, eta 0, x = 1, eps = 0.5
+    x = torch.ones(1, 1, 1, 1)
+    xp, x0 = odiff.p_sample_ddim(lambda x_, t_, c_: torch.full_like(x_, 0.5), x, None, torch.tensor([981]), 49,
+                                 odiff.ddim_schedule(s, 50, 0.0))
+    assert abs(float(x0) - 35.18726080835689) < 2e-3 and abs(float(xp) - 1.1040677094017173) < 1e-5
+
+
+def test_exact_topk_ties_and_order():
+    rng = np.random.default_rng(0)
+    db = (rng.standard_normal((1000, 64)) * 0.45).astype(np.float16)
+    db[500] = db[10]; db[700] = db[10]          # duplicates -> index tie-break
+    dbn = oret.normalize_db(db)
+    q = db[10:11].astype(np.float32)
+    idx, sc = oret.exact_topk(dbn, oret.normalize_queries(q), 4, chunk=300)
+    assert idx[0, :3].tolist() == [10, 500, 700]
+    assert np.all(np.diff(sc[0]) <= 0)
+
+
+def test_retro_cond_and_uint8():
+    q = np.arange(8, dtype=np.float32).reshape(2, 4)
+    r = np.arange(2 * 3 * 4, dtype=np.float16).reshape(2, 3, 4)
+    rc = oret.assemble_retro_cond(q, r, 3)
+    assert rc.shape == (2, 3, 4) and np.array_equal(rc[:, 0], q) and np.array_equal(rc[:, 1:], r[:, :2].astype(np.float32))
+    assert np.array_equal(oret.assemble_retro_cond(q, r, 3, omit_query=True), r.astype(np.float32))
+    uc = oret.unconditional_conditioning(np.ones(4, np.float32), (2, 3, 4), 0.0, 3)
+    assert uc.shape == (2, 3, 4) and not uc.any()
+    img = np.array([[[[-2.0, -1.0], [0.0, 0.999]]]], dtype=np.float32)
+    assert oret.custom_to_np_uint8(img).reshape(-1).tolist() == [0, 0, 127, 254]
+
+
+def test_tokenizer_known_answer_fixture():
+    g = golden("tokenizer.npz")
+    assert g["tokens"][0, :13].tolist() == [49406, 320, 900, 4298, 2337, 320, 8786, 267, 2870, 525, 7483, 49407, 0]
+
+
+def test_vq_oracle_shapes_and_quantise():
+    spec = ovq.tiny_vq_spec()
+    sd = ounet.synth_state_dict(ovq.vq_param_shapes(spec), seed=5)
+    z = torch.from_numpy(np.random.default_rng(1).standard_normal((1, 3, 16, 16)).astype(np.float32))
+    img, idx = ovq.vq_decode(sd, spec, z, return_indices=True)
+    assert img.shape == (1, 3, 64, 64) and idx.shape == (256,)
+    e = sd["quantize.embedding.weight"]
+    zf = z.permute(0, 2, 3, 1).reshape(-1, 3)
+    d = ((zf[:, None] - e[None]) ** 2).sum(-1)
+    assert (d.argmin(1) == idx).float().mean() > 0.99
