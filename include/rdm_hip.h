@@ -145,6 +145,13 @@ int rdm_knn(rdm_ctx* ctx, const float* q, int b, int k, uint32_t* idx_out, float
  * of the RAW (un-normalised) embeddings (rdm_db_load keeps a raw copy in HBM next to the normalised one). */
 int rdm_db_gather(rdm_ctx* ctx, const uint32_t* idx, long long n_idx, float* out);
 
+/* ---- measurement: optional HIP-event bracket around every GEMM-class launch on the context stream
+ * (kind 0 = conv3x3 implicit GEMM, 1 = linear/1x1).  collect: sums elapsed ms and ALGORITHMIC flops
+ * (2*M*N*K) of the launches recorded since the last reset. Used by bench.py for the roofline line. */
+int rdm_prof_enable(rdm_ctx* ctx, int on);
+int rdm_prof_collect(rdm_ctx* ctx, int kind, long long* launches, double* ms, double* flops);
+int rdm_prof_reset(rdm_ctx* ctx);
+
 /* ---- operator-level entry points (used by the parity tests; thin wrappers over the kernels) ---- */
 int rdm_op_linear(rdm_ctx* ctx, const void* a_bf16, const void* w_bf16, const float* bias, const void* residual_bf16,
                   void* out_bf16, float* out_f32, int M, int N, int K, int act, float alpha);

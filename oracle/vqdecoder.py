@@ -35,7 +35,7 @@ def shipped_vq_spec():
 
 
 def tiny_vq_spec():
-    return VQSpec(n_embed=512, ch=32, ch_mult=(1, 2, 4), num_res_blocks=1, resolution=64)
+    return VQSpec(n_embed=512, ch=64, ch_mult=(1, 2, 4), num_res_blocks=1, resolution=64)
 
 
 def _res_shapes(p, pre, cin, cout):

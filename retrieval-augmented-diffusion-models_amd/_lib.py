@@ -77,6 +77,9 @@ SIGNATURES = {
     "rdm_db_size": (C.c_longlong, [_P]),
     "rdm_knn": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "rdm_db_gather": (C.c_int, [_P, _P, C.c_longlong, _P]),
+    "rdm_prof_enable": (C.c_int, [_P, C.c_int]),
+    "rdm_prof_collect": (C.c_int, [_P, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rdm_prof_reset": (C.c_int, [_P]),
     "rdm_op_linear": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "rdm_op_conv3x3": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int]),
@@ -313,6 +316,18 @@ class Context:
         out = torch.empty((idx.numel(), dim), device=self.device, dtype=torch.float32)
         self._check(lib.rdm_db_gather(self._h, _ptr(idx), idx.numel(), _ptr(out)))
         return out.reshape(tuple(idx.shape) + (dim,))
+
+    # ---- measurement
+    def prof_enable(self, on=True):
+        self._check(lib.rdm_prof_enable(self._h, int(on)))
+
+    def prof_reset(self):
+        self._check(lib.rdm_prof_reset(self._h))
+
+    def prof_collect(self, kind):
+        n, ms, fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
+        self._check(lib.rdm_prof_collect(self._h, kind, C.byref(n), C.byref(ms), C.byref(fl)))
+        return int(n.value), float(ms.value), float(fl.value)
 
     # ---- operator-level (parity tests)
     def op_linear(self, a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, out_f32=False):

@@ -56,4 +56,5 @@ struct IgemmParams {
     // batching over blockIdx.z (element strides)
     long long sA, sW, sO;
     const void* zero_page;      // >= 16 B of zeros
+    int dbg;                    // debug ablation bits (env RDM_IGEMM_DBG): 1 no MFMA, 2 no in-loop staging, 4 no stores
 };

@@ -14,10 +14,12 @@
 // Zero padding of the 3x3 halo (and M/N tails) is done by pointing the lane at a zero page.
 // The skip-concat of the UNet decoder (th.cat([h, hs.pop()]), openaimodel.py:365) is never
 // materialised: the loader switches source tensor per K-slice (dual-source A).
+#include <stdlib.h>
+
 #include "kernels.h"
 
-template <int BM, int BN, bool CONV>
-__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+template <int BM, int BN, bool CONV, bool GEGLU>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     constexpr int BK = 64;
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int FM = WM / 32, FN = WN / 32;
@@ -131,9 +133,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         const int cur = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                       // tile kt landed; everyone is done reading buf cur^1
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-        const char* As = smem + cur * STAGE;
+        if (kt + 1 < nk && !(p.dbg & 2)) stage(kt + 1, cur ^ 1);
+        const char* As = smem + ((p.dbg & 2) ? 0 : cur) * STAGE;
         const char* Bs = As + A_BYTES;
+        if (p.dbg & 1) continue;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             bf16x8 af[FM], bfr[FN];
@@ -157,62 +160,78 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     }
 
     // ---- epilogue. D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // (all accumulator indices are compile-time constants: a runtime-indexed acc[][] would be demoted to
+    //  scratch memory and re-spilled every K iteration)
+    if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f && p.out_bf16) p.out_bf16[0] = 0; return; }
     bf16_t* ob = p.out_bf16 ? p.out_bf16 + zb * p.sO : nullptr;
     float* of = p.out_f32 ? p.out_f32 + zb * p.sO : nullptr;
-    const bool geglu = (p.act == ACT_GEGLU);
+    const bf16_t* rb = p.res_bf16 ? p.res_bf16 + zb * p.sO : nullptr;
+    const float* rf = p.res_f32 ? p.res_f32 + zb * p.sO : nullptr;
+    const bool uniform_sample = (p.rows_per_sample % 32) == 0;
 #pragma unroll
     for (int i = 0; i < FM; i++) {
+        const int mf = m0 + wm * WM + i * 32;                 // first row of this fragment
+        const float* rv = nullptr;
+        if (p.rowvec && uniform_sample) rv = p.rowvec + (long long)(mf / p.rows_per_sample) * p.rowvec_ld;
 #pragma unroll
         for (int j = 0; j < FN; j++) {
-            if (geglu && (j & 1)) continue;
+            if constexpr (GEGLU) { if (j & 1) continue; }
             const int ncol = n0 + wn * WN + j * 32 + frow;       // column in (permuted) weight space
-            if (ncol >= p.N) continue;
-            const int ocol = geglu ? ((n0 + wn * WN + j * 32) >> 1) + frow : ncol;
-            const float bias = p.bias ? p.bias[ncol] : 0.f;
-            float gbias = 0.f;
-            if (geglu && p.bias) gbias = p.bias[ncol + 32];
+            const bool col_ok = ncol < p.N;
+            const int ocol = GEGLU ? ((n0 + wn * WN + j * 32) >> 1) + frow : ncol;
+            float bias = 0.f, gbias = 0.f, rvv = 0.f;
+            if (col_ok) {
+                if (p.bias) { bias = p.bias[ncol]; if constexpr (GEGLU) gbias = p.bias[ncol + 32]; }
+                if (rv) rvv = rv[ncol];
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] * p.alpha + bias;
-                if (p.rowvec) v += p.rowvec[(long long)(m / p.rows_per_sample) * p.rowvec_ld + ncol];
-                if (geglu) {
-                    const float g = acc[i][(j + 1) % FN][r] * p.alpha + gbias;
-                    v = v * gelu_erf_f(g);
-                } else if (p.act == ACT_QUICKGELU) v = quickgelu_f(v);
-                else if (p.act == ACT_SILU) v = silu_f(v);
-                const long long o = (long long)m * p.ldo + ocol;
-                if (p.res_bf16) v += bf2f(p.res_bf16[zb * p.sO + o]);
-                if (p.res_f32) v += p.res_f32[zb * p.sO + o];
-                if (ob) ob[o] = f2bf(v);
-                if (of) of[o] = v;
+                const int m = mf + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                if (col_ok && m < p.M) {
+                    float v = acc[i][j][r] * p.alpha + bias + rvv;
+                    if (p.rowvec && !uniform_sample) v += p.rowvec[(long long)(m / p.rows_per_sample) * p.rowvec_ld + ncol];
+                    if constexpr (GEGLU) {
+                        const float g = acc[i][(j + 1) < FN ? (j + 1) : j][r] * p.alpha + gbias;
+                        v = v * gelu_erf_f(g);
+                    } else {
+                        if (p.act == ACT_QUICKGELU) v = quickgelu_f(v);
+                        else if (p.act == ACT_SILU) v = silu_f(v);
+                    }
+                    const long long o = (long long)m * p.ldo + ocol;
+                    if (rb) v += bf2f(rb[o]);
+                    if (rf) v += rf[o];
+                    if (ob) ob[o] = f2bf(v);
+                    if (of) of[o] = v;
+                }
             }
         }
     }
 }
 
-template <int BM, int BN, bool CONV>
+template <int BM, int BN, bool CONV, bool GEGLU>
 static hipError_t launch_cfg(const IgemmParams& p, int batch, hipStream_t st) {
     constexpr int smem = 2 * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, CONV>,
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, CONV, GEGLU>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     dim3 grid(nbm * nbn, 1, batch);
-    igemm_kernel<BM, BN, CONV><<<grid, 256, smem, st>>>(p);
+    igemm_kernel<BM, BN, CONV, GEGLU><<<grid, 256, smem, st>>>(p);
     return hipGetLastError();
 }
 
 // Host entry: picks the tile. K must be a multiple of 64 (and C0, C1 multiples of 64 for conv / dual).
-hipError_t launch_igemm(const IgemmParams& p, bool conv, int batch, hipStream_t st) {
+hipError_t launch_igemm(const IgemmParams& p_in, bool conv, int batch, hipStream_t st) {
+    static const int dbg = getenv("RDM_IGEMM_DBG") ? atoi(getenv("RDM_IGEMM_DBG")) : 0;
+    IgemmParams p = p_in; p.dbg = dbg;
     if (p.K % 64 != 0 || p.C0 % 64 != 0 || p.C1 % 64 != 0) return hipErrorInvalidValue;
     if (p.act == ACT_GEGLU && (p.N % 64 != 0)) return hipErrorInvalidValue;
-    const bool wide = (p.N % 192 == 0) && p.act != ACT_GEGLU;
-    if (conv) return wide ? launch_cfg<128, 192, true>(p, batch, st) : launch_cfg<128, 128, true>(p, batch, st);
-    return wide ? launch_cfg<128, 192, false>(p, batch, st) : launch_cfg<128, 128, false>(p, batch, st);
+    if (p.act == ACT_GEGLU) return conv ? hipErrorInvalidValue : launch_cfg<128, 128, false, true>(p, batch, st);
+    const bool wide = (p.N % 192 == 0);
+    if (conv) return wide ? launch_cfg<128, 192, true, false>(p, batch, st) : launch_cfg<128, 128, true, false>(p, batch, st);
+    return wide ? launch_cfg<128, 192, false, false>(p, batch, st) : launch_cfg<128, 128, false, false>(p, batch, st);
 }

@@ -293,6 +293,14 @@ struct rdm_ctx {
     UNet unet; VqModel vq; ClipModel clip; KnnDb db;
     float* gn_partial = nullptr; size_t gn_partial_bytes = 0;
     char* samp = nullptr; size_t samp_bytes = 0;     // sampler scratch
+    // optional per-launch HIP-event profiler for the GEMM-class kernels (bench.py roofline)
+    bool prof = false;
+    struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+    std::vector<ProfRec> prof_recs; std::vector<hipEvent_t> prof_pool;
+    hipEvent_t prof_event() {
+        if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
+        hipEvent_t e; hipEventCreate(&e); return e;
+    }
     int fail(int code, const char* fmt, ...) {
         va_list ap; va_start(ap, fmt); vsnprintf(err, sizeof err, fmt, ap); va_end(ap); return code;
     }
@@ -326,7 +334,9 @@ struct Ops {
         p.A0 = A0; p.A1 = A1; p.C0 = C0; p.C1 = C1; p.W = w<bf16_t>(woff); p.bias = has_bias ? w<float>(boff) : nullptr;
         p.act = act; p.res_bf16 = res; p.res_f32 = res_f32; p.out_bf16 = out; p.out_f32 = out_f32;
         if (act == ACT_GEGLU) p.ldo = N / 2;
+        prof_begin(1, 2.0 * M * N * (double)(C0 + C1));
         check(launch_igemm(p, false, 1, c->stream), "linear");
+        prof_end();
     }
     void conv3(const bf16_t* A0, const bf16_t* A1, int C0, int C1, size_t woff, size_t boff, int B, int Hin, int Win, int N,
                int stride, int ups, const float* rowvec, int rowvec_ld, const bf16_t* res, bf16_t* out) {
@@ -336,8 +346,16 @@ struct Ops {
         p.A0 = A0; p.A1 = A1; p.C0 = C0; p.C1 = C1; p.W = w<bf16_t>(woff); p.bias = w<float>(boff);
         p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.stride = stride; p.ups = ups;
         p.rowvec = rowvec; p.rowvec_ld = rowvec_ld; p.rows_per_sample = Hout * Wout; p.res_bf16 = res; p.out_bf16 = out;
+        prof_begin(0, 2.0 * p.M * N * (double)p.K);
         check(launch_igemm(p, true, 1, c->stream), "conv3x3");
+        prof_end();
     }
+    void prof_begin(int kind, double flops) {
+        if (!c->prof) return;
+        rdm_ctx::ProfRec r; r.a = c->prof_event(); r.b = c->prof_event(); r.kind = kind; r.flops = flops;
+        hipEventRecord(r.a, c->stream); c->prof_recs.push_back(r);
+    }
+    void prof_end() { if (c->prof) hipEventRecord(c->prof_recs.back().b, c->stream); }
     void groupnorm(const bf16_t* x0, const bf16_t* x1, int C0, int C1, int B, int HW, size_t g, size_t b, float eps, int silu,
                    bf16_t* out) {
         if (plan) return;
@@ -916,6 +934,32 @@ int rdm_db_gather(rdm_ctx* c, const uint32_t* idx, long long n_idx, float* out) 
     if (!c || !idx || !out) return -1;
     const char* msg = knn_gather(c->db, idx, n_idx, out, c->stream);
     return msg ? c->fail(-5, "rdm_db_gather: %s", msg) : 0;
+}
+
+// ---- profiler
+int rdm_prof_enable(rdm_ctx* c, int on) {
+    if (!c) return -1;
+    c->prof = on != 0;
+    return 0;
+}
+int rdm_prof_collect(rdm_ctx* c, int kind, long long* launches, double* ms, double* flops) {
+    if (!c) return -1;
+    RDM_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    long long n = 0; double t = 0, f = 0;
+    for (auto& r : c->prof_recs) {
+        if (r.kind != kind) continue;
+        float e = 0; hipEventElapsedTime(&e, r.a, r.b);
+        n++; t += e; f += r.flops;
+    }
+    if (launches) *launches = n; if (ms) *ms = t; if (flops) *flops = f;
+    return 0;
+}
+int rdm_prof_reset(rdm_ctx* c) {
+    if (!c) return -1;
+    RDM_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto& r : c->prof_recs) { c->prof_pool.push_back(r.a); c->prof_pool.push_back(r.b); }
+    c->prof_recs.clear();
+    return 0;
 }
 
 // ---- operator-level wrappers for the parity tests
