@@ -23,6 +23,16 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
+// hardware RNE pack of two fp32 into one dword of two bf16 (lo in bits 0-15)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// exchange with the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ float swap_adjacent_lane(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float quickgelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }

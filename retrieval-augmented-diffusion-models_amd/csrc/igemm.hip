@@ -7,7 +7,9 @@
 // (rdm/modules/attention.py:149-168), to_q/k/v/out Linear (attention.py:30-37), GEGLU FF,
 // time_embed / emb_layers linears (openaimodel.py:137-141).
 //
-// Structure: 128 x BN x 64 block tile, 4 waves (2x2), 32x32x16 bf16 MFMA, fp32 accumulate.
+// Structure: persistent blocks walk 128 x BN output tiles (XCD-aware order); per tile a 64-deep K loop,
+// 4 waves (2x2), 32x32x16 bf16 MFMA, fp32 accumulate; the first K-slice of the NEXT tile is prefetched
+// before the (register-only) epilogue so its HBM latency is hidden behind the stores.
 // A and B tiles are staged with 16-byte global_load_lds (LDS-DMA) into a double-buffered LDS ring;
 // the LDS image is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE
 // address and again on the ds_read (chunk ^= (row>>1)&7 -> conflict-free ds_read_b128).
@@ -18,68 +20,81 @@
 
 #include "kernels.h"
 
-template <int BM, int BN, bool CONV, bool GEGLU>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
+template <int BM, int BN, int WAVES_M, bool CONV, bool GEGLU>
+__global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) {
     constexpr int BK = 64;
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int WAVES_N = 2, NW = WAVES_M * WAVES_N, NT = NW * 64;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int FM = WM / 32, FN = WN / 32;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-    constexpr int AP = BM / 32, BP = BN / 32;   // loader passes (256 threads cover 32 rows x 8 chunks)
+    constexpr int RPP = NT / 8;                  // rows per loader pass (NT threads cover RPP rows x 8 chunks)
+    constexpr int AP = BM / RPP, BP = BN / RPP;
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && WM % 32 == 0 && WN % 32 == 0, "tile/wave geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int frow = lane & 31, fhalf = lane >> 5;
 
-    // ---- block -> tile (XCD-aware: consecutive tiles land on the same XCD/L2; N tiles fastest so
-    //      the blocks that share an A row-panel run back to back on one L2)
-    const int nbn = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int bm = bid / nbn, bn = bid % nbn;
-    const int m0 = bm * BM, n0 = bn * BN;
+    // ---- persistent tile walk. Blocks b = x (mod 8) run on XCD x (observed dispatch order; speed only):
+    //      XCD x owns a contiguous range of tiles (N tiles fastest), its blocks take them round-robin, so
+    //      the blocks resident on one L2 at any time share A row-panels and walk W in step.
+    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+    const int ntiles = nbm * nbn;
+    const int G = gridDim.x, xcd = blockIdx.x & 7;
+    const int gx = (G - xcd + 7) >> 3;                       // blocks on my XCD
+    const int tq = ntiles >> 3, tr = ntiles & 7;
+    const int t_begin = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int t_end = t_begin + tq + (xcd < tr ? 1 : 0);
+    int tile = t_begin + (blockIdx.x >> 3);
+    if (tile >= t_end) return;
 
     const long long zb = blockIdx.z;
     const bf16_t* A0 = p.A0 + zb * p.sA;
     const bf16_t* A1 = p.A1;
     const bf16_t* W = p.W + zb * p.sW;
     const char* zero = (const char*)p.zero_page;
-
-    // ---- loader state
-    const int lrow = tid >> 3;          // 0..31
-    const int pchunk = tid & 7;         // physical 16B chunk in the LDS row
-    int a_m[AP];                        // linear: row index m (or -1); conv: pixel base of sample
-    int a_yx[AP];                       // conv: (oy << 16) | ox
-    int a_src_chunk[AP];
-#pragma unroll
-    for (int i = 0; i < AP; i++) {
-        const int r = i * 32 + lrow;
-        const int m = m0 + r;
-        a_src_chunk[i] = pchunk ^ ((r >> 1) & 7);
-        if (CONV) {
-            if (m < p.M) {
-                const int hw = p.Hout * p.Wout;
-                const int b = m / hw, rem = m - b * hw;
-                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-                a_m[i] = b * p.Hin * p.Win;
-                a_yx[i] = (oy << 16) | ox;
-            } else { a_m[i] = -1; a_yx[i] = 0; }
-        } else {
-            a_m[i] = (m < p.M) ? m : -1; a_yx[i] = 0;
-        }
-    }
-    long long b_off[BP];
-#pragma unroll
-    for (int i = 0; i < BP; i++) {
-        const int r = i * 32 + lrow;
-        const int n = n0 + r;
-        const int c = pchunk ^ ((r >> 1) & 7);
-        b_off[i] = (n < p.N) ? ((long long)n * p.K + c * 8) : -1;
-    }
+    bf16_t* ob = p.out_bf16 ? p.out_bf16 + zb * p.sO : nullptr;
+    float* of = p.out_f32 ? p.out_f32 + zb * p.sO : nullptr;
+    const bf16_t* rb = p.res_bf16 ? p.res_bf16 + zb * p.sO : nullptr;
+    const float* rf = p.res_f32 ? p.res_f32 + zb * p.sO : nullptr;
     const int Cin = p.C0 + p.C1;
+    const int nk = p.K / BK;
+
+    // ---- loader state (per tile)
+    const int lrow = tid >> 3;          // 0..RPP-1
+    const int pchunk = tid & 7;         // physical 16B chunk in the LDS row
+    int m0, n0;
+    int a_m[AP];                        // linear: row index m (or -1); conv: pixel base of sample (or -1)
+    int a_yx[AP];                       // conv: (oy << 16) | ox
+    long long b_off[BP];
+
+    auto setup = [&](int t) {
+        const int bm = t / nbn, bn = t - bm * nbn;
+        m0 = bm * BM; n0 = bn * BN;
+#pragma unroll
+        for (int i = 0; i < AP; i++) {
+            const int m = m0 + i * RPP + lrow;
+            if (CONV) {
+                if (m < p.M) {
+                    const int hw = p.Hout * p.Wout;
+                    const int b = m / hw, rem = m - b * hw;
+                    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                    a_m[i] = b * p.Hin * p.Win;
+                    a_yx[i] = (oy << 16) | ox;
+                } else { a_m[i] = -1; a_yx[i] = 0; }
+            } else {
+                a_m[i] = (m < p.M) ? m : -1; a_yx[i] = 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BP; i++) {
+            const int r = i * RPP + lrow;
+            const int n = n0 + r;
+            const int c = pchunk ^ ((r >> 1) & 7);
+            b_off[i] = (n < p.N) ? ((long long)n * p.K + c * 8) : -1;
+        }
+    };
 
     auto stage = [&](int kt, int buf) {
         char* As = smem + buf * STAGE;
@@ -92,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 #pragma unroll
         for (int i = 0; i < AP; i++) {
             const void* g = zero;
+            const int sc = pchunk ^ (((i * RPP + lrow) >> 1) & 7);      // source chunk (swizzle on the SOURCE side)
             if (a_m[i] >= 0) {
                 if (CONV) {
                     const int oy = a_yx[i] >> 16, ox = a_yx[i] & 0xffff;
@@ -104,123 +120,167 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
                         iy = oy * p.stride + dy - 1; ix = ox * p.stride + dx - 1;
                         ok = (iy >= 0) & (iy < p.Hin) & (ix >= 0) & (ix < p.Win);
                     }
-                    if (ok) g = src + ((long long)(a_m[i] + iy * p.Win + ix) * ld + cofs + a_src_chunk[i] * 8);
+                    if (ok) g = src + ((long long)(a_m[i] + iy * p.Win + ix) * ld + cofs + sc * 8);
                 } else {
-                    g = src + ((long long)a_m[i] * ld + cofs + a_src_chunk[i] * 8);
+                    g = src + ((long long)a_m[i] * ld + cofs + sc * 8);
                 }
             }
-            glds16(g, As + (i * 32 + wave * 8) * 128);
+            glds16(g, As + (i * RPP + wave * 8) * 128);
         }
 #pragma unroll
         for (int i = 0; i < BP; i++) {
             const void* g = (b_off[i] >= 0) ? (const void*)(W + b_off[i] + (long long)kt * BK) : (const void*)zero;
-            glds16(g, Bs + (i * 32 + wave * 8) * 128);
+            glds16(g, Bs + (i * RPP + wave * 8) * 128);
         }
     };
 
-    f32x16 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; i++)
-#pragma unroll
-        for (int j = 0; j < FN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    const int nk = p.K / BK;
+    setup(tile);
     stage(0, 0);
-    const int frow = lane & 31, fhalf = lane >> 5;
-    for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                       // tile kt landed; everyone is done reading buf cur^1
-        if (kt + 1 < nk && !(p.dbg & 2)) stage(kt + 1, cur ^ 1);
-        const char* As = smem + ((p.dbg & 2) ? 0 : cur) * STAGE;
-        const char* Bs = As + A_BYTES;
-        if (p.dbg & 1) continue;
+    int cur = 0;
+    const bool uniform_sample = (p.rows_per_sample % 32) == 0;
+
+    while (true) {
+        f32x16 acc[FM][FN];
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            bf16x8 af[FM], bfr[FN];
-            const int chunk = kk * 2 + fhalf;
+        for (int i = 0; i < FM; i++)
+#pragma unroll
+            for (int j = 0; j < FN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+        const int em0 = m0, en0 = n0;                 // this tile's origin (setup(next) overwrites m0/n0)
+        const int next = tile + gx;
+        const bool has_next = next < t_end;
+
+        for (int kt = 0; kt < nk; kt++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                       // K-slice kt landed; everyone is done reading buffer cur^1
+            if (!(p.dbg & 2)) {
+                if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+                else if (has_next) { setup(next); stage(0, cur ^ 1); }   // prefetch the NEXT tile across the epilogue
+            }
+            const char* As = smem + cur * STAGE;
+            const char* Bs = As + A_BYTES;
+            cur ^= 1;
+            if (p.dbg & 1) continue;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                bf16x8 af[FM], bfr[FN];
+                const int chunk = kk * 2 + fhalf;
+#pragma unroll
+                for (int i = 0; i < FM; i++) {
+                    const int row = wm * WM + i * 32 + frow;
+                    af[i] = *(const bf16x8*)(As + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < FN; j++) {
+                    const int row = wn * WN + j * 32 + frow;
+                    bfr[j] = *(const bf16x8*)(Bs + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < FM; i++)
+#pragma unroll
+                    for (int j = 0; j < FN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+
+        // ---- epilogue (registers only, overlaps the prefetch of the next tile).
+        // D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5). All accumulator indices are
+        // compile-time constants (a runtime-indexed acc[][] would be demoted to scratch and re-spilled per K step).
+        // VALU diet: neighbouring lanes (adjacent columns) swap one value per register pair through DPP so that
+        // every lane owns two adjacent columns of one row -> one v_cvt_pk_bf16_f32 + one 4-byte store per pair;
+        // addresses are a per-fragment base pointer plus compile-time multiples of ldo; bounds checks only on
+        // tail tiles.
+        if (!(p.dbg & 4)) {
+            const bool full = (em0 + BM <= p.M) && (en0 + BN <= p.N);
+            const int odd = lane & 1;
 #pragma unroll
             for (int i = 0; i < FM; i++) {
-                const int row = wm * WM + i * 32 + frow;
-                af[i] = *(const bf16x8*)(As + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-            }
+                const int mf = em0 + wm * WM + i * 32;                 // first row of this fragment
+                const float* rv = nullptr;
+                if (p.rowvec && uniform_sample && mf < p.M) rv = p.rowvec + (long long)(mf / p.rows_per_sample) * p.rowvec_ld;
 #pragma unroll
-            for (int j = 0; j < FN; j++) {
-                const int row = wn * WN + j * 32 + frow;
-                bfr[j] = *(const bf16x8*)(Bs + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < FM; i++)
-#pragma unroll
-                for (int j = 0; j < FN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-    }
-
-    // ---- epilogue. D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    // (all accumulator indices are compile-time constants: a runtime-indexed acc[][] would be demoted to
-    //  scratch memory and re-spilled every K iteration)
-    if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f && p.out_bf16) p.out_bf16[0] = 0; return; }
-    bf16_t* ob = p.out_bf16 ? p.out_bf16 + zb * p.sO : nullptr;
-    float* of = p.out_f32 ? p.out_f32 + zb * p.sO : nullptr;
-    const bf16_t* rb = p.res_bf16 ? p.res_bf16 + zb * p.sO : nullptr;
-    const float* rf = p.res_f32 ? p.res_f32 + zb * p.sO : nullptr;
-    const bool uniform_sample = (p.rows_per_sample % 32) == 0;
-#pragma unroll
-    for (int i = 0; i < FM; i++) {
-        const int mf = m0 + wm * WM + i * 32;                 // first row of this fragment
-        const float* rv = nullptr;
-        if (p.rowvec && uniform_sample) rv = p.rowvec + (long long)(mf / p.rows_per_sample) * p.rowvec_ld;
-#pragma unroll
-        for (int j = 0; j < FN; j++) {
-            if constexpr (GEGLU) { if (j & 1) continue; }
-            const int ncol = n0 + wn * WN + j * 32 + frow;       // column in (permuted) weight space
-            const bool col_ok = ncol < p.N;
-            const int ocol = GEGLU ? ((n0 + wn * WN + j * 32) >> 1) + frow : ncol;
-            float bias = 0.f, gbias = 0.f, rvv = 0.f;
-            if (col_ok) {
-                if (p.bias) { bias = p.bias[ncol]; if constexpr (GEGLU) gbias = p.bias[ncol + 32]; }
-                if (rv) rvv = rv[ncol];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = mf + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                if (col_ok && m < p.M) {
-                    float v = acc[i][j][r] * p.alpha + bias + rvv;
-                    if (p.rowvec && !uniform_sample) v += p.rowvec[(long long)(m / p.rows_per_sample) * p.rowvec_ld + ncol];
-                    if constexpr (GEGLU) {
-                        const float g = acc[i][(j + 1) < FN ? (j + 1) : j][r] * p.alpha + gbias;
-                        v = v * gelu_erf_f(g);
-                    } else {
-                        if (p.act == ACT_QUICKGELU) v = quickgelu_f(v);
-                        else if (p.act == ACT_SILU) v = silu_f(v);
+                for (int j = 0; j < FN; j++) {
+                    if constexpr (GEGLU) { if (j & 1) continue; }
+                    const int ncol = en0 + wn * WN + j * 32 + frow;      // column in (permuted) weight space
+                    const bool col_ok = full || ncol < p.N;
+                    const int ocol = GEGLU ? ((en0 + wn * WN + j * 32) >> 1) + frow : ncol;
+                    float bias = 0.f, gbias = 0.f;
+                    if (col_ok) {
+                        if (p.bias) { bias = p.bias[ncol]; if constexpr (GEGLU) gbias = p.bias[ncol + 32]; }
+                        if (rv) bias += rv[ncol];
                     }
-                    const long long o = (long long)m * p.ldo + ocol;
-                    if (rb) v += bf2f(rb[o]);
-                    if (rf) v += rf[o];
-                    if (ob) ob[o] = f2bf(v);
-                    if (of) of[o] = v;
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        float x = acc[i][j][r] * p.alpha + bias;
+                        if (p.rowvec && !uniform_sample) {
+                            const int m = mf + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                            if (col_ok && m < p.M) x += p.rowvec[(long long)(m / p.rows_per_sample) * p.rowvec_ld + ncol];
+                        }
+                        if constexpr (GEGLU) {
+                            const float g = acc[i][(j + 1) < FN ? (j + 1) : j][r] * p.alpha + gbias;
+                            x = x * gelu_erf_f(g);
+                        } else {
+                            if (p.act == ACT_QUICKGELU) x = quickgelu_f(x);
+                            else if (p.act == ACT_SILU) x = silu_f(x);
+                        }
+                        v[r] = x;
+                    }
+                    // pair (r = 2t, 2t+1): even lane keeps row R(2t) cols (c, c+1); odd lane keeps row R(2t)+1 cols (c-1, c)
+                    const int mrow = mf + 4 * fhalf + odd;
+                    const int pcol = ocol - odd;
+                    const bool pair_ok = full || (pcol + 1 < (GEGLU ? p.N / 2 : p.N));
+                    const long long base = (long long)mrow * p.ldo + pcol;
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        const int roff = ((2 * t) & 3) + 8 * ((2 * t) >> 2);      // R(2t): 0,2,8,10,16,18,24,26
+                        const float give = odd ? v[2 * t] : v[2 * t + 1];
+                        const float got = swap_adjacent_lane(give);
+                        float lo = odd ? got : v[2 * t];
+                        float hi = odd ? v[2 * t + 1] : got;
+                        if (full || (pair_ok && mrow + roff < p.M)) {
+                            const long long o = base + (long long)roff * p.ldo;
+                            if (rb) { const uint32_t u = *(const uint32_t*)(rb + o); lo += __uint_as_float(u << 16); hi += __uint_as_float(u & 0xffff0000u); }
+                            if (rf) { const float2 f = *(const float2*)(rf + o); lo += f.x; hi += f.y; }
+                            if (ob) *(uint32_t*)(ob + o) = cvt_pk_bf16(lo, hi);
+                            if (of) *(float2*)(of + o) = make_float2(lo, hi);
+                        }
+                    }
                 }
             }
         }
+        if (!has_next) break;
+        tile = next;
     }
 }
 
-template <int BM, int BN, bool CONV, bool GEGLU>
+template <int BM, int BN, int WAVES_M, bool CONV, bool GEGLU>
 static hipError_t launch_cfg(const IgemmParams& p, int batch, hipStream_t st) {
     constexpr int smem = 2 * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, CONV, GEGLU>,
+    constexpr int NT = WAVES_M * 128;
+    static int blocks_per_cu = 0, ncu = 0;
+    if (!blocks_per_cu) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WAVES_M, CONV, GEGLU>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        int dev = 0; hipGetDevice(&dev);
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        int occ = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)igemm_kernel<BM, BN, WAVES_M, CONV, GEGLU>, NT, smem);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = occ < 1 ? 1 : occ;
     }
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-    dim3 grid(nbm * nbn, 1, batch);
-    igemm_kernel<BM, BN, CONV, GEGLU><<<grid, 256, smem, st>>>(p);
+    const long long ntiles = (long long)nbm * nbn;
+    long long g = (long long)ncu * blocks_per_cu;            // persistent: one resident wave of blocks
+    if (batch > 1) g = (g + batch - 1) / batch;
+    g = (g + 7) & ~7LL;                                      // multiple of the XCD count
+    if (g > ntiles) g = ntiles;
+    if (g < 1) g = 1;
+    dim3 grid((unsigned)g, 1, batch);
+    igemm_kernel<BM, BN, WAVES_M, CONV, GEGLU><<<grid, NT, smem, st>>>(p);
     return hipGetLastError();
 }
 
@@ -229,9 +289,24 @@ hipError_t launch_igemm(const IgemmParams& p_in, bool conv, int batch, hipStream
     static const int dbg = getenv("RDM_IGEMM_DBG") ? atoi(getenv("RDM_IGEMM_DBG")) : 0;
     IgemmParams p = p_in; p.dbg = dbg;
     if (p.K % 64 != 0 || p.C0 % 64 != 0 || p.C1 % 64 != 0) return hipErrorInvalidValue;
+    if (p.N % 2 != 0 || p.ldo % 2 != 0 || p.sO % 2 != 0) return hipErrorInvalidValue;   // paired-column epilogue
     if (p.act == ACT_GEGLU && (p.N % 64 != 0)) return hipErrorInvalidValue;
-    if (p.act == ACT_GEGLU) return conv ? hipErrorInvalidValue : launch_cfg<128, 128, false, true>(p, batch, st);
+    // tall 256-row tiles (8 waves, 1 block/CU) cut the L2->LDS operand traffic per FLOP by 1.44x; use them
+    // whenever there are enough row tiles to fill the chip, else the 128-row tile (4 waves, 2 blocks/CU).
+    static const int force_bm = getenv("RDM_IGEMM_BM") ? atoi(getenv("RDM_IGEMM_BM")) : 0;
     const bool wide = (p.N % 192 == 0);
-    if (conv) return wide ? launch_cfg<128, 192, true, false>(p, batch, st) : launch_cfg<128, 128, true, false>(p, batch, st);
-    return wide ? launch_cfg<128, 192, false, false>(p, batch, st) : launch_cfg<128, 128, false, false>(p, batch, st);
+    const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.N + (wide ? 191 : 127)) / (wide ? 192 : 128)) * batch;
+    bool tall = tiles256 >= 512;
+    if (force_bm == 128) tall = false;
+    if (force_bm == 256) tall = true;
+    if (p.act == ACT_GEGLU) {
+        if (conv) return hipErrorInvalidValue;
+        return tall ? launch_cfg<256, 128, 4, false, true>(p, batch, st) : launch_cfg<128, 128, 2, false, true>(p, batch, st);
+    }
+    if (conv) {
+        if (wide) return tall ? launch_cfg<256, 192, 4, true, false>(p, batch, st) : launch_cfg<128, 192, 2, true, false>(p, batch, st);
+        return tall ? launch_cfg<256, 128, 4, true, false>(p, batch, st) : launch_cfg<128, 128, 2, true, false>(p, batch, st);
+    }
+    if (wide) return tall ? launch_cfg<256, 192, 4, false, false>(p, batch, st) : launch_cfg<128, 192, 2, false, false>(p, batch, st);
+    return tall ? launch_cfg<256, 128, 4, false, false>(p, batch, st) : launch_cfg<128, 128, 2, false, false>(p, batch, st);
 }
