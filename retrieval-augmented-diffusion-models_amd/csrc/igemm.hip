@@ -20,7 +20,7 @@
 
 #include "kernels.h"
 
-template <int BM, int BN, int WAVES_M, bool CONV, bool GEGLU>
+template <int BM, int BN, int WAVES_M, int CONV, bool GEGLU>   // CONV: 0 linear, 1 conv3x3, 2 conv3x3 on a 2x nearest-upsampled input
 __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) {
     constexpr int BK = 64;
     constexpr int WAVES_N = 2, NW = WAVES_M * WAVES_N, NT = NW * 64;
@@ -29,10 +29,11 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     constexpr int RPP = NT / 8;                  // rows per loader pass (NT threads cover RPP rows x 8 chunks)
     constexpr int AP = BM / RPP, BP = BN / RPP;
-    static_assert(BM % RPP == 0 && BN % RPP == 0 && WM % 32 == 0 && WN % 32 == 0, "tile/wave geometry");
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && WM % 32 == 0 && WN % 32 == 0 && RPP % 16 == 0, "tile/wave geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform (LDS-DMA base, wave tile)
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int frow = lane & 31, fhalf = lane >> 5;
 
@@ -61,13 +62,15 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
     const int Cin = p.C0 + p.C1;
     const int nk = p.K / BK;
 
-    // ---- loader state (per tile)
+    // ---- loader state (per tile): one pixel/row index and one 9-bit tap-validity mask per loader pass. A K-slice
+    //      adds a wave-uniform scalar (channel offset + tap displacement) and tests one mask bit.
     const int lrow = tid >> 3;          // 0..RPP-1
     const int pchunk = tid & 7;         // physical 16B chunk in the LDS row
+    const int sc8 = (pchunk ^ ((lrow >> 1) & 7)) * 8;   // source chunk (swizzle on the SOURCE side); RPP % 16 == 0
     int m0, n0;
-    int a_m[AP];                        // linear: row index m (or -1); conv: pixel base of sample (or -1)
-    int a_yx[AP];                       // conv: (oy << 16) | ox
-    long long b_off[BP];
+    int a_pix[AP];                      // linear: row m; conv: centre pixel index (fused-upsample: sample base pixel)
+    int a_mask[AP];                     // bit t: tap t readable (linear: 0x1ff or 0); upsample: | oy << 9 | ox << 20
+    int b_n[BP];                        // weight row (or -1)
 
     auto setup = [&](int t) {
         const int bm = t / nbn, bn = t - bm * nbn;
@@ -75,63 +78,81 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
 #pragma unroll
         for (int i = 0; i < AP; i++) {
             const int m = m0 + i * RPP + lrow;
-            if (CONV) {
-                if (m < p.M) {
+            a_pix[i] = 0; a_mask[i] = 0;
+            if (m < p.M) {
+                if (CONV) {
                     const int hw = p.Hout * p.Wout;
                     const int b = m / hw, rem = m - b * hw;
                     const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-                    a_m[i] = b * p.Hin * p.Win;
-                    a_yx[i] = (oy << 16) | ox;
-                } else { a_m[i] = -1; a_yx[i] = 0; }
-            } else {
-                a_m[i] = (m < p.M) ? m : -1; a_yx[i] = 0;
+                    int mask = 0;
+                    if (CONV == 2) {
+                        a_pix[i] = b * p.Hin * p.Win;
+#pragma unroll
+                        for (int tp = 0; tp < 9; tp++) {
+                            const int uy = oy + tp / 3 - 1, ux = ox + tp % 3 - 1;
+                            if (uy >= 0 && uy < p.Hout && ux >= 0 && ux < p.Wout) mask |= 1 << tp;
+                        }
+                        mask |= (oy << 9) | (ox << 20);
+                    } else {
+                        const int cy = oy * p.stride, cx = ox * p.stride;
+                        a_pix[i] = (b * p.Hin + cy) * p.Win + cx;
+#pragma unroll
+                        for (int tp = 0; tp < 9; tp++) {
+                            const int iy = cy + tp / 3 - 1, ix = cx + tp % 3 - 1;
+                            if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) mask |= 1 << tp;
+                        }
+                    }
+                    a_mask[i] = mask;
+                } else {
+                    a_pix[i] = m; a_mask[i] = 0x1ff;
+                }
             }
         }
 #pragma unroll
         for (int i = 0; i < BP; i++) {
-            const int r = i * RPP + lrow;
-            const int n = n0 + r;
-            const int c = pchunk ^ ((r >> 1) & 7);
-            b_off[i] = (n < p.N) ? ((long long)n * p.K + c * 8) : -1;
+            const int n = n0 + i * RPP + lrow;
+            b_n[i] = (n < p.N) ? n : -1;
         }
     };
 
+    // K-slice bookkeeping (wave-uniform): channel offset inside the current tap, tap index
+    int k_ci = 0, k_tap = 0;
     auto stage = [&](int kt, int buf) {
         char* As = smem + buf * STAGE;
         char* Bs = As + A_BYTES;
-        // which source / channel offset / tap does this K-slice belong to?
-        int kc = kt * BK, dy = 0, dx = 0;
-        if (CONV) { const int tap = kc / Cin; kc -= tap * Cin; dy = tap / 3; dx = tap - dy * 3; }
-        const bf16_t* src; int ld, cofs;
-        if (kc < p.C0) { src = A0; ld = p.C0; cofs = kc; } else { src = A1; ld = p.C1; cofs = kc - p.C0; }
+        if (kt == 0) { k_ci = 0; k_tap = 0; }
+        const int dy = k_tap / 3, dx = k_tap - dy * 3;
+        const bool second = k_ci >= p.C0;
+        const bf16_t* src = second ? A1 : A0;
+        const int ld = second ? p.C1 : p.C0;
+        const int cofs = second ? k_ci - p.C0 : k_ci;
+        const bf16_t* lane_src = src + (cofs + sc8);
+        if (CONV == 2) {
 #pragma unroll
-        for (int i = 0; i < AP; i++) {
-            const void* g = zero;
-            const int sc = pchunk ^ (((i * RPP + lrow) >> 1) & 7);      // source chunk (swizzle on the SOURCE side)
-            if (a_m[i] >= 0) {
-                if (CONV) {
-                    const int oy = a_yx[i] >> 16, ox = a_yx[i] & 0xffff;
-                    int iy, ix; bool ok;
-                    if (p.ups) {
-                        const int uy = oy + dy - 1, ux = ox + dx - 1;
-                        ok = (uy >= 0) & (uy < p.Hout) & (ux >= 0) & (ux < p.Wout);
-                        iy = uy >> 1; ix = ux >> 1;
-                    } else {
-                        iy = oy * p.stride + dy - 1; ix = ox * p.stride + dx - 1;
-                        ok = (iy >= 0) & (iy < p.Hin) & (ix >= 0) & (ix < p.Win);
-                    }
-                    if (ok) g = src + ((long long)(a_m[i] + iy * p.Win + ix) * ld + cofs + sc * 8);
-                } else {
-                    g = src + ((long long)a_m[i] * ld + cofs + sc * 8);
-                }
+            for (int i = 0; i < AP; i++) {
+                const int oy = (a_mask[i] >> 9) & 0x7ff, ox = (a_mask[i] >> 20) & 0x7ff;
+                const int pix = a_pix[i] + ((oy + dy - 1) >> 1) * p.Win + ((ox + dx - 1) >> 1);
+                const bool ok = (a_mask[i] >> k_tap) & 1;
+                const void* g = ok ? (const void*)(lane_src + (long long)pix * ld) : (const void*)zero;
+                glds16(g, As + (i * RPP + wave * 8) * 128);
             }
-            glds16(g, As + (i * RPP + wave * 8) * 128);
+        } else {
+            const int dpix = CONV ? (dy - 1) * p.Win + (dx - 1) : 0;
+#pragma unroll
+            for (int i = 0; i < AP; i++) {
+                const bool ok = (a_mask[i] >> k_tap) & 1;
+                const void* g = ok ? (const void*)(lane_src + (long long)(a_pix[i] + dpix) * ld) : (const void*)zero;
+                glds16(g, As + (i * RPP + wave * 8) * 128);
+            }
         }
+        const bf16_t* lane_w = W + ((long long)kt * BK + sc8);
 #pragma unroll
         for (int i = 0; i < BP; i++) {
-            const void* g = (b_off[i] >= 0) ? (const void*)(W + b_off[i] + (long long)kt * BK) : (const void*)zero;
+            const void* g = (b_n[i] >= 0) ? (const void*)(lane_w + (long long)b_n[i] * p.K) : (const void*)zero;
             glds16(g, Bs + (i * RPP + wave * 8) * 128);
         }
+        k_ci += BK;
+        if (CONV && k_ci >= Cin) { k_ci = 0; k_tap++; }
     };
 
     setup(tile);
@@ -256,7 +277,7 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
     }
 }
 
-template <int BM, int BN, int WAVES_M, bool CONV, bool GEGLU>
+template <int BM, int BN, int WAVES_M, int CONV, bool GEGLU>
 static hipError_t launch_cfg(const IgemmParams& p, int batch, hipStream_t st) {
     constexpr int smem = 2 * (BM + BN) * 128;
     constexpr int NT = WAVES_M * 128;
@@ -301,12 +322,16 @@ hipError_t launch_igemm(const IgemmParams& p_in, bool conv, int batch, hipStream
     if (force_bm == 256) tall = true;
     if (p.act == ACT_GEGLU) {
         if (conv) return hipErrorInvalidValue;
-        return tall ? launch_cfg<256, 128, 4, false, true>(p, batch, st) : launch_cfg<128, 128, 2, false, true>(p, batch, st);
+        return tall ? launch_cfg<256, 128, 4, 0, true>(p, batch, st) : launch_cfg<128, 128, 2, 0, true>(p, batch, st);
+    }
+    if (conv && p.ups) {
+        if (wide) return tall ? launch_cfg<256, 192, 4, 2, false>(p, batch, st) : launch_cfg<128, 192, 2, 2, false>(p, batch, st);
+        return tall ? launch_cfg<256, 128, 4, 2, false>(p, batch, st) : launch_cfg<128, 128, 2, 2, false>(p, batch, st);
     }
     if (conv) {
-        if (wide) return tall ? launch_cfg<256, 192, 4, true, false>(p, batch, st) : launch_cfg<128, 192, 2, true, false>(p, batch, st);
-        return tall ? launch_cfg<256, 128, 4, true, false>(p, batch, st) : launch_cfg<128, 128, 2, true, false>(p, batch, st);
+        if (wide) return tall ? launch_cfg<256, 192, 4, 1, false>(p, batch, st) : launch_cfg<128, 192, 2, 1, false>(p, batch, st);
+        return tall ? launch_cfg<256, 128, 4, 1, false>(p, batch, st) : launch_cfg<128, 128, 2, 1, false>(p, batch, st);
     }
-    if (wide) return tall ? launch_cfg<256, 192, 4, false, false>(p, batch, st) : launch_cfg<128, 192, 2, false, false>(p, batch, st);
-    return tall ? launch_cfg<256, 128, 4, false, false>(p, batch, st) : launch_cfg<128, 128, 2, false, false>(p, batch, st);
+    if (wide) return tall ? launch_cfg<256, 192, 4, 0, false>(p, batch, st) : launch_cfg<128, 192, 2, 0, false>(p, batch, st);
+    return tall ? launch_cfg<256, 128, 4, 0, false>(p, batch, st) : launch_cfg<128, 128, 2, 0, false>(p, batch, st);
 }
