@@ -29,7 +29,8 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     constexpr int RPP = NT / 8;                  // rows per loader pass (NT threads cover RPP rows x 8 chunks)
     constexpr int AP = BM / RPP, BP = BN / RPP;
-    static_assert(BM % RPP == 0 && BN % RPP == 0 && WM % 32 == 0 && WN % 32 == 0 && RPP % 16 == 0, "tile/wave geometry");
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && WM % 64 == 0 && WN % 32 == 0 && RPP % 16 == 0, "tile/wave geometry");
+    static_assert((WN * 128) % 2048 == 0 && (FM + FN == 5 || FM + FN == 4), "fragment addressing / counted waits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -184,25 +185,43 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
             const char* Bs = As + A_BYTES;
             cur ^= 1;
             if (p.dbg & 1) continue;
+            // Hand-pipelined LDS->MFMA loop: the fragments of k-step kk+1 are requested (inline-asm ds_read_b128,
+            // invisible to hipcc's waitcnt bookkeeping) before the MFMAs of k-step kk; a COUNTED lgkmcnt leaves
+            // them in flight behind the matrix pipe.  All fragments of a lane share one swizzle term, so one
+            // address VGPR per operand + immediate offsets serve every fragment; k-steps differ by an XOR.
+            {
+                const unsigned lofs = (unsigned)(frow * 128 + ((fhalf ^ ((frow >> 1) & 7)) << 4));
+                const unsigned va = (unsigned)(size_t)(As - smem) + (unsigned)(wm * WM * 128) + lofs;
+                const unsigned vb = (unsigned)(size_t)(Bs - smem) + (unsigned)(wn * WN * 128) + lofs;
+                bf16x8 fa[2][FM], fb[2][FN];
+#define RDM_LDS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                bf16x8 af[FM], bfr[FN];
-                const int chunk = kk * 2 + fhalf;
+                for (int i = 0; i < FM; i++) RDM_LDS_READ(fa[0][i], va, i * 4096);
 #pragma unroll
-                for (int i = 0; i < FM; i++) {
-                    const int row = wm * WM + i * 32 + frow;
-                    af[i] = *(const bf16x8*)(As + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+                for (int j = 0; j < FN; j++) RDM_LDS_READ(fb[0][j], vb, j * 4096);
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const int cs = kk & 1, ns = cs ^ 1;
+                    if (kk < 3) {
+                        const unsigned van = va ^ (unsigned)((kk + 1) << 5), vbn = vb ^ (unsigned)((kk + 1) << 5);
+#pragma unroll
+                        for (int i = 0; i < FM; i++) RDM_LDS_READ(fa[ns][i], van, i * 4096);
+#pragma unroll
+                        for (int j = 0; j < FN; j++) RDM_LDS_READ(fb[ns][j], vbn, j * 4096);
+                        if constexpr (FM + FN == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+                        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < FM; i++)
+#pragma unroll
+                        for (int j = 0; j < FN; j++)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cs][i], fb[cs][j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int j = 0; j < FN; j++) {
-                    const int row = wn * WN + j * 32 + frow;
-                    bfr[j] = *(const bf16x8*)(Bs + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < FM; i++)
-#pragma unroll
-                    for (int j = 0; j < FN; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+#undef RDM_LDS_READ
             }
         }
 

@@ -17,11 +17,13 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* x, const floa
     for (int i = threadIdx.x; i < Cout; i += 256) ws[K * Cout + i] = bias[i];
     __syncthreads();
     const int VC = Cout / 8;
-    const long long total = (long long)B * H * W * VC;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int v = (int)(i % VC);
-        const long long pix = i / VC;
-        const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+    const int total = H * W * VC;                      // per sample (blockIdx.y = sample)
+    const int b = blockIdx.y;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int v = i % VC;
+        const int lp = i / VC;
+        const int xw = lp % W, yh = lp / W;
+        const long long pix = (long long)b * H * W + lp;
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) acc[e] = ws[K * Cout + v * 8 + e];
@@ -49,9 +51,10 @@ hipError_t launch_conv_in(const float* x, const float* w, const float* bias, bf1
     if (Cout % 8) return hipErrorInvalidValue;
     const size_t sm = (size_t)(Cin * 9 + 1) * Cout * sizeof(float);
     if (sm > 64 * 1024) return hipErrorInvalidValue;
-    const long long total = (long long)B * H * W * (Cout / 8);
-    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-    conv_in_kernel<<<grid, 256, sm, st>>>(x, w, bias, out, B, Cin, H, W, Cout);
+    const long long total = (long long)H * W * (Cout / 8);
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    int grid = (int)((total + 255) / 256); const int cap_in = (2048 + B - 1) / B; if (grid > cap_in) grid = cap_in;
+    conv_in_kernel<<<dim3(grid, B), 256, sm, st>>>(x, w, bias, out, B, Cin, H, W, Cout);
     return hipGetLastError();
 }
 
@@ -70,9 +73,10 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* x, const fl
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int VC = Cin / 8, items = 9 * VC;
-    const long long npix = (long long)B * H * W;
-    for (long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (long long)gridDim.x * 4) {
-        const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+    const int npix = H * W;                            // per sample (blockIdx.y = sample)
+    const int b = blockIdx.y;
+    for (int pix = blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += gridDim.x * 4) {
+        const int xw = pix % W, yh = pix / W;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int it = lane; it < items; it += 64) {
             const int t = it / VC, v = it - t * VC;
@@ -107,9 +111,9 @@ hipError_t launch_conv_out(const bf16_t* x, const float* w, const float* bias, f
     if (Cin % 8 || Cout > 4) return hipErrorInvalidValue;
     const size_t sm = (size_t)Cout * 9 * Cin * sizeof(float);
     if (sm > 64 * 1024) return hipErrorInvalidValue;
-    const long long npix = (long long)B * H * W;
-    int grid = (int)((npix + 3) / 4); if (grid > 16384) grid = 16384;
-    conv_out_kernel<<<grid, 256, sm, st>>>(x, w, bias, out, B, H, W, Cin, Cout);
+    const int npix = H * W;
+    int grid = (npix + 3) / 4; const int cap_out = (4096 + B - 1) / B; if (grid > cap_out) grid = cap_out;
+    conv_out_kernel<<<dim3(grid, B), 256, sm, st>>>(x, w, bias, out, B, H, W, Cin, Cout);
     return hipGetLastError();
 }
 

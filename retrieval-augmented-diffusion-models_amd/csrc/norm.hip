@@ -83,9 +83,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
         sm[c * 2] = a; sm[c * 2 + 1] = p.beta[c] - gstat[g][0] * a;
     }
     __syncthreads();
-    const long long total = (long long)p.HW * VC;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int row = (int)(i / VC), v = (int)(i - (long long)row * VC);
+    const int total = p.HW * VC;                       // per sample; fits int32 (checked by the launcher)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int row = i / VC, v = i - row * VC;
         const bf16x8 d = *(const bf16x8*)gn_src(p, b, row, v * 8);
         uint32_t o[4];
 #pragma unroll
@@ -112,9 +112,15 @@ hipError_t launch_groupnorm(GnParams p, hipStream_t st) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const long long total = (long long)p.HW * VC;
-    int nblk = (int)((total + 256 * 4 - 1) / (256 * 4));
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    // fat blocks: the per-block prologue (fold partials, build the per-channel FMA table) is amortised over
+    // >= 32 vectors per thread, while keeping >= ~2k blocks in flight across the batch
+    int nblk = (int)((total + 256 * 32 - 1) / (256 * 32));
+    const int min_blocks = (2048 + p.B - 1) / p.B;
+    if (nblk < min_blocks) nblk = min_blocks;
+    const int max_blocks = (int)((total + 255) / 256);
+    if (nblk > max_blocks) nblk = max_blocks;
     if (nblk < 1) nblk = 1;
-    if (nblk > 2048) nblk = 2048;
     gn_apply_kernel<<<dim3(nblk, p.B), 256, (size_t)C * 2 * sizeof(float), st>>>(p);
     return hipGetLastError();
 }
