@@ -8,6 +8,8 @@
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* x, const float* w /*[Cout][Cin][3][3]*/,
                                                       const float* bias, bf16_t* out, int B, int Cin, int H, int W,
                                                       int Cout) {
+    // thread = one output pixel: its 9*Cin input taps live in registers, every thread of the block reads the same
+    // weight vector at the same time (LDS broadcast), 16-byte stores of 8 output channels.
     extern __shared__ float ws[];   // [Cin*9][Cout] + bias[Cout]
     const int K = Cin * 9;
     for (int i = threadIdx.x; i < K * Cout; i += 256) {
@@ -16,33 +18,37 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* x, const floa
     }
     for (int i = threadIdx.x; i < Cout; i += 256) ws[K * Cout + i] = bias[i];
     __syncthreads();
-    const int VC = Cout / 8;
-    const int total = H * W * VC;                      // per sample (blockIdx.y = sample)
-    const int b = blockIdx.y;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int v = i % VC;
-        const int lp = i / VC;
+    const int b = blockIdx.y, npix = H * W;
+    for (int lp = blockIdx.x * 256 + threadIdx.x; lp < npix; lp += gridDim.x * 256) {
         const int xw = lp % W, yh = lp / W;
-        const long long pix = (long long)b * H * W + lp;
-        float acc[8];
+        float patch[36];                              // Cin <= 4
 #pragma unroll
-        for (int e = 0; e < 8; e++) acc[e] = ws[K * Cout + v * 8 + e];
-        for (int ci = 0; ci < Cin; ci++) {
-            const float* xp = x + ((long long)(b * Cin + ci) * H) * W;
+        for (int ci = 0; ci < 4; ci++) {
 #pragma unroll
             for (int t = 0; t < 9; t++) {
                 const int iy = yh + t / 3 - 1, ix = xw + t % 3 - 1;
-                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-                const float xv = xp[iy * W + ix];
-                const float* wr = ws + (ci * 9 + t) * Cout + v * 8;
-#pragma unroll
-                for (int e = 0; e < 8; e++) acc[e] += xv * wr[e];
+                float v = 0.f;
+                if (ci < Cin && iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((long long)(b * Cin + ci) * H + iy) * W + ix];
+                patch[ci * 9 + t] = v;
             }
         }
-        uint4 o;
-        o.x = pack2bf(acc[0], acc[1]); o.y = pack2bf(acc[2], acc[3]);
-        o.z = pack2bf(acc[4], acc[5]); o.w = pack2bf(acc[6], acc[7]);
-        *(uint4*)(out + pix * Cout + v * 8) = o;
+        bf16_t* op = out + ((long long)b * npix + lp) * Cout;
+#pragma unroll 1
+        for (int v8 = 0; v8 < Cout; v8 += 8) {
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] = ws[K * Cout + v8 + e];
+#pragma unroll
+            for (int k = 0; k < 36; k++) {
+                if (k < K) {
+                    const float4 w0 = *(const float4*)(ws + k * Cout + v8), w1 = *(const float4*)(ws + k * Cout + v8 + 4);
+                    const float pv = patch[k];
+                    acc[0] += pv * w0.x; acc[1] += pv * w0.y; acc[2] += pv * w0.z; acc[3] += pv * w0.w;
+                    acc[4] += pv * w1.x; acc[5] += pv * w1.y; acc[6] += pv * w1.z; acc[7] += pv * w1.w;
+                }
+            }
+            *(uint4*)(op + v8) = make_uint4(cvt_pk_bf16(acc[0], acc[1]), cvt_pk_bf16(acc[2], acc[3]), cvt_pk_bf16(acc[4], acc[5]), cvt_pk_bf16(acc[6], acc[7]));
+        }
     }
 }
 
@@ -51,9 +57,8 @@ hipError_t launch_conv_in(const float* x, const float* w, const float* bias, bf1
     if (Cout % 8) return hipErrorInvalidValue;
     const size_t sm = (size_t)(Cin * 9 + 1) * Cout * sizeof(float);
     if (sm > 64 * 1024) return hipErrorInvalidValue;
-    const long long total = (long long)H * W * (Cout / 8);
-    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
-    int grid = (int)((total + 255) / 256); const int cap_in = (2048 + B - 1) / B; if (grid > cap_in) grid = cap_in;
+    if (Cin > 4 || Cout % 8) return hipErrorInvalidValue;
+    int grid = (H * W + 255) / 256; const int cap_in = (2048 + B - 1) / B; if (grid > cap_in) grid = cap_in; if (grid < 1) grid = 1;
     conv_in_kernel<<<dim3(grid, B), 256, sm, st>>>(x, w, bias, out, B, Cin, H, W, Cout);
     return hipGetLastError();
 }
@@ -65,40 +70,50 @@ hipError_t launch_conv_in(const float* x, const float* w, const float* bias, bf1
 __global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* x, const float* w /*[Cout][Cin][3][3]*/,
                                                        const float* bias, float* out, int B, int H, int W, int Cin,
                                                        int Cout) {
+    // block = 32 pixels x 8 channel groups (lane & 7): a pixel's channel row is read by 8 neighbouring lanes in
+    // 16-byte pieces (coalesced), partial sums are combined with three xor-shuffles inside the 8-lane group.
     extern __shared__ float ws[];   // [Cout][9][Cin]
     for (int i = threadIdx.x; i < Cout * Cin * 9; i += 256) {
         const int co = i / (Cin * 9), r = i % (Cin * 9), ci = r / 9, t = r % 9;
         ws[(co * 9 + t) * Cin + ci] = w[i];
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int VC = Cin / 8, items = 9 * VC;
-    const int npix = H * W;                            // per sample (blockIdx.y = sample)
-    const int b = blockIdx.y;
-    for (int pix = blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += gridDim.x * 4) {
-        const int xw = pix % W, yh = pix / W;
+    const int g = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int VPG = Cin / 64;                            // 16-byte vectors per channel group per tap
+    const int b = blockIdx.y, npix = H * W;
+    for (int p0 = blockIdx.x * 32; p0 < npix; p0 += gridDim.x * 32) {
+        const int pix = p0 + pl;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int it = lane; it < items; it += 64) {
-            const int t = it / VC, v = it - t * VC;
-            const int iy = yh + t / 3 - 1, ix = xw + t % 3 - 1;
-            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-            const bf16x8 d = *(const bf16x8*)(x + (((long long)b * H + iy) * W + ix) * Cin + v * 8);
+        if (pix < npix) {
+            const int xw = pix % W, yh = pix / W;
 #pragma unroll
-            for (int co = 0; co < 4; co++) {
-                if (co < Cout) {
-                    const float* wr = ws + (co * 9 + t) * Cin + v * 8;
-                    float s = 0.f;
+            for (int t = 0; t < 9; t++) {
+                const int iy = yh + t / 3 - 1, ix = xw + t % 3 - 1;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                const bf16_t* xp = x + (((long long)b * H + iy) * W + ix) * Cin;
+                for (int v = 0; v < VPG; v++) {
+                    const int c = (v * 8 + g) * 8;        // consecutive lanes -> consecutive 16-byte pieces
+                    const bf16x8 d = *(const bf16x8*)(xp + c);
+                    float f[8];
 #pragma unroll
-                    for (int e = 0; e < 8; e++) s += bf2f((bf16_t)d[e]) * wr[e];
-                    acc[co] += s;
+                    for (int e = 0; e < 8; e++) f[e] = bf2f((bf16_t)d[e]);
+#pragma unroll
+                    for (int co = 0; co < 4; co++) {
+                        if (co < Cout) {
+                            const float* wr = ws + (co * 9 + t) * Cin + c;
+                            const float4 w0 = *(const float4*)wr, w1 = *(const float4*)(wr + 4);
+                            acc[co] += f[0] * w0.x + f[1] * w0.y + f[2] * w0.z + f[3] * w0.w + f[4] * w1.x + f[5] * w1.y + f[6] * w1.z + f[7] * w1.w;
+                        }
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int co = 0; co < 4; co++)
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) acc[co] += __shfl_xor(acc[co], o);
-        if (lane == 0) {
+        for (int co = 0; co < 4; co++) {
+            acc[co] += __shfl_xor(acc[co], 1); acc[co] += __shfl_xor(acc[co], 2); acc[co] += __shfl_xor(acc[co], 4);
+        }
+        if (g == 0 && pix < npix) {
+            const int xw = pix % W, yh = pix / W;
 #pragma unroll
             for (int co = 0; co < 4; co++)
                 if (co < Cout) out[((long long)(b * Cout + co) * H + yh) * W + xw] = acc[co] + bias[co];
@@ -108,11 +123,11 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* x, const fl
 
 hipError_t launch_conv_out(const bf16_t* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin,
                            int Cout, hipStream_t st) {
-    if (Cin % 8 || Cout > 4) return hipErrorInvalidValue;
+    if (Cin % 64 || Cout > 4) return hipErrorInvalidValue;
     const size_t sm = (size_t)Cout * 9 * Cin * sizeof(float);
     if (sm > 64 * 1024) return hipErrorInvalidValue;
     const int npix = H * W;
-    int grid = (npix + 3) / 4; const int cap_out = (4096 + B - 1) / B; if (grid > cap_out) grid = cap_out;
+    int grid = (npix + 31) / 32; const int cap_out = (4096 + B - 1) / B; if (grid > cap_out) grid = cap_out; if (grid < 1) grid = 1;
     conv_out_kernel<<<dim3(grid, B), 256, sm, st>>>(x, w, bias, out, B, H, W, Cin, Cout);
     return hipGetLastError();
 }

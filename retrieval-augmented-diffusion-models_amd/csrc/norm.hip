@@ -59,10 +59,13 @@ __global__ void gn_stats_kernel(GnParams p) {
     }
 }
 
-// grid (nblk, B); block 256. Each block first folds the partials of its sample into per-channel (a, b).
-__global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
-    extern __shared__ float sm[];          // [C][2]
+// grid (nblk, B); block = VC * R threads (same shape as the stats kernel). Every thread owns ONE 8-channel vector
+// for the whole launch, so (mean, rstd, gamma, beta) fold into 16 registers and the body is a pure 16-byte stream:
+// no LDS table (a per-channel table read with a 64-byte lane stride is a 16-way bank conflict).
+__global__ void gn_apply_kernel(GnParams p) {
     const int C = p.C0 + p.C1, VC = C >> 3, cg = C / p.groups;
+    const int R = blockDim.x / VC;
+    const int v = threadIdx.x % VC, rr = threadIdx.x / VC;
     const int b = blockIdx.y;
     __shared__ float gstat[64][2];
     if (threadIdx.x < p.groups) {
@@ -77,26 +80,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
         gstat[threadIdx.x][1] = (float)(1.0 / sqrt(var + (double)p.eps));
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const int g = c / cg;
-        const float a = gstat[g][1] * p.gamma[c];
-        sm[c * 2] = a; sm[c * 2 + 1] = p.beta[c] - gstat[g][0] * a;
-    }
-    __syncthreads();
-    const int total = p.HW * VC;                       // per sample; fits int32 (checked by the launcher)
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int row = i / VC, v = i - row * VC;
-        const bf16x8 d = *(const bf16x8*)gn_src(p, b, row, v * 8);
-        uint32_t o[4];
+    if (rr >= R) return;
+    float fa[8], fb[8];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int c = v * 8 + j * 2;
-            float y0 = bf2f((bf16_t)d[j * 2]) * sm[c * 2] + sm[c * 2 + 1];
-            float y1 = bf2f((bf16_t)d[j * 2 + 1]) * sm[c * 2 + 2] + sm[c * 2 + 3];
-            if (p.silu) { y0 = silu_f(y0); y1 = silu_f(y1); }
-            o[j] = pack2bf(y0, y1);
+    for (int e = 0; e < 8; e++) {
+        const int c = v * 8 + e, g = c / cg;
+        fa[e] = gstat[g][1] * p.gamma[c];
+        fb[e] = p.beta[c] - gstat[g][0] * fa[e];
+    }
+    const int rows_per = (p.HW + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows_per, r1 = min(p.HW, r0 + rows_per);
+    for (int row = r0 + rr; row < r1; row += R) {
+        const bf16x8 d = *(const bf16x8*)gn_src(p, b, row, v * 8);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            y[e] = bf2f((bf16_t)d[e]) * fa[e] + fb[e];
+            if (p.silu) y[e] = silu_f(y[e]);
         }
-        *(uint4*)(p.out + ((long long)(b * p.HW + row) * C + v * 8)) = make_uint4(o[0], o[1], o[2], o[3]);
+        *(uint4*)(p.out + ((long long)(b * p.HW + row) * C + v * 8)) =
+            make_uint4(cvt_pk_bf16(y[0], y[1]), cvt_pk_bf16(y[2], y[3]), cvt_pk_bf16(y[4], y[5]), cvt_pk_bf16(y[6], y[7]));
     }
 }
 
@@ -111,17 +114,13 @@ hipError_t launch_groupnorm(GnParams p, hipStream_t st) {
     gn_stats_kernel<<<dim3(p.nchunk, p.B), threads, sm1, st>>>(p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const long long total = (long long)p.HW * VC;
-    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
-    // fat blocks: the per-block prologue (fold partials, build the per-channel FMA table) is amortised over
-    // >= 32 vectors per thread, while keeping >= ~2k blocks in flight across the batch
-    int nblk = (int)((total + 256 * 32 - 1) / (256 * 32));
+    // apply: ~64 rows per thread-row, at least ~2k blocks across the batch
+    int nblk = (p.HW + 64 * R - 1) / (64 * R);
     const int min_blocks = (2048 + p.B - 1) / p.B;
     if (nblk < min_blocks) nblk = min_blocks;
-    const int max_blocks = (int)((total + 255) / 256);
-    if (nblk > max_blocks) nblk = max_blocks;
+    if (nblk > p.HW) nblk = p.HW;
     if (nblk < 1) nblk = 1;
-    gn_apply_kernel<<<dim3(nblk, p.B), 256, (size_t)C * 2 * sizeof(float), st>>>(p);
+    gn_apply_kernel<<<dim3(nblk, p.B), threads, 0, st>>>(p);
     return hipGetLastError();
 }
 
