@@ -92,8 +92,110 @@ __global__ __launch_bounds__(256) void flash_d32_kernel(FlashParams p) {
     }
 }
 
+// ---- LDS-shared variant (n % 64 == 0): the 4 waves of a block (128 query rows) share every 64-key chunk of K and V^T
+// through LDS instead of each fetching it from L2 (4x less L2 traffic: at n = 1024 the per-wave version moves 6.3 GB
+// per layer through L2).  Chunks are register-staged one iteration ahead (global loads issued before the MFMA work,
+// written to LDS after it), XOR-swizzled so the ds_read_b128 fragment reads are bank-conflict free.
+__global__ __launch_bounds__(256) void flash_d32_lds_kernel(FlashParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[2][8192];      // per buffer: K [64][32] bf16 | V^T [32][64] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const bool active = q0 < p.n;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int l31 = lane & 31, hf = lane >> 5;
+    const long long tok0 = (long long)b * p.n;
+
+    bf16x8 qf[2];
+    if (active) {
+        const bf16_t* qp = p.q + (tok0 + q0 + l31) * p.ldq + h * 32 + hf * 8;
+        qf[0] = *(const bf16x8*)(qp); qf[1] = *(const bf16x8*)(qp + 16);
+    }
+    // loader roles: K chunk = 64 rows x 4 pieces (t>>2, t&3); V^T chunk = 32 rows x 8 pieces (t>>3, t&7)
+    const int kr = tid >> 2, kc = tid & 3, vr = tid >> 3, vc = tid & 7;
+    const bf16_t* kg = p.k + (tok0 + kr) * p.ldk + h * 32 + kc * 8;
+    const bf16_t* vg = p.vt + ((long long)b * p.C + h * 32 + vr) * p.n + vc * 8;
+    const int k_st = kr * 64 + ((kc ^ ((kr >> 2) & 3)) << 4);              // swizzled LDS byte offsets (store side)
+    const int v_st = 4096 + vr * 128 + ((vc ^ ((vr >> 1) & 7)) << 4);
+    // fragment read offsets: K position l31 holds key pi(l31) (bits 2,3 swapped) of each 32-key sub-tile
+    const int pi = (l31 & ~0xc) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    bf16x8 kreg = *(const bf16x8*)kg, vreg = *(const bf16x8*)vg;
+    *(bf16x8*)(lds[0] + k_st) = kreg; *(bf16x8*)(lds[0] + v_st) = vreg;
+    __syncthreads();
+    const int nchunk = p.n >> 6;
+    for (int c = 0; c < nchunk; c++) {
+        const char* L = lds[c & 1];
+        if (c + 1 < nchunk) {                                  // stage the next chunk: loads now, LDS write after the math
+            kreg = *(const bf16x8*)(kg + (long long)(c + 1) * 64 * p.ldk);
+            vreg = *(const bf16x8*)(vg + (c + 1) * 64);
+        }
+        if (active) {
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++) {
+                const int krow = sub * 32 + pi;
+                const bf16x8 k0 = *(const bf16x8*)(L + krow * 64 + (((0 + hf) ^ ((krow >> 2) & 3)) << 4));
+                const bf16x8 k1 = *(const bf16x8*)(L + krow * 64 + (((2 + hf) ^ ((krow >> 2) & 3)) << 4));
+                const int vch = sub * 4 + hf;                  // 16-byte piece index of keys sub*32 + j*16 + hf*8
+                const bf16x8 v0 = *(const bf16x8*)(L + 4096 + l31 * 128 + (((vch) ^ ((l31 >> 1) & 7)) << 4));
+                const bf16x8 v1 = *(const bf16x8*)(L + 4096 + l31 * 128 + (((vch + 2) ^ ((l31 >> 1) & 7)) << 4));
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; r++) s[r] = 0.f;
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1], s, 0, 0, 0);
+                float mx = s[0];
+#pragma unroll
+                for (int r = 1; r < 16; r++) mx = fmaxf(mx, s[r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float mnew = fmaxf(m, mx * p.scale_log2e);
+                const float alpha = exp2f(m - mnew);
+                float ps = 0.f, pr[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) { pr[r] = exp2f(s[r] * p.scale_log2e - mnew); ps += pr[r]; }
+                l = l * alpha + ps; m = mnew;
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[r] *= alpha;
+                union { bf16x8 v; uint32_t u[4]; } pb0, pb1;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    pb0.u[i] = cvt_pk_bf16(pr[2 * i], pr[2 * i + 1]);
+                    pb1.u[i] = cvt_pk_bf16(pr[8 + 2 * i], pr[8 + 2 * i + 1]);
+                }
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb0.v, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb1.v, o, 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunk) {
+            char* Ln = lds[(c + 1) & 1];
+            *(bf16x8*)(Ln + k_st) = kreg; *(bf16x8*)(Ln + v_st) = vreg;
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    l += __shfl_xor(l, 32);
+    const float inv = 1.f / l;
+    bf16_t* op = p.out + (tok0 + q0 + l31) * p.ldo + h * 32 + 4 * hf;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        uint2 w;
+        w.x = cvt_pk_bf16(o[g * 4 + 0] * inv, o[g * 4 + 1] * inv);
+        w.y = cvt_pk_bf16(o[g * 4 + 2] * inv, o[g * 4 + 3] * inv);
+        *(uint2*)(op + 8 * g) = w;
+    }
+}
+
 hipError_t launch_flash_d32(const FlashParams& p, int heads, int batch, hipStream_t st) {
     if (p.n % 32 != 0 || p.C != heads * 32) return hipErrorInvalidValue;
+    if (p.n % 64 == 0) {
+        dim3 grid((p.n / 32 + 3) / 4, heads, batch);
+        flash_d32_lds_kernel<<<grid, 256, 0, st>>>(p);
+        return hipGetLastError();
+    }
     int nw = p.n / 32; if (nw > 4) nw = 4;
     dim3 grid((p.n / 32 + nw - 1) / nw, heads, batch);
     flash_d32_kernel<<<grid, nw * 64, 0, st>>>(p);

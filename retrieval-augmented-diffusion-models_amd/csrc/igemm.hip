@@ -336,7 +336,8 @@ hipError_t launch_igemm(const IgemmParams& p_in, bool conv, int batch, hipStream
     static const int force_bm = getenv("RDM_IGEMM_BM") ? atoi(getenv("RDM_IGEMM_BM")) : 0;
     const bool wide = (p.N % 192 == 0);
     const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.N + (wide ? 191 : 127)) / (wide ? 192 : 128)) * batch;
-    bool tall = tiles256 >= 512;
+    // short-K linears are latency/HBM-bound: two independent 4-wave blocks per CU hide more than one 8-wave block
+    bool tall = tiles256 >= 512 && (conv || p.K >= 1024);
     if (force_bm == 128) tall = false;
     if (force_bm == 256) tall = true;
     if (p.act == ACT_GEGLU) {
