@@ -162,6 +162,29 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
     const bool uniform_sample = (p.rows_per_sample % 32) == 0;
 
     while (true) {
+        const int em0 = m0, en0 = n0;                 // this tile's origin (setup(next) overwrites m0/n0)
+        // ---- tile prologue: fetch bias (+ time-embedding row) into registers now; consumed in the epilogue, so their
+        // latency hides under the K loop.  (The residual stays an epilogue load: vmcnt retires in order, so anything
+        // issued here would stall the first K-slice wait by a full HBM round trip.)
+        const bool full = (em0 + BM <= p.M) && (en0 + BN <= p.N);
+        const int odd = lane & 1;
+        float pbias[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; i++) {
+            const int mf = em0 + wm * WM + i * 32;
+            const float* rv = nullptr;
+            if (p.rowvec && uniform_sample && mf < p.M) rv = p.rowvec + (long long)(mf / p.rows_per_sample) * p.rowvec_ld;
+#pragma unroll
+            for (int j = 0; j < FN; j++) {
+                const int ncol = en0 + wn * WN + j * 32 + frow;
+                float bv = 0.f;
+                if (full || ncol < p.N) {
+                    if (p.bias) bv = p.bias[ncol];          // GEGLU: x and gate fragments each get their own (permuted) bias
+                    if (rv) bv += rv[ncol];
+                }
+                pbias[i][j] = bv;
+            }
+        }
         f32x16 acc[FM][FN];
 #pragma unroll
         for (int i = 0; i < FM; i++)
@@ -170,7 +193,6 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-        const int em0 = m0, en0 = n0;                 // this tile's origin (setup(next) overwrites m0/n0)
         const int next = tile + gx;
         const bool has_next = next < t_end;
 
@@ -233,24 +255,44 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
         // addresses are a per-fragment base pointer plus compile-time multiples of ldo; bounds checks only on
         // tail tiles.
         if (!(p.dbg & 4)) {
-            const bool full = (em0 + BM <= p.M) && (en0 + BN <= p.N);
-            const int odd = lane & 1;
 #pragma unroll
             for (int i = 0; i < FM; i++) {
                 const int mf = em0 + wm * WM + i * 32;                 // first row of this fragment
-                const float* rv = nullptr;
-                if (p.rowvec && uniform_sample && mf < p.M) rv = p.rowvec + (long long)(mf / p.rows_per_sample) * p.rowvec_ld;
+                // bf16 residual words are requested two fragments at a time, ahead of the stores: loads must not trail
+                // the previous fragment's stores (out may alias the residual, so the compiler will not hoist them),
+                // and 16 words in flight per lane is what the register budget of the 192-wide tiles allows
+                constexpr bool BATCH_RES = !GEGLU && (CONV == 0 || BN == 128);   // the 192-wide conv tiles have no registers to spare
+                uint32_t rw[2][8];
+                auto load_res = [&](int j0) {
+                    if constexpr (BATCH_RES) {
+                        if (rb) {
+#pragma unroll
+                            for (int jj = 0; jj < 2; jj++) {
+                                const int j = j0 + jj;
+                                if (j >= FN) continue;
+                                const int pc = en0 + wn * WN + j * 32 + frow - odd;
+                                const long long rbase = (long long)(mf + 4 * fhalf + odd) * p.ldo + pc;
+                                const bool pok = full || (pc + 1 < p.N);
+#pragma unroll
+                                for (int t = 0; t < 8; t++) {
+                                    const int roff = ((2 * t) & 3) + 8 * ((2 * t) >> 2);
+                                    rw[jj][t] = 0;
+                                    if (full || (pok && mf + 4 * fhalf + odd + roff < p.M)) rw[jj][t] = *(const uint32_t*)(rb + rbase + (long long)roff * p.ldo);
+                                }
+                            }
+                        }
+                    }
+                };
 #pragma unroll
                 for (int j = 0; j < FN; j++) {
                     if constexpr (GEGLU) { if (j & 1) continue; }
+                    if ((j & 1) == 0) load_res(j);
                     const int ncol = en0 + wn * WN + j * 32 + frow;      // column in (permuted) weight space
                     const bool col_ok = full || ncol < p.N;
                     const int ocol = GEGLU ? ((en0 + wn * WN + j * 32) >> 1) + frow : ncol;
-                    float bias = 0.f, gbias = 0.f;
-                    if (col_ok) {
-                        if (p.bias) { bias = p.bias[ncol]; if constexpr (GEGLU) gbias = p.bias[ncol + 32]; }
-                        if (rv) bias += rv[ncol];
-                    }
+                    const float bias = pbias[i][j];
+                    float gbias = 0.f;
+                    if constexpr (GEGLU) gbias = pbias[i][(j + 1) < FN ? (j + 1) : j];
                     float v[16];
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
@@ -282,7 +324,8 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
                         float hi = odd ? v[2 * t + 1] : got;
                         if (full || (pair_ok && mrow + roff < p.M)) {
                             const long long o = base + (long long)roff * p.ldo;
-                            if (rb) { const uint32_t u = *(const uint32_t*)(rb + o); lo += __uint_as_float(u << 16); hi += __uint_as_float(u & 0xffff0000u); }
+                            if constexpr (BATCH_RES) { if (rb) { const uint32_t u = rw[j & 1][t]; lo += __uint_as_float(u << 16); hi += __uint_as_float(u & 0xffff0000u); } }
+                            else { if (rb) { const uint32_t u = *(const uint32_t*)(rb + o); lo += __uint_as_float(u << 16); hi += __uint_as_float(u & 0xffff0000u); } }
                             if (rf) { const float2 f = *(const float2*)(rf + o); lo += f.x; hi += f.y; }
                             if (ob) *(uint32_t*)(ob + o) = cvt_pk_bf16(lo, hi);
                             if (of) *(float2*)(of + o) = make_float2(lo, hi);
