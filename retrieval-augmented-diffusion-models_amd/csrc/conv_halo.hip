@@ -1,0 +1,283 @@
+// Input-stationary 3x3 convolution (stride 1, pad 1) for NHWC bf16 on gfx950 — the UNet's dominant kernel.
+//
+// The generic implicit GEMM (igemm.hip) re-stages the A tile from L2 for each of the 9 taps; profiling shows it is
+// bound by the L2->LDS fabric (~12 TB/s; operand staging alone takes as long as the MFMA loop).  Here a block owns
+// 256 consecutive output pixels (whole image rows) and, per 64-channel slice, stages the (rows+2) x (W+2) HALO of the
+// input in LDS ONCE; the 9 taps are then 9 K-slices whose A fragments are read from the halo at a tap-shifted
+// position (a wave-uniform LDS offset), so only the 24 KB weight slice streams per K-slice: L2->LDS traffic per
+// K-slice drops from 56 KB to ~30 KB (A/9 + B).  Zero padding = halo positions outside the image point at a zero page.
+// Same persistent XCD-aware tile walk, hand-pipelined ds_read/MFMA loop and DPP-paired epilogue as igemm.hip.
+// Replaces conv_nd(2, C, C', 3, padding=1) inside ResBlock in_layers/out_layers (ldm, via
+// rdm/modules/diffusionmodules/openaimodel.py:144-305) — 44 of the 49 3x3 convs per UNet forward.
+#include <stdlib.h>
+
+#include "kernels.h"
+
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
+    constexpr int BM = 256, BK = 64, NT = 512;
+    constexpr int WM = 64, WN = BN / 2, FM = 2, FN = WN / 32;
+    constexpr int HALO_BYTES = 400 * 128;                 // <= 400 halo positions x 64 channels bf16
+    constexpr int B_BYTES = BN * BK * 2;
+    constexpr int BP = BN / 64;                           // weight loader passes (512 threads = 64 rows x 8 chunks)
+    constexpr int HPASS = 7;                              // halo loader passes (64 positions each)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [halo0][halo1][B0][B1]
+    char* const halo_base = smem;
+    char* const b_base = smem + 2 * HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 31, fhalf = lane >> 5;
+
+    // ---- geometry (uniform)
+    const int H = p.Hin, W = p.Win, HW = H * W;
+    const int RS = (HW >= BM) ? BM / W : H;               // image rows per sample-part of a tile
+    const int NS = BM / (RS * W);                         // samples per tile (1, or 4 at 8x8)
+    const int HPW = W + 2, HPS = (RS + 2) * HPW, HP = NS * HPS;
+    const int Cin = p.C0 + p.C1, nslice = Cin / BK;
+
+    const int nbn = p.N / BN, nbm = p.M / BM;
+    const int ntiles = nbm * nbn;
+    const int G = gridDim.x, xcd = blockIdx.x & 7;
+    const int gx = (G - xcd + 7) >> 3;
+    const int tq = ntiles >> 3, tr = ntiles & 7;
+    const int t_begin = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int t_end = t_begin + tq + (xcd < tr ? 1 : 0);
+    int tile = t_begin + (blockIdx.x >> 3);
+    if (tile >= t_end) return;
+
+    const char* zero = (const char*)p.zero_page;
+    const int lrow = tid >> 3, pchunk = tid & 7;
+    const int sc8 = (pchunk ^ ((lrow >> 1) & 7)) * 8;     // source chunk for LDS row (pos) == lrow (mod 16): 64 | pass stride
+
+    // ---- per-tile loader state
+    int hpix[HPASS];                                      // pixel index of my halo position in each pass, or -1
+    int b_n[BP];
+    int m0, n0;
+    auto setup = [&](int t) {
+        const int bm = t / nbn, bn = t - bm * nbn;
+        m0 = bm * BM; n0 = bn * BN;
+        const int b0 = m0 / HW, y0 = (m0 - b0 * HW) / W;
+#pragma unroll
+        for (int ps = 0; ps < HPASS; ps++) {
+            const int hp = ps * 64 + lrow;
+            int pix = -1;
+            if (hp < HP) {
+                const int s = hp / HPS, r = hp - s * HPS;
+                const int hy = r / HPW, hx = r - hy * HPW;
+                const int y = y0 + hy - 1, x = hx - 1;
+                if (y >= 0 && y < H && x >= 0 && x < W) pix = ((b0 + s) * H + y) * W + x;
+            }
+            hpix[ps] = pix;
+        }
+#pragma unroll
+        for (int i = 0; i < BP; i++) b_n[i] = n0 + i * 64 + lrow;
+    };
+    // one pass of the halo of channel slice `sl` -> halo buffer hb
+    auto stage_halo_pass = [&](int ps, int sl, int hb) {
+        if (ps * 64 >= HP) return;
+        const int kc = sl * BK;
+        const bool second = kc >= p.C0;
+        const bf16_t* src = second ? p.A1 : p.A0;
+        const int ld = second ? p.C1 : p.C0;
+        const bf16_t* lane_src = src + ((second ? kc - p.C0 : kc) + sc8);
+        const void* g = (hpix[ps] >= 0) ? (const void*)(lane_src + (long long)hpix[ps] * ld) : (const void*)zero;
+        // lanes past the last halo position stay masked off: their LDS slot would lie beyond this halo buffer
+        if (ps * 64 + lrow < HP) glds16(g, halo_base + hb * HALO_BYTES + (ps * 64 + wave * 8) * 128);
+    };
+    auto stage_b = [&](int sl, int tap, int bb) {
+        const bf16_t* lane_w = p.W + ((long long)tap * Cin + sl * BK + sc8);
+#pragma unroll
+        for (int i = 0; i < BP; i++)
+            glds16(lane_w + (long long)b_n[i] * p.K, b_base + bb * B_BYTES + (i * 64 + wave * 8) * 128);
+    };
+
+    // ---- fragment addressing: pixel row -> halo position of tap (0,0)
+    int hp0[FM];
+    {
+#pragma unroll
+        for (int i = 0; i < FM; i++) {
+            const int pl = wm * WM + i * 32 + frow;                    // pixel within the tile
+            const int s = pl / (RS * W), r = pl - s * RS * W;
+            const int ly = r / W, x = r - ly * W;
+            hp0[i] = s * HPS + ly * HPW + x;
+        }
+    }
+    const unsigned vb0 = (unsigned)(2 * HALO_BYTES) + (unsigned)(wn * WN * 128) + (unsigned)(frow * 128 + ((fhalf ^ ((frow >> 1) & 7)) << 4));
+
+    bf16_t* ob = p.out_bf16;
+    const bf16_t* rb = p.res_bf16;
+    const bool uniform_sample = (p.rows_per_sample % 32) == 0;
+    const int odd = lane & 1;
+
+    // ---- pipeline prologue: halo of slice 0 and weights of (slice 0, tap 0)
+    setup(tile);
+#pragma unroll
+    for (int ps = 0; ps < HPASS; ps++) stage_halo_pass(ps, 0, 0);
+    stage_b(0, 0, 0);
+    int hcur = 0, bcur = 0;
+
+    while (true) {
+        const int em0 = m0, en0 = n0;
+        const int next = tile + gx;
+        const bool has_next = next < t_end;
+        float pbias[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; i++) {
+            const int mf = em0 + wm * WM + i * 32;
+            const float* rv = (p.rowvec && uniform_sample) ? p.rowvec + (long long)(mf / p.rows_per_sample) * p.rowvec_ld : nullptr;
+#pragma unroll
+            for (int j = 0; j < FN; j++) {
+                const int ncol = en0 + wn * WN + j * 32 + frow;
+                float bv = p.bias ? p.bias[ncol] : 0.f;
+                if (rv) bv += rv[ncol];
+                pbias[i][j] = bv;
+            }
+        }
+        f32x16 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; i++)
+#pragma unroll
+            for (int j = 0; j < FN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+        for (int sl = 0; sl < nslice; sl++) {
+            const bool last_slice = sl + 1 == nslice;
+#pragma unroll 1
+            for (int tap = 0; tap < 9; tap++) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();          // weights (sl,tap) [+ halo sl at tap 0] landed; previous buffers are free
+                // ---- issue the next loads: weights of the next K-slice, one pass of the next halo
+                if (tap < 8) stage_b(sl, tap + 1, bcur ^ 1);
+                else if (!last_slice) stage_b(sl + 1, 0, bcur ^ 1);
+                else if (has_next) {      // cross-tile prefetch: weights + halo of the next tile's first slice
+                    setup(next);
+                    stage_b(0, 0, bcur ^ 1);
+#pragma unroll
+                    for (int ps = 0; ps < HPASS; ps++) stage_halo_pass(ps, 0, hcur ^ 1);
+                }
+                if (!last_slice && tap < HPASS) stage_halo_pass(tap, sl + 1, hcur ^ 1);
+
+                // ---- MFMA over this K-slice (64 channels of one tap), A from the halo at a tap-shifted position
+                const int dy = tap / 3, dx = tap - dy * 3;
+                const int tapoff = dy * HPW + dx;
+                unsigned va[FM];
+#pragma unroll
+                for (int i = 0; i < FM; i++) {
+                    const int hp = hp0[i] + tapoff;
+                    va[i] = (unsigned)(hcur * HALO_BYTES) + (unsigned)(hp * 128 + ((fhalf ^ ((hp >> 1) & 7)) << 4));
+                }
+                const unsigned vb = vb0 + (unsigned)(bcur * B_BYTES);
+                bf16x8 fa[2][FM], fb[2][FN];
+#define RDM_LDS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#pragma unroll
+                for (int i = 0; i < FM; i++) RDM_LDS_READ(fa[0][i], va[i], 0);
+#pragma unroll
+                for (int j = 0; j < FN; j++) RDM_LDS_READ(fb[0][j], vb, j * 4096);
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const int cs = kk & 1, ns = cs ^ 1;
+                    if (kk < 3) {
+                        const unsigned x = (unsigned)((kk + 1) << 5);
+#pragma unroll
+                        for (int i = 0; i < FM; i++) { const unsigned a = va[i] ^ x; RDM_LDS_READ(fa[ns][i], a, 0); }
+                        const unsigned vbn = vb ^ x;
+#pragma unroll
+                        for (int j = 0; j < FN; j++) RDM_LDS_READ(fb[ns][j], vbn, j * 4096);
+                        if constexpr (FM + FN == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+                        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < FM; i++)
+#pragma unroll
+                        for (int j = 0; j < FN; j++)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cs][i], fb[cs][j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef RDM_LDS_READ
+                bcur ^= 1;
+            }
+            hcur ^= 1;
+        }
+
+        // ---- epilogue (same scheme as igemm.hip: DPP lane-pair swap -> one packed 4-byte store per register pair)
+#pragma unroll
+        for (int i = 0; i < FM; i++) {
+            const int mf = em0 + wm * WM + i * 32;
+#pragma unroll
+            for (int j = 0; j < FN; j++) {
+                const int ncol = en0 + wn * WN + j * 32 + frow;
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    float x = acc[i][j][r] + pbias[i][j];
+                    if (p.rowvec && !uniform_sample) {
+                        const int m = mf + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                        x += p.rowvec[(long long)(m / p.rows_per_sample) * p.rowvec_ld + ncol];
+                    }
+                    v[r] = x;
+                }
+                const int mrow = mf + 4 * fhalf + odd;
+                const long long base = (long long)mrow * p.ldo + (ncol - odd);
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const int roff = ((2 * t) & 3) + 8 * ((2 * t) >> 2);
+                    const float give = odd ? v[2 * t] : v[2 * t + 1];
+                    const float got = swap_adjacent_lane(give);
+                    float lo = odd ? got : v[2 * t];
+                    float hi = odd ? v[2 * t + 1] : got;
+                    const long long o = base + (long long)roff * p.ldo;
+                    if (rb) { const uint32_t u = *(const uint32_t*)(rb + o); lo += __uint_as_float(u << 16); hi += __uint_as_float(u & 0xffff0000u); }
+                    *(uint32_t*)(ob + o) = cvt_pk_bf16(lo, hi);
+                }
+            }
+        }
+        if (!has_next) break;
+        tile = next;
+    }
+}
+
+template <int BN>
+static hipError_t launch_halo(const IgemmParams& p, hipStream_t st) {
+    constexpr int smem = 2 * 400 * 128 + 2 * BN * 128;
+    static int ncu = 0;
+    if (!ncu) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        int dev = 0; hipGetDevice(&dev);
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    const long long ntiles = (long long)(p.M / 256) * (p.N / BN);
+    long long g = (ncu + 7) & ~7;
+    if (g > ntiles) g = ntiles;
+    conv3x3_halo_kernel<BN><<<dim3((unsigned)g), 512, smem, st>>>(p);
+    return hipGetLastError();
+}
+
+// true if the halo kernel can take this conv (else the caller uses the generic implicit GEMM)
+bool conv_halo_supported(const IgemmParams& p) {
+    static const int off = getenv("RDM_NO_HALO") ? atoi(getenv("RDM_NO_HALO")) : 0;
+    if (off) return false;
+    const int W = p.Win, H = p.Hin;
+    if (p.stride != 1 || p.ups || p.Hout != H || p.Wout != W) return false;
+    if (W < 4 || W > 64 || 256 % W != 0) return false;
+    const int HW = H * W;
+    if (HW >= 256) { if (HW % 256 != 0 || H % (256 / W) != 0) return false; }
+    else if (256 % HW != 0) return false;
+    if (p.M % 256 != 0 || (p.N % 192 != 0 && p.N % 128 != 0)) return false;
+    if (p.C0 % 64 || p.C1 % 64 || p.alpha != 1.0f || p.act != ACT_NONE || !p.out_bf16 || p.out_f32 || p.res_f32) return false;
+    if (p.ldo % 2 || p.K != 9 * (p.C0 + p.C1)) return false;
+    const int RS = (HW >= 256) ? 256 / W : H, NS = 256 / (RS * W);
+    if (NS * (RS + 2) * (W + 2) > 400) return false;
+    if ((long long)p.M * (p.C0 > p.C1 ? p.C0 : p.C1) >= 0x7fffffffLL * 1LL) return false;
+    return true;
+}
+
+hipError_t launch_conv_halo(const IgemmParams& p, hipStream_t st) {
+    return (p.N % 192 == 0) ? launch_halo<192>(p, st) : launch_halo<128>(p, st);
+}

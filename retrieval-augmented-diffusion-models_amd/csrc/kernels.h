@@ -43,6 +43,12 @@ struct DdpmStepParams {
 };
 
 hipError_t launch_igemm(const IgemmParams& p, bool conv, int batch, hipStream_t st);
+bool conv_halo_supported(const IgemmParams& p);
+hipError_t launch_conv_halo(const IgemmParams& p, hipStream_t st);
+// 3x3 conv dispatcher: input-stationary halo kernel when the geometry allows, else the generic implicit GEMM
+inline hipError_t launch_conv3x3(const IgemmParams& p, hipStream_t st) {
+    return conv_halo_supported(p) ? launch_conv_halo(p, st) : launch_igemm(p, true, 1, st);
+}
 hipError_t launch_groupnorm(GnParams p, hipStream_t st);
 hipError_t launch_layernorm(const void* x, int in_is_f32, const float* gamma, const float* beta, void* out, int out_is_f32,
                             int M, int C, float eps, hipStream_t st);

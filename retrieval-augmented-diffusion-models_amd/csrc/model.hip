@@ -347,7 +347,7 @@ struct Ops {
         p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.stride = stride; p.ups = ups;
         p.rowvec = rowvec; p.rowvec_ld = rowvec_ld; p.rows_per_sample = Hout * Wout; p.res_bf16 = res; p.out_bf16 = out;
         prof_begin(0, 2.0 * p.M * N * (double)p.K);
-        check(launch_igemm(p, true, 1, c->stream), "conv3x3");
+        check(launch_conv3x3(p, c->stream), "conv3x3");
         prof_end();
     }
     void prof_begin(int kind, double flops) {
@@ -982,7 +982,7 @@ int rdm_op_conv3x3(rdm_ctx* c, const void* x0, const void* x1, int C0, int C1, c
     p.A0 = (const bf16_t*)x0; p.A1 = (const bf16_t*)x1; p.C0 = C0; p.C1 = C1; p.W = (const bf16_t*)w; p.bias = bias;
     p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.stride = stride; p.ups = ups;
     p.rowvec = rowvec; p.rowvec_ld = rowvec_ld; p.rows_per_sample = Hout * Wout; p.res_bf16 = (const bf16_t*)res; p.out_bf16 = (bf16_t*)out;
-    RDM_CHECK_HIP(c, launch_igemm(p, true, 1, c->stream));
+    RDM_CHECK_HIP(c, launch_conv3x3(p, c->stream));
     return 0;
 }
 int rdm_op_groupnorm(rdm_ctx* c, const void* x0, const void* x1, int C0, int C1, int B, int HW, const float* gamma,

@@ -91,6 +91,27 @@ def test_conv3x3(ctx, B, H, W, C, N, stride, ups):
     _close(out, ref, what="conv3x3")
 
 
+@pytest.mark.parametrize("B,H,W,C0,C1,N", [(4, 8, 8, 64, 0, 192), (8, 8, 8, 128, 64, 192), (1, 16, 16, 64, 64, 128), (2, 32, 32, 64, 0, 192),
+                                            (1, 64, 64, 64, 0, 384), (1, 64, 64, 128, 0, 128), (3, 16, 16, 192, 0, 192)])
+def test_conv3x3_halo_kernel(ctx, B, H, W, C0, C1, N):
+    """Shapes the input-stationary halo kernel takes (B*H*W % 256 == 0, W <= 64): every tile geometry (4 samples per
+    tile at 8x8, whole image at 16x16, 8 / 4 rows at 32 / 64 wide), dual source, time-embedding row and residual."""
+    d = ctx.device
+    C = C0 + C1
+    x0 = bf16_round(_rand((B, H, W, C0), 40))
+    x1 = bf16_round(_rand((B, H, W, C1), 41)) if C1 else None
+    w, b = bf16_round(_rand((N, C, 3, 3), 42, (9 * C) ** -0.5)), _rand((N,), 43, 0.1)
+    temb, res = _rand((B, N), 44), bf16_round(_rand((B, H, W, N), 45))
+    xc = x0 if x1 is None else torch.cat([x0, x1], -1)
+    ref = _conv_ref(xc, w, b) + temb[:, None, None, :] + res
+    out = ctx.op_conv3x3(x0.to(d, torch.bfloat16), _pack_conv(w).to(d, torch.bfloat16), b.to(d),
+                         x1=None if x1 is None else x1.to(d, torch.bfloat16), rowvec=temb.to(d), residual=res.to(d, torch.bfloat16))
+    _close(out, ref, what="conv3x3 halo")
+    out2 = ctx.op_conv3x3(x0.to(d, torch.bfloat16), _pack_conv(w).to(d, torch.bfloat16), b.to(d),
+                          x1=None if x1 is None else x1.to(d, torch.bfloat16))
+    _close(out2, _conv_ref(xc, w, b), what="conv3x3 halo plain")
+
+
 def test_conv3x3_dual_source_rowvec_residual(ctx):
     d = ctx.device
     B, H, W, C0, C1, N = 2, 8, 8, 128, 64, 192
