@@ -117,6 +117,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
     for (int ps = 0; ps < HPASS; ps++) stage_halo_pass(ps, 0, 0);
     stage_b(0, 0, 0);
     int hcur = 0, bcur = 0;
+    int pending_stores = -1;
 
     while (true) {
         const int em0 = m0, en0 = n0;
@@ -147,7 +148,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
             const bool last_slice = sl + 1 == nslice;
 #pragma unroll 1
             for (int tap = 0; tap < 9; tap++) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // first K-slice of a tile: its weights + halo were prefetched BEFORE the previous epilogue's stores;
+                // leave those stores in flight (vmcnt retires in order and counts stores) instead of draining them
+                if (sl == 0 && tap == 0 && pending_stores == FM * FN * 8) {
+                    if constexpr (FM * FN * 8 == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();          // weights (sl,tap) [+ halo sl at tap 0] landed; previous buffers are free
                 // ---- issue the next loads: weights of the next K-slice, one pass of the next halo
                 if (tap < 8) stage_b(sl, tap + 1, bcur ^ 1);
@@ -239,6 +245,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
         }
         if (!has_next) break;
         tile = next;
+        pending_stores = FM * FN * 8;      // every tile of this kernel is full: one 4-byte store per register pair
     }
 }
 

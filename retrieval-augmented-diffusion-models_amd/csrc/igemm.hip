@@ -159,6 +159,7 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
     setup(tile);
     stage(0, 0);
     int cur = 0;
+    int pending_stores = -1;             // stores the previous tile's epilogue issued after this tile's prefetch (-1: unknown)
     const bool uniform_sample = (p.rows_per_sample % 32) == 0;
 
     while (true) {
@@ -197,7 +198,15 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
         const bool has_next = next < t_end;
 
         for (int kt = 0; kt < nk; kt++) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // vmcnt retires in order and counts STORES too: draining to 0 here would expose the whole write latency
+            // of the previous tile's epilogue.  This tile's first K-slice was prefetched BEFORE those stores, so it
+            // has landed once at most `pending_stores` operations (all of them younger) remain in flight.  (A smaller
+            // count than the number of younger operations actually issued is always safe; the bias loads issued
+            // after the stores only make the wait release a few stores later.)
+            if (kt == 0 && pending_stores == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+            else if (kt == 0 && pending_stores == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (kt == 0 && pending_stores == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                       // K-slice kt landed; everyone is done reading buffer cur^1
             if (!(p.dbg & 2)) {
                 if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
@@ -336,6 +345,11 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
         }
         if (!has_next) break;
         tile = next;
+        {
+            constexpr int NFRAG = GEGLU ? FM * FN / 2 : FM * FN;
+            const int nout = (ob ? 1 : 0) + (of ? 1 : 0);
+            pending_stores = (full && !(p.dbg & 4)) ? NFRAG * 8 * nout : -1;      // exact only for full tiles
+        }
     }
 }
 
