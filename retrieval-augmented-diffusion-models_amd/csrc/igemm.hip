@@ -62,20 +62,29 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
     const float* rf = p.res_f32 ? p.res_f32 + zb * p.sO : nullptr;
     const int Cin = p.C0 + p.C1;
     const int nk = p.K / BK;
+    const bool uniform_sample = (p.rows_per_sample % 32) == 0;
 
-    // ---- loader state (per tile): one pixel/row index and one 9-bit tap-validity mask per loader pass. A K-slice
-    //      adds a wave-uniform scalar (channel offset + tap displacement) and tests one mask bit.
+    // ---- operand streams.  K-slices are consumed in one continuous stream that runs across tile boundaries
+    //      (slice index g = 0,1,2,... of this block).  A (activations: HBM latency) is requested TWO slices ahead
+    //      into a 3-slot LDS ring, B (weights: L2-resident) ONE slice ahead into a 2-slot ring; each stream carries
+    //      its own tile state, so the prefetch runs through the epilogue of the tile being finished.  vmcnt retires in
+    //      order (and counts stores), so every wait is COUNTED: it leaves the A slice requested after the needed B
+    //      slice, and the previous tile's epilogue stores, in flight.
     const int lrow = tid >> 3;          // 0..RPP-1
     const int pchunk = tid & 7;         // physical 16B chunk in the LDS row
     const int sc8 = (pchunk ^ ((lrow >> 1) & 7)) * 8;   // source chunk (swizzle on the SOURCE side); RPP % 16 == 0
-    int m0, n0;
+    constexpr int A_SLOTS = (BM >= 256) ? 3 : 2;        // 128-row tiles keep 2 slots (80 KB -> two blocks per CU)
+    char* const a_ring = smem;                          // [A_SLOTS][A_BYTES]
+    char* const b_ring = smem + A_SLOTS * A_BYTES;      // [2][B_BYTES]
+
+    // A stream
+    int a_tile = tile, a_kt = 0, a_g = 0;
+    bool a_live = true;
     int a_pix[AP];                      // linear: row m; conv: centre pixel index (fused-upsample: sample base pixel)
     int a_mask[AP];                     // bit t: tap t readable (linear: 0x1ff or 0); upsample: | oy << 9 | ox << 20
-    int b_n[BP];                        // weight row (or -1)
-
-    auto setup = [&](int t) {
-        const int bm = t / nbn, bn = t - bm * nbn;
-        m0 = bm * BM; n0 = bn * BN;
+    int k_ci = 0, k_tap = 0;            // channel offset inside the current tap, tap index (wave-uniform)
+    auto setup_a = [&](int t) {
+        const int m0 = (t / nbn) * BM;
 #pragma unroll
         for (int i = 0; i < AP; i++) {
             const int m = m0 + i * RPP + lrow;
@@ -109,25 +118,16 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
                 }
             }
         }
-#pragma unroll
-        for (int i = 0; i < BP; i++) {
-            const int n = n0 + i * RPP + lrow;
-            b_n[i] = (n < p.N) ? n : -1;
-        }
     };
-
-    // K-slice bookkeeping (wave-uniform): channel offset inside the current tap, tap index
-    int k_ci = 0, k_tap = 0;
-    auto stage = [&](int kt, int buf) {
-        char* As = smem + buf * STAGE;
-        char* Bs = As + A_BYTES;
-        if (kt == 0) { k_ci = 0; k_tap = 0; }
+    // request the A slice at the head of the A stream, then advance the stream
+    auto issue_a = [&]() {
+        char* As = a_ring + (a_g % A_SLOTS) * A_BYTES;
+        if (a_kt == 0) { k_ci = 0; k_tap = 0; }
         const int dy = k_tap / 3, dx = k_tap - dy * 3;
         const bool second = k_ci >= p.C0;
         const bf16_t* src = second ? A1 : A0;
         const int ld = second ? p.C1 : p.C0;
-        const int cofs = second ? k_ci - p.C0 : k_ci;
-        const bf16_t* lane_src = src + (cofs + sc8);
+        const bf16_t* lane_src = src + ((second ? k_ci - p.C0 : k_ci) + sc8);
         if (CONV == 2) {
 #pragma unroll
             for (int i = 0; i < AP; i++) {
@@ -146,27 +146,72 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
                 glds16(g, As + (i * RPP + wave * 8) * 128);
             }
         }
-        const bf16_t* lane_w = W + ((long long)kt * BK + sc8);
+        k_ci += BK;
+        if (CONV && k_ci >= Cin) { k_ci = 0; k_tap++; }
+        a_g++;
+        if (++a_kt == nk) {
+            a_kt = 0; a_tile += gx;
+            a_live = a_tile < t_end;
+            if (a_live) setup_a(a_tile);
+        }
+    };
+    // B stream
+    int b_tile = tile, b_kt = 0, b_g = 0;
+    bool b_live = true;
+    int b_n[BP];                        // weight row (or -1)
+    auto setup_b = [&](int t) {
+        const int n0 = (t % nbn) * BN;
+#pragma unroll
+        for (int i = 0; i < BP; i++) {
+            const int n = n0 + i * RPP + lrow;
+            b_n[i] = (n < p.N) ? n : -1;
+        }
+    };
+    auto issue_b = [&]() {
+        char* Bs = b_ring + (b_g & 1) * B_BYTES;
+        const bf16_t* lane_w = W + ((long long)b_kt * BK + sc8);
 #pragma unroll
         for (int i = 0; i < BP; i++) {
             const void* g = (b_n[i] >= 0) ? (const void*)(lane_w + (long long)b_n[i] * p.K) : (const void*)zero;
             glds16(g, Bs + (i * RPP + wave * 8) * 128);
         }
-        k_ci += BK;
-        if (CONV && k_ci >= Cin) { k_ci = 0; k_tap++; }
+        b_g++;
+        if (++b_kt == nk) {
+            b_kt = 0; b_tile += gx;
+            b_live = b_tile < t_end;
+            if (b_live) setup_b(b_tile);
+        }
     };
 
-    setup(tile);
-    stage(0, 0);
-    int cur = 0;
-    int pending_stores = -1;             // stores the previous tile's epilogue issued after this tile's prefetch (-1: unknown)
-    const bool uniform_sample = (p.rows_per_sample % 32) == 0;
+    // counted wait: at most n VMEM operations (all younger than the slices needed now) may remain in flight
+    auto wait_vm = [&](int n) {
+        switch (n) {
+            case 52: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
+            case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+            case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+            case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+            case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 8:  asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 4:  asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    static_assert(AP == 4, "counted waits assume 4 A requests per thread per slice");
+
+    // ---- prologue: A(0), B(0), A(1)
+    setup_a(tile); setup_b(tile);
+    issue_a();
+    issue_b();
+    bool a_ahead = false;               // was an A slice requested AFTER the most recent B slice (3-slot ring only)?
+    if (A_SLOTS == 3) { a_ahead = a_live; if (a_live) issue_a(); }
+    int c_g = 0;                        // compute stream position
+    int pending_stores = 0;             // stores issued after the most recent B request (previous tile's epilogue)
 
     while (true) {
-        const int em0 = m0, en0 = n0;                 // this tile's origin (setup(next) overwrites m0/n0)
-        // ---- tile prologue: fetch bias (+ time-embedding row) into registers now; consumed in the epilogue, so their
-        // latency hides under the K loop.  (The residual stays an epilogue load: vmcnt retires in order, so anything
-        // issued here would stall the first K-slice wait by a full HBM round trip.)
+        const int em0 = (tile / nbn) * BM, en0 = (tile % nbn) * BN;
+        // bias (+ time-embedding row) into registers now; consumed in the epilogue, latency hides under the K loop
         const bool full = (em0 + BM <= p.M) && (en0 + BN <= p.N);
         const int odd = lane & 1;
         float pbias[FM][FN];
@@ -197,24 +242,19 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
         const int next = tile + gx;
         const bool has_next = next < t_end;
 
-        for (int kt = 0; kt < nk; kt++) {
-            // vmcnt retires in order and counts STORES too: draining to 0 here would expose the whole write latency
-            // of the previous tile's epilogue.  This tile's first K-slice was prefetched BEFORE those stores, so it
-            // has landed once at most `pending_stores` operations (all of them younger) remain in flight.  (A smaller
-            // count than the number of younger operations actually issued is always safe; the bias loads issued
-            // after the stores only make the wait release a few stores later.)
-            if (kt == 0 && pending_stores == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-            else if (kt == 0 && pending_stores == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else if (kt == 0 && pending_stores == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                       // K-slice kt landed; everyone is done reading buffer cur^1
+        for (int kt = 0; kt < nk; kt++, c_g++) {
+            // needed now: A(c_g) [requested two slices ago] and B(c_g).  Younger than B(c_g): the A slice requested right
+            // after it (if any) and, at a tile start, the previous epilogue's stores.
+            wait_vm((a_ahead ? AP : 0) + pending_stores);
+            pending_stores = 0;
+            __syncthreads();                       // slices landed for every wave; ring slots of slice c_g-1 are free
             if (!(p.dbg & 2)) {
-                if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-                else if (has_next) { setup(next); stage(0, cur ^ 1); }   // prefetch the NEXT tile across the epilogue
-            }
-            const char* As = smem + cur * STAGE;
-            const char* Bs = As + A_BYTES;
-            cur ^= 1;
+                if (b_live) issue_b();             // B(c_g+1)
+                a_ahead = (A_SLOTS == 3) && a_live;
+                if (a_live) issue_a();             // A(c_g+2), or A(c_g+1) with the 2-slot ring
+            } else a_ahead = false;
+            const char* As = a_ring + (c_g % A_SLOTS) * A_BYTES;
+            const char* Bs = b_ring + (c_g & 1) * B_BYTES;
             if (p.dbg & 1) continue;
             // Hand-pipelined LDS->MFMA loop: the fragments of k-step kk+1 are requested (inline-asm ds_read_b128,
             // invisible to hipcc's waitcnt bookkeeping) before the MFMAs of k-step kk; a COUNTED lgkmcnt leaves
@@ -263,7 +303,85 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
         // every lane owns two adjacent columns of one row -> one v_cvt_pk_bf16_f32 + one 4-byte store per pair;
         // addresses are a per-fragment base pointer plus compile-time multiples of ldo; bounds checks only on
         // tail tiles.
-        if (!(p.dbg & 4)) {
+        // Vector-memory STORE INSTRUCTIONS, not bytes, are what the epilogue pays for (~70 cycles per wave-store per CU
+        // whatever the width): bf16 outputs therefore go through a wave-private LDS transpose -- packed column pairs
+        // are written with conflict-free ds_write_b32, read back as whole rows, and leave as 16-byte-per-lane stores
+        // (4x fewer store instructions; the residual arrives as 16-byte loads of the same rows).  The staging area is
+        // the ring slots of the K-slice just consumed (free until the next request), so it costs one barrier per tile.
+        constexpr int WNO = GEGLU ? WN / 2 : WN;                        // output columns per wave
+        const int No = GEGLU ? p.N / 2 : p.N;
+        const bool lds_epi = ob && !of && !rf && (No % 8 == 0) && (p.ldo % 8 == 0) && !(p.dbg & 4);
+        if (lds_epi) {
+            constexpr int ROWB = WNO * 2, CPR = WNO / 8, NIT = (32 * CPR) / 64;
+            static_assert((32 * CPR) % 64 == 0 && 32 * ROWB * 4 <= B_BYTES, "epilogue staging geometry");
+            __syncthreads();                                            // every wave is done reading slice c_g-1
+            char* stg = (wave < 4) ? (char*)b_ring + ((c_g - 1) & 1) * B_BYTES + wave * (32 * ROWB)
+                                   : (char*)a_ring + ((c_g - 1) % A_SLOTS) * A_BYTES + (wave - 4) * (32 * ROWB);
+            const int eno = (GEGLU ? en0 / 2 : en0) + wn * WNO;         // first output column of this wave
+#pragma unroll
+            for (int i = 0; i < FM; i++) {
+                const int mf = em0 + wm * WM + i * 32;
+#pragma unroll
+                for (int j = 0; j < FN; j++) {
+                    if constexpr (GEGLU) { if (j & 1) continue; }
+                    const float bias = pbias[i][j];
+                    float gbias = 0.f;
+                    if constexpr (GEGLU) gbias = pbias[i][(j + 1) < FN ? (j + 1) : j];
+                    const int ncol = en0 + wn * WN + j * 32 + frow;
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        float x = acc[i][j][r] * p.alpha + bias;
+                        if (p.rowvec && !uniform_sample) {
+                            const int m = mf + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                            if (ncol < p.N && m < p.M) x += p.rowvec[(long long)(m / p.rows_per_sample) * p.rowvec_ld + ncol];
+                        }
+                        if constexpr (GEGLU) {
+                            const float g = acc[i][(j + 1) < FN ? (j + 1) : j][r] * p.alpha + gbias;
+                            x = x * gelu_erf_f(g);
+                        } else {
+                            if (p.act == ACT_QUICKGELU) x = quickgelu_f(x);
+                            else if (p.act == ACT_SILU) x = silu_f(x);
+                        }
+                        v[r] = x;
+                    }
+                    // even lane: row R(2t), cols (c, c+1); odd lane: row R(2t)+1, cols (c-1, c)
+                    const int lc = (GEGLU ? (j >> 1) : j) * 32 + frow - odd;          // local column of the pair
+                    char* wp = stg + (4 * fhalf + odd) * ROWB + lc * 2;
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        const int roff = ((2 * t) & 3) + 8 * ((2 * t) >> 2);
+                        const float give = odd ? v[2 * t] : v[2 * t + 1];
+                        const float got = swap_adjacent_lane(give);
+                        const float lo = odd ? got : v[2 * t], hi = odd ? v[2 * t + 1] : got;
+                        *(uint32_t*)(wp + roff * ROWB) = cvt_pk_bf16(lo, hi);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's tile is in LDS (LDS ops retire in order)
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const int idx = it * 64 + lane, row = idx / CPR, ch = idx - row * CPR;
+                    const int m = mf + row, col = eno + ch * 8;
+                    uint4 u = *(const uint4*)(stg + row * ROWB + ch * 16);
+                    if (full || (m < p.M && col < No)) {
+                        long long o = (long long)m * p.ldo + col;
+                        if (rb) {
+                            const uint4 r4 = *(const uint4*)(rb + o);
+                            const uint32_t uu[4] = {u.x, u.y, u.z, u.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+                            uint32_t oo[4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                                oo[e] = cvt_pk_bf16(__uint_as_float(uu[e] << 16) + __uint_as_float(rr[e] << 16),
+                                                    __uint_as_float(uu[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u));
+                            u = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+                        }
+                        if (p.dbg & 8) o &= 0xfff8;
+                        *(uint4*)(ob + o) = u;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next fragment row overwrites
+            }
+        } else if (!(p.dbg & 4)) {
 #pragma unroll
             for (int i = 0; i < FM; i++) {
                 const int mf = em0 + wm * WM + i * 32;                 // first row of this fragment
@@ -332,7 +450,8 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
                         float lo = odd ? got : v[2 * t];
                         float hi = odd ? v[2 * t + 1] : got;
                         if (full || (pair_ok && mrow + roff < p.M)) {
-                            const long long o = base + (long long)roff * p.ldo;
+                            long long o = base + (long long)roff * p.ldo;
+                            if (p.dbg & 8) o &= 0xfffe;            // ablation: all stores land in one 64 KB window (no HBM write stream)
                             if constexpr (BATCH_RES) { if (rb) { const uint32_t u = rw[j & 1][t]; lo += __uint_as_float(u << 16); hi += __uint_as_float(u & 0xffff0000u); } }
                             else { if (rb) { const uint32_t u = *(const uint32_t*)(rb + o); lo += __uint_as_float(u << 16); hi += __uint_as_float(u & 0xffff0000u); } }
                             if (rf) { const float2 f = *(const float2*)(rf + o); lo += f.x; hi += f.y; }
@@ -348,14 +467,16 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
         {
             constexpr int NFRAG = GEGLU ? FM * FN / 2 : FM * FN;
             const int nout = (ob ? 1 : 0) + (of ? 1 : 0);
-            pending_stores = (full && !(p.dbg & 4)) ? NFRAG * 8 * nout : -1;      // exact only for full tiles
+            if (lds_epi) pending_stores = full ? FM * ((32 * (WNO / 8)) / 64) : 0;     // 16-byte row stores per lane
+            else pending_stores = (full && nout == 1 && !(p.dbg & 4)) ? NFRAG * 8 : 0;      // exact only for full tiles
+            if (pending_stores == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // unknown count: drain now
         }
     }
 }
 
 template <int BM, int BN, int WAVES_M, int CONV, bool GEGLU>
 static hipError_t launch_cfg(const IgemmParams& p, int batch, hipStream_t st) {
-    constexpr int smem = 2 * (BM + BN) * 128;
+    constexpr int smem = ((BM >= 256 ? 3 : 2) * BM + 2 * BN) * 128;     // A ring (3 slots for 256-row tiles) + B ring of 2
     constexpr int NT = WAVES_M * 128;
     static int blocks_per_cu = 0, ncu = 0;
     if (!blocks_per_cu) {
@@ -393,8 +514,7 @@ hipError_t launch_igemm(const IgemmParams& p_in, bool conv, int batch, hipStream
     static const int force_bm = getenv("RDM_IGEMM_BM") ? atoi(getenv("RDM_IGEMM_BM")) : 0;
     const bool wide = (p.N % 192 == 0);
     const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.N + (wide ? 191 : 127)) / (wide ? 192 : 128)) * batch;
-    // short-K linears are latency/HBM-bound: two independent 4-wave blocks per CU hide more than one 8-wave block
-    bool tall = tiles256 >= 512 && (conv || p.K >= 1024);
+    bool tall = tiles256 >= 256;      // 8 waves, 3-deep A ring: the HBM latency of the activation stream is covered
     if (force_bm == 128) tall = false;
     if (force_bm == 256) tall = true;
     if (p.act == ACT_GEGLU) {
