@@ -62,11 +62,11 @@ __global__ __launch_bounds__(256) void flash_d32_kernel(FlashParams p) {
         for (int r = 1; r < 16; r++) mx = fmaxf(mx, s[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float mnew = fmaxf(m, mx * p.scale_log2e);
-        const float alpha = exp2f(m - mnew);
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
         float ps = 0.f;
         float pr[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) { pr[r] = exp2f(s[r] * p.scale_log2e - mnew); ps += pr[r]; }
+        for (int r = 0; r < 16; r++) { pr[r] = __builtin_amdgcn_exp2f(s[r] * p.scale_log2e - mnew); ps += pr[r]; }
         l = l * alpha + ps;
         m = mnew;
 #pragma unroll
@@ -94,11 +94,15 @@ __global__ __launch_bounds__(256) void flash_d32_kernel(FlashParams p) {
 
 // ---- LDS-shared variant (n % 64 == 0): the 4 waves of a block (128 query rows) share every 64-key chunk of K and V^T
 // through LDS instead of each fetching it from L2 (4x less L2 traffic: at n = 1024 the per-wave version moves 6.3 GB
-// per layer through L2).  Chunks are register-staged one iteration ahead (global loads issued before the MFMA work,
-// written to LDS after it), XOR-swizzled so the ds_read_b128 fragment reads are bank-conflict free.
-__global__ __launch_bounds__(256) void flash_d32_lds_kernel(FlashParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[2][8192];      // per buffer: K [64][32] bf16 | V^T [32][64] bf16
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// per layer through L2).  Chunks arrive by 16-byte LDS-DMA into a 4-deep ring, requested THREE chunks ahead with
+// counted vmcnt waits (the K/V tensors of a layer do not fit L2, so a chunk pays a full HBM/MALL round trip: one chunk
+// of look-ahead left the kernel latency-bound).  The ring image is lane-linear, so the bank-conflict swizzle sits on
+// the source address and again on the ds_read_b128 fragment reads.
+__global__ __launch_bounds__(256, 2) void flash_d32_lds_kernel(FlashParams p) {
+    constexpr int DEPTH = 4, CH = 8192;                               // per slot: K [64][32] bf16 | V^T [32][64] bf16
+    __shared__ __attribute__((aligned(16))) char lds[DEPTH * CH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q0 = (blockIdx.x * 4 + wave) * 32;
     const bool active = q0 < p.n;
     const int h = blockIdx.y, b = blockIdx.z;
@@ -110,30 +114,36 @@ __global__ __launch_bounds__(256) void flash_d32_lds_kernel(FlashParams p) {
         const bf16_t* qp = p.q + (tok0 + q0 + l31) * p.ldq + h * 32 + hf * 8;
         qf[0] = *(const bf16x8*)(qp); qf[1] = *(const bf16x8*)(qp + 16);
     }
-    // loader roles: K chunk = 64 rows x 4 pieces (t>>2, t&3); V^T chunk = 32 rows x 8 pieces (t>>3, t&7)
-    const int kr = tid >> 2, kc = tid & 3, vr = tid >> 3, vc = tid & 7;
-    const bf16_t* kg = p.k + (tok0 + kr) * p.ldk + h * 32 + kc * 8;
-    const bf16_t* vg = p.vt + ((long long)b * p.C + h * 32 + vr) * p.n + vc * 8;
-    const int k_st = kr * 64 + ((kc ^ ((kr >> 2) & 3)) << 4);              // swizzled LDS byte offsets (store side)
-    const int v_st = 4096 + vr * 128 + ((vc ^ ((vr >> 1) & 7)) << 4);
-    // fragment read offsets: K position l31 holds key pi(l31) (bits 2,3 swapped) of each 32-key sub-tile
-    const int pi = (l31 & ~0xc) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    // loader roles (LDS image is lane-linear: thread t fills bytes [16t, 16t+16) of the K block and of the V^T block):
+    //   K block: row kr = t>>2 (64 B rows), physical piece t&3 holds source piece (t&3) ^ ((kr>>2)&3)
+    //   V block: row vr = t>>3 (128 B rows), physical piece t&7 holds source piece (t&7) ^ ((vr>>1)&7)
+    const int kr = tid >> 2, vr = tid >> 3;
+    const int ksp = (tid & 3) ^ ((kr >> 2) & 3), vsp = (tid & 7) ^ ((vr >> 1) & 7);
+    const bf16_t* kg = p.k + (tok0 + kr) * p.ldk + h * 32 + ksp * 8;
+    const bf16_t* vg = p.vt + ((long long)b * p.C + h * 32 + vr) * p.n + vsp * 8;
+    const int nchunk = p.n >> 6;
+    auto request = [&](int c) {
+        char* slot = lds + (c & (DEPTH - 1)) * CH;
+        glds16(kg + (long long)c * 64 * p.ldk, slot + wave * 1024);
+        glds16(vg + c * 64, slot + 4096 + wave * 1024);
+    };
+    const int pi = (l31 & ~0xc) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);   // key permutation inside a 32-key sub-tile
 
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; r++) o[r] = 0.f;
     float m = -INFINITY, l = 0.f;
 
-    bf16x8 kreg = *(const bf16x8*)kg, vreg = *(const bf16x8*)vg;
-    *(bf16x8*)(lds[0] + k_st) = kreg; *(bf16x8*)(lds[0] + v_st) = vreg;
-    __syncthreads();
-    const int nchunk = p.n >> 6;
+    for (int c = 0; c < DEPTH - 1 && c < nchunk; c++) request(c);
     for (int c = 0; c < nchunk; c++) {
-        const char* L = lds[c & 1];
-        if (c + 1 < nchunk) {                                  // stage the next chunk: loads now, LDS write after the math
-            kreg = *(const bf16x8*)(kg + (long long)(c + 1) * 64 * p.ldk);
-            vreg = *(const bf16x8*)(vg + (c + 1) * 64);
-        }
+        // chunk c landed once at most 2 * (requests issued after it) loads remain in flight
+        const int ahead = min(nchunk - 1 - c, DEPTH - 2);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                     // chunk c visible to all waves; slot of chunk c-1 is free again
+        if (c + DEPTH - 1 < nchunk) request(c + DEPTH - 1);
+        const char* L = lds + (c & (DEPTH - 1)) * CH;
         if (active) {
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
@@ -152,14 +162,21 @@ __global__ __launch_bounds__(256) void flash_d32_lds_kernel(FlashParams p) {
 #pragma unroll
                 for (int r = 1; r < 16; r++) mx = fmaxf(mx, s[r]);
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
+                // raw v_exp_f32 (exp2f() expands to ~6 instructions of denormal range handling per call; inputs here are
+                // <= 0 and underflow to 0 is exactly what softmax wants).  The O rescale is skipped while the running
+                // max of every row in the wave is unchanged (alpha == 1 exactly).
                 const float mnew = fmaxf(m, mx * p.scale_log2e);
-                const float alpha = exp2f(m - mnew);
                 float ps = 0.f, pr[16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) { pr[r] = exp2f(s[r] * p.scale_log2e - mnew); ps += pr[r]; }
-                l = l * alpha + ps; m = mnew;
+                for (int r = 0; r < 16; r++) { pr[r] = __builtin_amdgcn_exp2f(s[r] * p.scale_log2e - mnew); ps += pr[r]; }
+                if (__builtin_amdgcn_ballot_w64(mnew != m) != 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(m - mnew);      // m = -inf on the first tile -> alpha = 0
+                    l *= alpha;
 #pragma unroll
-                for (int r = 0; r < 16; r++) o[r] *= alpha;
+                    for (int r = 0; r < 16; r++) o[r] *= alpha;
+                    m = mnew;
+                }
+                l += ps;
                 union { bf16x8 v; uint32_t u[4]; } pb0, pb1;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -170,11 +187,6 @@ __global__ __launch_bounds__(256) void flash_d32_lds_kernel(FlashParams p) {
                 o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb1.v, o, 0, 0, 0);
             }
         }
-        if (c + 1 < nchunk) {
-            char* Ln = lds[(c + 1) & 1];
-            *(bf16x8*)(Ln + k_st) = kreg; *(bf16x8*)(Ln + v_st) = vreg;
-        }
-        __syncthreads();
     }
     if (!active) return;
     l += __shfl_xor(l, 32);

@@ -98,6 +98,9 @@ def test_sample_with_query_and_from_rdata(model, retriever):
     q = (rng.standard_normal((B, 512)) * 0.45).astype(np.float32)
     x_T = torch.from_numpy(rng.standard_normal((B, 3, 16, 16)).astype(np.float32))
     model.unconditional_guidance_vex = torch.randn(512, device=model.device)
+    latents = []
+    real_decode = model.decode_first_stage
+    model.decode_first_stage = lambda z, **kw: (latents.append(z.clone()), real_decode(z, **kw))[1]     # capture the latent
     out = model.sample_with_query(query=torch.from_numpy(q), query_embedded=True, k_nn=k, ddim=True, ddim_steps=S, x_T=x_T,
                                   unconditional_guidance_scale=2.0, unconditional_retro_guidance_label=0., visualize_nns=False)
     img = out["query_samples"]
@@ -108,8 +111,13 @@ def test_sample_with_query_and_from_rdata(model, retriever):
     z_ref, _ = odiff.ddim_sample(apply, odiff.Schedule(), S, x_T, rc, scale=2.0, uncond=torch.zeros_like(rc))
     ref = ovq.vq_decode(model.sd_vq, model.vspec, z_ref)
     assert img.shape == (B, 3, 64, 64)
-    print("sample_with_query rel L2:", rel_l2(img, ref))
-    assert rel_l2(img, ref) <= 0.12          # VQ snaps near-tie latents to different codes: loose end-to-end bound
+    # the latent is compared at the stated DDIM tolerance; the image is compared against the ORACLE decode of the
+    # GPU latent (the VQ snap turns tiny latent differences into different codes, so image-vs-image through two
+    # different latents is not a meaningful bound), plus a loose end-to-end sanity bound
+    print("sample_with_query latent rel L2:", rel_l2(latents[0], z_ref), "image rel L2:", rel_l2(img, ref))
+    assert rel_l2(latents[0], z_ref) <= 4e-2
+    assert rel_l2(img, ovq.vq_decode(model.sd_vq, model.vspec, latents[0].cpu())) <= 4e-2
+    assert rel_l2(img, ref) <= 0.25
     # unconditional path: qids given, query NOT prepended (ddpm.py:921)
     qids = np.array([11, 222])
     out2 = model.sample_from_rdata(B, qids=qids, k_nn=k, ddim=True, ddim_steps=S, x_T=x_T, unconditional_guidance_scale=1.0)
@@ -118,7 +126,10 @@ def test_sample_with_query_and_from_rdata(model, retriever):
     rc2 = torch.from_numpy(retriever.data_pool["embedding"][nns].astype(np.float32))
     z2, _ = odiff.ddim_sample(apply, odiff.Schedule(), S, x_T, rc2)
     ref2 = ovq.vq_decode(model.sd_vq, model.vspec, z2)
-    assert rel_l2(out2["samples_with_sampled_nns"], ref2) <= 0.12
+    assert rel_l2(latents[1], z2) <= 4e-2
+    assert rel_l2(out2["samples_with_sampled_nns"], ovq.vq_decode(model.sd_vq, model.vspec, latents[1].cpu())) <= 4e-2
+    assert rel_l2(out2["samples_with_sampled_nns"], ref2) <= 0.25
+    model.decode_first_stage = real_decode
 
 
 def test_clip_retriever_wrappers(ctx):

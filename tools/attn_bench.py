@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import rdm_amd
+from rdm_amd import _lib
+ctx = _lib.Context(0); d = ctx.device
+for (B, n, heads) in ((128, 1024, 12), (128, 256, 18), (128, 64, 30)):
+    C = heads * 32
+    qk = torch.randn(B, n, 2 * C, device=d).bfloat16(); vt = torch.randn(B, C, n, device=d).bfloat16()
+    for _ in range(3): ctx.op_self_attention(qk, vt, heads)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): ctx.op_self_attention(qk, vt, heads)
+    torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 10
+    fl = 4.0 * n * n * 32 * heads * B
+    print(f"attn B={B} n={n} heads={heads}: {t*1e6:8.1f} us  {fl/t/1e12:6.1f} TF", flush=True)
