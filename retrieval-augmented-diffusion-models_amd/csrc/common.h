@@ -33,7 +33,8 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 __device__ __forceinline__ float swap_adjacent_lane(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: these run once per activation element
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // exact-erf GELU. erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 output resolution):
 // ~12 VALU instead of the ~30 of erff() -- the GEGLU epilogue evaluates this 201 M times per 32x32-level FF layer.
 __device__ __forceinline__ float gelu_erf_f(float x) {
@@ -43,7 +44,7 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     const float erf_abs = 1.0f - poly * __expf(-z * z);
     return 0.5f * x + 0.5f * fabsf(x) * erf_abs;      // 0.5 x (1 + sign(x) erf|.|)
 }
-__device__ __forceinline__ float quickgelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quickgelu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 
 // 16-byte async global->LDS copy: LDS address = wave-uniform `lds_wave_base` + lane*16.
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
