@@ -150,9 +150,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
             for (int tap = 0; tap < 9; tap++) {
                 // first K-slice of a tile: its weights + halo were prefetched BEFORE the previous epilogue's stores;
                 // leave those stores in flight (vmcnt retires in order and counts stores) instead of draining them
-                if (sl == 0 && tap == 0 && pending_stores == FM * FN * 8) {
-                    if constexpr (FM * FN * 8 == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                if (sl == 0 && tap == 0 && pending_stores > 0) {
+                    if constexpr (WN == 96) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();          // weights (sl,tap) [+ halo sl at tap 0] landed; previous buffers are free
                 // ---- issue the next loads: weights of the next K-slice, one pass of the next halo
@@ -211,41 +211,66 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
             hcur ^= 1;
         }
 
-        // ---- epilogue (same scheme as igemm.hip: DPP lane-pair swap -> one packed 4-byte store per register pair)
+        // ---- epilogue (same scheme as igemm.hip): per-column bias / time-embedding add in registers, DPP lane-pair swap
+        // to packed column pairs, wave-private LDS transpose (staged in the halo buffer just consumed: its successor
+        // was prefetched into the other buffer), whole rows leave as 16-byte stores, the residual arrives as 16-byte
+        // loads.  Vector-memory instruction count, not bytes, is what an epilogue pays for.
+        {
+            constexpr int ROWB = WN * 2, CPR = WN / 8, NIT = (32 * CPR) / 64;
+            static_assert(8 * 32 * ROWB <= HALO_BYTES && (32 * CPR) % 64 == 0, "epilogue staging geometry");
+            __syncthreads();                                            // every wave is done with the last K-slice
+            char* stg = halo_base + (hcur ^ 1) * HALO_BYTES + wave * (32 * ROWB);   // hcur already toggled: ^1 = consumed buffer
+            const int eno = en0 + wn * WN;
 #pragma unroll
-        for (int i = 0; i < FM; i++) {
-            const int mf = em0 + wm * WM + i * 32;
+            for (int i = 0; i < FM; i++) {
+                const int mf = em0 + wm * WM + i * 32;
 #pragma unroll
-            for (int j = 0; j < FN; j++) {
-                const int ncol = en0 + wn * WN + j * 32 + frow;
-                float v[16];
+                for (int j = 0; j < FN; j++) {
+                    const int ncol = en0 + wn * WN + j * 32 + frow;
+                    float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    float x = acc[i][j][r] + pbias[i][j];
-                    if (p.rowvec && !uniform_sample) {
-                        const int m = mf + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                        x += p.rowvec[(long long)(m / p.rows_per_sample) * p.rowvec_ld + ncol];
+                    for (int r = 0; r < 16; r++) {
+                        float x = acc[i][j][r] + pbias[i][j];
+                        if (p.rowvec && !uniform_sample) {
+                            const int m = mf + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                            x += p.rowvec[(long long)(m / p.rows_per_sample) * p.rowvec_ld + ncol];
+                        }
+                        v[r] = x;
                     }
-                    v[r] = x;
-                }
-                const int mrow = mf + 4 * fhalf + odd;
-                const long long base = (long long)mrow * p.ldo + (ncol - odd);
+                    char* wp = stg + (4 * fhalf + odd) * ROWB + (j * 32 + frow - odd) * 2;
 #pragma unroll
-                for (int t = 0; t < 8; t++) {
-                    const int roff = ((2 * t) & 3) + 8 * ((2 * t) >> 2);
-                    const float give = odd ? v[2 * t] : v[2 * t + 1];
-                    const float got = swap_adjacent_lane(give);
-                    float lo = odd ? got : v[2 * t];
-                    float hi = odd ? v[2 * t + 1] : got;
-                    const long long o = base + (long long)roff * p.ldo;
-                    if (rb) { const uint32_t u = *(const uint32_t*)(rb + o); lo += __uint_as_float(u << 16); hi += __uint_as_float(u & 0xffff0000u); }
-                    *(uint32_t*)(ob + o) = cvt_pk_bf16(lo, hi);
+                    for (int t = 0; t < 8; t++) {
+                        const int roff = ((2 * t) & 3) + 8 * ((2 * t) >> 2);
+                        const float give = odd ? v[2 * t] : v[2 * t + 1];
+                        const float got = swap_adjacent_lane(give);
+                        const float lo = odd ? got : v[2 * t], hi = odd ? v[2 * t + 1] : got;
+                        *(uint32_t*)(wp + roff * ROWB) = cvt_pk_bf16(lo, hi);
+                    }
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const int idx = it * 64 + lane, row = idx / CPR, ch = idx - row * CPR;
+                    uint4 u = *(const uint4*)(stg + row * ROWB + ch * 16);
+                    const long long o = (long long)(mf + row) * p.ldo + eno + ch * 8;
+                    if (rb) {
+                        const uint4 r4 = *(const uint4*)(rb + o);
+                        const uint32_t uu[4] = {u.x, u.y, u.z, u.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+                        uint32_t oo[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            oo[e] = cvt_pk_bf16(__uint_as_float(uu[e] << 16) + __uint_as_float(rr[e] << 16),
+                                                __uint_as_float(uu[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u));
+                        u = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+                    }
+                    *(uint4*)(ob + o) = u;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
         if (!has_next) break;
         tile = next;
-        pending_stores = FM * FN * 8;      // every tile of this kernel is full: one 4-byte store per register pair
+        pending_stores = FM * ((32 * (WN / 8)) / 64);      // every tile is full: 16-byte row stores per lane
     }
 }
 
@@ -278,7 +303,7 @@ bool conv_halo_supported(const IgemmParams& p) {
     else if (256 % HW != 0) return false;
     if (p.M % 256 != 0 || (p.N % 192 != 0 && p.N % 128 != 0)) return false;
     if (p.C0 % 64 || p.C1 % 64 || p.alpha != 1.0f || p.act != ACT_NONE || !p.out_bf16 || p.out_f32 || p.res_f32) return false;
-    if (p.ldo % 2 || p.K != 9 * (p.C0 + p.C1)) return false;
+    if (p.ldo % 8 || p.K != 9 * (p.C0 + p.C1)) return false;
     const int RS = (HW >= 256) ? 256 / W : H, NS = 256 / (RS * W);
     if (NS * (RS + 2) * (W + 2) > 400) return false;
     if ((long long)p.M * (p.C0 > p.C1 ? p.C0 : p.C1) >= 0x7fffffffLL * 1LL) return false;
