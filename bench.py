@@ -14,9 +14,11 @@ For N > 1 the driver launches this file under torch.distributed.run (one rank pe
 sharded (64 images per GPU, weak scaling), the only collective is the all-gather of finished images.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel = the 3x3-conv implicit-GEMM (63 % of all FLOPs), MFMA-bound; achieved =
-                algorithmic FLOPs (2*M*N*9*Cin per launch) / HIP-event time of those launches, measured live in
-                the timed region on the library's stream; peak = 2.5 PFLOP/s dense bf16.
+  roofline      dominant kernel = the 3x3 convolution (input-stationary halo kernel + the generic implicit GEMM for
+                strided / upsampled / decoder convs; 63 % of all FLOPs), MFMA-bound; achieved = algorithmic FLOPs
+                (2*M*N*9*Cin per launch) / HIP-event time of those launches, measured live in the timed region on the
+                library's stream; peak = 2.5 PFLOP/s dense bf16.  `traffic` is null in the live line: the PMC passes
+                (FETCH_SIZE / WRITE_SIZE, separate runs) are committed under profiles/ with their summary.
   cpu_baseline  the fp32 PyTorch oracle (kind "port") timed on this box's host cores on a bounded sample.
 """
 import argparse
@@ -177,7 +179,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": world * B, "ddim_steps": a.ddim_steps, "k": k,
                        "guidance_scale": a.scale, "db_rows": N, "parallelism": f"dp{world} (batch-sharded, DB replicated, "
                                                                                 "all-gather of images only)"},
-            "roofline": {"kernel": "igemm_kernel<128,BN,conv3x3> (3x3 conv implicit GEMM, bf16 MFMA)", "bound": "mfma",
+            "roofline": {"kernel": "conv3x3_halo_kernel<192> + igemm_kernel<..,conv> (3x3 conv, bf16 MFMA, fp32 accumulate)", "bound": "mfma",
                          "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": None,
                          "launches": n_conv, "avg_launch_ms": ms_conv / max(n_conv, 1),
                          "algorithmic_tflop_per_launch": fl_conv / max(n_conv, 1) / 1e12,
