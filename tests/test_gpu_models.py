@@ -141,6 +141,22 @@ def test_vq_decode_tiny(ctx):
     assert np.array_equal(u8, ref_u8)
 
 
+def test_kl_first_stage_decode(ctx):
+    """AutoencoderKL.decode = same decoder, post_quant_conv, no quantiser (rdm_vq_cfg.kl = 1)."""
+    from rdm_amd import _lib, packing
+    spec = ovq.tiny_vq_spec()
+    shapes = {k: v for k, v in ovq.vq_param_shapes(spec).items() if not k.startswith("quantize.")}
+    sd = ounet.synth_state_dict(shapes, seed=6)
+    cfg = _lib.make_vq_cfg(embed_dim=3, n_embed=spec.n_embed, z_channels=3, ch=spec.ch, ch_mult=spec.ch_mult,
+                           num_res_blocks=spec.num_res_blocks, resolution=spec.resolution, kl=True)
+    ctx.load_vq(cfg, packing.pack("vq", cfg, sd))
+    z = torch.from_numpy(np.random.default_rng(3).standard_normal((3, 3, 16, 16)).astype(np.float32))
+    ref = ovq.vq_decode(sd, spec, z, force_not_quantize=True)
+    img = ctx.vq_decode(z)
+    torch.cuda.synchronize()
+    assert rel_l2(img, ref) <= 2.5e-2
+
+
 def test_clip_tiny_golden(ctx):
     from rdm_amd import packing
     g = golden("clip_tiny.npz")
@@ -157,7 +173,7 @@ def test_clip_tiny_golden(ctx):
     assert rel_l2(i, torch.from_numpy(g["image_out"])) <= 2e-2
 
 
-@pytest.mark.parametrize("N,B,k", [(100_000, 8, 4), (33_333, 70, 16), (1000, 3, 1), (300_000, 64, 4)])
+@pytest.mark.parametrize("N,B,k", [(100_000, 8, 4), (33_333, 70, 16), (1000, 3, 1), (300_000, 64, 4), (50_001, 1, 28), (257, 2, 20)])
 def test_knn_bit_exact(ctx, N, B, k):
     rng = np.random.default_rng(7)
     db = (rng.standard_normal((N, 512), dtype=np.float32) * 0.45).astype(np.float16)
