@@ -9,9 +9,13 @@
 // Same persistent XCD-aware tile walk, hand-pipelined ds_read/MFMA loop and DPP-paired epilogue as igemm.hip.
 // Replaces conv_nd(2, C, C', 3, padding=1) inside ResBlock in_layers/out_layers (ldm, via
 // rdm/modules/diffusionmodules/openaimodel.py:144-305) — 44 of the 49 3x3 convs per UNet forward.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "kernels.h"
+
+// dev-only phase clock (env RDM_HALO_PROF=1): shader cycles spent by wave 0 of every block in [main loop, epilogue]
+__device__ unsigned long long g_halo_prof[4];
 
 template <int BN>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
@@ -119,7 +123,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
     int hcur = 0, bcur = 0;
     int pending_stores = -1;
 
+    unsigned long long tprof[2] = {0, 0};
     while (true) {
+        unsigned long long tp0 = 0, tp1 = 0;
+        if (p.dbg & 16) tp0 = __builtin_readcyclecounter();
         const int em0 = m0, en0 = n0;
         const int next = tile + gx;
         const bool has_next = next < t_end;
@@ -211,6 +218,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
             hcur ^= 1;
         }
 
+        if (p.dbg & 16) { tp1 = __builtin_readcyclecounter(); tprof[0] += tp1 - tp0; }
         // ---- epilogue (same scheme as igemm.hip): per-column bias / time-embedding add in registers, DPP lane-pair swap
         // to packed column pairs, wave-private LDS transpose (staged in the halo buffer just consumed: its successor
         // was prefetched into the other buffer), whole rows leave as 16-byte stores, the residual arrives as 16-byte
@@ -268,9 +276,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
+        if (p.dbg & 16) tprof[1] += __builtin_readcyclecounter() - tp1;
         if (!has_next) break;
         tile = next;
         pending_stores = FM * ((32 * (WN / 8)) / 64);      // every tile is full: 16-byte row stores per lane
+    }
+    if ((p.dbg & 16) && tid == 0) {
+        atomicAdd(&g_halo_prof[0], tprof[0]); atomicAdd(&g_halo_prof[1], tprof[1]); atomicAdd(&g_halo_prof[3], 1ull);
     }
 }
 
@@ -287,6 +299,18 @@ static hipError_t launch_halo(const IgemmParams& p, hipStream_t st) {
     const long long ntiles = (long long)(p.M / 256) * (p.N / BN);
     long long g = (ncu + 7) & ~7;
     if (g > ntiles) g = ntiles;
+    static const int prof = getenv("RDM_HALO_PROF") ? atoi(getenv("RDM_HALO_PROF")) : 0;
+    if (prof) {      // dev-only: synchronous launch, prints wave-0 shader cycles per block
+        IgemmParams q = p; q.dbg |= 16 | (prof & ~1);
+        unsigned long long z[4] = {0, 0, 0, 0}, r[4];
+        hipMemcpyToSymbol(HIP_SYMBOL(g_halo_prof), z, sizeof(z));
+        conv3x3_halo_kernel<BN><<<dim3((unsigned)g), 512, smem, st>>>(q);
+        hipStreamSynchronize(st);
+        hipMemcpyFromSymbol(r, HIP_SYMBOL(g_halo_prof), sizeof(r));
+        fprintf(stderr, "[halo<%d> M=%d N=%d K=%d] blocks=%llu per-block cycles: main %.0f epilogue %.0f (tiles/block %.2f)\n", BN, p.M, p.N, p.K,
+                r[3], (double)r[0] / r[3], (double)r[1] / r[3], (double)ntiles / g);
+        return hipGetLastError();
+    }
     conv3x3_halo_kernel<BN><<<dim3((unsigned)g), 512, smem, st>>>(p);
     return hipGetLastError();
 }
