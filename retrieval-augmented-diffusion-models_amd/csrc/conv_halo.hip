@@ -32,6 +32,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    const int grp = wave >> 2;                            // ping-pong group: waves w and w+4 share a SIMD
     const int frow = lane & 31, fhalf = lane >> 5;
 
     // ---- geometry (uniform)
@@ -151,29 +152,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+        // ---- main loop: two wave groups in ping-pong.  Waves w and w+4 share a SIMD; group 1 (waves 4..7) runs one barrier
+        // interval behind group 0, so in every interval one wave of each SIMD is in its MFMA section (12 MFMAs, raised
+        // priority) while its partner is in its load section (the 10 ds_read_b128 of its next 12 MFMAs, the LDS-DMA issue for
+        // the next tap, the waits).  A phase = half a tap (2 k-steps of 16); intervals per tap: g0 [L0|M0|L1|M1], g1 the same
+        // shifted by one.  Waits are counted: weights of tap t+1 are issued in L0 and must have landed before the barrier that
+        // ends interval 4t+3 (g0: after M1, g1: after L1); a halo pass (due at the next SLICE) stays in flight across taps.
+        // Buffers are re-staged only after a barrier that follows the lgkmcnt(0) retiring their last reads.
+#define RDM_LDS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+        if (pending_stores > 0) {
+            if constexpr (WN == 96) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // first slice's halo + weights of tap 0 landed (all waves)
+        if (grp) __builtin_amdgcn_s_barrier();    // stagger: group 1 starts one interval late
         for (int sl = 0; sl < nslice; sl++) {
             const bool last_slice = sl + 1 == nslice;
 #pragma unroll 1
             for (int tap = 0; tap < 9; tap++) {
-                // first K-slice of a tile: its weights + halo were prefetched BEFORE the previous epilogue's stores;
-                // leave those stores in flight (vmcnt retires in order and counts stores) instead of draining them
-                if (sl == 0 && tap == 0 && pending_stores > 0) {
-                    if constexpr (WN == 96) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();          // weights (sl,tap) [+ halo sl at tap 0] landed; previous buffers are free
-                // ---- issue the next loads: weights of the next K-slice, one pass of the next halo
-                if (tap < 8) stage_b(sl, tap + 1, bcur ^ 1);
-                else if (!last_slice) stage_b(sl + 1, 0, bcur ^ 1);
-                else if (has_next) {      // cross-tile prefetch: weights + halo of the next tile's first slice
-                    setup(next);
-                    stage_b(0, 0, bcur ^ 1);
-#pragma unroll
-                    for (int ps = 0; ps < HPASS; ps++) stage_halo_pass(ps, 0, hcur ^ 1);
-                }
-                if (!last_slice && tap < HPASS) stage_halo_pass(tap, sl + 1, hcur ^ 1);
-
-                // ---- MFMA over this K-slice (64 channels of one tap), A from the halo at a tap-shifted position
                 const int dy = tap / 3, dx = tap - dy * 3;
                 const int tapoff = dy * HPW + dx;
                 unsigned va[FM];
@@ -183,40 +179,63 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
                     va[i] = (unsigned)(hcur * HALO_BYTES) + (unsigned)(hp * 128 + ((fhalf ^ ((hp >> 1) & 7)) << 4));
                 }
                 const unsigned vb = vb0 + (unsigned)(bcur * B_BYTES);
-                bf16x8 fa[2][FM], fb[2][FN];
-#define RDM_LDS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+                const bool tile_end = last_slice && tap == 8;
+                // one pass of the next slice's halo this tap -- true only if THIS wave has a lane in it (else nothing is issued
+                // and the counted wait below must not leave a weight piece in flight instead)
+                const bool halo_now = !last_slice && tap < HPASS && (tap * 64 + wave * 8 < HP);
 #pragma unroll
-                for (int i = 0; i < FM; i++) RDM_LDS_READ(fa[0][i], va[i], 0);
+                for (int half = 0; half < 2; half++) {
+                    bf16x8 fa[2][FM], fb[2][FN];
+                    // ---- load section
 #pragma unroll
-                for (int j = 0; j < FN; j++) RDM_LDS_READ(fb[0][j], vb, j * 4096);
+                    for (int k2 = 0; k2 < 2; k2++) {
+                        const unsigned x = (unsigned)((half * 2 + k2) << 5);
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    const int cs = kk & 1, ns = cs ^ 1;
-                    if (kk < 3) {
-                        const unsigned x = (unsigned)((kk + 1) << 5);
+                        for (int j = 0; j < FN; j++) { const unsigned b = vb ^ x; RDM_LDS_READ(fb[k2][j], b, j * 4096); }
 #pragma unroll
-                        for (int i = 0; i < FM; i++) { const unsigned a = va[i] ^ x; RDM_LDS_READ(fa[ns][i], a, 0); }
-                        const unsigned vbn = vb ^ x;
-#pragma unroll
-                        for (int j = 0; j < FN; j++) RDM_LDS_READ(fb[ns][j], vbn, j * 4096);
-                        if constexpr (FM + FN == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
-                        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                    } else {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        for (int i = 0; i < FM; i++) { const unsigned a = va[i] ^ x; RDM_LDS_READ(fa[k2][i], a, 0); }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (half == 0) {
+                        if (tap < 8) stage_b(sl, tap + 1, bcur ^ 1);
+                        else if (!last_slice) stage_b(sl + 1, 0, bcur ^ 1);
+                        else if (has_next) { setup(next); stage_b(0, 0, bcur ^ 1); }     // cross-tile prefetch
+                    } else {
+                        if (halo_now) stage_halo_pass(tap, sl + 1, hcur ^ 1);
+                        else if (tile_end && has_next) {
 #pragma unroll
-                    for (int i = 0; i < FM; i++)
-#pragma unroll
-                        for (int j = 0; j < FN; j++)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cs][i], fb[cs][j], acc[i][j], 0, 0, 0);
+                            for (int ps = 0; ps < HPASS; ps++) stage_halo_pass(ps, 0, hcur ^ 1);
+                        }
+                        if (grp && !tile_end) {
+                            if (halo_now) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    // ---- MFMA section
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                        for (int i = 0; i < FM; i++)
+#pragma unroll
+                            for (int j = 0; j < FN; j++)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k2][i], fb[k2][j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (half == 1 && !grp && !tile_end) {
+                        if (halo_now) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_s_barrier();
                 }
-#undef RDM_LDS_READ
                 bcur ^= 1;
             }
             hcur ^= 1;
         }
+        if (!grp) __builtin_amdgcn_s_barrier();   // re-align the groups
+#undef RDM_LDS_READ
 
         if (p.dbg & 16) { tp1 = __builtin_readcyclecounter(); tprof[0] += tp1 - tp0; }
         // ---- epilogue (same scheme as igemm.hip): per-column bias / time-embedding add in registers, DPP lane-pair swap
