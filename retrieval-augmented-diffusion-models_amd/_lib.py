@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librdm_hip.so")
+LIB_PATH = os.environ.get("RDM_HIP_LIB") or os.path.join(_HERE, "librdm_hip.so")   # env override: A/B builds (dev)
 
 RDM_MAX_LEVELS = 8
 ACT_NONE, ACT_GEGLU, ACT_QUICKGELU, ACT_SILU = 0, 1, 2, 3

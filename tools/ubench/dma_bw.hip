@@ -48,7 +48,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(const char* src, long lo
 int main(int argc, char** argv) {
     int dev = 0; CK(hipSetDevice(dev));
     int ncu = 0; CK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    const long long ld = 6912;                 // weight row stride of a 384-channel 3x3 conv (K = 3456 bf16)
+    const long long ld = argc > 1 ? atoll(argv[1]) : 6912;   // weight row stride (6912 = 384-channel 3x3 conv, K = 3456 bf16; 128 = packed tile)
     const int rows = 192, iters = 2000;
     const size_t tile = (size_t)rows * ld;     // 1.3 MB per tile, 8 tiles in rotation
     const size_t bytes = (size_t)ncu * 8 * tile + (1 << 20);
