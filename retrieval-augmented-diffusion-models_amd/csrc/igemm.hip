@@ -16,9 +16,13 @@
 // Zero padding of the 3x3 halo (and M/N tails) is done by pointing the lane at a zero page.
 // The skip-concat of the UNet decoder (th.cat([h, hs.pop()]), openaimodel.py:365) is never
 // materialised: the loader switches source tensor per K-slice (dual-source A).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "kernels.h"
+
+// dev-only phase clock (env RDM_IGEMM_PROF=1): shader cycles spent by wave 0 of every block in [K loop, epilogue, wait at tile start]
+__device__ unsigned long long g_igemm_prof[4];
 
 template <int BM, int BN, int WAVES_M, int CONV, bool GEGLU>   // CONV: 0 linear, 1 conv3x3, 2 conv3x3 on a 2x nearest-upsampled input
 __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) {
@@ -58,10 +62,16 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
     const char* zero = (const char*)p.zero_page;
     bf16_t* ob = p.out_bf16 ? p.out_bf16 + zb * p.sO : nullptr;
     float* of = p.out_f32 ? p.out_f32 + zb * p.sO : nullptr;
-    const bf16_t* rb = p.res_bf16 ? p.res_bf16 + zb * p.sO : nullptr;
+    const bf16_t* rb = (p.res_bf16 && !p.res_k) ? p.res_bf16 + zb * p.sO : nullptr;
+    const bf16_t* const rk = p.res_k ? p.res_bf16 + zb * p.sO : nullptr;
     const float* rf = p.res_f32 ? p.res_f32 + zb * p.sO : nullptr;
     const int Cin = p.C0 + p.C1;
-    const int nk = p.K / BK;
+    // residual as K columns (linear GEMMs, set by launch_igemm): out = [A | R_tile] . [W | I]^T -- the residual tile streams
+    // through the deep-prefetched A pipeline instead of being fetched (latency exposed, behind the next tile's operands in
+    // the in-order memory queue) by the epilogue; BN/BK extra K-slices of MFMA work per tile, exact in the fp32 accumulator
+    const int nkw = p.K / BK;                            // K-slices of the weight matrix proper
+    const int nk = nkw + ((CONV == 0 && !GEGLU && p.res_k) ? BN / BK : 0);
+    const bf16_t* const eye = (const bf16_t*)((const char*)p.zero_page + RDM_EYE_OFFSET);
     const bool uniform_sample = (p.rows_per_sample % 32) == 0;
 
     // ---- operand streams.  K-slices are consumed in one continuous stream that runs across tile boundaries
@@ -126,8 +136,12 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
         const int dy = k_tap / 3, dx = k_tap - dy * 3;
         const bool second = k_ci >= p.C0;
         const bf16_t* src = second ? A1 : A0;
-        const int ld = second ? p.C1 : p.C0;
+        int ld = second ? p.C1 : p.C0;
         const bf16_t* lane_src = src + ((second ? k_ci - p.C0 : k_ci) + sc8);
+        if (CONV == 0 && !GEGLU && a_kt >= nkw) {       // residual slice: columns of this tile's own output block
+            ld = p.ldo;
+            lane_src = rk + ((a_tile % nbn) * BN + (a_kt - nkw) * BK + sc8);
+        }
         if (CONV == 2) {
 #pragma unroll
             for (int i = 0; i < AP; i++) {
@@ -169,11 +183,17 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
     };
     auto issue_b = [&]() {
         char* Bs = b_ring + (b_g & 1) * B_BYTES;
-        const bf16_t* lane_w = W + ((long long)b_kt * BK + sc8);
+        if (CONV == 0 && !GEGLU && b_kt >= nkw) {       // identity slice (rows are tile-local)
+            const bf16_t* lane_e = eye + ((b_kt - nkw) * BK + sc8);
 #pragma unroll
-        for (int i = 0; i < BP; i++) {
-            const void* g = (b_n[i] >= 0) ? (const void*)(lane_w + (long long)b_n[i] * p.K) : (const void*)zero;
-            glds16(g, Bs + (i * RPP + wave * 8) * 128);
+            for (int i = 0; i < BP; i++) glds16(lane_e + (i * RPP + lrow) * RDM_EYE_N, Bs + (i * RPP + wave * 8) * 128);
+        } else {
+            const bf16_t* lane_w = W + ((long long)b_kt * BK + sc8);
+#pragma unroll
+            for (int i = 0; i < BP; i++) {
+                const void* g = (b_n[i] >= 0) ? (const void*)(lane_w + (long long)b_n[i] * p.K) : (const void*)zero;
+                glds16(g, Bs + (i * RPP + wave * 8) * 128);
+            }
         }
         b_g++;
         if (++b_kt == nk) {
@@ -209,7 +229,10 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
     int c_g = 0;                        // compute stream position
     int pending_stores = 0;             // stores issued after the most recent B request (previous tile's epilogue)
 
+    unsigned long long tprof[3] = {0, 0, 0};
     while (true) {
+        unsigned long long tp0 = 0, tp1 = 0;
+        if (p.dbg & 16) tp0 = __builtin_readcyclecounter();
         const int em0 = (tile / nbn) * BM, en0 = (tile % nbn) * BN;
         // bias (+ time-embedding row) into registers now; consumed in the epilogue, latency hides under the K loop
         const bool full = (em0 + BM <= p.M) && (en0 + BN <= p.N);
@@ -245,9 +268,12 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
         for (int kt = 0; kt < nk; kt++, c_g++) {
             // needed now: A(c_g) [requested two slices ago] and B(c_g).  Younger than B(c_g): the A slice requested right
             // after it (if any) and, at a tile start, the previous epilogue's stores.
+            unsigned long long tw0 = 0;
+            if ((p.dbg & 16) && kt == 0) tw0 = __builtin_readcyclecounter();
             wait_vm((a_ahead ? AP : 0) + pending_stores);
             pending_stores = 0;
             __syncthreads();                       // slices landed for every wave; ring slots of slice c_g-1 are free
+            if ((p.dbg & 16) && kt == 0) tprof[2] += __builtin_readcyclecounter() - tw0;
             if (!(p.dbg & 2)) {
                 if (b_live) issue_b();             // B(c_g+1)
                 a_ahead = (A_SLOTS == 3) && a_live;
@@ -308,6 +334,7 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
         // are written with conflict-free ds_write_b32, read back as whole rows, and leave as 16-byte-per-lane stores
         // (4x fewer store instructions; the residual arrives as 16-byte loads of the same rows).  The staging area is
         // the ring slots of the K-slice just consumed (free until the next request), so it costs one barrier per tile.
+        if (p.dbg & 16) { tp1 = __builtin_readcyclecounter(); tprof[0] += tp1 - tp0; }
         constexpr int WNO = GEGLU ? WN / 2 : WN;                        // output columns per wave
         const int No = GEGLU ? p.N / 2 : p.N;
         const bool lds_epi = ob && !of && !rf && (No % 8 == 0) && (p.ldo % 8 == 0) && !(p.dbg & 4);
@@ -462,6 +489,7 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
                 }
             }
         }
+        if (p.dbg & 16) tprof[1] += __builtin_readcyclecounter() - tp1;
         if (!has_next) break;
         tile = next;
         {
@@ -471,6 +499,10 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
             else pending_stores = (full && nout == 1 && !(p.dbg & 4)) ? NFRAG * 8 : 0;      // exact only for full tiles
             if (pending_stores == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // unknown count: drain now
         }
+    }
+    if ((p.dbg & 16) && tid == 0) {
+        atomicAdd(&g_igemm_prof[0], tprof[0]); atomicAdd(&g_igemm_prof[1], tprof[1]); atomicAdd(&g_igemm_prof[2], tprof[2]);
+        atomicAdd(&g_igemm_prof[3], 1ull);
     }
 }
 
@@ -498,6 +530,18 @@ static hipError_t launch_cfg(const IgemmParams& p, int batch, hipStream_t st) {
     if (g > ntiles) g = ntiles;
     if (g < 1) g = 1;
     dim3 grid((unsigned)g, 1, batch);
+    static const int prof = getenv("RDM_IGEMM_PROF") ? atoi(getenv("RDM_IGEMM_PROF")) : 0;
+    if (prof) {      // dev-only: synchronous launch, prints wave-0 shader cycles per block
+        IgemmParams q = p; q.dbg |= 16;
+        unsigned long long z[4] = {0, 0, 0, 0}, r[4];
+        hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_prof), z, sizeof(z));
+        igemm_kernel<BM, BN, WAVES_M, CONV, GEGLU><<<grid, NT, smem, st>>>(q);
+        hipStreamSynchronize(st);
+        hipMemcpyFromSymbol(r, HIP_SYMBOL(g_igemm_prof), sizeof(r));
+        fprintf(stderr, "[igemm<%d,%d,%d,%d> M=%d N=%d K=%d] blocks=%llu per-block cycles: kloop %.0f (of which tile-start wait %.0f) epilogue %.0f (tiles/block %.2f)\n",
+                BM, BN, CONV, (int)GEGLU, p.M, p.N, p.K, r[3], (double)r[0] / r[3], (double)r[2] / r[3], (double)r[1] / r[3], (double)ntiles / g);
+        return hipGetLastError();
+    }
     igemm_kernel<BM, BN, WAVES_M, CONV, GEGLU><<<grid, NT, smem, st>>>(p);
     return hipGetLastError();
 }
@@ -506,6 +550,8 @@ static hipError_t launch_cfg(const IgemmParams& p, int batch, hipStream_t st) {
 hipError_t launch_igemm(const IgemmParams& p_in, bool conv, int batch, hipStream_t st) {
     static const int dbg = getenv("RDM_IGEMM_DBG") ? atoi(getenv("RDM_IGEMM_DBG")) : 0;
     IgemmParams p = p_in; p.dbg = dbg;
+    static const int no_resk = getenv("RDM_NO_RESK") ? atoi(getenv("RDM_NO_RESK")) : 0;
+    p.res_k = 0;
     if (p.K % 64 != 0 || p.C0 % 64 != 0 || p.C1 % 64 != 0) return hipErrorInvalidValue;
     if (p.N % 2 != 0 || p.ldo % 2 != 0 || p.sO % 2 != 0) return hipErrorInvalidValue;   // paired-column epilogue
     if (p.act == ACT_GEGLU && (p.N % 64 != 0)) return hipErrorInvalidValue;
@@ -529,6 +575,10 @@ hipError_t launch_igemm(const IgemmParams& p_in, bool conv, int batch, hipStream
         if (wide) return tall ? launch_cfg<256, 192, 4, 1, false>(p, batch, st) : launch_cfg<128, 192, 2, 1, false>(p, batch, st);
         return tall ? launch_cfg<256, 128, 4, 1, false>(p, batch, st) : launch_cfg<128, 128, 2, 1, false>(p, batch, st);
     }
+    // linear with a bf16 residual: feed the residual tile through the A stream against an identity block (see the kernel)
+    if (!no_resk && p.res_bf16 && !p.res_f32 && p.out_bf16 && !p.out_f32 && p.alpha == 1.0f && p.act == ACT_NONE && batch == 1 &&
+        p.N % (wide ? 192 : 128) == 0 && p.ldo % 8 == 0 && p.ldo >= p.N)
+        p.res_k = 1;
     if (wide) return tall ? launch_cfg<256, 192, 4, 0, false>(p, batch, st) : launch_cfg<128, 192, 2, 0, false>(p, batch, st);
     return tall ? launch_cfg<256, 128, 4, 0, false>(p, batch, st) : launch_cfg<128, 128, 2, 0, false>(p, batch, st);
 }

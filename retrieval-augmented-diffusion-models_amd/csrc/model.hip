@@ -685,7 +685,12 @@ int rdm_ctx_create(int device_id, rdm_ctx** out) {
     if (hipSetDevice(device_id) != hipSuccess) return -2;
     rdm_ctx* c = new rdm_ctx();
     c->device = device_id;
-    if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) { delete c; return -2; }
+    {   // zero page + identity matrix (the residual-as-K-columns operand of the linear GEMMs, igemm.hip)
+        const size_t bytes = RDM_EYE_OFFSET + (size_t)RDM_EYE_N * RDM_EYE_N * 2;
+        std::vector<uint16_t> host(bytes / 2, 0);
+        for (int i = 0; i < RDM_EYE_N; i++) host[RDM_EYE_OFFSET / 2 + (size_t)i * RDM_EYE_N + i] = 0x3F80;   // bf16 1.0
+        if (hipMalloc(&c->zero_page, bytes) != hipSuccess || hipMemcpy(c->zero_page, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { delete c; return -2; }
+    }
     *out = c;
     return 0;
 }
