@@ -54,7 +54,7 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
 // epilogue activation ids (igemm)
 enum { ACT_NONE = 0, ACT_GEGLU = 1, ACT_QUICKGELU = 2, ACT_SILU = 3 };
 
-constexpr int RDM_EYE_OFFSET = 4096, RDM_EYE_N = 192;
+constexpr int RDM_EYE_OFFSET = 4096, RDM_EYE_N = 256;
 
 struct IgemmParams {
     // A operand: logical [M, K].  Two channel-concatenated sources (A1 may be null, C1 = 0).
@@ -76,7 +76,7 @@ struct IgemmParams {
     int act;
     // batching over blockIdx.z (element strides)
     long long sA, sW, sO;
-    const void* zero_page;      // 4 KiB of zeros, followed by a 192 x 192 bf16 identity matrix (RDM_EYE_OFFSET)
+    const void* zero_page;      // 4 KiB of zeros, followed by a 256 x 256 bf16 identity matrix (RDM_EYE_OFFSET)
     int res_k;                  // set by launch_igemm: the bf16 residual enters as BN extra K columns against that identity
     int dbg;                    // debug ablation bits (env RDM_IGEMM_DBG): 1 no MFMA, 2 no in-loop staging, 4 no stores
 };

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
     constexpr int RPP = NT / 8;                  // rows per loader pass (NT threads cover RPP rows x 8 chunks)
     constexpr int AP = BM / RPP, BP = BN / RPP;
     static_assert(BM % RPP == 0 && BN % RPP == 0 && WM % 64 == 0 && WN % 32 == 0 && RPP % 16 == 0, "tile/wave geometry");
-    static_assert((WN * 128) % 2048 == 0 && (FM + FN == 5 || FM + FN == 4), "fragment addressing / counted waits");
+    static_assert((WN * 128) % 2048 == 0 && (FM + FN == 6 || FM + FN == 5 || FM + FN == 4), "fragment addressing / counted waits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -305,7 +305,8 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
                         for (int i = 0; i < FM; i++) RDM_LDS_READ(fa[ns][i], van, i * 4096);
 #pragma unroll
                         for (int j = 0; j < FN; j++) RDM_LDS_READ(fb[ns][j], vbn, j * 4096);
-                        if constexpr (FM + FN == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+                        if constexpr (FM + FN == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                        else if constexpr (FM + FN == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
                         else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
                     } else {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -565,6 +566,11 @@ hipError_t launch_igemm(const IgemmParams& p_in, bool conv, int batch, hipStream
     if (force_bm == 256) tall = true;
     if (p.act == ACT_GEGLU) {
         if (conv) return hipErrorInvalidValue;
+        // 256-wide tile (x and gate interleaved: 128 outputs): the A tile is re-read once per column tile, and the
+        // L2->LDS path (1 KiB per ~20 cycles per CU), not the MFMA pipe, bounds the 128-wide tile's K loop
+        static const int geglu_bn = getenv("RDM_GEGLU_BN") ? atoi(getenv("RDM_GEGLU_BN")) : 256;
+        if (tall && geglu_bn == 256 && p.N % 256 == 0 && (long long)((p.M + 255) / 256) * (p.N / 256) * batch >= 256)
+            return launch_cfg<256, 256, 4, 0, true>(p, batch, st);
         return tall ? launch_cfg<256, 128, 4, 0, true>(p, batch, st) : launch_cfg<128, 128, 2, 0, true>(p, batch, st);
     }
     if (conv && p.ups) {
