@@ -186,6 +186,102 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(ScanParams p) {
     }
 }
 
+// ---------------------------------------------------------------- scan, dim == 512 (CLIP ViT-B/32: the reference's only database)
+// The queries never touch LDS: wave w owns 32 queries (w & 1) and keeps their hi / lo fp16 words for ALL 512 dimensions as
+// MFMA B fragments in registers (2 x 32 fragments = 256 registers; one wave per SIMD has 512), against 128 of the tile's 256
+// rows (w >> 1).  LDS holds only the database ring (3 stages of 256 rows x 64 dims, requested two stages ahead with counted
+// vmcnt across raw barriers), so a stage costs 32 LDS-DMA pieces instead of 48 and 4 instead of 6 LDS reads per k-step; the
+// K loop of a tile is fully unrolled (the register-resident fragments need compile-time indices).
+// Measured (20.9 M x 512, 64 queries): 5.5 ms = 3.9 TB/s of database streamed, vs 6.6 ms for the LDS-staged-query kernel; the
+// bare LDS-DMA stream of the same walk runs at 6.3 TB/s (tools/ubench/hbm_pattern.hip), the gap is LDS-DMA issue time that a
+// single wave per SIMD cannot overlap with its own MFMAs.
+template <int KSEL>
+__global__ __launch_bounds__(256, 1) void knn_scan512_kernel(ScanParams p) {
+    constexpr int DB_BYTES = KNN_ROWS * 128, NKC = 8, DIM = 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = tid >> 3, pchunk = tid & 7;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int rh = wave >> 1, qt = wave & 1;
+    const char* zero = (const char*)p.zero_page;
+
+    f16x8 qh[32], ql[32];
+    {
+        const _Float16* qhp = p.qh + (long long)(qt * 32 + frow) * DIM + fhalf * 8;
+        const _Float16* qlp = p.ql + (long long)(qt * 32 + frow) * DIM + fhalf * 8;
+#pragma unroll
+        for (int kk = 0; kk < 32; kk++) { qh[kk] = *(const f16x8*)(qhp + kk * 16); ql[kk] = *(const f16x8*)(qlp + kk * 16); }
+    }
+    float ls[KSEL]; uint32_t li[KSEL];
+#pragma unroll
+    for (int j = 0; j < KSEL; j++) { ls[j] = -INFINITY; li[j] = 0xffffffffu; }
+
+    const long long my_tiles = (p.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const long long iters = my_tiles * NKC;
+    auto stage_db = [&](long long it) {
+        const long long tl = it / NKC; const int kc = (int)(it - tl * NKC);
+        const long long tile = blockIdx.x + tl * gridDim.x;
+        char* Ds = smem + (int)(it % 3) * DB_BYTES;
+#pragma unroll
+        for (int i = 0; i < KNN_ROWS / 32; i++) {
+            const int r = i * 32 + lrow;
+            const long long row = tile * KNN_ROWS + r;
+            const int c = pchunk ^ ((r >> 1) & 7);
+            const void* g = (row < p.n) ? (const void*)(p.dbn + row * DIM + kc * KNN_BK + c * 8) : (const void*)zero;
+            glds16(g, Ds + (i * 32 + wave * 8) * 128);
+        }
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
+
+    if (iters > 0) stage_db(0);
+    if (iters > 1) stage_db(1);
+    long long it = 0;
+    for (long long tl = 0; tl < my_tiles; tl++) {
+#pragma unroll
+        for (int kc = 0; kc < NKC; kc++, it++) {
+            // needed now: stage `it`; the 8 pieces of stage it+1 (requested after it) may stay in flight
+            if (it + 1 < iters) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                 // raw barrier (a __syncthreads would drain vmcnt): stage landed for all
+            if (it + 2 < iters) stage_db(it + 2);         // waves; the slot of stage it-1 is free (its reads fed MFMAs already)
+            const char* Ds = smem + (int)(it % 3) * DB_BYTES;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int chunk = k * 2 + fhalf, kk = kc * 4 + k;
+                f16x8 a[4];
+#pragma unroll
+                for (int rf = 0; rf < 4; rf++) {
+                    const int row = rh * 128 + rf * 32 + frow;
+                    a[rf] = *(const f16x8*)(Ds + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int rf = 0; rf < 4; rf++) {
+                    acc[rf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rf], ql[kk], acc[rf], 0, 0, 0);
+                    acc[rf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rf], qh[kk], acc[rf], 0, 0, 0);
+                }
+            }
+        }
+        const long long tile = blockIdx.x + tl * gridDim.x;
+        const long long rbase = tile * KNN_ROWS + rh * 128 + 4 * fhalf;
+#pragma unroll
+        for (int rf = 0; rf < 4; rf++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const long long row = rbase + rf * 32 + (r & 3) + 8 * (r >> 2);
+                if (row < p.n) list_insert<KSEL>(ls, li, acc[rf][r], (uint32_t)row);
+                acc[rf][r] = 0.f;
+            }
+    }
+    const int list_id = blockIdx.x * 4 + rh * 2 + fhalf;
+    const long long base = ((long long)(qt * 32 + frow) * p.nlists + list_id) * KSEL;
+#pragma unroll
+    for (int j = 0; j < KSEL; j++) { p.cand_s[base + j] = ls[j]; p.cand_i[base + j] = li[j]; }
+}
+
 // ---------------------------------------------------------------- merge + exact re-score
 struct MergeParams {
     const float* cand_s; const uint32_t* cand_i; int nlists;
@@ -305,7 +401,8 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const long long ntiles = (db.n + KNN_ROWS - 1) / KNN_ROWS;
     int grid = (int)(ntiles < ncu ? ntiles : ncu);
-    const int nlists = grid * 8;
+    const bool d512 = db.dim == 512;                 // register-resident queries (4 lists per block and query instead of 8)
+    const int nlists = grid * (d512 ? 4 : 8);
     const size_t qn_b = (size_t)KNN_Q * db.dim * 4, qh_b = (size_t)KNN_Q * db.dim * 2;
     const size_t cand_b = (size_t)KNN_Q * nlists * KSEL * 4;
     const size_t need = qn_b + 2 * qh_b + 2 * cand_b + 1024;
@@ -319,10 +416,12 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
     static void* zero_page = nullptr;
     if (!zero_page) { KNN_TRY(hipMalloc(&zero_page, 256)); KNN_TRY(hipMemset(zero_page, 0, 256)); }
     constexpr int scan_smem = 2 * (KNN_ROWS * 128 + 2 * KNN_Q * 128);
+    constexpr int scan512_smem = 3 * KNN_ROWS * 128;
     constexpr int merge_smem = 256 * KSEL * 8;
     static bool attr = false;
     if (!attr) {
         KNN_TRY(hipFuncSetAttribute((const void*)knn_scan_kernel<KSEL>, hipFuncAttributeMaxDynamicSharedMemorySize, scan_smem));
+        KNN_TRY(hipFuncSetAttribute((const void*)knn_scan512_kernel<KSEL>, hipFuncAttributeMaxDynamicSharedMemorySize, scan512_smem));
         KNN_TRY(hipFuncSetAttribute((const void*)knn_merge_kernel<KSEL>, hipFuncAttributeMaxDynamicSharedMemorySize, merge_smem));
         attr = true;
     }
@@ -332,7 +431,8 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
         KNN_TRY(hipGetLastError());
         ScanParams sp{}; sp.dbn = (const _Float16*)db.dbn; sp.n = db.n; sp.dim = db.dim; sp.ntiles = ntiles; sp.qh = qh; sp.ql = ql;
         sp.cand_s = cs; sp.cand_i = ci; sp.nlists = nlists; sp.zero_page = zero_page;
-        knn_scan_kernel<KSEL><<<grid, 256, scan_smem, st>>>(sp);
+        if (d512) knn_scan512_kernel<KSEL><<<grid, 256, scan512_smem, st>>>(sp);
+        else knn_scan_kernel<KSEL><<<grid, 256, scan_smem, st>>>(sp);
         KNN_TRY(hipGetLastError());
         MergeParams mp{}; mp.cand_s = cs; mp.cand_i = ci; mp.nlists = nlists; mp.dbn = (const _Float16*)db.dbn; mp.qn = qn;
         mp.dim = db.dim; mp.n = db.n; mp.k = k; mp.idx_out = idx_out; mp.score_out = score_out; mp.qbase = q0;

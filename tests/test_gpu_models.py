@@ -191,3 +191,20 @@ def test_knn_bit_exact(ctx, N, B, k):
     # gather of raw embeddings (dsetbuilder.py:493)
     emb = ctx.db_gather(torch.from_numpy(ref_i.astype(np.int64).astype(np.int32)).to(ctx.device), 512).cpu().numpy()
     assert np.array_equal(emb, db[ref_i].astype(np.float32))
+
+
+@pytest.mark.parametrize("dim", [256, 1024])
+def test_knn_other_dims_bit_exact(ctx, dim):
+    """Embedding widths other than CLIP ViT-B/32's 512 take the generic scan kernel (queries staged through LDS)."""
+    N, B, k = 20_011, 5, 4
+    rng = np.random.default_rng(3)
+    db = (rng.standard_normal((N, dim), dtype=np.float32) * 0.45).astype(np.float16)
+    db[N - 2] = db[5]
+    q = (np.random.default_rng(4).standard_normal((B, dim)) * 0.45).astype(np.float32)
+    q[1] = db[5].astype(np.float32)
+    ctx.db_load(db)
+    idx, sc = ctx.knn(torch.from_numpy(q), k)
+    torch.cuda.synchronize()
+    ref_i, ref_s = oret.exact_topk(oret.normalize_db(db), oret.normalize_queries(q), k)
+    assert np.array_equal(idx.cpu().numpy().view(np.uint32), ref_i)
+    assert np.abs(sc.cpu().numpy() - ref_s).max() <= 1e-6
