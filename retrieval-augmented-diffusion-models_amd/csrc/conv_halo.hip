@@ -36,7 +36,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
     const int frow = lane & 31, fhalf = lane >> 5;
 
     // ---- geometry (uniform)
-    const int H = p.Hin, W = p.Win, HW = H * W;
+    const int H = p.Hout, W = p.Wout, HW = H * W;          // the conv's (virtual) input: for ups the 2x nearest-upsampled image
     const int RS = (HW >= BM) ? BM / W : H;               // image rows per sample-part of a tile
     const int NS = BM / (RS * W);                         // samples per tile (1, or 4 at 8x8)
     const int HPW = W + 2, HPS = (RS + 2) * HPW, HP = NS * HPS;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
                 const int s = hp / HPS, r = hp - s * HPS;
                 const int hy = r / HPW, hx = r - hy * HPW;
                 const int y = y0 + hy - 1, x = hx - 1;
-                if (y >= 0 && y < H && x >= 0 && x < W) pix = ((b0 + s) * H + y) * W + x;
+                if (y >= 0 && y < H && x >= 0 && x < W) pix = p.ups ? ((b0 + s) * p.Hin + (y >> 1)) * p.Win + (x >> 1) : ((b0 + s) * H + y) * W + x;
             }
             hpix[ps] = pix;
         }
@@ -338,8 +338,10 @@ static hipError_t launch_halo(const IgemmParams& p, hipStream_t st) {
 bool conv_halo_supported(const IgemmParams& p) {
     static const int off = getenv("RDM_NO_HALO") ? atoi(getenv("RDM_NO_HALO")) : 0;
     if (off) return false;
-    const int W = p.Win, H = p.Hin;
-    if (p.stride != 1 || p.ups || p.Hout != H || p.Wout != W) return false;
+    static const int no_ups = getenv("RDM_NO_HALO_UPS") ? atoi(getenv("RDM_NO_HALO_UPS")) : 0;
+    const int W = p.Wout, H = p.Hout;
+    if (p.stride != 1) return false;
+    if (p.ups ? (no_ups || p.Hout != 2 * p.Hin || p.Wout != 2 * p.Win) : (p.Hout != p.Hin || p.Wout != p.Win)) return false;
     if (W < 4 || W > 64 || 256 % W != 0) return false;
     const int HW = H * W;
     if (HW >= 256) { if (HW % 256 != 0 || H % (256 / W) != 0) return false; }
