@@ -30,7 +30,18 @@ __global__ void gn_stats_kernel(GnParams p) {
 #pragma unroll
     for (int i = 0; i < 8; i++) { s[i] = 0.f; q[i] = 0.f; }
     if (rr < R) {
-        for (int row = r0 + rr; row < r1; row += R) {
+        // four independent 16-byte loads in flight per thread (a single dependent load per iteration leaves the HBM idle)
+        int row = r0 + rr;
+        for (; row + 3 * R < r1; row += 4 * R) {
+            bf16x8 d[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) d[u] = *(const bf16x8*)gn_src(p, b, row + u * R, v * 8);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) { const float f = bf2f((bf16_t)d[u][i]); s[i] += f; q[i] += f * f; }
+        }
+        for (; row < r1; row += R) {
             const bf16x8 d = *(const bf16x8*)gn_src(p, b, row, v * 8);
 #pragma unroll
             for (int i = 0; i < 8; i++) { const float f = bf2f((bf16_t)d[i]); s[i] += f; q[i] += f * f; }
