@@ -32,6 +32,7 @@ struct SmallAttnParams {
 struct DdimStepParams {
     const float* x; const float* eps; const float* noise;   // noise may be null (eta == 0)
     float* x_prev; float* pred_x0;                           // pred_x0 may be null
+    float* x_dup;                                            // second copy of x_prev (the CFG-doubled batch) or null
     long long n_per_batch;                                   // B*C*H*W
     float a_t, a_prev, sigma_t, sqrt_one_minus_at, scale, temperature;
     int cfg;

@@ -176,7 +176,9 @@ __global__ void ddim_step_kernel(DdimStepParams p) {
         const float x0 = (x - p.sqrt_one_minus_at * e) / sa;
         const float dir = dirc * e;
         const float nz = p.noise ? p.sigma_t * p.noise[i] * p.temperature : 0.f;
-        p.x_prev[i] = sap * x0 + dir + nz;
+        const float xp = sap * x0 + dir + nz;
+        p.x_prev[i] = xp;
+        if (p.x_dup) p.x_dup[i] = xp;
         if (p.pred_x0) p.pred_x0[i] = x0;
     }
 }

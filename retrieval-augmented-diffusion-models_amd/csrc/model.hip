@@ -844,12 +844,12 @@ int rdm_ddim_sample(rdm_ctx* c, const rdm_ddim_args* a, const float* x_T, const 
     int n_logged = 0;
     for (int i = 0; i < total; i++) {
         const int index = total - i - 1;
-        if (cfg) RDM_CHECK_HIP(c, hipMemcpyAsync(x2 + n1, x2, n1 * 4, hipMemcpyDeviceToDevice, c->stream));
+        if (cfg && i == 0) RDM_CHECK_HIP(c, hipMemcpyAsync(x2 + n1, x2, n1 * 4, hipMemcpyDeviceToDevice, c->stream));   // later steps: ddim_step writes both halves
         RDM_TRY(unet_forward_impl(c, x2, (const int64_t*)(tdev + (size_t)index * nb), nullptr, u.kv_cache, nb, k, a->height, a->width, eps));
         const bool log = (index % a->log_every_t == 0) || (index == total - 1);
         DdimStepParams p{};
         p.x = x2; p.eps = eps; p.noise = (noise && a->eta != 0.f) ? noise + (size_t)i * n1 : nullptr;
-        p.x_prev = x2; p.pred_x0 = (log && pred_x0_inter) ? pred_x0_inter + (size_t)n_logged * n1 : nullptr;
+        p.x_prev = x2; p.x_dup = cfg ? x2 + n1 : nullptr; p.pred_x0 = (log && pred_x0_inter) ? pred_x0_inter + (size_t)n_logged * n1 : nullptr;
         p.n_per_batch = n1; p.a_t = at[index]; p.a_prev = ap[index]; p.sigma_t = sg[index]; p.sqrt_one_minus_at = s1m[index];
         p.scale = a->unconditional_guidance_scale; p.temperature = a->temperature; p.cfg = cfg ? 1 : 0;
         RDM_CHECK_HIP(c, launch_ddim_step(p, c->stream));
