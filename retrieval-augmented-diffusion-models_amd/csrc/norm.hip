@@ -9,6 +9,8 @@
 // depend on scheduling, so batch sharding over GPUs is bit-reproducible); (2) an elementwise
 // normalise+affine(+SiLU) pass that folds (mean, rstd, gamma, beta) into one per-channel FMA held in
 // LDS.  Both passes read the decoder's skip-concat as two source tensors (never materialised).
+#include <stdlib.h>
+
 #include "kernels.h"
 
 
@@ -190,6 +192,61 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* x, const floa
     }
 }
 
+// bf16 -> bf16 rows with C % 8 == 0 (every LayerNorm of the UNet): 16-byte loads and stores, 8 channels per lane.  A store
+// costs ~70 cycles per wave-instruction whatever its width, so the 4-byte-per-lane kernel above is bound by its store COUNT
+// (256 B per instruction ~ 1.9 TB/s chip-wide); this one moves 1 KiB per instruction.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(const bf16_t* x, const float* gamma, const float* beta,
+                                                               bf16_t* out, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bf16_t* xr = x + row * C;
+    const int nvec = C >> 3;
+    float v[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int vi = lane + j * 64;
+        if (vi < nvec) {
+            const bf16x8 d = *(const bf16x8*)(xr + vi * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { v[j][e] = bf2f((bf16_t)d[e]); s += v[j][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[j][e] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+        if (lane + j * 64 < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float d = v[j][e] - mean; q += d * d; }
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / C + eps);
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int vi = lane + j * 64;
+        if (vi < nvec) {
+            const float4 g0 = *(const float4*)(gamma + vi * 8), g1 = *(const float4*)(gamma + vi * 8 + 4);
+            const float4 b0 = *(const float4*)(beta + vi * 8), b1 = *(const float4*)(beta + vi * 8 + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                o[e] = pack2bf((v[j][2 * e] - mean) * rstd * gg[2 * e] + bb[2 * e], (v[j][2 * e + 1] - mean) * rstd * gg[2 * e + 1] + bb[2 * e + 1]);
+            *(uint4*)(out + row * C + vi * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 template <int NP>
 static void ln_dispatch(const void* x, int in_is_f32, const float* g, const float* b, void* out, int out_is_f32, int M, int C,
                         float eps, hipStream_t st) {
@@ -206,6 +263,14 @@ static void ln_dispatch(const void* x, int in_is_f32, const float* g, const floa
 hipError_t launch_layernorm(const void* x, int in_is_f32, const float* gamma, const float* beta, void* out, int out_is_f32,
                             int M, int C, float eps, hipStream_t st) {
     if (C % 2 || C > 4096) return hipErrorInvalidValue;
+    static const int no_vec = getenv("RDM_LN_NOVEC") ? atoi(getenv("RDM_LN_NOVEC")) : 0;
+    if (!no_vec && !in_is_f32 && !out_is_f32 && C % 8 == 0 && C <= 1024 && ((size_t)x % 16 == 0) && ((size_t)out % 16 == 0) &&
+        ((size_t)gamma % 16 == 0) && ((size_t)beta % 16 == 0)) {
+        const int grid = (M + 3) / 4;
+        if (C <= 512) layernorm_bf16x8_kernel<1><<<grid, 256, 0, st>>>((const bf16_t*)x, gamma, beta, (bf16_t*)out, M, C, eps);
+        else layernorm_bf16x8_kernel<2><<<grid, 256, 0, st>>>((const bf16_t*)x, gamma, beta, (bf16_t*)out, M, C, eps);
+        return hipGetLastError();
+    }
     if (C <= 1024) ln_dispatch<8>(x, in_is_f32, gamma, beta, out, out_is_f32, M, C, eps, st);
     else ln_dispatch<32>(x, in_is_f32, gamma, beta, out, out_is_f32, M, C, eps, st);
     return hipGetLastError();
