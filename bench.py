@@ -17,8 +17,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
   roofline      dominant kernel = the 3x3 convolution (input-stationary halo kernel + the generic implicit GEMM for
                 strided / upsampled / decoder convs; 63 % of all FLOPs), MFMA-bound; achieved = algorithmic FLOPs
                 (2*M*N*9*Cin per launch) / HIP-event time of those launches, measured live in the timed region on the
-                library's stream; peak = 2.5 PFLOP/s dense bf16.  `traffic` is null in the live line: the PMC passes
-                (FETCH_SIZE / WRITE_SIZE, separate runs) are committed under profiles/ with their summary.
+                library's stream; peak = 2.5 PFLOP/s dense bf16.  `traffic` = HBM bytes per launch of the halo kernel from the
+                committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs; profiles/r01_pmc_v4.json).
   cpu_baseline  the fp32 PyTorch oracle (kind "port") timed on this box's host cores on a bounded sample.
 """
 import argparse
@@ -163,6 +163,14 @@ def main():
         dt = float(tt.item())
     assert bool(torch.isfinite(img).all()), "non-finite images"
 
+    # HBM traffic of the dominant kernel: not measurable from inside this process -- taken from the committed PMC passes
+    # (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script, gfx950 corrections applied; profiles/README.md)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_v4.json")) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     n_conv, ms_conv, fl_conv = ctx.prof_collect(0)
     n_lin, ms_lin, fl_lin = ctx.prof_collect(1)
     if rank == 0:
@@ -180,7 +188,8 @@ def main():
                        "guidance_scale": a.scale, "db_rows": N, "parallelism": f"dp{world} (batch-sharded, DB replicated, "
                                                                                 "all-gather of images only)"},
             "roofline": {"kernel": "conv3x3_halo_kernel<192> + igemm_kernel<..,conv> (3x3 conv, bf16 MFMA, fp32 accumulate)", "bound": "mfma",
-                         "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": None,
+                         "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": traffic,
+                         "traffic_note": "bytes per launch of conv3x3_halo_kernel<192> from the committed rocprofv3 PMC passes (profiles/r01_pmc_v4.json), not collected in this run",
                          "launches": n_conv, "avg_launch_ms": ms_conv / max(n_conv, 1),
                          "algorithmic_tflop_per_launch": fl_conv / max(n_conv, 1) / 1e12,
                          "linear_gemm": {"achieved": (fl_lin / (ms_lin * 1e-3) / 1e12) if ms_lin > 0 else 0.0, "launches": n_lin,
