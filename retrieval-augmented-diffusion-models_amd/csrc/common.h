@@ -77,6 +77,7 @@ struct IgemmParams {
     // batching over blockIdx.z (element strides)
     long long sA, sW, sO;
     const void* zero_page;      // 4 KiB of zeros, followed by a 256 x 256 bf16 identity matrix (RDM_EYE_OFFSET)
+    int ksplit; float* ws;      // halo conv split-K (conv_halo.hip): ksplit fp32 partial tiles [ksplit][M][N] in ws, summed by a finisher
     int res_k;                  // set by launch_igemm: the bf16 residual enters as BN extra K columns against that identity
     int dbg;                    // debug ablation bits (env RDM_IGEMM_DBG): 1 no MFMA, 2 no in-loop staging, 4 no stores
 };

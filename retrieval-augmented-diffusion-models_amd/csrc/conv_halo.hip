@@ -43,7 +43,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
     const int Cin = p.C0 + p.C1, nslice = Cin / BK;
 
     const int nbn = p.N / BN, nbm = p.M / BM;
-    const int ntiles = nbm * nbn;
+    const int ntiles_mn = nbm * nbn;
+    // split-K: work item t = part * ntiles_mn + tile; a part covers a contiguous range of 64-channel slices (all 9 taps each)
+    const int S = p.ksplit > 1 ? p.ksplit : 1;
+    const int ntiles = ntiles_mn * S;
     const int G = gridDim.x, xcd = blockIdx.x & 7;
     const int gx = (G - xcd + 7) >> 3;
     const int tq = ntiles >> 3, tr = ntiles & 7;
@@ -61,6 +64,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
     int b_n[BP];
     int m0, n0;
     auto setup = [&](int t) {
+        t = t % ntiles_mn;
         const int bm = t / nbn, bn = t - bm * nbn;
         m0 = bm * BM; n0 = bn * BN;
         const int b0 = m0 / HW, y0 = (m0 - b0 * HW) / W;
@@ -118,9 +122,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
 
     // ---- pipeline prologue: halo of slice 0 and weights of (slice 0, tap 0)
     setup(tile);
+    {
+        const int s0 = ((tile / ntiles_mn) * nslice) / S;
 #pragma unroll
-    for (int ps = 0; ps < HPASS; ps++) stage_halo_pass(ps, 0, 0);
-    stage_b(0, 0, 0);
+        for (int ps = 0; ps < HPASS; ps++) stage_halo_pass(ps, s0, 0);
+        stage_b(s0, 0, 0);
+    }
     int hcur = 0, bcur = 0;
     int pending_stores = -1;
 
@@ -131,6 +138,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
         const int em0 = m0, en0 = n0;
         const int next = tile + gx;
         const bool has_next = next < t_end;
+        const int part = tile / ntiles_mn;
+        const int s_begin = (part * nslice) / S, s_end = ((part + 1) * nslice) / S;
+        const int ns_begin = has_next ? ((next / ntiles_mn) * nslice) / S : 0;
         float pbias[FM][FN];
 #pragma unroll
         for (int i = 0; i < FM; i++) {
@@ -160,14 +170,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
         // ends interval 4t+3 (g0: after M1, g1: after L1); a halo pass (due at the next SLICE) stays in flight across taps.
         // Buffers are re-staged only after a barrier that follows the lgkmcnt(0) retiring their last reads.
 #define RDM_LDS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
-        if (pending_stores > 0) {
-            if constexpr (WN == 96) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (pending_stores == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (pending_stores == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (pending_stores == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (pending_stores == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();             // first slice's halo + weights of tap 0 landed (all waves)
         if (grp) __builtin_amdgcn_s_barrier();    // stagger: group 1 starts one interval late
-        for (int sl = 0; sl < nslice; sl++) {
-            const bool last_slice = sl + 1 == nslice;
+        for (int sl = s_begin; sl < s_end; sl++) {
+            const bool last_slice = sl + 1 == s_end;
 #pragma unroll 1
             for (int tap = 0; tap < 9; tap++) {
                 const int dy = tap / 3, dx = tap - dy * 3;
@@ -198,12 +209,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
                     if (half == 0) {
                         if (tap < 8) stage_b(sl, tap + 1, bcur ^ 1);
                         else if (!last_slice) stage_b(sl + 1, 0, bcur ^ 1);
-                        else if (has_next) { setup(next); stage_b(0, 0, bcur ^ 1); }     // cross-tile prefetch
+                        else if (has_next) { setup(next); stage_b(ns_begin, 0, bcur ^ 1); }     // cross-tile prefetch
                     } else {
                         if (halo_now) stage_halo_pass(tap, sl + 1, hcur ^ 1);
                         else if (tile_end && has_next) {
 #pragma unroll
-                            for (int ps = 0; ps < HPASS; ps++) stage_halo_pass(ps, 0, hcur ^ 1);
+                            for (int ps = 0; ps < HPASS; ps++) stage_halo_pass(ps, ns_begin, hcur ^ 1);
                         }
                         if (grp && !tile_end) {
                             if (halo_now) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
@@ -242,7 +253,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
         // to packed column pairs, wave-private LDS transpose (staged in the halo buffer just consumed: its successor
         // was prefetched into the other buffer), whole rows leave as 16-byte stores, the residual arrives as 16-byte
         // loads.  Vector-memory instruction count, not bytes, is what an epilogue pays for.
-        {
+        if (S > 1) {
+            // split-K: this part's raw fp32 accumulators go to its plane of the workspace (bias, time-embedding row, residual and
+            // the bf16 rounding happen once, in splitk_finish_kernel).  One 32x32 fragment at a time through a wave-private 4 KB
+            // LDS tile: 16 ds_write_b32 (rows of 32 floats), back as 4 float4 per lane, out as 16-byte stores.
+            __syncthreads();
+            float* stg = (float*)(halo_base + (hcur ^ 1) * HALO_BYTES + wave * 4096);
+            float* wsp = p.ws + (long long)part * p.M * p.N;
+#pragma unroll
+            for (int i = 0; i < FM; i++)
+#pragma unroll
+                for (int j = 0; j < FN; j++) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) stg[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * 32 + frow] = acc[i][j][r];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int it = 0; it < 4; it++) {
+                        const int idx = it * 64 + lane, row = idx >> 3, ch = idx & 7;
+                        const float4 u = *(const float4*)(stg + row * 32 + ch * 4);
+                        *(float4*)(wsp + (long long)(em0 + wm * WM + i * 32 + row) * p.N + en0 + wn * WN + j * 32 + ch * 4) = u;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+        } else {
             constexpr int ROWB = WN * 2, CPR = WN / 8, NIT = (32 * CPR) / 64;
             static_assert(8 * 32 * ROWB <= HALO_BYTES && (32 * CPR) % 64 == 0, "epilogue staging geometry");
             __syncthreads();                                            // every wave is done with the last K-slice
@@ -298,10 +331,44 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
         if (p.dbg & 16) tprof[1] += __builtin_readcyclecounter() - tp1;
         if (!has_next) break;
         tile = next;
-        pending_stores = FM * ((32 * (WN / 8)) / 64);      // every tile is full: 16-byte row stores per lane
+        pending_stores = (S > 1) ? FM * FN * 4 : FM * ((32 * (WN / 8)) / 64);      // every tile is full: 16-byte stores per lane
     }
     if ((p.dbg & 16) && tid == 0) {
         atomicAdd(&g_halo_prof[0], tprof[0]); atomicAdd(&g_halo_prof[1], tprof[1]); atomicAdd(&g_halo_prof[3], 1ull);
+    }
+}
+
+// out = bf16(sum of the ksplit fp32 partial planes + bias + time-embedding row + residual), 8 columns per thread
+__global__ __launch_bounds__(256) void splitk_finish_kernel(IgemmParams p) {
+    const long long nvec = (long long)p.M * (p.N >> 3);
+    const long long plane = (long long)p.M * p.N;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
+        const long long m = v / (p.N >> 3); const int n = (int)(v - m * (p.N >> 3)) * 8;
+        float a[8];
+        { const float4 b0 = p.bias ? *(const float4*)(p.bias + n) : make_float4(0, 0, 0, 0), b1 = p.bias ? *(const float4*)(p.bias + n + 4) : make_float4(0, 0, 0, 0);
+          a[0] = b0.x; a[1] = b0.y; a[2] = b0.z; a[3] = b0.w; a[4] = b1.x; a[5] = b1.y; a[6] = b1.z; a[7] = b1.w; }
+        for (int s = 0; s < p.ksplit; s++) {                  // fixed order: deterministic
+            const float* w = p.ws + s * plane + m * p.N + n;
+            const float4 w0 = *(const float4*)w, w1 = *(const float4*)(w + 4);
+            a[0] += w0.x; a[1] += w0.y; a[2] += w0.z; a[3] += w0.w; a[4] += w1.x; a[5] += w1.y; a[6] += w1.z; a[7] += w1.w;
+        }
+        if (p.rowvec) {
+            const float* rv = p.rowvec + (m / p.rows_per_sample) * p.rowvec_ld + n;
+#pragma unroll
+            for (int e = 0; e < 8; e++) a[e] += rv[e];
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = cvt_pk_bf16(a[2 * e], a[2 * e + 1]);
+        if (p.res_bf16) {     // same double rounding as the fused epilogue: bf16(bf16(conv) + residual)
+            const uint4 r4 = *(const uint4*)(p.res_bf16 + m * p.ldo + n);
+            const uint32_t rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                o[e] = cvt_pk_bf16(__uint_as_float(o[e] << 16) + __uint_as_float(rr[e] << 16),
+                                   __uint_as_float(o[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u));
+        }
+        *(uint4*)(p.out_bf16 + m * p.ldo + n) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -315,7 +382,7 @@ static hipError_t launch_halo(const IgemmParams& p, hipStream_t st) {
         int dev = 0; hipGetDevice(&dev);
         hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     }
-    const long long ntiles = (long long)(p.M / 256) * (p.N / BN);
+    const long long ntiles = (long long)(p.M / 256) * (p.N / BN) * (p.ksplit > 1 ? p.ksplit : 1);
     long long g = (ncu + 7) & ~7;
     if (g > ntiles) g = ntiles;
     static const int prof = getenv("RDM_HALO_PROF") ? atoi(getenv("RDM_HALO_PROF")) : 0;
@@ -355,6 +422,30 @@ bool conv_halo_supported(const IgemmParams& p) {
     return true;
 }
 
+// K-split only pays when the MxN tiles leave most of the chip idle (the 8x8 level: 160 tiles on 256 CUs): S parts per tile
+// turn one 62 %-occupied round into ceil(160 S / 256) rounds of 1/S the length
+int conv_halo_ksplit(const IgemmParams& p) {
+    static const int off = getenv("RDM_NO_SPLITK") ? atoi(getenv("RDM_NO_SPLITK")) : 0;
+    if (off || !conv_halo_supported(p)) return 1;
+    int dev = 0, ncu = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int bn = (p.N % 192 == 0) ? 192 : 128;
+    const long long tiles = (long long)(p.M / 256) * (p.N / bn);
+    const int nslice = (p.C0 + p.C1) / 64;
+    if (tiles * 4 > (long long)ncu * 3 || p.N % 8 || p.ldo % 8) return 1;
+    int best = 1; double bestc = 1.0;                       // cost = rounds / S (+6 % per extra plane for the fp32 round trip)
+    for (int S = 2; S <= 3; S++) {
+        if (nslice < 2 * S) continue;
+        const double c = (double)((tiles * S + ncu - 1) / ncu) / S * (1.0 + 0.06 * (S - 1));
+        if (c < bestc - 0.08) { bestc = c; best = S; }
+    }
+    return best;
+}
+
 hipError_t launch_conv_halo(const IgemmParams& p, hipStream_t st) {
-    return (p.N % 192 == 0) ? launch_halo<192>(p, st) : launch_halo<128>(p, st);
+    hipError_t e = (p.N % 192 == 0) ? launch_halo<192>(p, st) : launch_halo<128>(p, st);
+    if (e != hipSuccess || p.ksplit <= 1) return e;
+    const long long nvec = (long long)p.M * (p.N >> 3);
+    long long g = (nvec + 255) / 256; if (g > 4096) g = 4096;
+    splitk_finish_kernel<<<dim3((unsigned)g), 256, 0, st>>>(p);
+    return hipGetLastError();
 }

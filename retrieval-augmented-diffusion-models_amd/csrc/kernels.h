@@ -45,6 +45,7 @@ struct DdpmStepParams {
 
 hipError_t launch_igemm(const IgemmParams& p, bool conv, int batch, hipStream_t st);
 bool conv_halo_supported(const IgemmParams& p);
+int conv_halo_ksplit(const IgemmParams& p);                // K-split factor worth using for this conv (1 = none); needs p.ws of ksplit*M*N floats
 hipError_t launch_conv_halo(const IgemmParams& p, hipStream_t st);
 // 3x3 conv dispatcher: input-stationary halo kernel when the geometry allows, else the generic implicit GEMM
 inline hipError_t launch_conv3x3(const IgemmParams& p, hipStream_t st) {

@@ -292,6 +292,7 @@ struct rdm_ctx {
     void* zero_page = nullptr;
     UNet unet; VqModel vq; ClipModel clip; KnnDb db;
     float* gn_partial = nullptr; size_t gn_partial_bytes = 0;
+    char* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;   // fp32 partial planes of the K-split halo convs
     char* samp = nullptr; size_t samp_bytes = 0;     // sampler scratch
     // optional per-launch HIP-event profiler for the GEMM-class kernels (bench.py roofline)
     bool prof = false;
@@ -346,6 +347,8 @@ struct Ops {
         p.A0 = A0; p.A1 = A1; p.C0 = C0; p.C1 = C1; p.W = w<bf16_t>(woff); p.bias = w<float>(boff);
         p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.stride = stride; p.ups = ups;
         p.rowvec = rowvec; p.rowvec_ld = rowvec_ld; p.rows_per_sample = Hout * Wout; p.res_bf16 = res; p.out_bf16 = out;
+        const int ks = conv_halo_ksplit(p);
+        if (ks > 1 && ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)ks * p.M * N * 4) == 0) { p.ksplit = ks; p.ws = (float*)c->splitk_ws; }
         prof_begin(0, 2.0 * p.M * N * (double)p.K);
         check(launch_conv3x3(p, c->stream), "conv3x3");
         prof_end();
@@ -700,7 +703,7 @@ void rdm_ctx_destroy(rdm_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     void* ptrs[] = {c->zero_page, c->unet.blob, c->unet.arena.base, c->unet.kv_cache, c->vq.blob, c->vq.arena.base,
-                    c->clip.blob, c->clip.arena.base, c->gn_partial, c->samp};
+                    c->clip.blob, c->clip.arena.base, c->gn_partial, c->samp, c->splitk_ws};
     for (void* p : ptrs) if (p) hipFree(p);
     knn_free(c->db);
     delete c;
@@ -987,6 +990,8 @@ int rdm_op_conv3x3(rdm_ctx* c, const void* x0, const void* x1, int C0, int C1, c
     p.A0 = (const bf16_t*)x0; p.A1 = (const bf16_t*)x1; p.C0 = C0; p.C1 = C1; p.W = (const bf16_t*)w; p.bias = bias;
     p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.stride = stride; p.ups = ups;
     p.rowvec = rowvec; p.rowvec_ld = rowvec_ld; p.rows_per_sample = Hout * Wout; p.res_bf16 = (const bf16_t*)res; p.out_bf16 = (bf16_t*)out;
+    const int ks = conv_halo_ksplit(p);
+    if (ks > 1) { RDM_TRY(ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)ks * p.M * N * 4)); p.ksplit = ks; p.ws = (float*)c->splitk_ws; }
     RDM_CHECK_HIP(c, launch_conv3x3(p, c->stream));
     return 0;
 }

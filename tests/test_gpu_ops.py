@@ -94,7 +94,9 @@ def test_conv3x3(ctx, B, H, W, C, N, stride, ups):
 
 
 @pytest.mark.parametrize("B,H,W,C0,C1,N", [(4, 8, 8, 64, 0, 192), (8, 8, 8, 128, 64, 192), (1, 16, 16, 64, 64, 128), (2, 32, 32, 64, 0, 192),
-                                            (1, 64, 64, 64, 0, 384), (1, 64, 64, 128, 0, 128), (3, 16, 16, 192, 0, 192)])
+                                            (1, 64, 64, 64, 0, 384), (1, 64, 64, 128, 0, 128), (3, 16, 16, 192, 0, 192),
+                                            # few tiles -> K-split (2 or 3 fp32 partial planes + finisher): 8x8 level shapes, uneven slice split, dual source
+                                            (8, 8, 8, 320, 0, 192), (16, 8, 8, 192, 128, 384), (4, 8, 8, 256, 0, 128), (2, 16, 16, 384, 0, 192)])
 def test_conv3x3_halo_kernel(ctx, B, H, W, C0, C1, N):
     """Shapes the input-stationary halo kernel takes (B*H*W % 256 == 0, W <= 64): every tile geometry (4 samples per
     tile at 8x8, whole image at 16x16, 8 / 4 rows at 32 / 64 wide), dual source, time-embedding row and residual."""
