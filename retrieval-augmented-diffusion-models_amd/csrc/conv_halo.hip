@@ -63,11 +63,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
     int hpix[HPASS];                                      // pixel index of my halo position in each pass, or -1
     int b_n[BP];
     int m0, n0;
-    auto setup = [&](int t) {
+    auto setup_mn = [&](int t) {
         t = t % ntiles_mn;
         const int bm = t / nbn, bn = t - bm * nbn;
         m0 = bm * BM; n0 = bn * BN;
-        const int b0 = m0 / HW, y0 = (m0 - b0 * HW) / W;
+#pragma unroll
+        for (int i = 0; i < BP; i++) b_n[i] = n0 + i * 64 + lrow;
+    };
+    auto setup_halo = [&](int t) {
+        t = t % ntiles_mn;
+        const int tm0 = (t / nbn) * BM;
+        const int b0 = tm0 / HW, y0 = (tm0 - b0 * HW) / W;
 #pragma unroll
         for (int ps = 0; ps < HPASS; ps++) {
             const int hp = ps * 64 + lrow;
@@ -80,8 +86,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
             }
             hpix[ps] = pix;
         }
-#pragma unroll
-        for (int i = 0; i < BP; i++) b_n[i] = n0 + i * 64 + lrow;
     };
     // one pass of the halo of channel slice `sl` -> halo buffer hb
     auto stage_halo_pass = [&](int ps, int sl, int hb) {
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
     const int odd = lane & 1;
 
     // ---- pipeline prologue: halo of slice 0 and weights of (slice 0, tap 0)
-    setup(tile);
+    setup_mn(tile); setup_halo(tile);
     {
         const int s0 = ((tile / ntiles_mn) * nslice) / S;
 #pragma unroll
@@ -193,7 +197,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
                 const bool tile_end = last_slice && tap == 8;
                 // one pass of the next slice's halo this tap -- true only if THIS wave has a lane in it (else nothing is issued
                 // and the counted wait below must not leave a weight piece in flight instead)
-                const bool halo_now = !last_slice && tap < HPASS && (tap * 64 + wave * 8 < HP);
+                // (in the LAST slice of a tile the passes are those of the next tile's first slice: eight taps of lead instead
+                // of one, the HBM latency of a tile's first halo no longer shows at the tile start)
+                const bool halo_now = (!last_slice || has_next) && tap < HPASS && (tap * 64 + wave * 8 < HP);
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     bf16x8 fa[2][FM], fb[2][FN];
@@ -207,15 +213,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
                         for (int i = 0; i < FM; i++) { const unsigned a = va[i] ^ x; RDM_LDS_READ(fa[k2][i], a, 0); }
                     }
                     if (half == 0) {
+                        if (last_slice && tap == 0 && has_next) setup_halo(next);        // this tile's halo is all requested
                         if (tap < 8) stage_b(sl, tap + 1, bcur ^ 1);
                         else if (!last_slice) stage_b(sl + 1, 0, bcur ^ 1);
-                        else if (has_next) { setup(next); stage_b(ns_begin, 0, bcur ^ 1); }     // cross-tile prefetch
+                        else if (has_next) { setup_mn(next); stage_b(ns_begin, 0, bcur ^ 1); }     // cross-tile prefetch
                     } else {
-                        if (halo_now) stage_halo_pass(tap, sl + 1, hcur ^ 1);
-                        else if (tile_end && has_next) {
-#pragma unroll
-                            for (int ps = 0; ps < HPASS; ps++) stage_halo_pass(ps, ns_begin, hcur ^ 1);
-                        }
+                        if (halo_now) stage_halo_pass(tap, last_slice ? ns_begin : sl + 1, hcur ^ 1);
                         if (grp && !tile_end) {
                             if (halo_now) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
