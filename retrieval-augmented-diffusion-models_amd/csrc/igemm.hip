@@ -19,10 +19,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 // dev-only phase clock (env RDM_IGEMM_PROF=1): shader cycles spent by wave 0 of every block in [K loop, epilogue, wait at tile start]
-__device__ unsigned long long g_igemm_prof[4];
+__device__ unsigned long long g_igemm_prof[5];
 
 template <int BM, int BN, int WAVES_M, int CONV, bool GEGLU>   // CONV: 0 linear, 1 conv3x3, 2 conv3x3 on a 2x nearest-upsampled input
 __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) {
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
     int c_g = 0;                        // compute stream position
     int pending_stores = 0;             // stores issued after the most recent B request (previous tile's epilogue)
 
-    unsigned long long tprof[3] = {0, 0, 0};
+    unsigned long long tprof[4] = {0, 0, 0, 0};
     while (true) {
         unsigned long long tp0 = 0, tp1 = 0;
         if (p.dbg & 16) tp0 = __builtin_readcyclecounter();
@@ -339,10 +341,15 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
         constexpr int WNO = GEGLU ? WN / 2 : WN;                        // output columns per wave
         const int No = GEGLU ? p.N / 2 : p.N;
         const bool lds_epi = ob && !of && !rf && (No % 8 == 0) && (p.ldo % 8 == 0) && !(p.dbg & 4);
-        if (lds_epi) {
+        // PLAIN = no activation, alpha 1, no per-row time-embedding lookup: every UNet projection except the GEGLU one.  The flag is
+        // a compile-time parameter of the body: as run-time tests inside the unrolled element loops hipcc kept a compare + branch
+        // (+ hazard nops) per ELEMENT, and the epilogue took twice as long as the halo kernel's for the same tile.
+        auto lds_epilogue = [&](auto plain_tag) {
+            constexpr bool PLAIN = decltype(plain_tag)::value;
             constexpr int ROWB = WNO * 2, CPR = WNO / 8, NIT = (32 * CPR) / 64;
             static_assert((32 * CPR) % 64 == 0 && 32 * ROWB * 4 <= B_BYTES, "epilogue staging geometry");
             __syncthreads();                                            // every wave is done reading slice c_g-1
+            if (p.dbg & 16) tprof[3] += __builtin_readcyclecounter() - tp1;
             char* stg = (wave < 4) ? (char*)b_ring + ((c_g - 1) & 1) * B_BYTES + wave * (32 * ROWB)
                                    : (char*)a_ring + ((c_g - 1) % A_SLOTS) * A_BYTES + (wave - 4) * (32 * ROWB);
             const int eno = (GEGLU ? en0 / 2 : en0) + wn * WNO;         // first output column of this wave
@@ -359,15 +366,20 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
                     float v[16];
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        float x = acc[i][j][r] * p.alpha + bias;
-                        if (p.rowvec && !uniform_sample) {
-                            const int m = mf + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                            if (ncol < p.N && m < p.M) x += p.rowvec[(long long)(m / p.rows_per_sample) * p.rowvec_ld + ncol];
+                        float x;
+                        if constexpr (PLAIN) x = acc[i][j][r] + bias;
+                        else {
+                            x = acc[i][j][r] * p.alpha + bias;
+                            if (p.rowvec && !uniform_sample) {
+                                const int m = mf + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                                if (ncol < p.N && m < p.M) x += p.rowvec[(long long)(m / p.rows_per_sample) * p.rowvec_ld + ncol];
+                            }
                         }
                         if constexpr (GEGLU) {
-                            const float g = acc[i][(j + 1) < FN ? (j + 1) : j][r] * p.alpha + gbias;
+                            float g = acc[i][(j + 1) < FN ? (j + 1) : j][r];
+                            if constexpr (PLAIN) g += gbias; else g = g * p.alpha + gbias;
                             x = x * gelu_erf_f(g);
-                        } else {
+                        } else if constexpr (!PLAIN) {
                             if (p.act == ACT_QUICKGELU) x = quickgelu_f(x);
                             else if (p.act == ACT_SILU) x = silu_f(x);
                         }
@@ -409,6 +421,10 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next fragment row overwrites
             }
+        };
+        if (lds_epi) {
+            const bool plain = p.alpha == 1.0f && (GEGLU || p.act == ACT_NONE) && !(p.rowvec && !uniform_sample);
+            if (plain) lds_epilogue(std::true_type{}); else lds_epilogue(std::false_type{});
         } else if (!(p.dbg & 4)) {
 #pragma unroll
             for (int i = 0; i < FM; i++) {
@@ -503,6 +519,7 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
     }
     if ((p.dbg & 16) && tid == 0) {
         atomicAdd(&g_igemm_prof[0], tprof[0]); atomicAdd(&g_igemm_prof[1], tprof[1]); atomicAdd(&g_igemm_prof[2], tprof[2]);
+        atomicAdd(&g_igemm_prof[4], tprof[3]);
         atomicAdd(&g_igemm_prof[3], 1ull);
     }
 }
@@ -534,13 +551,13 @@ static hipError_t launch_cfg(const IgemmParams& p, int batch, hipStream_t st) {
     static const int prof = getenv("RDM_IGEMM_PROF") ? atoi(getenv("RDM_IGEMM_PROF")) : 0;
     if (prof) {      // dev-only: synchronous launch, prints wave-0 shader cycles per block
         IgemmParams q = p; q.dbg |= 16;
-        unsigned long long z[4] = {0, 0, 0, 0}, r[4];
+        unsigned long long z[5] = {0, 0, 0, 0, 0}, r[5];
         hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_prof), z, sizeof(z));
         igemm_kernel<BM, BN, WAVES_M, CONV, GEGLU><<<grid, NT, smem, st>>>(q);
         hipStreamSynchronize(st);
         hipMemcpyFromSymbol(r, HIP_SYMBOL(g_igemm_prof), sizeof(r));
-        fprintf(stderr, "[igemm<%d,%d,%d,%d> M=%d N=%d K=%d] blocks=%llu per-block cycles: kloop %.0f (of which tile-start wait %.0f) epilogue %.0f (tiles/block %.2f)\n",
-                BM, BN, CONV, (int)GEGLU, p.M, p.N, p.K, r[3], (double)r[0] / r[3], (double)r[2] / r[3], (double)r[1] / r[3], (double)ntiles / g);
+        fprintf(stderr, "[igemm<%d,%d,%d,%d> M=%d N=%d K=%d] blocks=%llu per-block cycles: kloop %.0f (of which tile-start wait %.0f) epilogue %.0f (of which waiting for the other waves %.0f) (tiles/block %.2f)\n",
+                BM, BN, CONV, (int)GEGLU, p.M, p.N, p.K, r[3], (double)r[0] / r[3], (double)r[2] / r[3], (double)r[1] / r[3], (double)r[4] / r[3], (double)ntiles / g);
         return hipGetLastError();
     }
     igemm_kernel<BM, BN, WAVES_M, CONV, GEGLU><<<grid, NT, smem, st>>>(p);
