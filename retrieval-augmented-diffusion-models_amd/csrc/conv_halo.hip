@@ -293,12 +293,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
                     float v[16];
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        float x = acc[i][j][r] + pbias[i][j];
-                        if (p.rowvec && !uniform_sample) {
-                            const int m = mf + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                            x += p.rowvec[(long long)(m / p.rows_per_sample) * p.rowvec_ld + ncol];
-                        }
-                        v[r] = x;
+                        v[r] = acc[i][j][r] + pbias[i][j];    // (a time-embedding row never changes inside a 32-row fragment here:
+                                                              //  conv_halo_supported; run-time tests per ELEMENT are expensive, igemm.hip)
                     }
                     char* wp = stg + (4 * fhalf + odd) * ROWB + (j * 32 + frow - odd) * 2;
 #pragma unroll
@@ -419,6 +415,7 @@ bool conv_halo_supported(const IgemmParams& p) {
     if (p.M % 256 != 0 || (p.N % 192 != 0 && p.N % 128 != 0)) return false;
     if (p.C0 % 64 || p.C1 % 64 || p.alpha != 1.0f || p.act != ACT_NONE || !p.out_bf16 || p.out_f32 || p.res_f32) return false;
     if (p.ldo % 8 || p.K != 9 * (p.C0 + p.C1)) return false;
+    if (p.rowvec && p.rows_per_sample % 32 != 0) return false;       // the epilogue folds the per-sample row per 32-row fragment
     const int RS = (HW >= 256) ? 256 / W : H, NS = 256 / (RS * W);
     if (NS * (RS + 2) * (W + 2) > 400) return false;
     if ((long long)p.M * (p.C0 > p.C1 ? p.C0 : p.C1) >= 0x7fffffffLL * 1LL) return false;
