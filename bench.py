@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--scale", type=float, default=2.0)
     p.add_argument("--db-rows", type=int, default=20_927_907, help="OpenImages DB rows (SURVEY §8 a-13)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extras", action="store_true", help="skip the untimed extras (CLIP text encode, guidance-scale-1.0 step)")
     return p.parse_args()
 
 
@@ -129,13 +130,21 @@ def main():
     uncond = torch.zeros((B, k, D), device=dev)
     gathered = torch.empty((world * B, 3, 256, 256), device=dev) if world > 1 else None
 
-    def step(i):
+    ev_ret = []                                                         # (start, end) events around the retrieval of each timed step
+
+    def step(i, scale=None, record=False):
+        scale = a.scale if scale is None else scale
         q = queries[i]
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
         idx, _ = ctx.knn(q, k)
         nbrs = ctx.db_gather(idx, D)                                   # [B,k,512] raw neighbour embeddings
+        if record:
+            e1.record(torch.cuda.current_stream()); ev_ret.append((e0, e1))
         cond = torch.cat([q[:, None], nbrs[:, :k - 1]], dim=1).contiguous()   # ddpm.py:775 (query first)
-        z, _, _ = ctx.ddim_sample(a.ddim_steps, x_Ts[i], cond, uncond if a.scale > 1 else None, sched.alphas_cumprod,
-                                  eta=0.0, scale=a.scale)
+        z, _, _ = ctx.ddim_sample(a.ddim_steps, x_Ts[i], cond, uncond if scale > 1 else None, sched.alphas_cumprod,
+                                  eta=0.0, scale=scale)
         img = ctx.vq_decode(z)
         if world > 1:
             dist.all_gather_into_tensor(gathered, img)
@@ -153,7 +162,7 @@ def main():
     ctx.prof_enable(True)
     t0 = time.perf_counter()
     for i in range(a.warmup, total_steps):
-        img = step(i)
+        img = step(i, record=True)
     fence()
     dt = time.perf_counter() - t0
     ctx.prof_enable(False)
@@ -171,6 +180,29 @@ def main():
             traffic = json.load(f)["hbm_bytes_per_launch"]
     except Exception:
         pass
+    # ---- untimed extras (SURVEY 8d asks for them next to the headline): retrieval latency per batch, one step without
+    # classifier-free guidance (no batch doubling), CLIP text encoding of one batch of captions
+    extras = {}
+    if rank == 0:
+        try:
+            extras["retrieval_ms_per_batch"] = sum(e0.elapsed_time(e1) for e0, e1 in ev_ret) / max(len(ev_ret), 1)
+        except Exception:      # events of another stream: library runs on the legacy stream by default
+            pass
+    if rank == 0 and not a.no_extras:
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        step(0, scale=1.0)
+        torch.cuda.synchronize()
+        extras["images_per_s_guidance_scale_1"] = B / (time.perf_counter() - t1)
+        from oracle import clip as oclip
+        from _util import spec_to_clip_cfg
+        cspec = oclip.vitb32_spec()
+        ccfg = spec_to_clip_cfg(cspec)
+        ctx.load_clip(ccfg, packing.pack("clip", ccfg, ounet.synth_state_dict(oclip.clip_param_shapes(cspec), seed=99)))
+        toks = torch.randint(1, cspec.vocab_size - 2, (B, cspec.context_length), device=dev)
+        toks[:, 0] = cspec.vocab_size - 2; toks[:, 20] = cspec.vocab_size - 1          # <start> ... <end> (argmax position)
+        ctx.clip_encode_text(toks); torch.cuda.synchronize(); t1 = time.perf_counter()
+        ctx.clip_encode_text(toks); torch.cuda.synchronize()
+        extras["clip_text_encode_ms_per_batch"] = (time.perf_counter() - t1) * 1e3
     n_conv, ms_conv, fl_conv = ctx.prof_collect(0)
     n_lin, ms_lin, fl_lin = ctx.prof_collect(1)
     if rank == 0:
@@ -196,6 +228,8 @@ def main():
                                          "time_ms": ms_lin},
                          "conv_time_frac_of_step": ms_conv * 1e-3 / dt},
         }
+        if extras:
+            out["extras"] = extras
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd_unet, spec, sd_vq, vspec, a.ddim_steps, a.scale)
         print(json.dumps(out), flush=True)
