@@ -1,7 +1,8 @@
 """Native counterpart of the sampling-path methods of rdm/data/retrieval_dataset/dsetbuilder.py::DatasetBuilder:
 load_embeddings / load_single_file / load_multi_files (:181-236), train_searcher (:534-619), search_k_nearest
 (:478-518), embed (:461-473), and the `.searcher.search_batched / .search` surface of the ScaNN object
-(:490, rdm/data/base.py:81).
+(:490, rdm/data/base.py:81); plus the database-construction side: build_data_pool (:317-437),
+save_datapool (:238-259), reset_data_pool (:261-262) with the CLIP image tower running on the GPU.
 
 The searcher is exact brute force on the GPU (the reference's ScaNN tree-AH is approximate): the
 database is normalised and held in HBM as fp16 (dsetbuilder.py:574), a batch of queries streams it once.
@@ -41,6 +42,8 @@ class DatasetBuilder(object):
     def __init__(self, saved_embeddings=None, k=20, retriever=None, retriever_config=None, ctx=None, device=0,
                  data_pool=None, load_patch_dataset=False, batch_size=100, max_pool_size=None, **ignored):
         self.k = k
+        self.out_dir = ignored.get('out_dir')
+        self.max_pool_size = max_pool_size
         self.batch_size = batch_size
         self.saved_embeddings = saved_embeddings
         self.load_patch_dataset = load_patch_dataset
@@ -115,6 +118,67 @@ class DatasetBuilder(object):
             out = self.retriever(batch)
             bs = batch.shape[0]
         return out.cpu().numpy().reshape(bs, -1)
+
+    # ---- dsetbuilder.py:261-262
+    def reset_data_pool(self):
+        self.data_pool = {key: [] for key in self.data_pool}
+
+    # ---- dsetbuilder.py:238-259: '<rows>x<dim>[-<postfix>].npz', compressed, keys embedding / img_id / patch_coords (/ class_id)
+    def save_datapool(self, postfix=None, out_dir=None):
+        out_dir = out_dir or self.out_dir
+        assert out_dir is not None, 'save_datapool needs an output directory (the reference hard-codes its NFS path)'
+        pool = {key: np.concatenate([np.asarray(v) for v in self.data_pool[key]]) for key in self.data_pool if len(self.data_pool[key]) > 0}
+        identifier = 'x'.join(str(s_) for s_ in pool['embedding'].shape)
+        if postfix:
+            identifier = identifier + '-' + postfix
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, identifier + '.npz')
+        np.savez_compressed(path, **pool)
+        self.saved_embeddings = out_dir
+        return path
+
+    # ---- dsetbuilder.py:317-437.  `loader` yields the reference's collated batches: {'patch': [b,(n,)h,w,c] in [-1,1],
+    # 'img_id': [b(,n)], 'patch_coords': [b(,n),4]} (+ optional 'class_id'); the patches are embedded by the retriever
+    # (CLIP image tower on the GPU incl. the bicubic 224x224 preprocessing, retrievers.py:83-95) and written in shards of
+    # `chunk_size` rows named 'part_<i>' exactly like the shipped databases (scripts/download_databases.sh:6-15).
+    def build_data_pool(self, loader, max_pool_size=None, chunk_size=None, save_embeddings=True, out_dir=None):
+        self.out_dir = out_dir or self.out_dir
+        max_pool_size = max_pool_size if max_pool_size is not None else (self.max_pool_size or float('inf'))
+        self.data_pool = {'embedding': [], 'img_id': [], 'patch_coords': []}
+        n_examples, part, files, kept = 0, 1, [], {'embedding': [], 'img_id': [], 'patch_coords': []}
+
+        def flush():
+            nonlocal part
+            if len(self.data_pool['embedding']) == 0:
+                return
+            if save_embeddings:
+                files.append(self.save_datapool(postfix=f'part_{part}' if chunk_size is not None else None))
+            for key in self.data_pool:
+                kept.setdefault(key, []).extend(self.data_pool[key])
+            self.reset_data_pool()
+            part += 1
+
+        for batch in loader:
+            if 'patch' not in batch:
+                break
+            patches = torch.as_tensor(batch['patch'])
+            if patches.ndim == 5:                                     # b n h w c -> (b n) h w c (dsetbuilder.py:463-464)
+                patches = patches.reshape((-1,) + tuple(patches.shape[2:]))
+            emb = self.embed(patches)
+            self.data_pool['embedding'].append(emb)
+            self.data_pool['img_id'].append(np.asarray(batch['img_id']).reshape(emb.shape[0]))
+            self.data_pool['patch_coords'].append(np.asarray(batch['patch_coords']).reshape(emb.shape[0], -1))
+            if 'class_id' in batch:
+                self.data_pool.setdefault('class_id', []).append(np.asarray(batch['class_id']).reshape(emb.shape[0]))
+            n_examples += emb.shape[0]
+            if chunk_size is not None and n_examples / chunk_size >= part:
+                flush()
+            if n_examples >= max_pool_size:
+                break
+        flush()
+        self.data_pool = {key: np.concatenate([np.asarray(v) for v in kept[key]]) for key in kept if len(kept[key]) > 0}
+        print(f'Finish extraction of {n_examples} feature embeddings')
+        return files
 
     # ---- dsetbuilder.py:478-518
     def search_k_nearest(self, queries, k=None, is_caption=False, visualize=None, query_embedded=False):

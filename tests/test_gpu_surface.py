@@ -151,3 +151,29 @@ def test_clip_retriever_wrappers(ctx):
     x = F.interpolate(img, size=(64, 64), mode="bicubic", align_corners=True)
     x = ((x + 1.) / 2. - r.mean.cpu()[None, :, None, None]) / r.std.cpu()[None, :, None, None]
     assert rel_l2(r(img), oclip.encode_image(sd, spec, x)) <= 2e-2
+
+
+def test_build_data_pool_on_device_and_search(ctx, tmp_path):
+    """patches -> CLIP image embeddings on the GPU -> npz shards in the reference format -> reload -> exact search:
+    every patch retrieves itself first, and the stored embeddings match the oracle's image tower."""
+    from rdm_amd.data.retrieval_dataset.dsetbuilder import DatasetBuilder
+    from rdm_amd.modules.retrievers import ClipImageRetriever
+    spec = oclip.ClipSpec(embed_dim=64, image_resolution=64, vision_layers=2, vision_width=128, vision_patch_size=32,
+                          context_length=77, vocab_size=49408, transformer_width=128, transformer_heads=2, transformer_layers=2)
+    sd = ounet.synth_state_dict(oclip.clip_param_shapes(spec), seed=3)
+    sd["positional_embedding"] = sd["positional_embedding"] * 0.1
+    r = ClipImageRetriever(state_dict=sd, ctx=ctx, clip_cfg=spec_to_clip_cfg(spec))
+    rng = np.random.default_rng(8)
+    batches = [{"patch": rng.uniform(-1, 1, (6, 64, 64, 3)).astype(np.float32), "img_id": np.arange(6) + 6 * i,
+                "patch_coords": rng.integers(0, 256, (6, 4))} for i in range(4)]
+    db = DatasetBuilder(retriever=r, ctx=ctx, out_dir=str(tmp_path))
+    files = db.build_data_pool(iter(batches), chunk_size=12)
+    assert len(files) == 2 and db.data_pool["embedding"].shape == (24, 64)
+    img = torch.from_numpy(np.concatenate([b["patch"] for b in batches])).permute(0, 3, 1, 2)
+    x = ((img + 1.) / 2. - r.mean.cpu()[None, :, None, None]) / r.std.cpu()[None, :, None, None]     # already 64x64: resize is identity
+    assert rel_l2(torch.from_numpy(db.data_pool["embedding"]), oclip.encode_image(sd, spec, x)) <= 2e-2
+    again = DatasetBuilder(saved_embeddings=str(tmp_path), retriever=r, ctx=ctx)
+    again.train_searcher()
+    out = again.search_k_nearest(batches[1]["patch"], k=3)
+    assert out["nns"][:, 0].astype(np.int64).tolist() == list(range(6, 12))
+    assert out["img_ids"][:, 0].tolist() == list(range(6, 12))

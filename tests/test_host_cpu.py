@@ -99,6 +99,35 @@ def test_dataset_builder_loads_npz_shards(tmp_path):
         db.search_k_nearest(np.zeros((1, 512), np.float32), k=2, query_embedded=True)
 
 
+def test_dataset_builder_builds_and_reloads_shards(tmp_path):
+    """build_data_pool / save_datapool (dsetbuilder.py:317-437, 238-259): shard naming '<rows>x<dim>-part_<i>.npz', keys,
+    chunking by rows, and the round trip through load_embeddings. The retriever is a stand-in (host logic only)."""
+    from rdm_amd.data.retrieval_dataset.dsetbuilder import DatasetBuilder
+
+    class FakeRetriever:
+        class model:
+            ctx = None
+        def __call__(self, x):                       # [b,3,h,w] -> [b,16]: deterministic, depends on the pixels
+            return x.float().reshape(x.shape[0], -1)[:, :16] * 2.0
+
+    rng = np.random.default_rng(1)
+    batches = [{"patch": rng.uniform(-1, 1, (4, 2, 8, 8, 3)).astype(np.float32), "img_id": np.arange(8).reshape(4, 2) + 10 * i,
+                "patch_coords": rng.integers(0, 64, (4, 2, 4))} for i in range(3)]
+    db = DatasetBuilder(retriever=FakeRetriever(), out_dir=str(tmp_path))
+    files = db.build_data_pool(iter(batches), chunk_size=10)
+    assert [os.path.basename(f) for f in files] == ["16x16-part_1.npz", "8x16-part_2.npz"]
+    assert db.data_pool["embedding"].shape == (24, 16) and db.data_pool["patch_coords"].shape == (24, 4)
+    want = np.concatenate([b["patch"].reshape(8, 8, 8, 3).transpose(0, 3, 1, 2).reshape(8, -1)[:, :16] * 2.0 for b in batches])
+    assert np.allclose(db.data_pool["embedding"], want)
+    again = DatasetBuilder(saved_embeddings=str(tmp_path))
+    assert np.array_equal(again.data_pool["embedding"], db.data_pool["embedding"])
+    assert again.data_pool["img_id"].tolist() == db.data_pool["img_id"].tolist() == sum([(np.arange(8) + 10 * i).tolist() for i in range(3)], [])
+    # a single un-chunked file, capped by max_pool_size
+    db2 = DatasetBuilder(retriever=FakeRetriever(), out_dir=str(tmp_path / "one"))
+    files2 = db2.build_data_pool(iter(batches), max_pool_size=16)
+    assert [os.path.basename(f) for f in files2] == ["16x16.npz"]
+
+
 def test_util_helpers():
     from rdm_amd.util import convert_nn_tree, ischannellastimage
     assert ischannellastimage(np.zeros((2, 8, 8, 3))) and not ischannellastimage(np.zeros((2, 3, 8, 8)))
