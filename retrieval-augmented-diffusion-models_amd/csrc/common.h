@@ -52,7 +52,7 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
 }
 
 // epilogue activation ids (igemm)
-enum { ACT_NONE = 0, ACT_GEGLU = 1, ACT_QUICKGELU = 2, ACT_SILU = 3 };
+enum { ACT_NONE = 0, ACT_GEGLU = 1, ACT_QUICKGELU = 2, ACT_SILU = 3, ACT_SOFTMAXG = 4 };   // SOFTMAXG: softmax over groups of sm_group (1, 2, 4) adjacent columns
 
 constexpr int RDM_EYE_OFFSET = 4096, RDM_EYE_N = 256;
 
@@ -74,6 +74,7 @@ struct IgemmParams {
     bf16_t* out_bf16; float* out_f32;   // either / both
     int ldo;                    // output row stride (elements)
     int act;
+    int sm_group;               // ACT_SOFTMAXG group size
     // batching over blockIdx.z (element strides)
     long long sA, sW, sO;
     const void* zero_page;      // 4 KiB of zeros, followed by a 256 x 256 bf16 identity matrix (RDM_EYE_OFFSET)

@@ -23,6 +23,22 @@
 
 #include "kernels.h"
 
+// softmax over groups of g (1, 2, 4) ADJACENT COLUMNS of an accumulator fragment: adjacent columns are adjacent lanes (D layout:
+// col = lane & 31), every r is one row.  Used by the skinny cross-attention scores GEMM (model.hip).
+__device__ __forceinline__ void softmax_group16(float (&v)[16], int g) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float mx = v[r];
+        if (g >= 2) mx = fmaxf(mx, __shfl_xor(mx, 1));
+        if (g >= 4) mx = fmaxf(mx, __shfl_xor(mx, 2));
+        const float e = __expf(v[r] - mx);
+        float sum = e;
+        if (g >= 2) sum += __shfl_xor(sum, 1);
+        if (g >= 4) sum += __shfl_xor(sum, 2);
+        v[r] = e / sum;
+    }
+}
+
 // dev-only phase clock (env RDM_IGEMM_PROF=1): shader cycles spent by wave 0 of every block in [K loop, epilogue, wait at tile start]
 __device__ unsigned long long g_igemm_prof[5];
 
@@ -344,8 +360,9 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
         // PLAIN = no activation, alpha 1, no per-row time-embedding lookup: every UNet projection except the GEGLU one.  The flag is
         // a compile-time parameter of the body: as run-time tests inside the unrolled element loops hipcc kept a compare + branch
         // (+ hazard nops) per ELEMENT, and the epilogue took twice as long as the halo kernel's for the same tile.
-        auto lds_epilogue = [&](auto plain_tag) {
-            constexpr bool PLAIN = decltype(plain_tag)::value;
+        auto lds_epilogue = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;            // 0 general, 1 plain, 2 plain + softmax over column groups
+            constexpr bool PLAIN = MODE != 0;
             constexpr int ROWB = WNO * 2, CPR = WNO / 8, NIT = (32 * CPR) / 64;
             static_assert((32 * CPR) % 64 == 0 && 32 * ROWB * 4 <= B_BYTES, "epilogue staging geometry");
             __syncthreads();                                            // every wave is done reading slice c_g-1
@@ -385,6 +402,7 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
                         }
                         v[r] = x;
                     }
+                    if constexpr (MODE == 2) softmax_group16(v, p.sm_group);
                     // even lane: row R(2t), cols (c, c+1); odd lane: row R(2t)+1, cols (c-1, c)
                     const int lc = (GEGLU ? (j >> 1) : j) * 32 + frow - odd;          // local column of the pair
                     char* wp = stg + (4 * fhalf + odd) * ROWB + lc * 2;
@@ -423,8 +441,13 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
             }
         };
         if (lds_epi) {
-            const bool plain = p.alpha == 1.0f && (GEGLU || p.act == ACT_NONE) && !(p.rowvec && !uniform_sample);
-            if (plain) lds_epilogue(std::true_type{}); else lds_epilogue(std::false_type{});
+            const bool simple = p.alpha == 1.0f && !(p.rowvec && !uniform_sample);
+            const bool plain = simple && (GEGLU || p.act == ACT_NONE);
+            bool done = false;
+            if constexpr (BN == 128 && CONV == 0 && !GEGLU) {          // only the 128-wide linear tiles carry the softmax variant
+                if (simple && p.act == ACT_SOFTMAXG) { lds_epilogue(std::integral_constant<int, 2>{}); done = true; }
+            }
+            if (!done) { if (plain) lds_epilogue(std::integral_constant<int, 1>{}); else lds_epilogue(std::integral_constant<int, 0>{}); }
         } else if (!(p.dbg & 4)) {
 #pragma unroll
             for (int i = 0; i < FM; i++) {
@@ -573,6 +596,9 @@ hipError_t launch_igemm(const IgemmParams& p_in, bool conv, int batch, hipStream
     if (p.K % 64 != 0 || p.C0 % 64 != 0 || p.C1 % 64 != 0) return hipErrorInvalidValue;
     if (p.N % 2 != 0 || p.ldo % 2 != 0 || p.sO % 2 != 0) return hipErrorInvalidValue;   // paired-column epilogue
     if (p.act == ACT_GEGLU && (p.N % 64 != 0)) return hipErrorInvalidValue;
+    if (p.act == ACT_SOFTMAXG && (conv || p.N % 192 == 0 || p.alpha != 1.0f || !p.out_bf16 || p.out_f32 || p.res_f32 || p.ldo % 8 ||
+                                  !(p.sm_group == 1 || p.sm_group == 2 || p.sm_group == 4)))
+        return hipErrorInvalidValue;                        // the column-group softmax lives in the 128-wide bf16 epilogue only
     // tall 256-row tiles (8 waves, 1 block/CU) cut the L2->LDS operand traffic per FLOP by 1.44x; use them
     // whenever there are enough row tiles to fill the chip, else the 128-row tile (4 waves, 2 blocks/CU).
     static const int force_bm = getenv("RDM_IGEMM_BM") ? atoi(getenv("RDM_IGEMM_BM")) : 0;
@@ -599,7 +625,7 @@ hipError_t launch_igemm(const IgemmParams& p_in, bool conv, int batch, hipStream
         return tall ? launch_cfg<256, 128, 4, 1, false>(p, batch, st) : launch_cfg<128, 128, 2, 1, false>(p, batch, st);
     }
     // linear with a bf16 residual: feed the residual tile through the A stream against an identity block (see the kernel)
-    if (!no_resk && p.res_bf16 && !p.res_f32 && p.out_bf16 && !p.out_f32 && p.alpha == 1.0f && p.act == ACT_NONE && batch == 1 &&
+    if (!no_resk && p.res_bf16 && !p.res_f32 && p.out_bf16 && !p.out_f32 && p.alpha == 1.0f && p.act == ACT_NONE &&
         p.N % (wide ? 192 : 128) == 0 && p.ldo % 8 == 0 && p.ldo >= p.N)
         p.res_k = 1;
     if (wide) return tall ? launch_cfg<256, 192, 4, 0, false>(p, batch, st) : launch_cfg<128, 192, 2, 0, false>(p, batch, st);

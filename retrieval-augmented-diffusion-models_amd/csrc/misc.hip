@@ -161,6 +161,45 @@ hipError_t launch_cast_f32_bf16(const float* x, bf16_t* y, long long n, hipStrea
     return hipGetLastError();
 }
 
+// y[c][r] = x[r][c] (small weight matrices, once per sampling call)
+__global__ void transpose_bf16_kernel(const bf16_t* x, bf16_t* y, int rows, int cols) {
+    __shared__ bf16_t tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < rows && c < cols) ? x[(long long)r * cols + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) y[(long long)c * rows + r] = tile[threadIdx.x][i];
+    }
+}
+hipError_t launch_transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st) {
+    transpose_bf16_kernel<<<dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st>>>(x, y, rows, cols);
+    return hipGetLastError();
+}
+
+// Block-diagonal head expansion of the cross-attention keys / values: out[b][h*k + j][n] = scale * kv[(b*k + j)*ld + n] if
+// n / hd == h else 0, rows >= heads*k zero.  out [B][NP][C], C = heads * hd.
+__global__ void expand_heads_kernel(const bf16_t* kv, int ld, int B, int k, int heads, int hd, int NP, float scale, bf16_t* out) {
+    const int C = heads * hd;
+    const long long total = (long long)B * NP * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % C); const long long rr = i / C; const int hj = (int)(rr % NP); const int b = (int)(rr / NP);
+        const int h = hj / k, j = hj - h * k;
+        float v = 0.f;
+        if (hj < heads * k && n / hd == h) v = scale * bf2f(kv[((long long)b * k + j) * ld + n]);
+        out[i] = f2bf(v);
+    }
+}
+hipError_t launch_expand_heads(const bf16_t* kv, int ld, int B, int k, int heads, int hd, int NP, float scale, bf16_t* out, hipStream_t st) {
+    const long long total = (long long)B * NP * heads * hd;
+    int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
+    expand_heads_kernel<<<grid, 256, 0, st>>>(kv, ld, B, k, heads, hd, NP, scale, out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ DDIM / DDPM updates (fp32)
 // rdm/models/diffusion/ddim.py:229-238 (CFG combine) + :253-267 (update), fused into one pass.
 // eps holds [B] rows (scale == 1) or [2B] rows (cond | uncond). Scalars are the fp32 values the

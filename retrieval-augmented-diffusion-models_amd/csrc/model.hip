@@ -65,9 +65,11 @@ struct Arena {
 
 // ------------------------------------------------------------------------------------ UNet description
 struct ResW { int cin, cout; size_t gn1g, gn1b, w1, b1, gn2g, gn2b, w2, b2, wsk, bsk; int emb_off; bool skip; };
+constexpr int XA_NP = 128;        // padded (heads x neighbours) width of the skinny cross-attention operands
+
 struct StW {
     int c, heads; size_t gng, gnb, win, bin, ln1g, ln1b, wqk, wv, wo1, bo1, ln2g, ln2b, wq2, wo2, bo2, ln3g, ln3b, wff1,
-        bff1, wff2, bff2, wout, bout; int kv_off;
+        bff1, wff2, bff2, wout, bout; int kv_off; long long xa_unit;   // xa_unit: per-sample element offset of this layer's (G, U) pair
 };
 struct ConvW { int c; size_t w, b; };
 struct ULayer { int kind; int idx; };            // 0 conv_in, 1 res, 2 st, 3 down, 4 up
@@ -78,7 +80,8 @@ struct UNet {
     bool loaded = false;
     std::vector<UBlock> blocks; std::vector<ResW> res; std::vector<StW> st; std::vector<ConvW> down, up;
     size_t te0w, te0b, te2w, te2b, embw, embb, kvw, cinw, cinb, outg, outb, outw, outbias;
-    int emb_total = 0, kv_total = 0;
+    int emb_total = 0, kv_total = 0; long long xa_total = 0;         // xa_total: per-sample elements of all (G, U) pairs
+    bf16_t* xa_cache = nullptr; size_t xa_cache_bytes = 0;
     char* blob = nullptr; size_t blob_bytes = 0;
     Arena arena;
     // cached cross-attention K/V for the current conditioning
@@ -95,7 +98,7 @@ static void build_unet(UNet& u, const rdm_unet_cfg& c, Manifest& mf) {
     u.te0w = bf("time_embed.0.weight", (size_t)ted * mc); u.te0b = f32("time_embed.0.bias", ted);
     u.te2w = bf("time_embed.2.weight", (size_t)ted * ted); u.te2b = f32("time_embed.2.bias", ted);
     std::string emb_w_srcs, emb_b_srcs, kv_srcs;
-    u.emb_total = 0; u.kv_total = 0;
+    u.emb_total = 0; u.kv_total = 0; u.xa_total = 0;
     auto in_attn = [&](int ds) { for (int i = 0; i < c.n_attention_resolutions; i++) if (c.attention_resolutions[i] == ds) return true; return false; };
     auto add_res = [&](const std::string& pre, int cin, int cout) {
         ResW r{}; r.cin = cin; r.cout = cout; r.skip = cin != cout;
@@ -127,6 +130,7 @@ static void build_unet(UNet& u, const rdm_unet_cfg& c, Manifest& mf) {
         s.wff2 = bf(tb + ".ff.net.2.weight", (size_t)ch * 4 * ch); s.bff2 = f32(tb + ".ff.net.2.bias", ch);
         s.wout = bf(pre + ".proj_out.weight", (size_t)ch * ch); s.bout = f32(pre + ".proj_out.bias", ch);
         s.kv_off = u.kv_total; u.kv_total += 2 * ch;
+        s.xa_unit = u.xa_total; u.xa_total += 2LL * XA_NP * ch;
         if (!kv_srcs.empty()) kv_srcs += ",";
         kv_srcs += tb + ".attn2.to_k.weight," + tb + ".attn2.to_v.weight";
         u.st.push_back(s); return (int)u.st.size() - 1;
@@ -388,7 +392,47 @@ static void unet_compute_kv(Ops& o, UNet& u, const float* context, int B, int k,
     o.linear(cb, nullptr, cd, 0, u.kvw, 0, false, B * k, u.kv_total, ACT_NONE, nullptr, kv_out);
 }
 
-static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const bf16_t* kv, int B, int k, int H, int W,
+// ---- cross-attention over k neighbours as two skinny GEMMs.  softmax(q K^T / sqrt d) V W_o^T with q = x W_q^T is re-associated
+// per sample:  scores = x G_b^T with G_b[(h,j), :] = (K_bj restricted to head h) W_q / sqrt d   -> [heads*k <= 128 columns]
+//              out    = P U_b^T  with U_b[:, (h,j)] = W_o (V_bj restricted to head h)            -> K = 128
+// G_b and U_b depend only on the conditioning (computed once per sampling call next to the K/V cache).  The per-forward work
+// drops from two C x C projections + an attention kernel (9 tensor passes) to N = 128 / K = 128 GEMMs (3.3 passes); identical
+// in exact arithmetic to rdm/modules/attention.py:52-72 (CrossAttention.forward).
+static bool xattn_skinny_ok(const UNet& u, int k) {
+    static const int off = getenv("RDM_NO_XSKINNY") ? atoi(getenv("RDM_NO_XSKINNY")) : 0;
+    if (off || !(k == 1 || k == 2 || k == 4)) return false;
+    for (const StW& s : u.st) if (s.heads * k > XA_NP || s.c != s.heads * 32) return false;
+    return !u.st.empty();
+}
+static void unet_compute_xattn(Ops& o, UNet& u, const bf16_t* kv, int B, int k, bf16_t* xa) {
+    int cmax = 0;
+    for (const StW& s : u.st) cmax = s.c > cmax ? s.c : cmax;
+    bf16_t* kexp = o.abf((size_t)B * XA_NP * cmax);
+    bf16_t* vexp = o.abf((size_t)B * XA_NP * cmax);
+    bf16_t* wqt = o.abf((size_t)cmax * cmax);
+    if (o.plan) return;
+    for (const StW& s : u.st) {
+        const int C = s.c;
+        bf16_t* G = xa + (size_t)B * s.xa_unit;                       // [B][NP][C]
+        bf16_t* U = G + (size_t)B * XA_NP * C;                        // [B][C][NP]
+        o.check(launch_expand_heads(kv + s.kv_off, u.kv_total, B, k, s.heads, 32, XA_NP, 1.0f / sqrtf(32.f), kexp, o.c->stream), "expand K");
+        o.check(launch_expand_heads(kv + s.kv_off + C, u.kv_total, B, k, s.heads, 32, XA_NP, 1.0f, vexp, o.c->stream), "expand V");
+        o.check(launch_transpose_bf16(o.w<bf16_t>(s.wq2), wqt, C, C, o.c->stream), "transpose Wq");
+        {   // G = Kexp . Wq   (contract over Wq's ROW index: weights operand = Wq^T)
+            IgemmParams p = o.base(B * XA_NP, C, C);
+            p.A0 = kexp; p.C0 = C; p.W = wqt; p.out_bf16 = G;
+            o.check(launch_igemm(p, false, 1, o.c->stream), "xattn G");
+        }
+        {   // U_b = Wo . Vexp_b^T  per sample (A shared)
+            IgemmParams p = o.base(C, XA_NP, C);
+            p.A0 = o.w<bf16_t>(s.wo2); p.C0 = C; p.W = vexp; p.sA = 0; p.sW = (long long)XA_NP * C; p.sO = (long long)C * XA_NP;
+            p.out_bf16 = U; p.ldo = XA_NP;
+            o.check(launch_igemm(p, false, B, o.c->stream), "xattn U");
+        }
+    }
+}
+
+static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const bf16_t* kv, const bf16_t* xa, int B, int k, int H, int W,
                       float* eps_out) {
     const rdm_unet_cfg& c = u.cfg;
     const int mc = c.model_channels, ted = mc * 4;
@@ -462,16 +506,35 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         // --- attn2 (cross over the k neighbours)
         bf16_t* l2 = o.abf((size_t)M * C);
         o.layernorm(t1, 0, s.ln2g, s.ln2b, l2, 0, M, C);
-        bf16_t* q2 = o.abf((size_t)M * C);
-        o.linear(l2, nullptr, C, 0, s.wq2, 0, false, M, C, ACT_NONE, nullptr, q2);
-        bf16_t* ao2 = o.abf((size_t)M * C);
-        if (!o.plan) {
-            SmallAttnParams p{}; p.q = q2; p.ldq = C; p.k = kv + s.kv_off; p.ldk = u.kv_total; p.v = kv + s.kv_off + C;
-            p.ldv = u.kv_total; p.out = ao2; p.ldo = C; p.nq = n; p.nkv = k; p.causal = 0; p.scale = 1.0f / sqrtf(32.f);
-            o.check(launch_small_attention(p, 32, s.heads, B, o.c->stream), "cross attention");
-        }
         bf16_t* t2 = o.abf((size_t)M * C);
-        o.linear(ao2, nullptr, C, 0, s.wo2, s.bo2, true, M, C, ACT_NONE, t1, t2);
+        if (xa) {       // two skinny per-sample GEMMs (see unet_compute_xattn)
+            bf16_t* P = o.abf((size_t)M * XA_NP);
+            if (!o.plan) {
+                const bf16_t* G = xa + (size_t)B * s.xa_unit; const bf16_t* U = G + (size_t)B * XA_NP * C;
+                IgemmParams p = o.base(n, XA_NP, C);
+                p.A0 = l2; p.C0 = C; p.sA = (long long)n * C; p.W = G; p.sW = (long long)XA_NP * C; p.out_bf16 = P; p.sO = (long long)n * XA_NP;
+                p.act = ACT_SOFTMAXG; p.sm_group = k;
+                o.prof_begin(1, 2.0 * M * XA_NP * (double)C);
+                o.check(launch_igemm(p, false, B, o.c->stream), "xattn scores");
+                o.prof_end();
+                IgemmParams q = o.base(n, C, XA_NP);
+                q.A0 = P; q.C0 = XA_NP; q.sA = (long long)n * XA_NP; q.W = U; q.sW = (long long)C * XA_NP; q.bias = o.w<float>(s.bo2);
+                q.res_bf16 = t1; q.out_bf16 = t2; q.sO = (long long)n * C;
+                o.prof_begin(1, 2.0 * M * C * (double)XA_NP);
+                o.check(launch_igemm(q, false, B, o.c->stream), "xattn out");
+                o.prof_end();
+            }
+        } else {
+            bf16_t* q2 = o.abf((size_t)M * C);
+            o.linear(l2, nullptr, C, 0, s.wq2, 0, false, M, C, ACT_NONE, nullptr, q2);
+            bf16_t* ao2 = o.abf((size_t)M * C);
+            if (!o.plan) {
+                SmallAttnParams p{}; p.q = q2; p.ldq = C; p.k = kv + s.kv_off; p.ldk = u.kv_total; p.v = kv + s.kv_off + C;
+                p.ldv = u.kv_total; p.out = ao2; p.ldo = C; p.nq = n; p.nkv = k; p.causal = 0; p.scale = 1.0f / sqrtf(32.f);
+                o.check(launch_small_attention(p, 32, s.heads, B, o.c->stream), "cross attention");
+            }
+            o.linear(ao2, nullptr, C, 0, s.wo2, s.bo2, true, M, C, ACT_NONE, t1, t2);
+        }
         // --- GEGLU feed-forward
         bf16_t* l3 = o.abf((size_t)M * C);
         o.layernorm(t2, 0, s.ln3g, s.ln3b, l3, 0, M, C);
@@ -703,7 +766,7 @@ void rdm_ctx_destroy(rdm_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     void* ptrs[] = {c->zero_page, c->unet.blob, c->unet.arena.base, c->unet.kv_cache, c->vq.blob, c->vq.arena.base,
-                    c->clip.blob, c->clip.arena.base, c->gn_partial, c->samp, c->splitk_ws};
+                    c->clip.blob, c->clip.arena.base, c->gn_partial, c->samp, c->splitk_ws, c->unet.xa_cache};
     for (void* p : ptrs) if (p) hipFree(p);
     knn_free(c->db);
     delete c;
@@ -763,12 +826,18 @@ static int unet_forward_impl(rdm_ctx* c, const float* x, const int64_t* t, const
     RDM_TRY(ensure_gn_partial(c, b));
     return run_with_arena(c, u.arena, u.blob, [&](Ops& o) {
         const bf16_t* kv = kv_cached;
+        const bf16_t* xa = (kv_cached && xattn_skinny_ok(u, k)) ? u.xa_cache : nullptr;
         if (!kv) {
             bf16_t* kvb = o.abf((size_t)b * k * u.kv_total);
             unet_compute_kv(o, u, context, b, k, kvb);
             kv = kvb;
+            if (xattn_skinny_ok(u, k)) {
+                bf16_t* xab = o.abf((size_t)b * u.xa_total);
+                unet_compute_xattn(o, u, kv, b, k, xab);
+                xa = xab;
+            }
         }
-        unet_body(o, u, x, (const long long*)t, kv, b, k, H, W, eps_out);
+        unet_body(o, u, x, (const long long*)t, kv, xa, b, k, H, W, eps_out);
     });
 }
 
@@ -796,7 +865,12 @@ static int prepare_kv(rdm_ctx* c, const float* cond, const float* uncond, int B,
     float* cat = (float*)c->samp;
     RDM_CHECK_HIP(c, hipMemcpyAsync(cat, cond, (size_t)B * k * cd * 4, hipMemcpyDeviceToDevice, c->stream));
     if (uncond) RDM_CHECK_HIP(c, hipMemcpyAsync(cat + (size_t)B * k * cd, uncond, (size_t)B * k * cd * 4, hipMemcpyDeviceToDevice, c->stream));
-    return run_with_arena(c, u.arena, u.blob, [&](Ops& o) { unet_compute_kv(o, u, cat, nb, k, u.kv_cache); });
+    const bool skinny = xattn_skinny_ok(u, k);
+    if (skinny) RDM_TRY(ensure_bytes(c, (char**)&u.xa_cache, &u.xa_cache_bytes, (size_t)nb * u.xa_total * 2));
+    return run_with_arena(c, u.arena, u.blob, [&](Ops& o) {
+        unet_compute_kv(o, u, cat, nb, k, u.kv_cache);
+        if (skinny) unet_compute_xattn(o, u, u.kv_cache, nb, k, u.xa_cache);
+    });
 }
 
 int rdm_ddim_sample(rdm_ctx* c, const rdm_ddim_args* a, const float* x_T, const float* cond, const float* uncond,
