@@ -604,7 +604,8 @@ hipError_t launch_igemm(const IgemmParams& p_in, bool conv, int batch, hipStream
     static const int force_bm = getenv("RDM_IGEMM_BM") ? atoi(getenv("RDM_IGEMM_BM")) : 0;
     const bool wide = (p.N % 192 == 0);
     const long long tiles256 = (long long)((p.M + 255) / 256) * ((p.N + (wide ? 191 : 127)) / (wide ? 192 : 128)) * batch;
-    bool tall = tiles256 >= 256;      // 8 waves, 3-deep A ring: the HBM latency of the activation stream is covered
+    bool tall = tiles256 >= 256 && p.M > 128;      // 8 waves, 3-deep A ring: the HBM latency of the activation stream is covered
+                                                   // (M <= 128 rows per batch item: a 256-row tile would be mostly padding)
     if (force_bm == 128) tall = false;
     if (force_bm == 256) tall = true;
     if (p.act == ACT_GEGLU) {
