@@ -69,7 +69,7 @@ constexpr int XA_NP = 128;        // padded (heads x neighbours) width of the sk
 
 struct StW {
     int c, heads; size_t gng, gnb, win, bin, ln1g, ln1b, wqk, wv, wo1, bo1, ln2g, ln2b, wq2, wo2, bo2, ln3g, ln3b, wff1,
-        bff1, wff2, bff2, wout, bout; int kv_off; long long xa_unit;   // xa_unit: per-sample element offset of this layer's (G, U) pair
+        bff1, wff2, bff2, wout, bout, wfo, bfo; int kv_off; long long xa_unit;   // xa_unit: per-sample element offset of this layer's (G, U) pair
 };
 struct ConvW { int c; size_t w, b; };
 struct ULayer { int kind; int idx; };            // 0 conv_in, 1 res, 2 st, 3 down, 4 up
@@ -129,6 +129,9 @@ static void build_unet(UNet& u, const rdm_unet_cfg& c, Manifest& mf) {
         s.bff1 = mf.add("geglu_b", tb + ".ff.net.0.proj.bias", (size_t)8 * ch * 4);
         s.wff2 = bf(tb + ".ff.net.2.weight", (size_t)ch * 4 * ch); s.bff2 = f32(tb + ".ff.net.2.bias", ch);
         s.wout = bf(pre + ".proj_out.weight", (size_t)ch * ch); s.bout = f32(pre + ".proj_out.bias", ch);
+        // ff.net.2 followed by proj_out is one linear map of [ff | t2]:  [W_out W_2 | W_out], bias W_out b_2 + b_out (packed in fp32)
+        s.wfo = mf.add("fuse_w", tb + ".ff.net.2.weight," + pre + ".proj_out.weight", (size_t)ch * 5 * ch * 2);
+        s.bfo = mf.add("fuse_b", tb + ".ff.net.2.bias," + pre + ".proj_out.weight," + pre + ".proj_out.bias", (size_t)ch * 4);
         s.kv_off = u.kv_total; u.kv_total += 2 * ch;
         s.xa_unit = u.xa_total; u.xa_total += 2LL * XA_NP * ch;
         if (!kv_srcs.empty()) kv_srcs += ",";
@@ -540,10 +543,17 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         o.layernorm(t2, 0, s.ln3g, s.ln3b, l3, 0, M, C);
         bf16_t* ff = o.abf((size_t)M * 4 * C);
         o.linear(l3, nullptr, C, 0, s.wff1, s.bff1, true, M, 8 * C, ACT_GEGLU, nullptr, ff);
-        bf16_t* t3 = o.abf((size_t)M * C);
-        o.linear(ff, nullptr, 4 * C, 0, s.wff2, s.bff2, true, M, C, ACT_NONE, t2, t3);
         bf16_t* out = o.abf((size_t)M * C);
-        o.linear(t3, nullptr, C, 0, s.wout, s.bout, true, M, C, ACT_NONE, a.p, out);
+        static const int no_ffout = getenv("RDM_NO_FFOUT") ? atoi(getenv("RDM_NO_FFOUT")) : 0;
+        if (!no_ffout) {
+            // t3 = ff W_2^T + b_2 + t2 and out = t3 W_out^T + b_out + x are one GEMM over the K-concatenated operand [ff | t2]
+            // (dual-source A) with the product weights built by the packer: t3 never exists (2 of 9 tensor passes, one launch)
+            o.linear(ff, t2, 4 * C, C, s.wfo, s.bfo, true, M, C, ACT_NONE, a.p, out);
+        } else {
+            bf16_t* t3 = o.abf((size_t)M * C);
+            o.linear(ff, nullptr, 4 * C, 0, s.wff2, s.bff2, true, M, C, ACT_NONE, t2, t3);
+            o.linear(t3, nullptr, C, 0, s.wout, s.bout, true, M, C, ACT_NONE, a.p, out);
+        }
         return Act{out, C, a.H, a.W};
     };
 

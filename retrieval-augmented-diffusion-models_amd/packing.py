@@ -53,6 +53,12 @@ def pack(kind: str, cfg, sd: Dict[str, torch.Tensor]) -> np.ndarray:
             data = _bf16_bytes(ts[0][_geglu_perm(ts[0].shape[0])])
         elif kd == "geglu_b":
             data = _f32_bytes(ts[0][_geglu_perm(ts[0].shape[0])])
+        elif kd == "fuse_w":      # [W_out W_2 | W_out]: ff.net.2 then proj_out as ONE linear map of [ff | t2] (model.hip transformer())
+            w2, wo = ts[0].double(), ts[1].reshape(ts[1].shape[0], -1).double()
+            data = _bf16_bytes(torch.cat([wo @ w2, wo], dim=1).float())
+        elif kd == "fuse_b":      # W_out b_2 + b_out
+            b2, wo, bo = ts[0].double(), ts[1].reshape(ts[1].shape[0], -1).double(), ts[2].double()
+            data = _f32_bytes((wo @ b2 + bo).float())
         else:
             raise ValueError(f"unknown manifest kind {kd}")
         if data.nbytes != nbytes:

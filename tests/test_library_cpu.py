@@ -45,8 +45,11 @@ def _check_manifest(kind, cfg, shapes):
     import rdm_amd  # noqa: F401
     from rdm_amd import _lib, packing
     entries, blob_bytes = _lib.manifest(kind, cfg)
-    used = [s for e in entries for s in e[3]]
-    assert sorted(used) == sorted(shapes), set(used) ^ set(shapes)      # every reference key exactly once
+    # every reference key exactly once among the plain entries; derived entries (products of two reference tensors, e.g. the
+    # fused ff.net.2 * proj_out map) may re-use keys
+    used = [s for e in entries if not e[2].startswith("fuse_") for s in e[3]]
+    assert sorted(used) == sorted(shapes), set(used) ^ set(shapes)
+    assert all(s in shapes for e in entries for s in e[3])
     ends = [off + nb for off, nb, _, _ in entries]
     offs = [off for off, _, _, _ in entries]
     assert all(o % 256 == 0 for o in offs) and all(a <= b for a, b in zip(ends[:-1], offs[1:])) and ends[-1] <= blob_bytes
@@ -69,8 +72,13 @@ def test_unet_manifest_matches_reference_state_dict():
     import rdm_amd  # noqa: F401
     from rdm_amd import _lib
     e2, nbytes = _lib.manifest("unet", spec_to_unet_cfg(full))
-    assert sorted(s for e in e2 for s in e[3]) == sorted(ounet.param_shapes(full))
-    assert 0.79e9 < nbytes < 0.83e9          # ~0.80 GB bf16
+    assert sorted(s for e in e2 if not e[2].startswith("fuse_") for s in e[3]) == sorted(ounet.param_shapes(full))
+    assert 0.79e9 < nbytes < 0.99e9          # ~0.80 GB bf16 + the derived ff.net.2 x proj_out product weights (0.13 GB)
+    # the derived entry is the product map: [W_out W_2 | W_out] and W_out b_2 + b_out
+    off, nb, kd, srcs = next(e for e in entries if e[2] == "fuse_w")
+    w2, wo = sd[srcs[0]].double(), sd[srcs[1]].reshape(sd[srcs[1]].shape[0], -1).double()
+    got = torch.from_numpy(blob[off:off + nb].view(np.int16).copy()).view(torch.bfloat16).float().reshape(wo.shape[0], -1)
+    assert torch.equal(got, torch.cat([wo @ w2, wo], dim=1).float().to(torch.bfloat16).float())
 
 
 def test_vq_and_clip_manifests():
