@@ -188,7 +188,7 @@ def main():
             extras["retrieval_ms_per_batch"] = sum(e0.elapsed_time(e1) for e0, e1 in ev_ret) / max(len(ev_ret), 1)
         except Exception:      # events of another stream: library runs on the legacy stream by default
             pass
-    if rank == 0 and not a.no_extras:
+    if world == 1 and not a.no_extras:      # single-process only: step() contains the all-gather collective when world > 1
         torch.cuda.synchronize(); t1 = time.perf_counter()
         step(0, scale=1.0)
         torch.cuda.synchronize()
