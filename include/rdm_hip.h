@@ -87,7 +87,10 @@ const char* rdm_version(void);
  * The library defines the packed-blob layout; rdm_*_manifest writes it as text, one line per entry:
  *     <offset> <nbytes> <kind> <src>[,<src>...]
  * where <src> are the reference's own state_dict keys and <kind> is one of
- *   f32 | bf16 | bf16_t | conv3 | geglu_w | geglu_b   (see DESIGN.md "Weight blob").
+ *   f32 | bf16 | bf16_t | conv3 | geglu_w | geglu_b   (see DESIGN.md section 2), or a DERIVED entry
+ *   fuse_w  <ff.net.2.weight>,<proj_out.weight>                  -> bf16 [C][5C] = [W_out W_2 | W_out]   (multiplied out in fp64)
+ *   fuse_b  <ff.net.2.bias>,<proj_out.weight>,<proj_out.bias>    -> f32  [C]     = W_out b_2 + b_out
+ * (the SpatialTransformer's ff.net.2 and proj_out run as one GEMM, attention.py:88-96 + 190-195).
  * The caller fills a host blob accordingly and hands it to rdm_load_*, which copies it to HBM.
  * Returns the number of bytes needed for the text (excluding NUL) if buf is too small. */
 long long rdm_unet_manifest(const rdm_unet_cfg* cfg, char* buf, size_t buflen, size_t* blob_bytes);
