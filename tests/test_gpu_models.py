@@ -75,11 +75,12 @@ def test_unet_shipped_golden(ctx):
 
 def test_unet_batch_invariance_and_k(ctx):
     """Samples are independent: row i of a batch equals the same sample run alone, bit for bit (this is
-    what makes batch sharding over GPUs exact). Also exercises k = 1 and k = 16."""
+    what makes batch sharding over GPUs exact). Also exercises k = 1, 2 (cross-attention as two skinny GEMMs, softmax groups
+    of 1 and 2 columns) and k = 3, 16 (attention kernel path)."""
     spec = ounet.tiny_spec()
     sd = _load_unet(ctx, spec)
     rng = np.random.default_rng(3)
-    for k in (1, 16):
+    for k in (1, 2, 3, 16):
         x = torch.from_numpy(rng.standard_normal((3, 3, 16, 16)).astype(np.float32))
         t = torch.tensor([5, 500, 981])
         c = torch.from_numpy((rng.standard_normal((3, k, 512)) * 0.45).astype(np.float32))
