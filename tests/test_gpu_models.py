@@ -191,7 +191,9 @@ def test_clip_tiny_golden(ctx):
     assert rel_l2(i, torch.from_numpy(g["image_out"])) <= 2e-2
 
 
-@pytest.mark.parametrize("N,B,k", [(100_000, 8, 4), (33_333, 70, 16), (1000, 3, 1), (300_000, 64, 4), (50_001, 1, 28), (257, 2, 20)])
+@pytest.mark.parametrize("N,B,k", [(100_000, 8, 4), (33_333, 70, 16), (1000, 3, 1), (300_000, 64, 4), (50_001, 1, 28), (257, 2, 20),
+                                   # B > 64 with k <= 4: bulk passes of 128 queries (+ a last group of <= 64 / of 65..128)
+                                   (60_000, 200, 4), (20_000, 129, 2), (5_000, 257, 1)])
 def test_knn_bit_exact(ctx, N, B, k):
     rng = np.random.default_rng(7)
     db = (rng.standard_normal((N, 512), dtype=np.float32) * 0.45).astype(np.float16)
