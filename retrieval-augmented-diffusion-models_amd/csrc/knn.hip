@@ -218,18 +218,24 @@ __global__ __launch_bounds__(256, 1) void knn_scan512_kernel(ScanParams p) {
 
     const long long my_tiles = (p.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const long long iters = my_tiles * NKC;
-    auto stage_db = [&](long long it) {
-        const long long tl = it / NKC; const int kc = (int)(it - tl * NKC);
-        const long long tile = blockIdx.x + tl * gridDim.x;
-        char* Ds = smem + (int)(it % 3) * DB_BYTES;
+    // Address arithmetic is the cost of an LDS-DMA request here (the 64-bit row * dim products of a naive loader took ~900 cycles
+    // per stage, more than the 32 requests' time on the memory path): one 64-bit lane pointer per TILE, pieces and K chunks are
+    // constant byte offsets from it; the swizzle term does not depend on the piece (32 | piece stride).
+    const int csw = (pchunk ^ ((lrow >> 1) & 7)) * 16;    // byte offset of my (swizzled) source chunk inside a 128-byte segment
+    auto tile_ptr = [&](long long tile) { return (const char*)p.dbn + (tile * KNN_ROWS + lrow) * (long long)(DIM * 2) + csw; };
+    auto tile_rows = [&](long long tile) { const long long left = p.n - tile * KNN_ROWS; return (int)(left > KNN_ROWS ? KNN_ROWS : left); };
+    // stage st_kc of the tile whose lane pointer is st_ptr (st_rows valid rows) -> ring slot st_slot; then advance the stream
+    const char* st_ptr = tile_ptr(blockIdx.x); int st_rows = tile_rows(blockIdx.x); int st_kc = 0, st_slot = 0; long long st_tile = blockIdx.x;
+    auto stage_next = [&]() {
+        char* Ds = smem + st_slot * DB_BYTES;
+        const char* src = st_ptr + st_kc * (KNN_BK * 2);
 #pragma unroll
         for (int i = 0; i < KNN_ROWS / 32; i++) {
-            const int r = i * 32 + lrow;
-            const long long row = tile * KNN_ROWS + r;
-            const int c = pchunk ^ ((r >> 1) & 7);
-            const void* g = (row < p.n) ? (const void*)(p.dbn + row * DIM + kc * KNN_BK + c * 8) : (const void*)zero;
+            const void* g = (i * 32 + lrow < st_rows) ? (const void*)(src + (long long)i * 32 * DIM * 2) : (const void*)zero;
             glds16(g, Ds + (i * 32 + wave * 8) * 128);
         }
+        st_slot = st_slot == 2 ? 0 : st_slot + 1;
+        if (++st_kc == NKC) { st_kc = 0; st_tile += gridDim.x; st_ptr = tile_ptr(st_tile); st_rows = tile_rows(st_tile); }
     };
     f32x16 acc[4];
 #pragma unroll
@@ -237,8 +243,8 @@ __global__ __launch_bounds__(256, 1) void knn_scan512_kernel(ScanParams p) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
 
-    if (iters > 0) stage_db(0);
-    if (iters > 1) stage_db(1);
+    if (iters > 0) stage_next();
+    if (iters > 1) stage_next();
     long long it = 0;
     for (long long tl = 0; tl < my_tiles; tl++) {
 #pragma unroll
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void knn_scan512_kernel(ScanParams p) {
             if (it + 1 < iters) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                 // raw barrier (a __syncthreads would drain vmcnt): stage landed for all
-            if (it + 2 < iters) stage_db(it + 2);         // waves; the slot of stage it-1 is free (its reads fed MFMAs already)
+            if (it + 2 < iters) stage_next();             // waves; the slot of stage it-1 is free (its reads fed MFMAs already)
             const char* Ds = smem + (int)(it % 3) * DB_BYTES;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
