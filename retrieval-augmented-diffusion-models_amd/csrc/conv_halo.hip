@@ -61,14 +61,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
 
     // ---- per-tile loader state
     int hpix[HPASS];                                      // pixel index of my halo position in each pass, or -1
-    int b_n[BP];
+    long long b_off[BP];                                  // element offset of my weight row + swizzled chunk (64-bit, once per tile:
+                                                          // the per-piece address is then one 64-bit add of a wave-uniform term)
     int m0, n0;
     auto setup_mn = [&](int t) {
         t = t % ntiles_mn;
         const int bm = t / nbn, bn = t - bm * nbn;
         m0 = bm * BM; n0 = bn * BN;
 #pragma unroll
-        for (int i = 0; i < BP; i++) b_n[i] = n0 + i * 64 + lrow;
+        for (int i = 0; i < BP; i++) b_off[i] = (long long)(n0 + i * 64 + lrow) * p.K + sc8;
     };
     auto setup_halo = [&](int t) {
         t = t % ntiles_mn;
@@ -100,10 +101,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
         if (ps * 64 + lrow < HP) glds16(g, halo_base + hb * HALO_BYTES + (ps * 64 + wave * 8) * 128);
     };
     auto stage_b = [&](int sl, int tap, int bb) {
-        const bf16_t* lane_w = p.W + ((long long)tap * Cin + sl * BK + sc8);
+        const bf16_t* slice_w = p.W + ((long long)tap * Cin + sl * BK);       // wave-uniform
 #pragma unroll
         for (int i = 0; i < BP; i++)
-            glds16(lane_w + (long long)b_n[i] * p.K, b_base + bb * B_BYTES + (i * 64 + wave * 8) * 128);
+            glds16(slice_w + b_off[i], b_base + bb * B_BYTES + (i * 64 + wave * 8) * 128);
     };
 
     // ---- fragment addressing: pixel row -> halo position of tap (0,0)
