@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(ScanParams p) {
 // rows (w >> 1).  LDS holds only the database ring (3 stages of 256 rows x 64 dims, requested two stages ahead with counted
 // vmcnt across raw barriers), so a stage costs 32 LDS-DMA pieces instead of 48 and 4 instead of 6 LDS reads per k-step; the
 // K loop of a tile is fully unrolled (the register-resident fragments need compile-time indices).
-// Measured (20.9 M x 512, 64 queries): 5.5 ms = 3.9 TB/s of database streamed, vs 6.6 ms for the LDS-staged-query kernel; the
+// Measured (20.9 M x 512, 64 queries): 5.2 ms = 4.1 TB/s of database streamed, vs 6.6 ms for the LDS-staged-query kernel; the
 // bare LDS-DMA stream of the same walk runs at 6.3 TB/s (tools/ubench/hbm_pattern.hip), the gap is LDS-DMA issue time that a
 // single wave per SIMD cannot overlap with its own MFMAs.
 template <int KSEL>
