@@ -15,6 +15,7 @@
 //                 products, the oracle's definition) and sorted by (score desc, index asc).
 // Any element of the true top-k survives every list level because every list keeps KSEL >= k + 4
 // entries of its subset; index ties resolve identically to the oracle.
+#include <stdlib.h>
 #include <string.h>
 
 #include "kernels.h"
@@ -288,6 +289,96 @@ __global__ __launch_bounds__(256, 1) void knn_scan512_kernel(ScanParams p) {
     for (int j = 0; j < KSEL; j++) { p.cand_s[base + j] = ls[j]; p.cand_i[base + j] = li[j]; }
 }
 
+// ---------------------------------------------------------------- scan, dim == 512, 8 waves (two per SIMD), KSEL == 8
+// Same idea as knn_scan512_kernel (queries resident in registers, database-only LDS ring) with 16x16x32 MFMAs: a wave owns 16
+// queries (128 registers of hi / lo fragments) x 128 rows, so 8 waves = 2 row halves x 4 query groups fit two per SIMD (256
+// registers each) and one wave's LDS-DMA issue, LDS latency and list insertion hide behind its SIMD partner's MFMAs.
+// D layout 16x16: col (query) = lane & 15, row = (lane >> 4) * 4 + reg -> still one query, one private top-k list per lane.
+template <int KSEL>
+__global__ __launch_bounds__(512, 2) void knn_scan512w8_kernel(ScanParams p) {
+    constexpr int DB_BYTES = KNN_ROWS * 128, NKC = 8, DIM = 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = tid >> 3, pchunk = tid & 7;             // loader: 64 rows x 8 chunks per piece
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int rh = wave >> 2, qg = wave & 3;
+    const char* zero = (const char*)p.zero_page;
+
+    f16x8 qh[16], ql[16];                                     // B fragments of my 16 queries, all 16 k-steps of 32
+    {
+        const _Float16* qhp = p.qh + (long long)(qg * 16 + l15) * DIM + kq * 8;
+        const _Float16* qlp = p.ql + (long long)(qg * 16 + l15) * DIM + kq * 8;
+#pragma unroll
+        for (int s = 0; s < 16; s++) { qh[s] = *(const f16x8*)(qhp + s * 32); ql[s] = *(const f16x8*)(qlp + s * 32); }
+    }
+    float ls[KSEL]; uint32_t li[KSEL];
+#pragma unroll
+    for (int j = 0; j < KSEL; j++) { ls[j] = -INFINITY; li[j] = 0xffffffffu; }
+
+    const long long my_tiles = (p.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const long long iters = my_tiles * NKC;
+    const int csw = (pchunk ^ ((lrow >> 1) & 7)) * 16;
+    auto tile_ptr = [&](long long tile) { return (const char*)p.dbn + (tile * KNN_ROWS + lrow) * (long long)(DIM * 2) + csw; };
+    auto tile_rows = [&](long long tile) { const long long left = p.n - tile * KNN_ROWS; return (int)(left > KNN_ROWS ? KNN_ROWS : left); };
+    const char* st_ptr = tile_ptr(blockIdx.x); int st_rows = tile_rows(blockIdx.x); int st_kc = 0, st_slot = 0; long long st_tile = blockIdx.x;
+    auto stage_next = [&]() {                                 // 4 pieces of 64 rows per thread
+        char* Ds = smem + st_slot * DB_BYTES;
+        const char* src = st_ptr + st_kc * (KNN_BK * 2);
+#pragma unroll
+        for (int i = 0; i < KNN_ROWS / 64; i++) {
+            const void* g = (i * 64 + lrow < st_rows) ? (const void*)(src + (long long)i * 64 * DIM * 2) : (const void*)zero;
+            glds16(g, Ds + (i * 64 + wave * 8) * 128);
+        }
+        st_slot = st_slot == 2 ? 0 : st_slot + 1;
+        if (++st_kc == NKC) { st_kc = 0; st_tile += gridDim.x; st_ptr = tile_ptr(st_tile); st_rows = tile_rows(st_tile); }
+    };
+    f32x4 acc[8];
+#pragma unroll
+    for (int a = 0; a < 8; a++) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (iters > 0) stage_next();
+    if (iters > 1) stage_next();
+    long long it = 0;
+    for (long long tl = 0; tl < my_tiles; tl++) {
+#pragma unroll
+        for (int kc = 0; kc < NKC; kc++, it++) {
+            if (it + 1 < iters) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // stage it landed; stage it+1 (4 pieces) may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (it + 2 < iters) stage_next();
+            const char* Ds = smem + (int)(it % 3) * DB_BYTES;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {                     // two k-steps of 32 per 64-dim stage
+                const int chunk = h * 4 + kq, s = kc * 2 + h;
+                f16x8 a[8];
+#pragma unroll
+                for (int rf = 0; rf < 8; rf++) {
+                    const int row = rh * 128 + rf * 16 + l15;
+                    a[rf] = *(const f16x8*)(Ds + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int rf = 0; rf < 8; rf++) acc[rf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rf], ql[s], acc[rf], 0, 0, 0);
+#pragma unroll
+                for (int rf = 0; rf < 8; rf++) acc[rf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rf], qh[s], acc[rf], 0, 0, 0);
+            }
+        }
+        const long long tile = blockIdx.x + tl * gridDim.x;
+        const long long rbase = tile * KNN_ROWS + rh * 128 + kq * 4;
+#pragma unroll
+        for (int rf = 0; rf < 8; rf++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const long long row = rbase + rf * 16 + r;
+                if (row < p.n) list_insert<KSEL>(ls, li, acc[rf][r], (uint32_t)row);
+                acc[rf][r] = 0.f;
+            }
+    }
+    const int list_id = blockIdx.x * 8 + rh * 4 + kq;
+    const long long base = ((long long)(qg * 16 + l15) * p.nlists + list_id) * KSEL;
+#pragma unroll
+    for (int j = 0; j < KSEL; j++) { p.cand_s[base + j] = ls[j]; p.cand_i[base + j] = li[j]; }
+}
+
 // ---------------------------------------------------------------- merge + exact re-score
 struct MergeParams {
     const float* cand_s; const uint32_t* cand_i; int nlists;
@@ -409,8 +500,9 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
     int grid = (int)(ntiles < ncu ? ntiles : ncu);
     const bool d512 = db.dim == 512;                 // register-resident queries (4 lists per block and query instead of 8)
     const int nlists = grid * (d512 ? 4 : 8);
+    const int nlists_cap = grid * 8;
     const size_t qn_b = (size_t)KNN_Q * db.dim * 4, qh_b = (size_t)KNN_Q * db.dim * 2;
-    const size_t cand_b = (size_t)KNN_Q * nlists * KSEL * 4;
+    const size_t cand_b = (size_t)KNN_Q * nlists_cap * KSEL * 4;
     const size_t need = qn_b + 2 * qh_b + 2 * cand_b + 1024;
     if (db.scratch_bytes < need) {
         if (db.scratch) { KNN_TRY(hipStreamSynchronize(st)); KNN_TRY(hipFree(db.scratch)); db.scratch = nullptr; db.scratch_bytes = 0; }
@@ -437,10 +529,16 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
         KNN_TRY(hipGetLastError());
         ScanParams sp{}; sp.dbn = (const _Float16*)db.dbn; sp.n = db.n; sp.dim = db.dim; sp.ntiles = ntiles; sp.qh = qh; sp.ql = ql;
         sp.cand_s = cs; sp.cand_i = ci; sp.nlists = nlists; sp.zero_page = zero_page;
-        if (d512) knn_scan512_kernel<KSEL><<<grid, 256, scan512_smem, st>>>(sp);
+        static const int w8 = getenv("RDM_KNN_W8") ? atoi(getenv("RDM_KNN_W8")) : 1;
+        if (d512 && KSEL == 8 && w8) {
+            static bool attr8 = false;
+            if (!attr8) { KNN_TRY(hipFuncSetAttribute((const void*)knn_scan512w8_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, scan512_smem)); attr8 = true; }
+            sp.nlists = grid * 8;
+            knn_scan512w8_kernel<8><<<grid, 512, scan512_smem, st>>>(sp);
+        } else if (d512) knn_scan512_kernel<KSEL><<<grid, 256, scan512_smem, st>>>(sp);
         else knn_scan_kernel<KSEL><<<grid, 256, scan_smem, st>>>(sp);
         KNN_TRY(hipGetLastError());
-        MergeParams mp{}; mp.cand_s = cs; mp.cand_i = ci; mp.nlists = nlists; mp.dbn = (const _Float16*)db.dbn; mp.qn = qn;
+        MergeParams mp{}; mp.cand_s = cs; mp.cand_i = ci; mp.nlists = sp.nlists; mp.dbn = (const _Float16*)db.dbn; mp.qn = qn;
         mp.dim = db.dim; mp.n = db.n; mp.k = k; mp.idx_out = idx_out; mp.score_out = score_out; mp.qbase = q0;
         knn_merge_kernel<KSEL><<<bq, 256, merge_smem, st>>>(mp);
         KNN_TRY(hipGetLastError());
