@@ -19,35 +19,49 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* x, const floa
     for (int i = threadIdx.x; i < Cout; i += 256) ws[K * Cout + i] = bias[i];
     __syncthreads();
     const int b = blockIdx.y, npix = H * W;
-    for (int lp = blockIdx.x * 256 + threadIdx.x; lp < npix; lp += gridDim.x * 256) {
-        const int xw = lp % W, yh = lp / W;
-        float patch[36];                              // Cin <= 4
+    // two pixels per thread: every broadcast weight read from LDS feeds 16 FMAs instead of 8 (the LDS reads, not the FMAs, bound
+    // the one-pixel version)
+    for (int lp0 = blockIdx.x * 512 + threadIdx.x; lp0 < npix; lp0 += gridDim.x * 512) {
+        float patch[2][36];                           // Cin <= 4
 #pragma unroll
-        for (int ci = 0; ci < 4; ci++) {
+        for (int q = 0; q < 2; q++) {
+            const int lp = lp0 + q * 256;
+            const int xw = lp % W, yh = lp / W;
 #pragma unroll
-            for (int t = 0; t < 9; t++) {
-                const int iy = yh + t / 3 - 1, ix = xw + t % 3 - 1;
-                float v = 0.f;
-                if (ci < Cin && iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((long long)(b * Cin + ci) * H + iy) * W + ix];
-                patch[ci * 9 + t] = v;
+            for (int ci = 0; ci < 4; ci++) {
+#pragma unroll
+                for (int t = 0; t < 9; t++) {
+                    const int iy = yh + t / 3 - 1, ix = xw + t % 3 - 1;
+                    float v = 0.f;
+                    if (lp < npix && ci < Cin && iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((long long)(b * Cin + ci) * H + iy) * W + ix];
+                    patch[q][ci * 9 + t] = v;
+                }
             }
         }
-        bf16_t* op = out + ((long long)b * npix + lp) * Cout;
 #pragma unroll 1
         for (int v8 = 0; v8 < Cout; v8 += 8) {
-            float acc[8];
+            float acc[2][8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) acc[e] = ws[K * Cout + v8 + e];
+            for (int e = 0; e < 8; e++) { acc[0][e] = ws[K * Cout + v8 + e]; acc[1][e] = acc[0][e]; }
 #pragma unroll
             for (int k = 0; k < 36; k++) {
                 if (k < K) {
                     const float4 w0 = *(const float4*)(ws + k * Cout + v8), w1 = *(const float4*)(ws + k * Cout + v8 + 4);
-                    const float pv = patch[k];
-                    acc[0] += pv * w0.x; acc[1] += pv * w0.y; acc[2] += pv * w0.z; acc[3] += pv * w0.w;
-                    acc[4] += pv * w1.x; acc[5] += pv * w1.y; acc[6] += pv * w1.z; acc[7] += pv * w1.w;
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const float pv = patch[q][k];
+                        acc[q][0] += pv * w0.x; acc[q][1] += pv * w0.y; acc[q][2] += pv * w0.z; acc[q][3] += pv * w0.w;
+                        acc[q][4] += pv * w1.x; acc[q][5] += pv * w1.y; acc[q][6] += pv * w1.z; acc[q][7] += pv * w1.w;
+                    }
                 }
             }
-            *(uint4*)(op + v8) = make_uint4(cvt_pk_bf16(acc[0], acc[1]), cvt_pk_bf16(acc[2], acc[3]), cvt_pk_bf16(acc[4], acc[5]), cvt_pk_bf16(acc[6], acc[7]));
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int lp = lp0 + q * 256;
+                if (lp < npix)
+                    *(uint4*)(out + ((long long)b * npix + lp) * Cout + v8) =
+                        make_uint4(cvt_pk_bf16(acc[q][0], acc[q][1]), cvt_pk_bf16(acc[q][2], acc[q][3]), cvt_pk_bf16(acc[q][4], acc[q][5]), cvt_pk_bf16(acc[q][6], acc[q][7]));
+            }
         }
     }
 }
@@ -58,7 +72,7 @@ hipError_t launch_conv_in(const float* x, const float* w, const float* bias, bf1
     const size_t sm = (size_t)(Cin * 9 + 1) * Cout * sizeof(float);
     if (sm > 64 * 1024) return hipErrorInvalidValue;
     if (Cin > 4 || Cout % 8) return hipErrorInvalidValue;
-    int grid = (H * W + 255) / 256; const int cap_in = (2048 + B - 1) / B; if (grid > cap_in) grid = cap_in; if (grid < 1) grid = 1;
+    int grid = (H * W + 511) / 512; const int cap_in = (2048 + B - 1) / B; if (grid > cap_in) grid = cap_in; if (grid < 1) grid = 1;
     conv_in_kernel<<<dim3(grid, B), 256, sm, st>>>(x, w, bias, out, B, Cin, H, W, Cout);
     return hipGetLastError();
 }
