@@ -148,10 +148,13 @@ int rdm_knn(rdm_ctx* ctx, const float* q, int b, int k, uint32_t* idx_out, float
  * of the RAW (un-normalised) embeddings (rdm_db_load keeps a raw copy in HBM next to the normalised one). */
 int rdm_db_gather(rdm_ctx* ctx, const uint32_t* idx, long long n_idx, float* out);
 
-/* ---- measurement: optional HIP-event bracket around every GEMM-class launch on the context stream
- * (kind 0 = conv3x3 implicit GEMM, 1 = linear/1x1).  collect: sums elapsed ms and ALGORITHMIC flops
- * (2*M*N*K) of the launches recorded since the last reset. Used by bench.py for the roofline line. */
-int rdm_prof_enable(rdm_ctx* ctx, int on);
+/* ---- measurement: optional HIP-event brackets around launches on the context stream, by kernel class.
+ * enable: bit mask of (1 << RDM_PROF_*) kinds to record (0 = off).  collect: sums elapsed ms and ALGORITHMIC work of the
+ * launches of one kind recorded since the last reset -- FLOPs (2*M*N*K; 4*n^2*d per attention head) for the MFMA-bound
+ * kinds, bytes (minimal tensor / database passes) for the HBM-bound kinds.  Used by bench.py for the roofline objects. */
+enum { RDM_PROF_CONV3X3 = 0, RDM_PROF_LINEAR = 1, RDM_PROF_KNN = 2, RDM_PROF_ATTENTION = 3, RDM_PROF_GROUPNORM = 4,
+       RDM_PROF_LAYERNORM = 5 };
+int rdm_prof_enable(rdm_ctx* ctx, int kind_mask);
 int rdm_prof_collect(rdm_ctx* ctx, int kind, long long* launches, double* ms, double* flops);
 int rdm_prof_reset(rdm_ctx* ctx);
 

@@ -115,3 +115,44 @@ def custom_to_np_uint8(x: np.ndarray) -> np.ndarray:
     x = (x + np.float32(1.0)) / np.float32(2.0)
     x = np.transpose(x, (0, 2, 3, 1))
     return (np.float32(255.0) * x).astype(np.uint8)
+
+
+class StreamingTopK:
+    """Exact top-k (score descending, index ascending) over a database presented in row chunks — same definition as
+    `exact_topk` (which it is checked against in tests/test_oracle_cpu.py), organised for databases that do not fit in
+    host memory twice: per chunk only the rows scoring >= the chunk's k-th best are merged (ties included, so the
+    tie-break stays exact).  torch CPU ops (multi-threaded) instead of numpy for the fp64 matmul / partition."""
+
+    def __init__(self, qn: np.ndarray, k: int):
+        import torch
+        self.t = torch
+        self.q64 = torch.from_numpy(np.ascontiguousarray(qn)).double()
+        self.k = k
+        B = qn.shape[0]
+        self.best_s = [np.zeros(0) for _ in range(B)]
+        self.best_i = [np.zeros(0, dtype=np.int64) for _ in range(B)]
+
+    @staticmethod
+    def normalize_chunk(raw):
+        """normalize_db for one chunk (torch tensor fp16/fp32 [n,D] on the host) -> fp16 tensor."""
+        x = raw.float()
+        n = x.double().pow(2).sum(dim=1, keepdim=True).sqrt().float()
+        return (x / n).half()
+
+    def push(self, dbn_chunk, row0: int):
+        """dbn_chunk: torch fp16 [n,D] normalised rows, global index of its first row = row0."""
+        t = self.t
+        sc = self.q64 @ dbn_chunk.double().t()                      # [B, n] fp64
+        n = sc.shape[1]
+        kk = min(self.k, n)
+        kth = t.topk(sc, kk, dim=1).values[:, -1:]                   # k-th best of the chunk per query
+        mask = sc >= kth
+        for b in range(sc.shape[0]):
+            cols = t.nonzero(mask[b]).reshape(-1)
+            cs = np.concatenate([self.best_s[b], sc[b, cols].numpy()])
+            ci = np.concatenate([self.best_i[b], cols.numpy().astype(np.int64) + row0])
+            order = np.lexsort((ci, -cs))[:self.k]
+            self.best_s[b], self.best_i[b] = cs[order], ci[order]
+
+    def result(self):
+        return (np.stack(self.best_i).astype(np.uint32), np.stack(self.best_s).astype(np.float32))

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("RDM_HIP_LIB") or os.path.join(_HERE, "librdm_hip.so")
 
 RDM_MAX_LEVELS = 8
 ACT_NONE, ACT_GEGLU, ACT_QUICKGELU, ACT_SILU = 0, 1, 2, 3
+PROF_CONV3X3, PROF_LINEAR, PROF_KNN, PROF_ATTENTION, PROF_GROUPNORM, PROF_LAYERNORM = range(6)
 
 
 class UNetCfg(C.Structure):
@@ -217,8 +218,27 @@ class Context:
     def _dev(self, t, dtype):
         return t.to(device=self.device, dtype=dtype).contiguous()
 
+    def _check_sampler_shapes(self, what, x, cond, uncond=None, noise=None, steps=None):
+        """The C ABI takes raw pointers: reject every shape it would silently mis-read (the reference raises a torch
+        shape error in the same situations, e.g. `torch.cat([c, uc])` in ddim.py:232 for an unconditional conditioning of
+        the wrong rank)."""
+        if self.unet_cfg is None:
+            raise RdmError(f"{what}: unet weights not loaded")
+        cd, cin = self.unet_cfg.context_dim, self.unet_cfg.in_channels
+        if x.ndim != 4 or x.shape[1] != cin:
+            raise RdmError(f"{what}: latent must be [B,{cin},H,W], got {tuple(x.shape)}")
+        if cond.ndim != 3 or cond.shape[0] != x.shape[0] or cond.shape[2] != cd or cond.shape[1] < 1:
+            raise RdmError(f"{what}: conditioning must be [B={x.shape[0]},k,{cd}], got {tuple(cond.shape)}")
+        if uncond is not None and tuple(uncond.shape) != tuple(cond.shape):
+            raise RdmError(f"{what}: unconditional conditioning {tuple(uncond.shape)} must match the conditioning {tuple(cond.shape)}")
+        if noise is not None and tuple(noise.shape) != (steps,) + tuple(x.shape):
+            raise RdmError(f"{what}: noise stack must be {(steps,) + tuple(x.shape)}, got {tuple(noise.shape)}")
+
     def unet_forward(self, x, t, context):
         x = self._dev(x, torch.float32); t = self._dev(t, torch.int64); context = self._dev(context, torch.float32)
+        self._check_sampler_shapes("unet_forward", x, context)
+        if t.ndim != 1 or t.shape[0] != x.shape[0]:
+            raise RdmError(f"unet_forward: timesteps must be [B={x.shape[0]}], got {tuple(t.shape)}")
         b, _, H, W = x.shape
         out = torch.empty((b, self.unet_cfg.out_channels, H, W), device=self.device, dtype=torch.float32)
         self._check(lib.rdm_unet_forward(self._h, _ptr(x), _ptr(t), _ptr(context), b, context.shape[1], H, W, _ptr(out)))
@@ -231,6 +251,10 @@ class Context:
         noise = None if noise is None else self._dev(noise, torch.float32)
         ac = np.ascontiguousarray(alphas_cumprod.detach().cpu().numpy() if isinstance(alphas_cumprod, torch.Tensor)
                                   else alphas_cumprod, dtype=np.float32)
+        total = len(range(0, ac.shape[0], max(ac.shape[0] // max(int(S), 1), 1)))
+        self._check_sampler_shapes("ddim_sample", x_T, cond, uncond, noise if eta != 0.0 else None, total)
+        if scale > 1.0 and uncond is None:
+            raise RdmError("ddim_sample: unconditional_conditioning is required when unconditional_guidance_scale > 1")
         B, Cc, H, W = x_T.shape
         a = DdimArgs(S=S, batch=B, k=cond.shape[1], channels=Cc, height=H, width=W, eta=eta, temperature=temperature,
                      unconditional_guidance_scale=scale, log_every_t=log_every_t, T=ac.shape[0],
@@ -251,6 +275,7 @@ class Context:
         x_T = self._dev(x_T, torch.float32); cond = self._dev(cond, torch.float32); noise = self._dev(noise, torch.float32)
         arrs = {k: np.ascontiguousarray(np.asarray(v, dtype=np.float32)) for k, v in sched.items()}
         fp = lambda k: arrs[k].ctypes.data_as(C.POINTER(C.c_float))
+        self._check_sampler_shapes("ddpm_sample", x_T, cond, None, noise, int(timesteps))
         B, Cc, H, W = x_T.shape
         a = DdpmArgs(timesteps=timesteps, batch=B, k=cond.shape[1], channels=Cc, height=H, width=W,
                      clip_denoised=int(clip_denoised), temperature=temperature, T=arrs["posterior_mean_coef1"].shape[0],
@@ -318,8 +343,14 @@ class Context:
         return out.reshape(tuple(idx.shape) + (dim,))
 
     # ---- measurement
-    def prof_enable(self, on=True):
-        self._check(lib.rdm_prof_enable(self._h, int(on)))
+    def prof_enable(self, kinds=(0, 1)):
+        """kinds: iterable of PROF_* kernel classes to bracket with HIP events (False / () = off; True = conv3x3 + linear)."""
+        if kinds is True:
+            kinds = (PROF_CONV3X3, PROF_LINEAR)
+        mask = 0
+        for k in (kinds or ()):
+            mask |= 1 << int(k)
+        self._check(lib.rdm_prof_enable(self._h, mask))
 
     def prof_reset(self):
         self._check(lib.rdm_prof_reset(self._h))

@@ -56,6 +56,11 @@ enum { ACT_NONE = 0, ACT_GEGLU = 1, ACT_QUICKGELU = 2, ACT_SILU = 3, ACT_SOFTMAX
 
 constexpr int RDM_EYE_OFFSET = 4096, RDM_EYE_N = 256;
 
+// one-shot launch setup (hipFuncSetAttribute, CU counts, occupancy) is PER DEVICE: caches are indexed by the calling
+// thread's current device (the C ABI binds it to the context's device at every entry point)
+constexpr int RDM_MAX_DEVICES = 32;
+inline int rdm_cur_device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < RDM_MAX_DEVICES) ? d : 0; }
+
 struct IgemmParams {
     // A operand: logical [M, K].  Two channel-concatenated sources (A1 may be null, C1 = 0).
     const bf16_t* A0; const bf16_t* A1;

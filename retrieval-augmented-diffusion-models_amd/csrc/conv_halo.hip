@@ -375,13 +375,14 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(IgemmParams p) {
 template <int BN>
 static hipError_t launch_halo(const IgemmParams& p, hipStream_t st) {
     constexpr int smem = 2 * 400 * 128 + 2 * BN * 128;
-    static int ncu = 0;
-    if (!ncu) {
+    static int ncu_dev[RDM_MAX_DEVICES] = {0};
+    const int dev = rdm_cur_device();
+    if (!ncu_dev[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
-        int dev = 0; hipGetDevice(&dev);
-        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        hipDeviceGetAttribute(&ncu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev);
     }
+    const int ncu = ncu_dev[dev];
     const long long ntiles = (long long)(p.M / 256) * (p.N / BN) * (p.ksplit > 1 ? p.ksplit : 1);
     long long g = (ncu + 7) & ~7;
     if (g > ntiles) g = ntiles;

@@ -551,18 +551,19 @@ template <int BM, int BN, int WAVES_M, int CONV, bool GEGLU>
 static hipError_t launch_cfg(const IgemmParams& p, int batch, hipStream_t st) {
     constexpr int smem = ((BM >= 256 ? 3 : 2) * BM + 2 * BN) * 128;     // A ring (3 slots for 256-row tiles) + B ring of 2
     constexpr int NT = WAVES_M * 128;
-    static int blocks_per_cu = 0, ncu = 0;
-    if (!blocks_per_cu) {
+    static int bpc_dev[RDM_MAX_DEVICES] = {0}, ncu_dev[RDM_MAX_DEVICES] = {0};
+    const int dev = rdm_cur_device();
+    if (!bpc_dev[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WAVES_M, CONV, GEGLU>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
-        int dev = 0; hipGetDevice(&dev);
-        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        hipDeviceGetAttribute(&ncu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev);
         int occ = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)igemm_kernel<BM, BN, WAVES_M, CONV, GEGLU>, NT, smem);
         if (e != hipSuccess) return e;
-        blocks_per_cu = occ < 1 ? 1 : occ;
+        bpc_dev[dev] = occ < 1 ? 1 : occ;
     }
+    const int blocks_per_cu = bpc_dev[dev], ncu = ncu_dev[dev];
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     const long long ntiles = (long long)nbm * nbn;
     long long g = (long long)ncu * blocks_per_cu;            // persistent: one resident wave of blocks

@@ -10,6 +10,7 @@ struct KnnDb {
     int raw_dtype = 0;          // 0 fp16, 1 fp32
     // search scratch
     void* scratch = nullptr; size_t scratch_bytes = 0;
+    void* zero_page = nullptr;  // 256 zero bytes on the database's device (source of padding lanes)
 };
 
 // all return nullptr on success, or a static error string

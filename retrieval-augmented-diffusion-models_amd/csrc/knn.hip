@@ -460,10 +460,11 @@ void knn_free(KnnDb& db) {
     if (db.dbn) hipFree(db.dbn);
     if (db.raw) hipFree(db.raw);
     if (db.scratch) hipFree(db.scratch);
+    if (db.zero_page) hipFree(db.zero_page);
     db = KnnDb();
 }
 
-const char* knn_load(KnnDb& db, const void* emb, long long n, int dim, int dtype, int is_device, hipStream_t st) {
+static const char* knn_load_impl(KnnDb& db, const void* emb, long long n, int dim, int dtype, int is_device, hipStream_t st) {
     if (n <= 0 || dim <= 0 || dim % 64 != 0 || dim > 4096) return "dim must be a positive multiple of 64";
     if (n >= 0xffffffffLL) return "database too large for uint32 indices";
     if (dtype != 0 && dtype != 1) return "dtype must be 0 (fp16) or 1 (fp32)";
@@ -491,6 +492,12 @@ const char* knn_load(KnnDb& db, const void* emb, long long n, int dim, int dtype
     return nullptr;
 }
 
+const char* knn_load(KnnDb& db, const void* emb, long long n, int dim, int dtype, int is_device, hipStream_t st) {
+    const char* msg = knn_load_impl(db, emb, n, dim, dtype, is_device, st);
+    if (msg) knn_free(db);       // never leave a half-loaded database behind (a failed second hipMalloc used to keep db.dbn with n = 0)
+    return msg;
+}
+
 template <int KSEL>
 static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t* idx_out, float* score_out, hipStream_t st) {
     int dev = 0, ncu = 256;
@@ -511,12 +518,13 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
     char* s = (char*)db.scratch;
     float* qn = (float*)s; _Float16* qh = (_Float16*)(s + qn_b); _Float16* ql = (_Float16*)(s + qn_b + qh_b);
     float* cs = (float*)(s + qn_b + 2 * qh_b); uint32_t* ci = (uint32_t*)(s + qn_b + 2 * qh_b + cand_b);
-    static void* zero_page = nullptr;
-    if (!zero_page) { KNN_TRY(hipMalloc(&zero_page, 256)); KNN_TRY(hipMemset(zero_page, 0, 256)); }
+    if (!db.zero_page) { KNN_TRY(hipMalloc(&db.zero_page, 256)); KNN_TRY(hipMemset(db.zero_page, 0, 256)); }
+    void* zero_page = db.zero_page;
     constexpr int scan_smem = 2 * (KNN_ROWS * 128 + 2 * KNN_Q * 128);
     constexpr int scan512_smem = 3 * KNN_ROWS * 128;
     constexpr int merge_smem = 256 * KSEL * 8;
-    static bool attr = false;
+    static bool attr_dev[RDM_MAX_DEVICES] = {false};
+    bool& attr = attr_dev[rdm_cur_device()];
     if (!attr) {
         KNN_TRY(hipFuncSetAttribute((const void*)knn_scan_kernel<KSEL>, hipFuncAttributeMaxDynamicSharedMemorySize, scan_smem));
         KNN_TRY(hipFuncSetAttribute((const void*)knn_scan512_kernel<KSEL>, hipFuncAttributeMaxDynamicSharedMemorySize, scan512_smem));
@@ -531,7 +539,8 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
         sp.cand_s = cs; sp.cand_i = ci; sp.nlists = nlists; sp.zero_page = zero_page;
         static const int w8 = getenv("RDM_KNN_W8") ? atoi(getenv("RDM_KNN_W8")) : 1;
         if (d512 && KSEL == 8 && w8) {
-            static bool attr8 = false;
+            static bool attr8_dev[RDM_MAX_DEVICES] = {false};
+            bool& attr8 = attr8_dev[rdm_cur_device()];
             if (!attr8) { KNN_TRY(hipFuncSetAttribute((const void*)knn_scan512w8_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, scan512_smem)); attr8 = true; }
             sp.nlists = grid * 8;
             knn_scan512w8_kernel<8><<<grid, 512, scan512_smem, st>>>(sp);

@@ -302,7 +302,8 @@ hipError_t launch_vq_quantize(const float* z, const float* codebook, int n_embed
                               float* out, int* idx_out, int B, int HW, int quantize, hipStream_t st) {
     const size_t sm = (size_t)n_embed * sizeof(float4);
     if (sm > 160 * 1024 - 256) return hipErrorInvalidValue;
-    static bool attr = false;
+    static bool attr_dev[RDM_MAX_DEVICES] = {false};
+    bool& attr = attr_dev[rdm_cur_device()];
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)vq_quantize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024 - 256);

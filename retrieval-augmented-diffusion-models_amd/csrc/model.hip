@@ -35,6 +35,20 @@
         if (_r != 0) return _r;  \
     } while (0)
 
+// Every C-ABI entry binds the calling thread to the context's device for the duration of the call and restores the
+// caller's current device on exit (a context for device 1 used from a thread whose current device is 0 must neither
+// launch on device 0 nor leave the caller's device changed).
+struct DevGuard {
+    int prev = -1; bool changed = false;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DevGuard() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
+    DevGuard(const DevGuard&) = delete; DevGuard& operator=(const DevGuard&) = delete;
+};
+#define RDM_ENTER(c) if (!(c)) return -1; DevGuard _dev_guard((c)->device)
+
 // ------------------------------------------------------------------------------------ manifest
 struct Manifest {
     std::string text;
@@ -302,7 +316,7 @@ struct rdm_ctx {
     char* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;   // fp32 partial planes of the K-split halo convs
     char* samp = nullptr; size_t samp_bytes = 0;     // sampler scratch
     // optional per-launch HIP-event profiler for the GEMM-class kernels (bench.py roofline)
-    bool prof = false;
+    unsigned prof = 0;           // bit k set: record HIP events around launches of kind k (RDM_PROF_* in rdm_hip.h)
     struct ProfRec { hipEvent_t a, b; int kind; double flops; };
     std::vector<ProfRec> prof_recs; std::vector<hipEvent_t> prof_pool;
     hipEvent_t prof_event() {
@@ -342,7 +356,7 @@ struct Ops {
         p.A0 = A0; p.A1 = A1; p.C0 = C0; p.C1 = C1; p.W = w<bf16_t>(woff); p.bias = has_bias ? w<float>(boff) : nullptr;
         p.act = act; p.res_bf16 = res; p.res_f32 = res_f32; p.out_bf16 = out; p.out_f32 = out_f32;
         if (act == ACT_GEGLU) p.ldo = N / 2;
-        prof_begin(1, 2.0 * M * N * (double)(C0 + C1));
+        prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)(C0 + C1));
         check(launch_igemm(p, false, 1, c->stream), "linear");
         prof_end();
     }
@@ -356,16 +370,18 @@ struct Ops {
         p.rowvec = rowvec; p.rowvec_ld = rowvec_ld; p.rows_per_sample = Hout * Wout; p.res_bf16 = res; p.out_bf16 = out;
         const int ks = conv_halo_ksplit(p);
         if (ks > 1 && ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)ks * p.M * N * 4) == 0) { p.ksplit = ks; p.ws = (float*)c->splitk_ws; }
-        prof_begin(0, 2.0 * p.M * N * (double)p.K);
+        prof_begin(RDM_PROF_CONV3X3, 2.0 * p.M * N * (double)p.K);
         check(launch_conv3x3(p, c->stream), "conv3x3");
         prof_end();
     }
-    void prof_begin(int kind, double flops) {
-        if (!c->prof) return;
-        rdm_ctx::ProfRec r; r.a = c->prof_event(); r.b = c->prof_event(); r.kind = kind; r.flops = flops;
+    bool prof_open = false;
+    void prof_begin(int kind, double work) {       // work: FLOPs (GEMM-class kinds) or bytes (bandwidth-class kinds)
+        prof_open = (c->prof >> kind) & 1u;
+        if (!prof_open) return;
+        rdm_ctx::ProfRec r; r.a = c->prof_event(); r.b = c->prof_event(); r.kind = kind; r.flops = work;
         hipEventRecord(r.a, c->stream); c->prof_recs.push_back(r);
     }
-    void prof_end() { if (c->prof) hipEventRecord(c->prof_recs.back().b, c->stream); }
+    void prof_end() { if (prof_open) hipEventRecord(c->prof_recs.back().b, c->stream); prof_open = false; }
     void groupnorm(const bf16_t* x0, const bf16_t* x1, int C0, int C1, int B, int HW, size_t g, size_t b, float eps, int silu,
                    bf16_t* out) {
         if (plan) return;
@@ -373,11 +389,15 @@ struct Ops {
         int nchunk = HW / 64; if (nchunk < 1) nchunk = 1; if (nchunk > 32) nchunk = 32;
         p.nchunk = nchunk; p.partial = c->gn_partial; p.gamma = w<float>(g); p.beta = w<float>(b); p.eps = eps; p.silu = silu;
         p.out = out;
+        prof_begin(RDM_PROF_GROUPNORM, (double)B * HW * (C0 + C1) * 6.0);       // two reads + one write of the bf16 tensor
         check(launch_groupnorm(p, c->stream), "groupnorm");
+        prof_end();
     }
     void layernorm(const void* x, int in_f32, size_t g, size_t b, void* out, int out_f32, int M, int C) {
         if (plan) return;
+        prof_begin(RDM_PROF_LAYERNORM, (double)M * C * ((in_f32 ? 4.0 : 2.0) + (out_f32 ? 4.0 : 2.0)));
         check(launch_layernorm(x, in_f32, w<float>(g), w<float>(b), out, out_f32, M, C, 1e-5f, c->stream), "layernorm");
+        prof_end();
     }
 };
 
@@ -493,7 +513,9 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                 o.check(launch_igemm(p, false, B, o.c->stream), "v^T gemm");
                 FlashParams f{}; f.q = qk; f.ldq = 2 * C; f.k = qk + C; f.ldk = 2 * C; f.vt = vt; f.out = ao; f.ldo = C;
                 f.n = n; f.C = C; f.scale_log2e = (1.0f / sqrtf(32.f)) * 1.4426950408889634f;
+                o.prof_begin(RDM_PROF_ATTENTION, 4.0 * B * s.heads * (double)n * n * 32);
                 o.check(launch_flash_d32(f, s.heads, B, o.c->stream), "flash attention");
+                o.prof_end();
             }
         } else {
             bf16_t* v = o.abf((size_t)M * C);
@@ -517,13 +539,13 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                 IgemmParams p = o.base(n, XA_NP, C);
                 p.A0 = l2; p.C0 = C; p.sA = (long long)n * C; p.W = G; p.sW = (long long)XA_NP * C; p.out_bf16 = P; p.sO = (long long)n * XA_NP;
                 p.act = ACT_SOFTMAXG; p.sm_group = k;
-                o.prof_begin(1, 2.0 * M * XA_NP * (double)C);
+                o.prof_begin(RDM_PROF_LINEAR, 2.0 * M * XA_NP * (double)C);
                 o.check(launch_igemm(p, false, B, o.c->stream), "xattn scores");
                 o.prof_end();
                 IgemmParams q = o.base(n, C, XA_NP);
                 q.A0 = P; q.C0 = XA_NP; q.sA = (long long)n * XA_NP; q.W = U; q.sW = (long long)C * XA_NP; q.bias = o.w<float>(s.bo2);
                 q.res_bf16 = t1; q.out_bf16 = t2; q.sO = (long long)n * C;
-                o.prof_begin(1, 2.0 * M * C * (double)XA_NP);
+                o.prof_begin(RDM_PROF_LINEAR, 2.0 * M * C * (double)XA_NP);
                 o.check(launch_igemm(q, false, B, o.c->stream), "xattn out");
                 o.prof_end();
             }
@@ -758,7 +780,7 @@ int rdm_ctx_create(int device_id, rdm_ctx** out) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return -4;      // no HIP device: fail loudly, there is no CPU path
     if (device_id < 0 || device_id >= n) return -1;
-    if (hipSetDevice(device_id) != hipSuccess) return -2;
+    DevGuard guard(device_id);
     rdm_ctx* c = new rdm_ctx();
     c->device = device_id;
     {   // zero page + identity matrix (the residual-as-K-columns operand of the linear GEMMs, igemm.hip)
@@ -773,7 +795,7 @@ int rdm_ctx_create(int device_id, rdm_ctx** out) {
 
 void rdm_ctx_destroy(rdm_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
+    DevGuard guard(c->device);
     hipDeviceSynchronize();
     void* ptrs[] = {c->zero_page, c->unet.blob, c->unet.arena.base, c->unet.kv_cache, c->vq.blob, c->vq.arena.base,
                     c->clip.blob, c->clip.arena.base, c->gn_partial, c->samp, c->splitk_ws, c->unet.xa_cache};
@@ -802,26 +824,26 @@ long long rdm_clip_manifest(const rdm_clip_cfg* cfg, char* buf, size_t buflen, s
 }
 
 int rdm_load_unet(rdm_ctx* c, const rdm_unet_cfg* cfg, const void* packed, size_t nbytes) {
+    RDM_ENTER(c);
     if (!c) return -1;
     RDM_TRY(cfg_check_unet(c, cfg));
-    RDM_CHECK_HIP(c, hipSetDevice(c->device));
     Manifest mf; build_unet(c->unet, *cfg, mf);
     return load_blob(c, c->unet, mf, packed, nbytes);
 }
 int rdm_load_vq(rdm_ctx* c, const rdm_vq_cfg* cfg, const void* packed, size_t nbytes) {
+    RDM_ENTER(c);
     if (!c || !cfg) return -1;
     if (cfg->embed_dim != 3 || cfg->z_channels != 3 || cfg->ch % 64 || cfg->out_ch > 4)
         return c->fail(-1, "unsupported vq cfg: embed_dim == z_channels == 3, ch %% 64 == 0 required");
-    RDM_CHECK_HIP(c, hipSetDevice(c->device));
     Manifest mf; build_vq(c->vq, *cfg, mf);
     return load_blob(c, c->vq, mf, packed, nbytes);
 }
 int rdm_load_clip(rdm_ctx* c, const rdm_clip_cfg* cfg, const void* packed, size_t nbytes) {
+    RDM_ENTER(c);
     if (!c || !cfg) return -1;
     if (cfg->transformer_width % 64 || cfg->vision_width % 64 || cfg->embed_dim % 8 ||
         cfg->transformer_width / cfg->transformer_heads != 64)
         return c->fail(-1, "unsupported clip cfg: widths %% 64 == 0 and 64-d heads required");
-    RDM_CHECK_HIP(c, hipSetDevice(c->device));
     Manifest mf; build_clip(c->clip, *cfg, mf);
     return load_blob(c, c->clip, mf, packed, nbytes);
 }
@@ -853,6 +875,7 @@ static int unet_forward_impl(rdm_ctx* c, const float* x, const int64_t* t, const
 
 int rdm_unet_forward(rdm_ctx* c, const float* x, const int64_t* t, const float* context, int b, int k, int H, int W,
                      float* eps_out) {
+    RDM_ENTER(c);
     if (!c || !x || !t || !context || !eps_out) return c ? c->fail(-1, "null argument") : -1;
     return unet_forward_impl(c, x, t, context, nullptr, b, k, H, W, eps_out);
 }
@@ -885,6 +908,7 @@ static int prepare_kv(rdm_ctx* c, const float* cond, const float* uncond, int B,
 
 int rdm_ddim_sample(rdm_ctx* c, const rdm_ddim_args* a, const float* x_T, const float* cond, const float* uncond,
                     const float* noise, float* z_out, float* x_inter, float* pred_x0_inter) {
+    RDM_ENTER(c);
     if (!c || !a || !x_T || !cond || !z_out) return c ? c->fail(-1, "null argument") : -1;
     UNet& u = c->unet;
     if (!u.loaded) return c->fail(-1, "unet weights not loaded");
@@ -893,7 +917,6 @@ int rdm_ddim_sample(rdm_ctx* c, const rdm_ddim_args* a, const float* x_T, const 
     if (cfg && !uncond) return c->fail(-1, "unconditional_conditioning required when scale > 1 (ddim.py:231)");
     if (a->eta != 0.f && !noise) return c->fail(-1, "eta > 0 needs an explicit noise stack [S,B,C,H,W] (device RNG parity is not defined)");
     if (a->S < 1 || a->S > a->T || !a->alphas_cumprod) return c->fail(-1, "bad schedule");
-    RDM_CHECK_HIP(c, hipSetDevice(c->device));
     const int B = a->batch, k = a->k, S = a->S;
     const long long n1 = (long long)B * a->channels * a->height * a->width;
     // schedule (ldm make_ddim_timesteps 'uniform' + make_ddim_sampling_parameters)
@@ -951,11 +974,11 @@ int rdm_ddim_sample(rdm_ctx* c, const rdm_ddim_args* a, const float* x_T, const 
 
 int rdm_ddpm_sample(rdm_ctx* c, const rdm_ddpm_args* a, const float* x_T, const float* cond, const float* noise,
                     float* z_out) {
+    RDM_ENTER(c);
     if (!c || !a || !x_T || !cond || !noise || !z_out) return c ? c->fail(-1, "null argument") : -1;
     UNet& u = c->unet;
     if (!u.loaded) return c->fail(-1, "unet weights not loaded");
     if (a->timesteps < 1 || a->timesteps > a->T) return c->fail(-1, "bad timesteps");
-    RDM_CHECK_HIP(c, hipSetDevice(c->device));
     const int B = a->batch, k = a->k, T = a->timesteps;
     const long long n1 = (long long)B * a->channels * a->height * a->width;
     const size_t cd_bytes = (size_t)B * k * u.cfg.context_dim * 4;
@@ -986,6 +1009,7 @@ int rdm_ddpm_sample(rdm_ctx* c, const rdm_ddpm_args* a, const float* x_T, const 
 }
 
 int rdm_vq_decode(rdm_ctx* c, const float* z, int b, int force_not_quantize, float* img_out, int32_t* indices_out) {
+    RDM_ENTER(c);
     if (!c || !z || !img_out) return c ? c->fail(-1, "null argument") : -1;
     if (!c->vq.loaded) return c->fail(-1, "vq weights not loaded");
     RDM_TRY(ensure_gn_partial(c, b));
@@ -993,17 +1017,20 @@ int rdm_vq_decode(rdm_ctx* c, const float* z, int b, int force_not_quantize, flo
 }
 
 int rdm_to_uint8(rdm_ctx* c, const float* img, int b, int ch, int h, int w, uint8_t* out) {
+    RDM_ENTER(c);
     if (!c || !img || !out) return -1;
     RDM_CHECK_HIP(c, launch_to_uint8_hwc(img, out, b, ch, h, w, c->stream));
     return 0;
 }
 
 int rdm_clip_encode_text(rdm_ctx* c, const int64_t* tokens, int b, float* out) {
+    RDM_ENTER(c);
     if (!c || !tokens || !out) return c ? c->fail(-1, "null argument") : -1;
     if (!c->clip.loaded) return c->fail(-1, "clip weights not loaded");
     return run_with_arena(c, c->clip.arena, c->clip.blob, [&](Ops& o) { clip_text_body(o, c->clip, (const long long*)tokens, b, out); });
 }
 int rdm_clip_encode_image(rdm_ctx* c, const float* image, int b, float* out) {
+    RDM_ENTER(c);
     if (!c || !image || !out) return c ? c->fail(-1, "null argument") : -1;
     if (!c->clip.loaded) return c->fail(-1, "clip weights not loaded");
     return run_with_arena(c, c->clip.arena, c->clip.blob, [&](Ops& o) { clip_image_body(o, c->clip, image, b, out); });
@@ -1011,30 +1038,40 @@ int rdm_clip_encode_image(rdm_ctx* c, const float* image, int b, float* out) {
 
 // ---- retrieval (kernels in knn.hip)
 int rdm_db_load(rdm_ctx* c, const void* emb, long long n, int dim, int dtype, int is_device) {
+    RDM_ENTER(c);
     if (!c || !emb) return -1;
-    RDM_CHECK_HIP(c, hipSetDevice(c->device));
     const char* msg = knn_load(c->db, emb, n, dim, dtype, is_device, c->stream);
     return msg ? c->fail(-5, "rdm_db_load: %s", msg) : 0;
 }
 long long rdm_db_size(rdm_ctx* c) { return c ? c->db.n : -1; }
 int rdm_knn(rdm_ctx* c, const float* q, int b, int k, uint32_t* idx_out, float* score_out) {
+    RDM_ENTER(c);
     if (!c || !q || !idx_out) return c ? c->fail(-1, "null argument") : -1;
+    const bool prof = (c->prof >> RDM_PROF_KNN) & 1u;
+    if (prof) {     // whole search (query prep + database scan + candidate merge); work = bytes of the database passes
+        rdm_ctx::ProfRec r; r.a = c->prof_event(); r.b = c->prof_event(); r.kind = RDM_PROF_KNN;
+        r.flops = (double)((b + 63) / 64) * (double)c->db.n * c->db.dim * 2.0;
+        hipEventRecord(r.a, c->stream); c->prof_recs.push_back(r);
+    }
     const char* msg = knn_search(c->db, q, b, k, idx_out, score_out, c->stream);
+    if (prof) hipEventRecord(c->prof_recs.back().b, c->stream);
     return msg ? c->fail(-5, "rdm_knn: %s", msg) : 0;
 }
 int rdm_db_gather(rdm_ctx* c, const uint32_t* idx, long long n_idx, float* out) {
+    RDM_ENTER(c);
     if (!c || !idx || !out) return -1;
     const char* msg = knn_gather(c->db, idx, n_idx, out, c->stream);
     return msg ? c->fail(-5, "rdm_db_gather: %s", msg) : 0;
 }
 
 // ---- profiler
-int rdm_prof_enable(rdm_ctx* c, int on) {
+int rdm_prof_enable(rdm_ctx* c, int kind_mask) {
     if (!c) return -1;
-    c->prof = on != 0;
+    c->prof = (unsigned)kind_mask;
     return 0;
 }
 int rdm_prof_collect(rdm_ctx* c, int kind, long long* launches, double* ms, double* flops) {
+    RDM_ENTER(c);
     if (!c) return -1;
     RDM_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     long long n = 0; double t = 0, f = 0;
@@ -1047,6 +1084,7 @@ int rdm_prof_collect(rdm_ctx* c, int kind, long long* launches, double* ms, doub
     return 0;
 }
 int rdm_prof_reset(rdm_ctx* c) {
+    RDM_ENTER(c);
     if (!c) return -1;
     RDM_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     for (auto& r : c->prof_recs) { c->prof_pool.push_back(r.a); c->prof_pool.push_back(r.b); }
@@ -1057,6 +1095,7 @@ int rdm_prof_reset(rdm_ctx* c) {
 // ---- operator-level wrappers for the parity tests
 int rdm_op_linear(rdm_ctx* c, const void* a, const void* w, const float* bias, const void* res, void* out, float* out_f32,
                   int M, int N, int K, int act, float alpha) {
+    RDM_ENTER(c);
     if (!c) return -1;
     IgemmParams p{}; p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.ldo = (act == ACT_GEGLU) ? N / 2 : N; p.zero_page = c->zero_page;
     p.Hin = p.Win = p.Hout = p.Wout = 1; p.stride = 1; p.rows_per_sample = 1;
@@ -1068,6 +1107,7 @@ int rdm_op_linear(rdm_ctx* c, const void* a, const void* w, const float* bias, c
 int rdm_op_conv3x3(rdm_ctx* c, const void* x0, const void* x1, int C0, int C1, const void* w, const float* bias,
                    const float* rowvec, int rowvec_ld, const void* res, void* out, int B, int Hin, int Win, int N, int stride,
                    int ups) {
+    RDM_ENTER(c);
     if (!c) return -1;
     const int Hout = ups ? Hin * 2 : (stride == 2 ? Hin / 2 : Hin), Wout = ups ? Win * 2 : (stride == 2 ? Win / 2 : Win);
     IgemmParams p{}; p.M = B * Hout * Wout; p.N = N; p.K = 9 * (C0 + C1); p.alpha = 1.f; p.ldo = N; p.zero_page = c->zero_page;
@@ -1081,6 +1121,7 @@ int rdm_op_conv3x3(rdm_ctx* c, const void* x0, const void* x1, int C0, int C1, c
 }
 int rdm_op_groupnorm(rdm_ctx* c, const void* x0, const void* x1, int C0, int C1, int B, int HW, const float* gamma,
                      const float* beta, float eps, int silu, void* out) {
+    RDM_ENTER(c);
     if (!c) return -1;
     RDM_TRY(ensure_gn_partial(c, B));
     GnParams p{}; p.x0 = (const bf16_t*)x0; p.x1 = (const bf16_t*)x1; p.C0 = C0; p.C1 = C1; p.HW = HW; p.B = B; p.groups = 32;
@@ -1091,11 +1132,13 @@ int rdm_op_groupnorm(rdm_ctx* c, const void* x0, const void* x1, int C0, int C1,
 }
 int rdm_op_layernorm(rdm_ctx* c, const void* x, int in_is_f32, const float* gamma, const float* beta, int M, int C, float eps,
                      void* out) {
+    RDM_ENTER(c);
     if (!c) return -1;
     RDM_CHECK_HIP(c, launch_layernorm(x, in_is_f32, gamma, beta, out, 0, M, C, eps, c->stream));
     return 0;
 }
 int rdm_op_self_attention(rdm_ctx* c, const void* qk, const void* vt, int B, int n, int heads, void* out) {
+    RDM_ENTER(c);
     if (!c) return -1;
     const int C = heads * 32;
     FlashParams f{}; f.q = (const bf16_t*)qk; f.ldq = 2 * C; f.k = (const bf16_t*)qk + C; f.ldk = 2 * C; f.vt = (const bf16_t*)vt;
@@ -1105,6 +1148,7 @@ int rdm_op_self_attention(rdm_ctx* c, const void* qk, const void* vt, int B, int
 }
 int rdm_op_small_attention(rdm_ctx* c, const void* q, int ldq, const void* k, const void* v, int ldkv, int B, int nq, int nkv,
                            int heads, int D, int causal, float scale, void* out, int ldo) {
+    RDM_ENTER(c);
     if (!c) return -1;
     SmallAttnParams p{}; p.q = (const bf16_t*)q; p.ldq = ldq; p.k = (const bf16_t*)k; p.ldk = ldkv; p.v = (const bf16_t*)v; p.ldv = ldkv;
     p.out = (bf16_t*)out; p.ldo = ldo; p.nq = nq; p.nkv = nkv; p.causal = causal; p.scale = scale;

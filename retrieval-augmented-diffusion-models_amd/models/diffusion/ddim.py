@@ -68,7 +68,7 @@ class DDIMSampler(object):
                                   log_every_t=log_every_t, unconditional_guidance_scale=unconditional_guidance_scale,
                                   unconditional_conditioning=unconditional_conditioning, random_guiding=random_guiding,
                                   content_cond=content_cond, style_cond=style_cond,
-                                  intermediates_to_cpu=intermediates_to_cpu, S=S, eta=eta)
+                                  intermediates_to_cpu=intermediates_to_cpu, S=S, eta=eta, noise=kwargs.get("noise"))
 
     @torch.no_grad()
     def ddim_sampling(self, cond, shape, x_T=None, ddim_use_original_steps=False, callback=None, timesteps=None,
@@ -102,7 +102,9 @@ class DDIMSampler(object):
         if callback is not None or img_callback is not None:
             return self._python_loop(cond, img, callback, img_callback, log_every_t, temperature, eta,
                                      unconditional_guidance_scale, unconditional_conditioning, intermediates_to_cpu)
-        noise = torch.randn((total_steps,) + tuple(shape), device=device) if eta != 0. else None
+        noise = kwargs.get("noise")             # [native] optional explicit per-step noise stack [S, B, C, H, W] (consumed in loop order)
+        if eta != 0. and noise is None:
+            noise = torch.randn((total_steps,) + tuple(shape), device=device)
         z, xi, pi = self.model.ctx.ddim_sample(S, img, cond, unconditional_conditioning if unconditional_guidance_scale > 1. else None,
                                                self.alphas_cumprod, eta=eta, scale=unconditional_guidance_scale, noise=noise,
                                                log_every_t=log_every_t, temperature=temperature, want_intermediates=True)

@@ -13,7 +13,7 @@ from contextlib import contextmanager
 import numpy as np
 import torch
 
-from ... import _lib, packing
+from ... import _lib, packing, parallel
 from ...util import ischannellastimage
 from .ddim import DDIMSampler
 
@@ -25,7 +25,8 @@ class MinimalRETRODiffusion(object):
                  parameterization="eps", **ignored):
         self._dev_index = device if isinstance(device, int) else (torch.device(device).index or 0)
         self._ctx = ctx                       # created lazily: constructing the object needs no GPU
-        self.device = torch.device("cuda", self._dev_index)
+        self.device = getattr(ctx, "device", None) or torch.device("cuda", self._dev_index)
+        self.distributed = False              # set_distributed(): shard every sampling batch over the process group
         uparams = unet_config.get("params", unet_config) if isinstance(unet_config, dict) else unet_config
         self.unet_cfg = _lib.make_unet_cfg(**uparams)
         self.vq_cfg = None
@@ -96,6 +97,45 @@ class MinimalRETRODiffusion(object):
 
     def eval(self): return self
     def to(self, device): return self
+
+    # ---- multi-GPU (new functionality; the reference samples on one GPU, scripts/rdm_sample.py:31-36, 181-185)
+    def set_distributed(self, enabled=True, group=None):
+        """Shard every `sample_with_query` / `sample_from_rdata` batch contiguously over the ranks of the initialised
+        torch.distributed group (one process per GPU): each rank retrieves, samples and decodes only its rows, the
+        starting noise of row i is a function of (shared seed, GLOBAL index i) — so the result does not depend on the
+        number of ranks — and the finished images are all-gathered (the only collective).  Weights and the database are
+        replicated.  With a single process the same per-row noise streams are used, which is what makes
+        "N ranks == 1 rank" checkable bit for bit."""
+        self.distributed, self._group = bool(enabled), group
+        return self
+
+    def _shard(self, n_total):
+        world, rank = parallel.world_rank(getattr(self, "_group", None))
+        if n_total < world:
+            raise ValueError(f"batch of {n_total} cannot be sharded over {world} ranks")
+        return parallel.shard_range(n_total, world, rank)
+
+    def _sample_shard(self, c, c_uncond, lo, hi, n_total, scale, kwargs):
+        """sample_log + decode_first_stage on rows [lo, hi) of a global batch of n_total, then the all-gather."""
+        shape = (self.channels, self.image_size, self.image_size)
+        if kwargs.get("x_T") is not None:
+            kwargs["x_T"] = kwargs["x_T"][lo:hi]
+        else:
+            base = parallel.shared_seed(self.device, getattr(self, "_group", None))
+            kwargs["x_T"] = parallel.per_sample_noise(base, range(lo, hi), shape, device=self.device)
+            steps = None
+            if kwargs.get("ddim", True) and kwargs.get("eta", 0.) != 0.:
+                steps = len(range(0, self.num_timesteps, self.num_timesteps // kwargs.get("S", kwargs.get("ddim_steps"))))
+            elif not kwargs.get("ddim", True):
+                steps = int(kwargs.get("timesteps") or self.num_timesteps)
+            if steps is not None and kwargs.get("noise") is None:      # per-step noise: [steps, b, C, H, W], row streams as above
+                nz = parallel.per_sample_noise(base + 1, range(lo, hi), (steps,) + shape, device=self.device)
+                kwargs["noise"] = nz.transpose(0, 1).contiguous()
+        with self.ema_scope("Plotting"):
+            samples, _ = self.sample_log(cond=c, batch_size=hi - lo, unconditional_guidance_scale=scale,
+                                         unconditional_conditioning=c_uncond, **kwargs)
+        img = self.decode_first_stage(samples)
+        return parallel.all_gather_images(img, n_total, getattr(self, "_group", None))
 
     @contextmanager
     def ema_scope(self, context=None):
@@ -209,6 +249,10 @@ class MinimalRETRODiffusion(object):
         assert is_caption or query_embedded or ischannellastimage(query)
         if k_nn is None:
             k_nn = self.k_nn
+        n_total = len(query)
+        lo, hi = self._shard(n_total) if self.distributed else (0, n_total)
+        if self.distributed:
+            query = query[lo:hi]            # every rank retrieves for its own rows only (the database is replicated)
         nn_dict = self.retriever.search_k_nearest(query, visualize=False, k=k_nn, is_caption=is_caption,
                                                   query_embedded=query_embedded)
         q_emb = torch.as_tensor(nn_dict['q_embeddings']).float()
@@ -227,9 +271,12 @@ class MinimalRETRODiffusion(object):
         c_uncond = self.get_unconditional_conditioning(c.shape, unconditional_guidance_label=unconditional_retro_guidance_label, k_nn=k_nn)
         if n_reps is not None:
             c_uncond = torch.cat([c_uncond] * n_reps, dim=1)
+        c_uncond = c_uncond.to(self.device).float().contiguous()
+        if self.distributed:
+            return {"query_samples": self._sample_shard(c, c_uncond, lo, hi, n_total, unconditional_guidance_scale, kwargs)}
         with self.ema_scope("Plotting"):
             samples, _ = self.sample_log(cond=c, batch_size=bs, unconditional_guidance_scale=unconditional_guidance_scale,
-                                         unconditional_conditioning=c_uncond.to(self.device).float().contiguous(), **kwargs)
+                                         unconditional_conditioning=c_uncond, **kwargs)
         return {"query_samples": self.decode_first_stage(samples)}
 
     def get_qids(self, memsize, N, qids=None, use_weights=False, verbose=False):
@@ -264,7 +311,12 @@ class MinimalRETRODiffusion(object):
             self.train_searcher()
         if k_nn is None:
             k_nn = self.k_nn
-        qids = self.get_qids(memsize, N, qids=qids, use_weights=use_weights, verbose=verbose)
+        qids = self.get_qids(memsize, N, qids=qids, use_weights=use_weights, verbose=verbose)   # numpy global RNG: same draw on every rank
+        lo, hi = self._shard(N) if self.distributed else (0, N)
+        if self.distributed:
+            qids = np.asarray(qids)[lo:hi]
+            if nn_embeddings is not None:
+                nn_embeddings = nn_embeddings[lo:hi]
         query_embeddings = self.retriever.data_pool['embedding'][qids]
         if nn_embeddings is None:
             nns, _ = self.retriever.searcher.search_batched(query_embeddings, final_num_neighbors=k_nn)   # normalises internally
@@ -273,7 +325,10 @@ class MinimalRETRODiffusion(object):
             retro_cond = nn_embeddings
         c = self.retrieval_encoder(retro_cond).contiguous()
         c_uncond = self.get_unconditional_conditioning(c.shape, unconditional_guidance_label=unconditional_retro_guidance_label, k_nn=k_nn)
+        c_uncond = c_uncond.to(self.device).float().contiguous()
+        if self.distributed:
+            return {"samples_with_sampled_nns": self._sample_shard(c, c_uncond, lo, hi, N, unconditional_guidance_scale, kwargs)}
         with self.ema_scope("Plotting"):
             samples, _ = self.sample_log(cond=c, batch_size=N, unconditional_guidance_scale=unconditional_guidance_scale,
-                                         unconditional_conditioning=c_uncond.to(self.device).float().contiguous(), **kwargs)
+                                         unconditional_conditioning=c_uncond, **kwargs)
         return {"samples_with_sampled_nns": self.decode_first_stage(samples)}

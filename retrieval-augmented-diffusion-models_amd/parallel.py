@@ -4,10 +4,42 @@ The reference has no multi-GPU sampling; samples are independe
 exists, so the batch is split contiguously over ranks, weights and the fp16 DB are replicated, and the only
 exchange is an all-gather of the decoded images (RCCL over xGMI on GPUs — backend "nccl" — or gloo in the CPU
 tests).  Per-sample RNG streams are a function of (seed, GLOBAL sample index) so results do not depend on the
-number of ranks.
+number of ranks.  Used by `MinimalRETRODiffusion.set_distributed()` (sample_with_query / sample_from_rdata),
+`scripts/rdm_sample.py --gpus N` and `bench.py`.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def init_distributed(backend: str = None):
+    """Join the process group described by the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
+    -> (rank, local_rank).  Backend: RCCL ("nccl") when a HIP device is visible, else gloo.  Must be called before
+    the library context is created so that each rank binds its own device."""
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, local
+
+
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def world_rank(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
 
 
 def shard_range(n_total: int, world: int, rank: int):
@@ -17,13 +49,27 @@ def shard_range(n_total: int, world: int, rank: int):
     return start, start + q + (1 if rank < r else 0)
 
 
+def shared_seed(device="cpu", group=None) -> int:
+    """One draw from torch's global CPU generator, rank 0's value on every rank: the per-call base seed of the
+    per-sample noise streams (follows `seed_everything`, so a seeded run repeats and an unseeded one does not)."""
+    s = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        s = s.to(device)
+        dist.broadcast(s, src=0, group=group)
+    return int(s.item())
+
+
 def per_sample_noise(seed: int, global_indices, shape, device="cpu", dtype=torch.float32):
-    """x_T for each global sample index from its own generator: invariant to the sharding."""
+    """Noise for each global sample index from its own generator (created ON `device`, so a GPU rank draws with the device's
+    Philox stream and nothing crosses PCIe): a function of (seed, global index) only, hence invariant to the sharding."""
+    device = torch.device(device)
     out = []
     for gi in global_indices:
-        g = torch.Generator(device="cpu").manual_seed((int(seed) * 1_000_003 + int(gi)) % (2 ** 63 - 1))
-        out.append(torch.randn(shape, generator=g, dtype=dtype))
-    return torch.stack(out).to(device)
+        g = torch.Generator(device=device).manual_seed((int(seed) * 1_000_003 + int(gi)) % (2 ** 63 - 1))
+        out.append(torch.randn(shape, generator=g, dtype=dtype, device=device))
+    if not out:
+        return torch.empty((0,) + tuple(shape), dtype=dtype, device=device)
+    return torch.stack(out)
 
 
 def all_gather_images(local: torch.Tensor, n_total: int = None, group=None) -> torch.Tensor:

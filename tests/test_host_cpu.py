@@ -135,30 +135,185 @@ def test_util_helpers():
     assert t["a"].dtype == np.int32 and t["b"]["c"].dtype == np.int32
 
 
-# ---- N > 1 path on CPU: world_size 2 over gloo
+# ---- N > 1 path on CPU: world_size 2 over gloo, through the REAL host glue (MinimalRETRODiffusion.set_distributed ->
+# sample_with_query / sample_from_rdata -> DatasetBuilder.search_k_nearest -> DDIMSampler / p_sample_loop -> decode ->
+# all_gather_images) around a stand-in for the library context (row-wise deterministic arithmetic on the CPU)
+class FakeCtx:
+    device = torch.device("cpu")
+
+    def db_load(self, emb):
+        self.db = torch.as_tensor(np.asarray(emb, dtype=np.float32))
+
+    def knn(self, q, k):
+        sc = torch.as_tensor(q).float() @ self.db.t()
+        v, i = torch.sort(sc, dim=1, descending=True, stable=True)
+        return i[:, :k].to(torch.int32), v[:, :k]
+
+    def ddim_sample(self, S, x_T, cond, uncond, alphas_cumprod, eta=0.0, scale=1.0, noise=None, log_every_t=100, temperature=1.0,
+                    want_intermediates=False):
+        z = x_T * 0.5 + cond.sum(dim=(1, 2))[:, None, None, None] * 0.01 * scale
+        if noise is not None:
+            z = z + eta * noise.sum(dim=0) * 0.1
+        return z, z[None], z[None]
+
+    def ddpm_sample(self, timesteps, x_T, cond, noise, sched, clip_denoised=True, temperature=1.0):
+        return x_T * 0.25 + cond.mean(dim=(1, 2))[:, None, None, None] + noise.sum(dim=0) * 0.01
+
+    def vq_decode(self, z, force_not_quantize=False, return_indices=False):
+        return z.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) + 1.0
+
+
+def _dist_model():
+    from rdm_amd.data.retrieval_dataset.dsetbuilder import DatasetBuilder
+    from rdm_amd.models.diffusion.ddpm import MinimalRETRODiffusion
+    ctx = FakeCtx()
+    rng = np.random.default_rng(3)
+    n = 300
+    pool = {"embedding": rng.standard_normal((n, 512)).astype(np.float16), "img_id": np.arange(n), "patch_coords": np.zeros((n, 4), np.int64)}
+    m = MinimalRETRODiffusion(unet_config={"params": {}}, ctx=ctx, image_size=8, nn_memory=np.arange(100), timesteps=1000)
+    m.retriever = DatasetBuilder(data_pool=pool, ctx=ctx)
+    m.set_distributed(True)
+    return m
+
+
+def _dist_run(n_total):
+    m = _dist_model()
+    out = []
+    q = (np.random.default_rng(9).standard_normal((n_total, 512)) * 0.45).astype(np.float32)
+    for kw in (dict(ddim=True, ddim_steps=10), dict(ddim=True, ddim_steps=10, eta=1.0), dict(ddim=False, ddim_steps=None, timesteps=5)):
+        torch.manual_seed(5); np.random.seed(5)
+        out.append(m.sample_with_query(query=torch.from_numpy(q), query_embedded=True, k_nn=4, unconditional_guidance_scale=2.0,
+                                       unconditional_retro_guidance_label=0., **kw)["query_samples"].numpy())
+        out.append(m.sample_from_rdata(n_total, k_nn=4, memsize=50, unconditional_guidance_scale=2.0,
+                                       unconditional_retro_guidance_label=0., **kw)["samples_with_sampled_nns"].numpy())
+    return out
+
+
 def _worker(rank, world, port, n_total, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from rdm_amd.parallel import all_gather_images, per_sample_noise, shard_range
-    a, b = shard_range(n_total, world, rank)
-    x = per_sample_noise(7, range(a, b), (3, 4, 4))
-    local = x * 2.0 + 1.0                                    # stand-in for "sample + decode" (per-sample independent)
-    out = all_gather_images(local, n_total)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from rdm_amd import parallel
+    assert parallel.init_distributed("gloo") == (rank, rank)
+    out = _dist_run(n_total)
     if rank == 0:
-        q.put(out.numpy())
-    dist.destroy_process_group()
+        q.put(out)
+    parallel.shutdown()
 
 
 @pytest.mark.parametrize("n_total", [8, 7])
 def test_batch_sharding_world2_gloo(n_total):
-    from rdm_amd.parallel import per_sample_noise, shard_range
+    from rdm_amd.parallel import shard_range
     assert shard_range(7, 2, 0) == (0, 4) and shard_range(7, 2, 1) == (4, 7)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + n_total
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
     for p in procs: p.start()
-    got = q.get(timeout=120)
+    got = q.get(timeout=180)
     for p in procs: p.join(timeout=60)
-    ref = per_sample_noise(7, range(n_total), (3, 4, 4)).numpy() * 2.0 + 1.0      # the 1-rank result
-    assert np.array_equal(got, ref)                                               # sharding is bit-invariant
+    ref = _dist_run(n_total)                                      # the 1-rank result (no process group: world 1)
+    assert len(got) == len(ref) == 6
+    for a, b in zip(got, ref):
+        assert a.shape == (n_total, 3, 16, 16)
+        assert np.array_equal(a, b)                               # sharding is bit-invariant
+
+
+def test_set_distributed_rejects_tiny_batches():
+    m = _dist_model()
+    m._shard(1)                                                   # world 1: fine
+    with pytest.raises(Exception):
+        m.sample_with_query(query=torch.zeros(0, 512), query_embedded=True)
+
+
+# ---- scripts/rdm_sample.py: the reference's CLI surface
+def _script():
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "rdm_sample.py")
+    spec = importlib.util.spec_from_file_location("rdm_sample_native", path)
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod
+
+
+def test_rdm_sample_flags_match_reference():
+    """Every flag of the reference parser (scripts/rdm_sample.py:22-143; table extracted by tools/gen_golden.py) exists with the
+    same option strings, type, action and default."""
+    import json
+    from pathlib import Path
+    mod = _script()
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rdm_sample_flags.json")) as f:
+        ref = json.load(f)
+    acts = {tuple(a.option_strings): a for a in mod.build_parser()._actions}
+    for e in ref:
+        a = acts.get(tuple(e["options"]))
+        assert a is not None, f"missing flag {e['options']}"
+        if e["action"] == "store_true":
+            assert a.const is True and a.default is False and a.nargs == 0
+        else:
+            assert a.type is {"int": int, "float": float, "str": str, "Path": Path}[e["type"]], e
+            assert a.default == e["default"] or str(a.default) == str(e["default"]), e
+    opt = mod.parse_args([])
+    assert (opt.batch_size, opt.n_runs, opt.guidance_scale, opt.top_m, opt.k_nn, opt.steps, opt.gpu) == (4, 2, 2.0, 0.01, 4, 100, -1)
+    assert mod.parse_args(["--top_m", "500"]).top_m == 500 and isinstance(mod.parse_args(["--top_m", "500"]).top_m, int)
+    assert str(mod.parse_args(["-s", "x/y"]).savepath) == "x/y"
+    mod.parse_args(["--seed", "3"])                               # the reference crashes here (opt.r_runs, :141)
+
+
+def test_rdm_sample_run_loops_follow_reference(tmp_path, monkeypatch):
+    """Run-loop semantics of scripts/rdm_sample.py:225-315 on a stand-in model: per-run seeding, k_nn = 1 with --only_caption,
+    omit_query masked by only_caption, no eta override, --increase_guidance, --keep_qids, file naming, uint8 truncation."""
+    mod = _script()
+    calls = []
+
+    class Clip:
+        def encode_text(self, tokens):
+            return torch.ones(tokens.shape[0], 512)
+
+    class Model:
+        device = torch.device("cpu")
+        class retriever:
+            class retriever:
+                model = Clip()
+        def get_qids(self, top_m, n, use_weights=False):
+            return np.arange(n)
+        def sample_with_query(self, **kw):
+            calls.append(("q", kw, float(torch.rand(1)), float(np.random.rand())))
+            return {"query_samples": torch.full((kw["query"].shape[0], 3, 4, 4), 0.999)}
+        def sample_from_rdata(self, n, **kw):
+            calls.append(("r", kw, float(torch.rand(1)), float(np.random.rand())))
+            return {"samples_with_sampled_nns": torch.full((n, 3, 4, 4), -0.5)}
+
+    opt = mod.parse_args(["-s", str(tmp_path), "-c", "a dog", "-bs", "3", "-n", "2", "--seed", "7", "--only_caption", "--omit_query",
+                          "--increase_guidance", "--steps", "9"])
+    stamp = mod.sample_conditional(Model(), opt)
+    assert [c[0] for c in calls] == ["q", "q"]
+    kw0, kw1 = calls[0][1], calls[1][1]
+    assert kw0["k_nn"] == 1 and kw0["omit_query"] is False and kw0["query_embedded"] and kw0["ddim"] and kw0["ddim_steps"] == 9
+    assert "eta" not in kw0 and kw0["unconditional_retro_guidance_label"] == 0.
+    assert kw0["unconditional_guidance_scale"] == 2.0 and kw1["unconditional_guidance_scale"] == 3.0
+    assert calls[0][2:] == calls[1][2:]                           # seed_everything before EVERY run
+    files = sorted(os.listdir(tmp_path))
+    assert files == sorted(f"{stamp}-query_samples-run{n}-sample{i}.png" for n in range(2) for i in range(3))
+    from PIL import Image
+    px = np.asarray(Image.open(tmp_path / files[0]))
+    assert px.shape == (4, 4, 3) and (px == int(255 * ((0.999 + 1.) / 2.))).all()      # truncation, not rounding (:203-214)
+    calls.clear()
+    opt = mod.parse_args(["-s", str(tmp_path / "u"), "-bs", "2", "-n", "1", "--keep_qids", "--top_m", "50", "--use_weights"])
+    (tmp_path / "u").mkdir()
+    mod.sample_unconditional(Model(), opt)
+    kw = calls[0][1]
+    assert calls[0][0] == "r" and np.array_equal(kw["qids"], np.arange(2)) and kw["memsize"] == 50 and kw["use_weights"] and kw["k_nn"] == 4
+    assert len(os.listdir(tmp_path / "u")) == 2
+
+
+def test_synthetic_weights_match_oracle_recipe():
+    """rdm_amd.synthetic (product side, used by bench.py / --synthetic) draws exactly the tensors the oracle's recipe draws, so the
+    committed golden fixtures apply to it."""
+    from oracle import clip as oclip, unet as ounet, vqdecoder as ovq
+    from rdm_amd import _lib, synthetic
+    assert synthetic.unet_param_shapes(_lib.make_unet_cfg()) == ounet.param_shapes(ounet.shipped_spec())
+    assert synthetic.vq_param_shapes(_lib.make_vq_cfg()) == ovq.vq_param_shapes(ovq.shipped_vq_spec())
+    assert synthetic.clip_param_shapes(_lib.make_clip_cfg()) == oclip.clip_param_shapes(oclip.vitb32_spec())
+    t = ounet.tiny_spec()
+    cfg = _lib.make_unet_cfg(model_channels=t.model_channels, num_res_blocks=t.num_res_blocks, attention_resolutions=t.attention_resolutions,
+                             channel_mult=t.channel_mult)
+    a, b = synthetic.unet_state_dict(cfg, 1234), ounet.synth_state_dict(ounet.param_shapes(t), 1234)
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)

@@ -128,3 +128,43 @@ def test_vq_oracle_shapes_and_quantise():
     zf = z.permute(0, 2, 3, 1).reshape(-1, 3)
     d = ((zf[:, None] - e[None]) ** 2).sum(-1)
     assert (d.argmin(1) == idx).float().mean() > 0.99
+
+
+# ---- full-size fixtures (tools/gen_golden_full.py): the oracle reproduces the stored reference values at the shipped size
+def test_streaming_topk_equals_exact_topk():
+    rng = np.random.default_rng(0)
+    db = (rng.standard_normal((5000, 64)) * 0.45).astype(np.float16); db[4000] = db[3]; db[4999] = db[3]
+    q = (rng.standard_normal((7, 64)) * 0.45).astype(np.float32); q[0] = db[3].astype(np.float32)
+    dbn, qn = oret.normalize_db(db), oret.normalize_queries(q)
+    want = oret.exact_topk(dbn, qn, 5)
+    st = oret.StreamingTopK(qn, 5)
+    for r0 in range(0, 5000, 1300):
+        n = oret.StreamingTopK.normalize_chunk(torch.from_numpy(db[r0:r0 + 1300]))
+        assert np.array_equal(n.numpy(), dbn[r0:r0 + 1300])
+        st.push(n, r0)
+    got = st.result()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+def test_full_vq_golden_reproduces():
+    g = golden("full_vq.npz")
+    vs = ovq.shipped_vq_spec()
+    sd = ounet.synth_state_dict(ovq.vq_param_shapes(vs), seed=int(g["seed"]))
+    img, idx = ovq.vq_decode(sd, vs, torch.from_numpy(g["z"]), return_indices=True)
+    assert np.array_equal(idx.numpy().astype(np.int32), g["indices"])
+    assert np.abs(img.numpy() - g["image"].astype(np.float32)).max() <= 4e-3          # stored as fp16
+
+
+def test_full_ddim_golden_first_step_reproduces():
+    """One CFG step of the 50-step trajectory at the shipped size (the stored values come from the reference UNetModel class)."""
+    g = golden("full_ddim_k4.npz")
+    spec = ounet.shipped_spec()
+    sd = ounet.synth_state_dict(ounet.param_shapes(spec), seed=1234)
+    sched = odiff.Schedule()
+    sch = odiff.ddim_schedule(sched, 50, 0.0)
+    x_T, cond = torch.from_numpy(g["x_T"]), torch.from_numpy(g["cond"])
+    assert np.array_equal(g["xin_0"], g["x_T"])
+    t = torch.full((1,), int(sch[0][-1]), dtype=torch.long)
+    x, px0 = odiff.p_sample_ddim(lambda x, t, c: ounet.unet_forward(sd, spec, x, t, c), x_T, cond, t, 49, sch, scale=2.0, uc=torch.zeros_like(cond))
+    assert np.abs(x.numpy() - g["x_0"]).max() <= 1e-4 * np.abs(g["x_0"]).max()
+    assert np.abs(px0.numpy() - g["px0_0"]).max() <= 1e-4 * np.abs(g["px0_0"]).max()

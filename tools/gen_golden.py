@@ -134,8 +134,31 @@ def gen_tokenizer():
     np.savez_compressed(os.path.join(OUT, "tokenizer.npz"), captions=np.array(caps), tokens=rows)
 
 
+def gen_script_flags():
+    """Flag table of the reference CLI (scripts/rdm_sample.py:22-143), read from its argparse calls with `ast` (the script
+    itself cannot be imported: torchvision / clip / omegaconf are absent).  Stored as data: option strings, type name,
+    default, action — what tests/test_host_cpu.py::test_rdm_sample_flags_match_reference compares our parser with."""
+    import ast
+    import json
+    src = open("/root/reference/scripts/rdm_sample.py").read()
+    flags = []
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "add_argument":
+            kw = {k.arg: k.value for k in node.keywords}
+            ent = {"options": [ast.literal_eval(a) for a in node.args],
+                   "type": (kw["type"].id if isinstance(kw.get("type"), ast.Name) else None),
+                   "action": ast.literal_eval(kw["action"]) if "action" in kw else None,
+                   "default": ast.literal_eval(kw["default"]) if "default" in kw else None}
+            flags.append(ent)
+    flags.sort(key=lambda e: e["options"][-1])
+    with open(os.path.join(OUT, "rdm_sample_flags.json"), "w") as f:
+        json.dump(flags, f, indent=1)
+    print(f"rdm_sample.py flag table: {len(flags)} flags")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    gen_script_flags()
     gen_attention()
     gen_unet("tiny", ounet.tiny_spec(), B=2, k=4, hw=16, seed=1234)
     gen_clip()
