@@ -4,7 +4,7 @@ generated in the build container from the reference's in-tree classes (tools/gen
 Stated tolerances (relative L2 against the fp32 reference; the HIP path stores activations in bf16 and accumulates in fp32):
     one UNet forward / one teacher-forced sampler step at the shipped size   <= 2.5e-2   (as tests/test_gpu_models.py)
     free-running trajectory, state after loop iteration i:
-        DDIM  (50 steps, eta 0, CFG 2.0)      rel L2(x_i)  <= DDIM_E0 * (1 + DDIM_G) ** i      (growth bound per step)
+        DDIM  (50 steps, eta 0, CFG 2.0)      rel L2(x_i)  <= DDIM_E0 * (1 + DDIM_G) ** i   with DDIM_G = 0: NO growth allowed
         DDPM  (250 ancestral steps, k = 16)   rel L2(z)    <= DDPM_FINAL
     VQ-f4 decode at the shipped size: code indices agree >= 99.5 %, image rel L2 <= 2.5e-2 when all codes agree
     ViT-B/32 towers <= 2e-2
@@ -28,10 +28,11 @@ pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
 # per-step growth bound of the free-running DDIM trajectory: the state error after loop iteration i (0-based) must stay
-# below DDIM_E0 * (1 + DDIM_G)^i.  E0 is the one-forward tolerance scaled by the step's |x|-relative weight; G was chosen
-# from the measured curve (profiles/r02_parity.md) with ~2x head-room.
-DDIM_E0, DDIM_G = 1.0e-2, 0.05
-DDPM_FINAL = 4e-2
+# below DDIM_E0 * (1 + DDIM_G)^i.  Measured (profiles/r02_parity.md): 2.1e-3 after the first step, 3.8e-3 from iteration 10 to
+# the final latent -- the error of 100 chained bf16 forwards does not accumulate (each step's eps error enters x scaled by
+# its DDIM coefficient, and later steps at low t contribute ~1e-5) -- so the bound is flat at ~2.5x the measured value.
+DDIM_E0, DDIM_G = 1.0e-2, 0.0
+DDPM_FINAL = 1.0e-2             # measured 4.1e-3 after 250 ancestral steps
 
 
 @pytest.fixture(scope="module")
