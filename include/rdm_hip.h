@@ -40,11 +40,28 @@ typedef struct {
     int num_head_channels, context_dim;
 } rdm_unet_cfg;
 
-/* ldm VQModelInterface ddconfig (models/rdm/imagenet/config.yaml:60-80). */
+/* First-stage decoder: ldm VQModelInterface ddconfig (models/rdm/imagenet/config.yaml:60-80) and taming VQModel ddconfig of the
+ * RARM models (models/rarm/imagenet/dogs/config.yaml:28-51: embed_dim = z_channels = 256, ch_mult 1,1,2,2,4, attn_resolutions [16]). */
 typedef struct {
     int embed_dim, n_embed, z_channels, ch, n_ch_mult, ch_mult[RDM_MAX_LEVELS];
     int num_res_blocks, out_ch, resolution, mid_attn, kl; /* kl=1: AutoencoderKL decode (no quantiser) */
+    int n_attn_resolutions, attn_resolutions[RDM_MAX_LEVELS];   /* AttnBlock after every ResnetBlock of the levels at these resolutions */
 } rdm_vq_cfg;
+
+/* RetrievalPatchTransformer constructor arguments of the RARM models (rdm/modules/attention.py:206-249;
+ * models/rarm/imagenet/dogs/config.yaml:14-27: continuous = false, causal, cross_attend, positional_encodings). */
+typedef struct {
+    int vocab_in, vocab_out;      /* in_channels (token embedding rows, incl. mask / sos tokens), out_channels (logits) */
+    int n_heads, d_head, depth, context_dim, sequence_length;
+} rdm_rarm_cfg;
+
+/* LatentImageRETRO.sample arguments (rdm/models/autoregression/transformer.py:224-294). */
+typedef struct {
+    int batch, k;                 /* sequences, neighbours per sequence in r [batch,k,context_dim] */
+    int cond_len, steps;          /* conditioning tokens c [batch,cond_len] (the sos token), tokens to sample */
+    float temperature; int top_k; /* top_k <= 0: no filter */
+    float guidance_scale;         /* > 1: batch doubled with zero neighbours, logits_u + s (logits_c - logits_u) (:237-253) */
+} rdm_rarm_sample_args;
 
 /* CLIP constructor arguments (rdm/modules/custom_clip/model.py:238-252). */
 typedef struct {
@@ -101,6 +118,10 @@ long long rdm_clip_manifest(const rdm_clip_cfg* cfg, char* buf, size_t buflen, s
 int rdm_load_unet(rdm_ctx* ctx, const rdm_unet_cfg* cfg, const void* packed, size_t nbytes);
 int rdm_load_vq(rdm_ctx* ctx, const rdm_vq_cfg* cfg, const void* packed, size_t nbytes);
 int rdm_load_clip(rdm_ctx* ctx, const rdm_clip_cfg* cfg, const void* packed, size_t nbytes);
+/* RARM transformer (state_dict keys of rdm.modules.attention.RetrievalPatchTransformer, prefix `transformer.` stripped);
+ * extra manifest kind  f32_t  = 2-D tensor stored transposed (positional_encoding [C,L] -> [L][C]). */
+long long rdm_rarm_manifest(const rdm_rarm_cfg* cfg, char* buf, size_t buflen, size_t* blob_bytes);
+int rdm_load_rarm(rdm_ctx* ctx, const rdm_rarm_cfg* cfg, const void* packed, size_t nbytes);
 
 /* ---- UNet: UNetModel.forward(x, timesteps, context) (openaimodel.py:335-371) via
  *      MinimalRETRODiffusion.apply_model (rdm/models/diffusion/ddpm.py:445-458).
@@ -126,14 +147,34 @@ int rdm_ddpm_sample(rdm_ctx* ctx, const rdm_ddpm_args* args, const float* x_T, c
  *      (called at rdm/models/diffusion/ddpm.py:840, 981). z [dev] f32 [b,3,h,w] -> img [dev] f32 [b,3,H,W];
  * indices_out [dev] int32 [b*h*w] or NULL. */
 int rdm_vq_decode(rdm_ctx* ctx, const float* z, int b, int force_not_quantize, float* img_out, int32_t* indices_out);
+/* taming Net2NetTransformer.decode_to_img (reached from rdm/models/autoregression/transformer.py:296-312): code indices
+ * [dev] int64 [b, h*w] -> quantize.get_codebook_entry -> post_quant_conv -> Decoder -> img_out [dev] f32 [b,3,R,R].
+ * For first stages with a wide latent (VQGAN-f16, z_channels % 64 == 0). */
+int rdm_vq_decode_indices(rdm_ctx* ctx, const int64_t* indices, int b, float* img_out);
 /* scripts/rdm_sample.py:203-214 custom_to_np/custom_to_pil: f32 NCHW [-1,1] -> uint8 NHWC (truncating). */
 int rdm_to_uint8(rdm_ctx* ctx, const float* img, int b, int c, int h, int w, uint8_t* out);
+
+/* ---- RARM: RetrievalPatchTransformer.forward(x, context) (rdm/modules/attention.py:199-272) and LatentImageRETRO.sample
+ *      (rdm/models/autoregression/transformer.py:224-294).  Both run token by token against a per-layer K/V cache (the
+ *      reference re-runs the whole prefix for every new token, :241-248).
+ * forward: tokens [dev] int64 [b,t]; context [dev] f32 [b,k,context_dim]; logits_out [dev] f32 [b,t,vocab_out].
+ * sample : cond_tokens [dev] int64 [b,cond_len]; context as above; uniforms [dev] f32 [steps,b] in [0,1) — the multinomial draw
+ *          of step s for sequence i is the inverse CDF (vocabulary order) at uniforms[s,i]; tokens_out [dev] int64 [b,steps]. */
+int rdm_rarm_forward(rdm_ctx* ctx, const int64_t* tokens, int b, int t, const float* context, int k, float* logits_out);
+int rdm_rarm_sample(rdm_ctx* ctx, const rdm_rarm_sample_args* args, const int64_t* cond_tokens, const float* context,
+                    const float* uniforms, int64_t* tokens_out);
 
 /* ---- CLIP: CLIP.encode_text / encode_image (rdm/modules/custom_clip/model.py:304-320), used by
  *      ClipImageRetriever / CLIPTextEmbedder (rdm/modules/retrievers.py:67-117).
  * tokens [dev] int64 [b,context_length]; image [dev] f32 [b,3,R,R] already CLIP-normalised; out [dev] f32 [b,embed]. */
 int rdm_clip_encode_text(rdm_ctx* ctx, const int64_t* tokens, int b, float* out);
 int rdm_clip_encode_image(rdm_ctx* ctx, const float* image, int b, float* out);
+/* ClipImageRetriever.preprocess (rdm/modules/retrievers.py:83-91): kornia bicubic resize (align_corners=True, no antialias)
+ * of image [dev] f32 [b,3,h,w] in [-1,1] to the tower resolution R, then (x+1)/2 and the CLIP mean/std -> out [dev] f32 [b,3,R,R]. */
+int rdm_clip_preprocess(rdm_ctx* ctx, const float* image, int b, int h, int w, float* out);
+/* ClipImageRetriever.forward (retrievers.py:93-95) = encode_image(preprocess(x)) with the preprocessing fused into the
+ * patch-embedding gather (the resized image is never materialised): image [dev] f32 [b,3,h,w] in [-1,1] -> out [dev] f32 [b,embed]. */
+int rdm_clip_encode_image_raw(rdm_ctx* ctx, const float* image, int b, int h, int w, float* out);
 
 /* ---- retrieval: DatasetBuilder.train_searcher + searcher.search_batched
  *      (rdm/data/retrieval_dataset/dsetbuilder.py:534-619, 490; call sites ddpm.py:298,734,906).
@@ -144,6 +185,10 @@ int rdm_clip_encode_image(rdm_ctx* ctx, const float* image, int b, float* out);
 int rdm_db_load(rdm_ctx* ctx, const void* emb, long long n, int dim, int dtype, int is_device);
 long long rdm_db_size(rdm_ctx* ctx);
 int rdm_knn(rdm_ctx* ctx, const float* q, int b, int k, uint32_t* idx_out, float* score_out);
+/* 1 if the last rdm_knn could not certify its MFMA-scored candidate set for some query (a cluster of near-duplicates within the
+ * score error bound around the k-th neighbour) and answered it by the exact fp64 pass instead; 0 otherwise.  Diagnostic only:
+ * the result is exact either way. */
+int rdm_knn_last_fallback(rdm_ctx* ctx);
 /* data_pool['embedding'][nns] gather (dsetbuilder.py:493): idx [dev] uint32 [n_idx] -> out [dev] f32 [n_idx,dim]
  * of the RAW (un-normalised) embeddings (rdm_db_load keeps a raw copy in HBM next to the normalised one). */
 int rdm_db_gather(rdm_ctx* ctx, const uint32_t* idx, long long n_idx, float* out);

@@ -24,6 +24,7 @@ class VQSpec:
     out_ch: int = 3
     resolution: int = 256
     mid_attn: bool = True
+    attn_resolutions: Tuple[int, ...] = ()
 
     @property
     def z_res(self):
@@ -32,6 +33,16 @@ class VQSpec:
 
 def shipped_vq_spec():
     return VQSpec()
+
+
+def vqgan_f16_spec():
+    """taming VQModel of the RARM models (models/rarm/imagenet/dogs/config.yaml:28-51)."""
+    return VQSpec(embed_dim=256, n_embed=16384, z_channels=256, ch=128, ch_mult=(1, 1, 2, 2, 4), num_res_blocks=2, resolution=256,
+                  attn_resolutions=(16,))
+
+
+def tiny_vqgan_spec():
+    return VQSpec(embed_dim=64, n_embed=512, z_channels=64, ch=64, ch_mult=(1, 2, 2), num_res_blocks=1, resolution=32, attn_resolutions=(8,))
 
 
 def tiny_vq_spec():
@@ -62,14 +73,21 @@ def vq_param_shapes(s: VQSpec) -> Dict[str, tuple]:
         for n in ("q", "k", "v", "proj_out"):
             p[f"{a}.{n}.weight"] = (block_in, block_in, 1, 1); p[f"{a}.{n}.bias"] = (block_in,)
     _res_shapes(p, "decoder.mid.block_2", block_in, block_in)
+    curr_res = s.z_res
     for lvl in reversed(range(nl)):
         block_out = s.ch * s.ch_mult[lvl]
         for i in range(s.num_res_blocks + 1):
             _res_shapes(p, f"decoder.up.{lvl}.block.{i}", block_in, block_out)
             block_in = block_out
+            if curr_res in s.attn_resolutions:
+                a = f"decoder.up.{lvl}.attn.{i}"
+                p[a + ".norm.weight"] = (block_in,); p[a + ".norm.bias"] = (block_in,)
+                for n in ("q", "k", "v", "proj_out"):
+                    p[f"{a}.{n}.weight"] = (block_in, block_in, 1, 1); p[f"{a}.{n}.bias"] = (block_in,)
         if lvl != 0:
             p[f"decoder.up.{lvl}.upsample.conv.weight"] = (block_in, block_in, 3, 3)
             p[f"decoder.up.{lvl}.upsample.conv.bias"] = (block_in,)
+            curr_res *= 2
     p["decoder.norm_out.weight"] = (block_in,); p["decoder.norm_out.bias"] = (block_in,)
     p["decoder.conv_out.weight"] = (s.out_ch, block_in, 3, 3); p["decoder.conv_out.bias"] = (s.out_ch,)
     return p
@@ -127,6 +145,19 @@ def vq_decode(sd, spec: VQSpec, z, scale_factor=1.0, force_not_quantize=False, r
     idx = None
     if not force_not_quantize:
         z, idx = vq_quantize(sd, z)
+    out = _decode_quantized(sd, spec, z)
+    return (out, idx) if return_indices else out
+
+
+def vq_decode_indices(sd, spec: VQSpec, indices):
+    """[taming] Net2NetTransformer.decode_to_img: quantize.get_codebook_entry(index, (b,h,w,c)) -> VQModel.decode
+    (post_quant_conv + Decoder); reached from rdm/models/autoregression/transformer.py:296-312.  indices int64 [b, h*w]."""
+    b = indices.shape[0]
+    zq = sd["quantize.embedding.weight"][indices.reshape(-1)].reshape(b, spec.z_res, spec.z_res, spec.embed_dim).permute(0, 3, 1, 2).contiguous()
+    return _decode_quantized(sd, spec, zq)
+
+
+def _decode_quantized(sd, spec: VQSpec, z):
     h = F.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
     h = F.conv2d(h, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"], padding=1)
     h = _resnet(sd, "decoder.mid.block_1", h)
@@ -136,9 +167,10 @@ def vq_decode(sd, spec: VQSpec, z, scale_factor=1.0, force_not_quantize=False, r
     for lvl in reversed(range(len(spec.ch_mult))):
         for i in range(spec.num_res_blocks + 1):
             h = _resnet(sd, f"decoder.up.{lvl}.block.{i}", h)
+            if f"decoder.up.{lvl}.attn.{i}.q.weight" in sd:
+                h = _attn(sd, f"decoder.up.{lvl}.attn.{i}", h)
         if lvl != 0:
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
             h = F.conv2d(h, sd[f"decoder.up.{lvl}.upsample.conv.weight"], sd[f"decoder.up.{lvl}.upsample.conv.bias"], padding=1)
     h = _swish(_gn(h, sd, "decoder.norm_out"))
-    out = F.conv2d(h, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
-    return (out, idx) if return_indices else out
+    return F.conv2d(h, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)

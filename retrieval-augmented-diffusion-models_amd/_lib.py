@@ -27,7 +27,18 @@ class UNetCfg(C.Structure):
 class VqCfg(C.Structure):
     _fields_ = [("embed_dim", C.c_int), ("n_embed", C.c_int), ("z_channels", C.c_int), ("ch", C.c_int),
                 ("n_ch_mult", C.c_int), ("ch_mult", C.c_int * RDM_MAX_LEVELS), ("num_res_blocks", C.c_int),
-                ("out_ch", C.c_int), ("resolution", C.c_int), ("mid_attn", C.c_int), ("kl", C.c_int)]
+                ("out_ch", C.c_int), ("resolution", C.c_int), ("mid_attn", C.c_int), ("kl", C.c_int),
+                ("n_attn_resolutions", C.c_int), ("attn_resolutions", C.c_int * RDM_MAX_LEVELS)]
+
+
+class RarmCfg(C.Structure):
+    _fields_ = [("vocab_in", C.c_int), ("vocab_out", C.c_int), ("n_heads", C.c_int), ("d_head", C.c_int), ("depth", C.c_int),
+                ("context_dim", C.c_int), ("sequence_length", C.c_int)]
+
+
+class RarmSampleArgs(C.Structure):
+    _fields_ = [("batch", C.c_int), ("k", C.c_int), ("cond_len", C.c_int), ("steps", C.c_int), ("temperature", C.c_float),
+                ("top_k", C.c_int), ("guidance_scale", C.c_float)]
 
 
 class ClipCfg(C.Structure):
@@ -66,6 +77,11 @@ SIGNATURES = {
     "rdm_load_unet": (C.c_int, [_P, C.POINTER(UNetCfg), _P, C.c_size_t]),
     "rdm_load_vq": (C.c_int, [_P, C.POINTER(VqCfg), _P, C.c_size_t]),
     "rdm_load_clip": (C.c_int, [_P, C.POINTER(ClipCfg), _P, C.c_size_t]),
+    "rdm_rarm_manifest": (C.c_longlong, [C.POINTER(RarmCfg), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rdm_load_rarm": (C.c_int, [_P, C.POINTER(RarmCfg), _P, C.c_size_t]),
+    "rdm_rarm_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "rdm_rarm_sample": (C.c_int, [_P, C.POINTER(RarmSampleArgs), _P, _P, _P, _P]),
+    "rdm_vq_decode_indices": (C.c_int, [_P, _P, C.c_int, _P]),
     "rdm_unet_forward": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_ddim_num_intermediates": (C.c_int, [C.c_int, C.c_int]),
     "rdm_ddim_sample": (C.c_int, [_P, C.POINTER(DdimArgs), _P, _P, _P, _P, _P, _P, _P]),
@@ -74,9 +90,12 @@ SIGNATURES = {
     "rdm_to_uint8": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_clip_encode_text": (C.c_int, [_P, _P, C.c_int, _P]),
     "rdm_clip_encode_image": (C.c_int, [_P, _P, C.c_int, _P]),
+    "rdm_clip_preprocess": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "rdm_clip_encode_image_raw": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_db_load": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, C.c_int]),
     "rdm_db_size": (C.c_longlong, [_P]),
     "rdm_knn": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "rdm_knn_last_fallback": (C.c_int, [_P]),
     "rdm_db_gather": (C.c_int, [_P, _P, C.c_longlong, _P]),
     "rdm_prof_enable": (C.c_int, [_P, C.c_int]),
     "rdm_prof_collect": (C.c_int, [_P, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -131,14 +150,32 @@ def make_unet_cfg(in_channels=3, out_channels=3, model_channels=192, num_res_blo
 
 
 def make_vq_cfg(embed_dim=3, n_embed=8192, z_channels=3, ch=128, ch_mult=(1, 2, 4), num_res_blocks=2, out_ch=3,
-                resolution=256, mid_attn=True, kl=False, **_ignored) -> VqCfg:
+                resolution=256, mid_attn=True, kl=False, attn_resolutions=(), **_ignored) -> VqCfg:
     c = VqCfg()
     c.embed_dim, c.n_embed, c.z_channels, c.ch = embed_dim, n_embed, z_channels, ch
     c.n_ch_mult = len(ch_mult)
     for i, v in enumerate(ch_mult):
         c.ch_mult[i] = int(v)
     c.num_res_blocks, c.out_ch, c.resolution, c.mid_attn, c.kl = num_res_blocks, out_ch, resolution, int(mid_attn), int(kl)
+    c.n_attn_resolutions = len(attn_resolutions)
+    for i, v in enumerate(attn_resolutions):
+        c.attn_resolutions[i] = int(v)
     return c
+
+
+def make_vqgan_f16_cfg(**kw) -> VqCfg:
+    """taming VQModel of the RARM models (models/rarm/imagenet/dogs/config.yaml:28-51)."""
+    d = dict(embed_dim=256, n_embed=16384, z_channels=256, ch=128, ch_mult=(1, 1, 2, 2, 4), num_res_blocks=2, out_ch=3, resolution=256,
+             attn_resolutions=(16,))
+    d.update(kw)
+    return make_vq_cfg(**d)
+
+
+def make_rarm_cfg(in_channels=16386, out_channels=16384, n_heads=12, d_head=64, depth=18, context_dim=512, sequence_length=256,
+                  **_ignored) -> RarmCfg:
+    """RetrievalPatchTransformer params (models/rarm/imagenet/dogs/config.yaml:14-27)."""
+    return RarmCfg(vocab_in=in_channels, vocab_out=out_channels, n_heads=n_heads, d_head=d_head, depth=depth, context_dim=context_dim,
+                   sequence_length=sequence_length)
 
 
 def make_clip_cfg(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=32,
@@ -154,7 +191,7 @@ def make_clip_cfg(embed_dim=512, image_resolution=224, vision_layers=12, vision_
 
 def manifest(kind: str, cfg):
     """-> (list of (offset, nbytes, kind, [src...]), blob_bytes)"""
-    fn = {"unet": lib.rdm_unet_manifest, "vq": lib.rdm_vq_manifest, "clip": lib.rdm_clip_manifest}[kind]
+    fn = {"unet": lib.rdm_unet_manifest, "vq": lib.rdm_vq_manifest, "clip": lib.rdm_clip_manifest, "rarm": lib.rdm_rarm_manifest}[kind]
     blob = C.c_size_t(0)
     n = fn(C.byref(cfg), None, 0, C.byref(blob))
     if n < 0:
@@ -184,7 +221,7 @@ class Context:
             raise RdmError(f"rdm_ctx_create failed ({rc}); no usable HIP device {device}")
         self._h = h
         self.device = torch.device("cuda", device)
-        self.unet_cfg = self.vq_cfg = self.clip_cfg = None
+        self.unet_cfg = self.vq_cfg = self.clip_cfg = self.rarm_cfg = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -213,6 +250,49 @@ class Context:
 
     def load_clip(self, cfg: ClipCfg, blob: np.ndarray):
         self._check(lib.rdm_load_clip(self._h, C.byref(cfg), blob.ctypes.data_as(_P), blob.nbytes)); self.clip_cfg = cfg
+
+    def load_rarm(self, cfg: RarmCfg, blob: np.ndarray):
+        self._check(lib.rdm_load_rarm(self._h, C.byref(cfg), blob.ctypes.data_as(_P), blob.nbytes)); self.rarm_cfg = cfg
+
+    # ---- RARM
+    def _check_rarm(self, what, context, b):
+        if self.rarm_cfg is None:
+            raise RdmError(f"{what}: rarm weights not loaded")
+        if context.ndim != 3 or context.shape[0] != b or context.shape[2] != self.rarm_cfg.context_dim:
+            raise RdmError(f"{what}: neighbours must be [b={b},k,{self.rarm_cfg.context_dim}], got {tuple(context.shape)}")
+
+    def rarm_forward(self, tokens, context):
+        """RetrievalPatchTransformer.forward: tokens int64 [b,t], context f32 [b,k,ctx] -> logits f32 [b,t,vocab_out]."""
+        tokens = self._dev(tokens, torch.int64); context = self._dev(context, torch.float32)
+        b, t = tokens.shape
+        self._check_rarm("rarm_forward", context, b)
+        out = torch.empty((b, t, self.rarm_cfg.vocab_out), device=self.device, dtype=torch.float32)
+        self._check(lib.rdm_rarm_forward(self._h, _ptr(tokens), b, t, _ptr(context), context.shape[1], _ptr(out)))
+        return out
+
+    def rarm_sample(self, cond_tokens, context, steps, uniforms, temperature=1.0, top_k=None, guidance_scale=1.0):
+        """LatentImageRETRO.sample with sample=True: -> tokens int64 [b,steps].  uniforms f32 [steps,b] in [0,1)."""
+        cond_tokens = self._dev(cond_tokens, torch.int64); context = self._dev(context, torch.float32)
+        uniforms = self._dev(uniforms, torch.float32)
+        b, tc = cond_tokens.shape
+        self._check_rarm("rarm_sample", context, b)
+        if tuple(uniforms.shape) != (steps, b):
+            raise RdmError(f"rarm_sample: uniforms must be [{steps},{b}], got {tuple(uniforms.shape)}")
+        a = RarmSampleArgs(batch=b, k=context.shape[1], cond_len=tc, steps=steps, temperature=temperature,
+                           top_k=int(top_k) if top_k is not None else 0, guidance_scale=guidance_scale)
+        out = torch.empty((b, steps), device=self.device, dtype=torch.int64)
+        self._check(lib.rdm_rarm_sample(self._h, C.byref(a), _ptr(cond_tokens), _ptr(context), _ptr(uniforms), _ptr(out)))
+        return out
+
+    def vq_decode_indices(self, indices):
+        """decode_to_img: code indices int64 [b, h*w] -> image f32 [b,out_ch,R,R] (VQGAN first stage with a wide latent)."""
+        indices = self._dev(indices, torch.int64)
+        zr = self.vq_cfg.resolution >> (self.vq_cfg.n_ch_mult - 1)
+        if indices.ndim != 2 or indices.shape[1] != zr * zr:
+            raise RdmError(f"vq_decode_indices: indices must be [b,{zr * zr}], got {tuple(indices.shape)}")
+        img = torch.empty((indices.shape[0], self.vq_cfg.out_ch, self.vq_cfg.resolution, self.vq_cfg.resolution), device=self.device, dtype=torch.float32)
+        self._check(lib.rdm_vq_decode_indices(self._h, _ptr(indices), indices.shape[0], _ptr(img)))
+        return img
 
     # ---- model calls (torch CUDA tensors in / out)
     def _dev(self, t, dtype):
@@ -314,6 +394,25 @@ class Context:
         self._check(lib.rdm_clip_encode_image(self._h, _ptr(image), image.shape[0], _ptr(out)))
         return out
 
+    def clip_preprocess(self, image):
+        """[b,3,h,w] in [-1,1] -> bicubic resize to the tower resolution + CLIP normalisation, f32 [b,3,R,R]."""
+        image = self._dev(image, torch.float32)
+        if image.ndim != 4 or image.shape[1] != 3:
+            raise RdmError(f"clip_preprocess: image must be [b,3,h,w], got {tuple(image.shape)}")
+        r = self.clip_cfg.image_resolution
+        out = torch.empty((image.shape[0], 3, r, r), device=self.device, dtype=torch.float32)
+        self._check(lib.rdm_clip_preprocess(self._h, _ptr(image), image.shape[0], image.shape[2], image.shape[3], _ptr(out)))
+        return out
+
+    def clip_encode_image_raw(self, image):
+        """ClipImageRetriever.forward: preprocess fused into the image tower's patch gather."""
+        image = self._dev(image, torch.float32)
+        if image.ndim != 4 or image.shape[1] != 3:
+            raise RdmError(f"clip_encode_image_raw: image must be [b,3,h,w], got {tuple(image.shape)}")
+        out = torch.empty((image.shape[0], self.clip_cfg.embed_dim), device=self.device, dtype=torch.float32)
+        self._check(lib.rdm_clip_encode_image_raw(self._h, _ptr(image), image.shape[0], image.shape[2], image.shape[3], _ptr(out)))
+        return out
+
     # ---- retrieval
     def db_load(self, emb):
         """emb: numpy fp16/fp32 [n,dim] (host) or torch CUDA tensor (device)."""
@@ -335,6 +434,9 @@ class Context:
         sc = torch.empty((q.shape[0], k), device=self.device, dtype=torch.float32)
         self._check(lib.rdm_knn(self._h, _ptr(q), q.shape[0], k, _ptr(idx), _ptr(sc)))
         return idx, sc
+
+    def knn_last_fallback(self):
+        return int(lib.rdm_knn_last_fallback(self._h))
 
     def db_gather(self, idx, dim):
         idx = idx.contiguous()

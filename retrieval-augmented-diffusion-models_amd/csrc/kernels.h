@@ -43,6 +43,29 @@ struct DdpmStepParams {
     float sqrt_recip, sqrt_recipm1, coef1, coef2, log_var; int clip, nonzero; float temperature;
 };
 
+// RARM decode step (rarm.hip)
+struct RarmAttnParams {
+    const bf16_t* q; int ldq;                 // q[b*ldq + h*64 + d]; k_new / v_new share ldq (one fused qkv row per sequence)
+    const bf16_t* k_new; const bf16_t* v_new; // self-attention: the new token's rows (appended to the cache at *pos); null for cross-attention
+    bf16_t* Kc; bf16_t* Vc;                   // cache [B][rows][row_stride]
+    long long batch_stride; int row_stride;
+    int nkv;                                  // cross-attention: rows to attend; self-attention: capacity (<= 1024)
+    const int* pos;                           // device step counter (self-attention attends rows 0..*pos)
+    float scale; bf16_t* out; int ldo;
+};
+struct RarmSampleParams {
+    const float* logits; int vocab; int B; int cfg; float scale, temperature; int top_k;
+    const float* uniforms;                    // [steps][B], row = *pos - pos0
+    int* pos; int pos0; int steps;            // tokens_out[b*steps + (*pos - pos0)]
+    long long* tokens_out; long long* next_tokens; int* done;
+};
+hipError_t launch_rarm_embed(const long long* tokens, const float* emb, const float* pos_t, const int* pos, float* x, int B, int C,
+                             int vocab, hipStream_t st);
+hipError_t launch_rarm_decode_attention(const RarmAttnParams& p, int heads, int batch, hipStream_t st);
+hipError_t launch_rarm_sample(const RarmSampleParams& p, hipStream_t st);
+hipError_t launch_codebook_gather(const long long* idx, const float* codebook, int n_embed, int E, long long n, bf16_t* out, hipStream_t st);
+hipError_t launch_set_int(int* p, int v, hipStream_t st);
+
 hipError_t launch_igemm(const IgemmParams& p, bool conv, int batch, hipStream_t st);
 bool conv_halo_supported(const IgemmParams& p);
 int conv_halo_ksplit(const IgemmParams& p);                // K-split factor worth using for this conv (1 = none); needs p.ws of ksplit*M*N floats
@@ -73,6 +96,8 @@ hipError_t launch_clip_embed(const long long* tokens, const float* tok_emb, cons
                              int Wd, hipStream_t st);
 hipError_t launch_clip_gather_eot(const long long* tokens, const float* x, float* out, int B, int L, int Wd, hipStream_t st);
 hipError_t launch_clip_patchify(const float* img, bf16_t* out, int B, int R, int P, hipStream_t st);
+// bicubic resize (align_corners) + (x+1)/2 + CLIP mean/std: into f32 [B,3,R,R] (out_patch null) or the bf16 patch matrix
+hipError_t launch_clip_preprocess(const float* img, int B, int H, int W, int R, int P, float* out_f32, bf16_t* out_patch, hipStream_t st);
 hipError_t launch_clip_vit_assemble(const float* patch, const float* cls, const float* pos, float* out, int B, int GG, int Wd,
                                     hipStream_t st);
 hipError_t launch_gather_rows_f32(const float* x, float* out, int B, long long row_stride, int Wd, hipStream_t st);

@@ -11,6 +11,7 @@ struct KnnDb {
     // search scratch
     void* scratch = nullptr; size_t scratch_bytes = 0;
     void* zero_page = nullptr;  // 256 zero bytes on the database's device (source of padding lanes)
+    int last_fallbacks = 0;     // 1 if the last search needed the exact fallback pass for at least one query
 };
 
 // all return nullptr on success, or a static error string

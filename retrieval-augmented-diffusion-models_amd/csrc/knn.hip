@@ -13,8 +13,15 @@
 //   merge kernel  per query: thread-local top-KSEL over all lane lists -> LDS bitonic sort ->
 //                 the best 2*KSEL candidates are re-scored EXACTLY (fp64 accumulation of exact
 //                 products, the oracle's definition) and sorted by (score desc, index asc).
-// Any element of the true top-k survives every list level because every list keeps KSEL >= k + 4
-// entries of its subset; index ties resolve identically to the oracle.
+// Exactness is a GUARANTEE, not a likelihood.  The approximate score differs from the exact one by at most KNN_EPS
+// (fp32 accumulation of 1024 exact f16 x f16 products with partial sums <= 1: <= 1024 * 2^-24 = 6.1e-5 when each step rounds
+// to nearest, doubled for an unknown rounding mode inside the MFMA, plus <= 7e-7 for the subnormal tail of the lo word).  Every
+// row that is dropped anywhere (lane list, merge-thread list, the cut after the best 2*KSEL) has an approximate score <= theta,
+// the maximum of the full lane lists' tails, the scores the merge threads rejected and the first score after the cut.  If
+// theta + KNN_EPS < tau (the k-th EXACT score among the re-scored candidates) no dropped row can belong to the top k and the result
+// is certified.  Otherwise (a cluster of near-duplicates around the k-th score -- real in OpenImages patches) the query is
+// flagged and an exact pass streams the database once more in fp64, collecting every row that beats the current k-th candidate
+// under the total order (score desc, index asc); the top k of those is the answer.  Unflagged batches pay three empty launches.
 #include <stdlib.h>
 #include <string.h>
 
@@ -25,6 +32,8 @@
 #define KNN_Q 64               // queries per pass
 #define KNN_BK 64              // K slice per stage
 
+constexpr float KNN_EPS = 2.0e-4f;   // bound on |approximate - exact| score (derivation above)
+constexpr int KNN_FB_CAP = 8192;      // exact-fallback candidates kept per query
 struct Cand { float s; uint32_t i; };
 __device__ __forceinline__ bool better(float s, uint32_t i, float ts, uint32_t ti) { return s > ts || (s == ts && i < ti); }
 
@@ -380,11 +389,29 @@ __global__ __launch_bounds__(512, 2) void knn_scan512w8_kernel(ScanParams p) {
 }
 
 // ---------------------------------------------------------------- merge + exact re-score
+struct Certify {
+    int* flag;                          // [64] 1 = candidate set not provably sufficient -> exact fallback for this query
+    double* tau; uint32_t* tau_idx;     // [64] the current k-th (exact score, index)
+    int* fb_count;                      // [64] rows collected by the fallback
+    double* fb_s; uint32_t* fb_i;       // [64][KNN_FB_CAP]
+    int* status;                        // sticky bits for the host: 1 = a fallback ran, 2 = a fallback overflowed KNN_FB_CAP
+};
 struct MergeParams {
     const float* cand_s; const uint32_t* cand_i; int nlists;
     const _Float16* dbn; const float* qn; int dim; long long n;
     int k; uint32_t* idx_out; float* score_out; int qbase;   // output row = qbase + blockIdx.x
+    Certify cert;
 };
+
+// the oracle's score: exact products, fp64 accumulation.  ONE summation order (lane-strided, xor-butterfly) shared by the merge
+// and the fallback so that a row scores bit-identically wherever it is evaluated.  All 64 lanes get the result.
+__device__ __forceinline__ double exact_score(const float* qn_row, const _Float16* db_row, int dim, int lane) {
+    double acc = 0.0;
+    for (int c = lane; c < dim; c += 64) acc += (double)qn_row[c] * (double)(float)db_row[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    return acc;
+}
 
 template <int KSEL>
 __global__ __launch_bounds__(256) void knn_merge_kernel(MergeParams p) {
@@ -396,9 +423,18 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(MergeParams p) {
 #pragma unroll
     for (int j = 0; j < KSEL; j++) { ls[j] = -INFINITY; li[j] = 0xffffffffu; }
     const long long total = (long long)p.nlists * KSEL, base = (long long)q * total;
-    for (long long c = tid; c < total; c += 256) list_insert<KSEL>(ls, li, p.cand_s[base + c], p.cand_i[base + c]);
+    float theta = -INFINITY;            // upper bound of the approximate score of every row dropped so far
+    for (long long c = tid; c < total; c += 256) {
+        const float s = p.cand_s[base + c]; const uint32_t i = p.cand_i[base + c];
+        if ((int)(c % KSEL) == KSEL - 1 && i != 0xffffffffu) theta = fmaxf(theta, s);   // tail of a FULL lane list bounds what that lane dropped
+        if (!better(s, i, ls[KSEL - 1], li[KSEL - 1])) { if (i != 0xffffffffu) theta = fmaxf(theta, s); continue; }
+        if (li[KSEL - 1] != 0xffffffffu) theta = fmaxf(theta, ls[KSEL - 1]);             // the entry this insertion evicts
+        list_insert<KSEL>(ls, li, s, i);
+    }
 #pragma unroll
     for (int j = 0; j < KSEL; j++) { ss[tid * KSEL + j] = ls[j]; si[tid * KSEL + j] = li[j]; }
+    __shared__ float s_theta[256];
+    s_theta[tid] = theta;
     __syncthreads();
     // bitonic sort, best first
     for (int size = 2; size <= NS; size <<= 1) {
@@ -419,14 +455,9 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(MergeParams p) {
     const int lane = tid & 63, wave = tid >> 6;
     for (int r = wave; r < R; r += 4) {
         const uint32_t id = si[r];
-        double acc = 0.0;
-        if (id != 0xffffffffu && (long long)id < p.n) {
-            for (int c = lane; c < p.dim; c += 64)
-                acc += (double)p.qn[(long long)q * p.dim + c] * (double)(float)p.dbn[(long long)id * p.dim + c];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) { ex[r] = (id != 0xffffffffu) ? acc : -INFINITY; exi[r] = id; }
+        const bool valid = id != 0xffffffffu && (long long)id < p.n;
+        const double acc = valid ? exact_score(p.qn + (long long)q * p.dim, p.dbn + (long long)id * p.dim, p.dim, lane) : 0.0;
+        if (lane == 0) { ex[r] = valid ? acc : -INFINITY; exi[r] = id; }
     }
     __syncthreads();
     if (tid == 0) {
@@ -439,6 +470,67 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(MergeParams p) {
             p.idx_out[(long long)(p.qbase + q) * p.k + j] = exi[j];
             if (p.score_out) p.score_out[(long long)(p.qbase + q) * p.k + j] = (float)ex[j];
         }
+        // certificate: nothing that was dropped can reach the k-th exact score
+        float th = (si[R] != 0xffffffffu) ? ss[R] : -INFINITY;          // first candidate after the re-scored prefix
+        for (int t = 0; t < 256; t++) th = fmaxf(th, s_theta[t]);
+        const double tau = ex[p.k - 1];
+        const bool certified = (double)th + (double)KNN_EPS < tau;
+        p.cert.flag[q] = certified ? 0 : 1;
+        p.cert.tau[q] = tau; p.cert.tau_idx[q] = exi[p.k - 1]; p.cert.fb_count[q] = 0;
+        if (!certified) atomicOr(p.cert.status, 1);
+    }
+}
+
+// ---------------------------------------------------------------- exact fallback (flagged queries only; normally none)
+// One wave per row: exact fp64 score against every flagged query; rows that beat-or-tie the query's current k-th candidate
+// under (score desc, index asc) are appended.  The true top k all do (the current k-th is the k-th best of a SUBSET).
+__global__ __launch_bounds__(256) void knn_exact_collect_kernel(Certify c, const _Float16* dbn, const float* qn, long long n, int dim, int nq) {
+    __shared__ int fq[KNN_Q]; __shared__ int nf;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) { int m = 0; for (int q = 0; q < nq; q++) if (c.flag[q]) fq[m++] = q; nf = m; }
+    __syncthreads();
+    if (nf == 0) return;
+    const long long wave0 = (long long)blockIdx.x * 4 + (tid >> 6), nwaves = (long long)gridDim.x * 4;
+    for (long long row = wave0; row < n; row += nwaves) {
+        for (int f = 0; f < nf; f++) {
+            const int q = fq[f];
+            const double s = exact_score(qn + (long long)q * dim, dbn + row * dim, dim, lane);
+            if (lane == 0) {
+                const double tau = c.tau[q]; const uint32_t ti = c.tau_idx[q];
+                if (s > tau || (s == tau && (uint32_t)row <= ti)) {
+                    const int slot = atomicAdd(&c.fb_count[q], 1);
+                    if (slot < KNN_FB_CAP) { c.fb_s[(long long)q * KNN_FB_CAP + slot] = s; c.fb_i[(long long)q * KNN_FB_CAP + slot] = (uint32_t)row; }
+                }
+            }
+        }
+    }
+}
+// top k of the collected rows by k rounds of block-wide arg-best (k <= 28, <= KNN_FB_CAP entries)
+__global__ __launch_bounds__(256) void knn_exact_finish_kernel(Certify c, int k, uint32_t* idx_out, float* score_out, int qbase) {
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (!c.flag[q]) return;
+    int cnt = c.fb_count[q];
+    if (cnt > KNN_FB_CAP) { if (tid == 0) atomicOr(c.status, 2); cnt = KNN_FB_CAP; }
+    double* fs = c.fb_s + (long long)q * KNN_FB_CAP; uint32_t* fi = c.fb_i + (long long)q * KNN_FB_CAP;
+    __shared__ double bs[256]; __shared__ uint32_t bi[256]; __shared__ int bp[256];
+    for (int j = 0; j < k; j++) {
+        double s = -INFINITY; uint32_t id = 0xffffffffu; int pos = -1;
+        for (int e = tid; e < cnt; e += 256) {
+            const double es = fs[e]; const uint32_t ei = fi[e];
+            if (ei != 0xffffffffu && (es > s || (es == s && ei < id))) { s = es; id = ei; pos = e; }
+        }
+        bs[tid] = s; bi[tid] = id; bp[tid] = pos;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o && (bs[tid + o] > bs[tid] || (bs[tid + o] == bs[tid] && bi[tid + o] < bi[tid]))) { bs[tid] = bs[tid + o]; bi[tid] = bi[tid + o]; bp[tid] = bp[tid + o]; }
+            __syncthreads();
+        }
+        if (tid == 0 && bp[0] >= 0) {
+            idx_out[(long long)(qbase + q) * k + j] = bi[0];
+            if (score_out) score_out[(long long)(qbase + q) * k + j] = (float)bs[0];
+            fi[bp[0]] = 0xffffffffu;                      // taken
+        }
+        __syncthreads();
     }
 }
 
@@ -510,7 +602,9 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
     const int nlists_cap = grid * 8;
     const size_t qn_b = (size_t)KNN_Q * db.dim * 4, qh_b = (size_t)KNN_Q * db.dim * 2;
     const size_t cand_b = (size_t)KNN_Q * nlists_cap * KSEL * 4;
-    const size_t need = qn_b + 2 * qh_b + 2 * cand_b + 1024;
+    const size_t cert_off = (qn_b + 2 * qh_b + 2 * cand_b + 255) & ~(size_t)255;
+    const size_t cert_b = 256 /*status*/ + KNN_Q * (4 + 8 + 4 + 4) + 256 + (size_t)KNN_Q * KNN_FB_CAP * 12;
+    const size_t need = cert_off + cert_b + 1024;
     if (db.scratch_bytes < need) {
         if (db.scratch) { KNN_TRY(hipStreamSynchronize(st)); KNN_TRY(hipFree(db.scratch)); db.scratch = nullptr; db.scratch_bytes = 0; }
         KNN_TRY(hipMalloc(&db.scratch, need)); db.scratch_bytes = need;
@@ -518,6 +612,18 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
     char* s = (char*)db.scratch;
     float* qn = (float*)s; _Float16* qh = (_Float16*)(s + qn_b); _Float16* ql = (_Float16*)(s + qn_b + qh_b);
     float* cs = (float*)(s + qn_b + 2 * qh_b); uint32_t* ci = (uint32_t*)(s + qn_b + 2 * qh_b + cand_b);
+    Certify cert{};
+    {
+        char* cb = s + cert_off;
+        cert.status = (int*)cb; cb += 256;
+        cert.tau = (double*)cb; cb += KNN_Q * 8;
+        cert.fb_s = (double*)cb; cb += (size_t)KNN_Q * KNN_FB_CAP * 8;
+        cert.fb_i = (uint32_t*)cb; cb += (size_t)KNN_Q * KNN_FB_CAP * 4;
+        cert.tau_idx = (uint32_t*)cb; cb += KNN_Q * 4;
+        cert.flag = (int*)cb; cb += KNN_Q * 4;
+        cert.fb_count = (int*)cb;
+    }
+    KNN_TRY(hipMemsetAsync(cert.status, 0, 4, st));
     if (!db.zero_page) { KNN_TRY(hipMalloc(&db.zero_page, 256)); KNN_TRY(hipMemset(db.zero_page, 0, 256)); }
     void* zero_page = db.zero_page;
     constexpr int scan_smem = 2 * (KNN_ROWS * 128 + 2 * KNN_Q * 128);
@@ -548,10 +654,20 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
         else knn_scan_kernel<KSEL><<<grid, 256, scan_smem, st>>>(sp);
         KNN_TRY(hipGetLastError());
         MergeParams mp{}; mp.cand_s = cs; mp.cand_i = ci; mp.nlists = sp.nlists; mp.dbn = (const _Float16*)db.dbn; mp.qn = qn;
-        mp.dim = db.dim; mp.n = db.n; mp.k = k; mp.idx_out = idx_out; mp.score_out = score_out; mp.qbase = q0;
+        mp.dim = db.dim; mp.n = db.n; mp.k = k; mp.idx_out = idx_out; mp.score_out = score_out; mp.qbase = q0; mp.cert = cert;
         knn_merge_kernel<KSEL><<<bq, 256, merge_smem, st>>>(mp);
         KNN_TRY(hipGetLastError());
+        // exact fallback for the flagged queries of this group (both kernels return at once when nothing is flagged)
+        knn_exact_collect_kernel<<<ncu * 4, 256, 0, st>>>(cert, (const _Float16*)db.dbn, qn, db.n, db.dim, bq);
+        KNN_TRY(hipGetLastError());
+        knn_exact_finish_kernel<<<bq, 256, 0, st>>>(cert, k, idx_out, score_out, q0);
+        KNN_TRY(hipGetLastError());
     }
+    int status = 0;
+    KNN_TRY(hipMemcpyAsync(&status, cert.status, 4, hipMemcpyDeviceToHost, st));
+    KNN_TRY(hipStreamSynchronize(st));
+    db.last_fallbacks = status & 1;
+    if (status & 2) return "exact fallback overflow: more than 8192 rows tie with the k-th neighbour within the score error bound";
     return nullptr;
 }
 

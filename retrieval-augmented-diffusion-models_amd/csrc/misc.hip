@@ -403,6 +403,59 @@ hipError_t launch_clip_patchify(const float* img, bf16_t* out, int B, int R, int
     clip_patchify_kernel<<<grid, 256, 0, st>>>(img, out, B, R, P);
     return hipGetLastError();
 }
+// ---------------------------------------------------------------- ClipImageRetriever.preprocess (rdm/modules/retrievers.py:83-91)
+// kornia.geometry.resize(x, (R,R), 'bicubic', align_corners=True, antialias=False) == torch upsample_bicubic2d: cubic
+// convolution with A = -0.75 over the 4x4 neighbourhood of the source position oy*(H-1)/(R-1), indices clamped to the image;
+// then (x+1)/2 and the CLIP mean / std.  One thread per output pixel and channel; PATCH = true writes straight into the bf16
+// patch matrix [B*G*G, 3*P*P] the patch-embedding GEMM reads (the f32 [B,3,R,R] intermediate never exists).
+__device__ __forceinline__ void cubic_coeffs(float t, float w[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.0f, x3 = 2.0f - t, x2 = 1.0f - t;
+    w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+    w[1] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+    w[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+    w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+struct PreprocParams { const float* img; int B, H, W, R, P; float sy, sx; float mean[3], istd[3]; };
+template <bool PATCH>
+__global__ __launch_bounds__(256) void clip_preprocess_kernel(PreprocParams p, float* out_f32, bf16_t* out_patch) {
+    const long long n = (long long)p.B * 3 * p.R * p.R;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % p.R), oy = (int)((i / p.R) % p.R), c = (int)((i / ((long long)p.R * p.R)) % 3), b = (int)(i / ((long long)3 * p.R * p.R));
+        const float ry = p.sy * oy, rx = p.sx * ox;
+        const float fy = floorf(ry), fx = floorf(rx);
+        const int iy = (int)fy, ix = (int)fx;
+        float wy[4], wx[4];
+        cubic_coeffs(ry - fy, wy); cubic_coeffs(rx - fx, wx);
+        const float* src = p.img + ((long long)b * 3 + c) * p.H * p.W;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const int yy = min(max(iy - 1 + a, 0), p.H - 1);
+            const float* row = src + (long long)yy * p.W;
+            float r = 0.f;
+#pragma unroll
+            for (int d = 0; d < 4; d++) r += wx[d] * row[min(max(ix - 1 + d, 0), p.W - 1)];
+            acc += wy[a] * r;
+        }
+        const float v = ((acc + 1.0f) * 0.5f - p.mean[c]) * p.istd[c];
+        if (PATCH) {
+            const int G = p.R / p.P, gy = oy / p.P, py = oy % p.P, gx = ox / p.P, px = ox % p.P;
+            out_patch[(((long long)b * G + gy) * G + gx) * (3 * p.P * p.P) + (c * p.P + py) * p.P + px] = f2bf(v);
+        } else out_f32[i] = v;
+    }
+}
+hipError_t launch_clip_preprocess(const float* img, int B, int H, int W, int R, int P, float* out_f32, bf16_t* out_patch, hipStream_t st) {
+    PreprocParams p{}; p.img = img; p.B = B; p.H = H; p.W = W; p.R = R; p.P = P;
+    p.sy = R > 1 ? (float)(H - 1) / (float)(R - 1) : 0.f; p.sx = R > 1 ? (float)(W - 1) / (float)(R - 1) : 0.f;   // area_pixel_compute_scale, align_corners
+    const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f}, sd[3] = {0.26862954f, 0.26130258f, 0.27577711f};     // retrievers.py:80-81
+    for (int c = 0; c < 3; c++) { p.mean[c] = mean[c]; p.istd[c] = 1.0f / sd[c]; }
+    const long long n = (long long)B * 3 * R * R;
+    int grid = (int)((n + 255) / 256); if (grid > 16384) grid = 16384; if (grid < 1) grid = 1;
+    if (out_patch) clip_preprocess_kernel<true><<<grid, 256, 0, st>>>(p, nullptr, out_patch);
+    else clip_preprocess_kernel<false><<<grid, 256, 0, st>>>(p, out_f32, nullptr);
+    return hipGetLastError();
+}
 // x[b, 0, :] = cls + pos[0]; x[b, 1+i, :] = patch[b*GG+i, :] + pos[1+i]  (model.py:221-222), f32
 __global__ void clip_vit_assemble_kernel(const float* patch, const float* cls, const float* pos, float* out, int B, int GG,
                                          int Wd) {

@@ -215,9 +215,12 @@ struct VqRes { int cin, cout; size_t n1g, n1b, w1, b1, n2g, n2b, w2, b2, wsk, bs
 struct VqAttn { int c; size_t ng, nb, wq, bq, wk, bk, wv, bv, wo, bo; };
 struct VqModel {
     rdm_vq_cfg cfg{}; bool loaded = false;
+    bool wide = false;                             // z_channels > 4 (taming VQGAN-f16: 256): latent handled as bf16 NHWC tokens, GEMM-class
+                                                   // post_quant_conv / conv_in; else the 3-channel VQ-f4 path (tiny fp32 stem kernels)
     size_t codebook, pqw, pqb, cinw, cinb, noutg, noutb, coutw, coutb;
     VqRes mid1, mid2; VqAttn attn;
     std::vector<std::vector<VqRes>> up_blocks;     // indexed by level
+    std::vector<std::vector<VqAttn>> up_attn;      // indexed by level: one AttnBlock per res block when the level's resolution is in attn_resolutions
     std::vector<ConvW> upsample;                   // indexed by level (level 0 unused)
     char* blob = nullptr; size_t blob_bytes = 0; Arena arena;
 };
@@ -235,32 +238,44 @@ static void build_vq(VqModel& v, const rdm_vq_cfg& c, Manifest& mf) {
         if (r.skip) { r.wsk = bf(pre + ".nin_shortcut.weight", (size_t)cout * cin); r.bsk = f32(pre + ".nin_shortcut.bias", cout); }
         return r;
     };
+    auto add_attn = [&](const std::string& p, int ch) {
+        VqAttn a{}; a.c = ch;
+        a.ng = f32(p + ".norm.weight", ch); a.nb = f32(p + ".norm.bias", ch);
+        a.wq = bf(p + ".q.weight", (size_t)ch * ch); a.bq = f32(p + ".q.bias", ch);
+        a.wk = bf(p + ".k.weight", (size_t)ch * ch); a.bk = f32(p + ".k.bias", ch);
+        a.wv = bf(p + ".v.weight", (size_t)ch * ch); a.bv = f32(p + ".v.bias", ch);
+        a.wo = bf(p + ".proj_out.weight", (size_t)ch * ch); a.bo = f32(p + ".proj_out.bias", ch);
+        return a;
+    };
+    v.wide = c.z_channels > 4;
     if (!c.kl) v.codebook = f32("quantize.embedding.weight", (size_t)c.n_embed * c.embed_dim);
-    v.pqw = f32("post_quant_conv.weight", (size_t)c.z_channels * c.embed_dim); v.pqb = f32("post_quant_conv.bias", c.z_channels);
     int bin = c.ch * c.ch_mult[c.n_ch_mult - 1];
-    v.cinw = f32("decoder.conv_in.weight", (size_t)bin * c.z_channels * 9); v.cinb = f32("decoder.conv_in.bias", bin);
-    v.mid1 = add_res("decoder.mid.block_1", bin, bin);
-    if (c.mid_attn) {
-        VqAttn a{}; a.c = bin; const std::string p = "decoder.mid.attn_1";
-        a.ng = f32(p + ".norm.weight", bin); a.nb = f32(p + ".norm.bias", bin);
-        a.wq = bf(p + ".q.weight", (size_t)bin * bin); a.bq = f32(p + ".q.bias", bin);
-        a.wk = bf(p + ".k.weight", (size_t)bin * bin); a.bk = f32(p + ".k.bias", bin);
-        a.wv = bf(p + ".v.weight", (size_t)bin * bin); a.bv = f32(p + ".v.bias", bin);
-        a.wo = bf(p + ".proj_out.weight", (size_t)bin * bin); a.bo = f32(p + ".proj_out.bias", bin);
-        v.attn = a;
+    if (v.wide) {
+        v.pqw = bf("post_quant_conv.weight", (size_t)c.z_channels * c.embed_dim); v.pqb = f32("post_quant_conv.bias", c.z_channels);
+        v.cinw = mf.add("conv3", "decoder.conv_in.weight", (size_t)bin * c.z_channels * 9 * 2); v.cinb = f32("decoder.conv_in.bias", bin);
+    } else {
+        v.pqw = f32("post_quant_conv.weight", (size_t)c.z_channels * c.embed_dim); v.pqb = f32("post_quant_conv.bias", c.z_channels);
+        v.cinw = f32("decoder.conv_in.weight", (size_t)bin * c.z_channels * 9); v.cinb = f32("decoder.conv_in.bias", bin);
     }
+    v.mid1 = add_res("decoder.mid.block_1", bin, bin);
+    if (c.mid_attn) v.attn = add_attn("decoder.mid.attn_1", bin);
     v.mid2 = add_res("decoder.mid.block_2", bin, bin);
-    v.up_blocks.assign(c.n_ch_mult, {}); v.upsample.assign(c.n_ch_mult, ConvW{});
+    v.up_blocks.assign(c.n_ch_mult, {}); v.upsample.assign(c.n_ch_mult, ConvW{}); v.up_attn.assign(c.n_ch_mult, {});
+    int curr_res = c.resolution >> (c.n_ch_mult - 1);
     for (int lvl = c.n_ch_mult - 1; lvl >= 0; lvl--) {
         const int bout = c.ch * c.ch_mult[lvl];
+        bool at = false;
+        for (int i = 0; i < c.n_attn_resolutions; i++) at = at || c.attn_resolutions[i] == curr_res;
         for (int i = 0; i <= c.num_res_blocks; i++) {
             char pre[64]; snprintf(pre, sizeof pre, "decoder.up.%d.block.%d", lvl, i);
             v.up_blocks[lvl].push_back(add_res(pre, bin, bout)); bin = bout;
+            if (at) { snprintf(pre, sizeof pre, "decoder.up.%d.attn.%d", lvl, i); v.up_attn[lvl].push_back(add_attn(pre, bin)); }
         }
         if (lvl != 0) {
             char pre[64]; snprintf(pre, sizeof pre, "decoder.up.%d.upsample.conv", lvl);
             ConvW u{}; u.c = bin; u.w = mf.add("conv3", std::string(pre) + ".weight", (size_t)bin * bin * 9 * 2);
             u.b = f32(std::string(pre) + ".bias", bin); v.upsample[lvl] = u;
+            curr_res *= 2;
         }
     }
     v.noutg = f32("decoder.norm_out.weight", bin); v.noutb = f32("decoder.norm_out.bias", bin);
@@ -307,11 +322,54 @@ static void build_clip(ClipModel& m, const rdm_clip_cfg& c, Manifest& mf) {
     m.tproj = mf.add("bf16_t", "text_projection", (size_t)tw * c.embed_dim * 2);
 }
 
+// ------------------------------------------------------------------------------------ RARM transformer description
+struct RarmBlk { size_t ln1g, ln1b, wqkv, wo1, bo1, ln2g, ln2b, wq2, wo2, bo2, ln3g, ln3b, wff1, bff1, wff2, bff2; };
+struct RarmModel {
+    rdm_rarm_cfg cfg{}; bool loaded = false; int C = 0, kv_total = 0;
+    std::vector<RarmBlk> blk;
+    size_t emb, pos, kvw, wpo, bpo;
+    char* blob = nullptr; size_t blob_bytes = 0; Arena arena;
+    // sampling state: per-layer self-attention K/V cache [depth][2][B'][L][C], projected neighbours [B'*k][depth*2*C],
+    // device step counter / completion counter / current tokens, logits of the current step
+    char* cache = nullptr; size_t cache_bytes = 0;
+    char* ctxkv = nullptr; size_t ctxkv_bytes = 0;
+    char* state = nullptr; size_t state_bytes = 0;
+};
+static void build_rarm(RarmModel& m, const rdm_rarm_cfg& c, Manifest& mf) {
+    m.cfg = c; m.blk.clear(); m.C = c.n_heads * c.d_head;
+    const int C = m.C;
+    auto f32 = [&](const std::string& n, size_t numel) { return mf.add("f32", n, numel * 4); };
+    auto bf = [&](const std::string& n, size_t numel) { return mf.add("bf16", n, numel * 2); };
+    m.emb = f32("proj_in.weight", (size_t)c.vocab_in * C);
+    m.pos = mf.add("f32_t", "positional_encoding", (size_t)C * c.sequence_length * 4);
+    std::string kv_srcs;
+    for (int i = 0; i < c.depth; i++) {
+        char b[64]; snprintf(b, sizeof b, "transformer_blocks.%d", i); const std::string p = b;
+        RarmBlk k{};
+        k.ln1g = f32(p + ".norm1.weight", C); k.ln1b = f32(p + ".norm1.bias", C);
+        k.wqkv = bf(p + ".attn1.to_q.weight," + p + ".attn1.to_k.weight," + p + ".attn1.to_v.weight", (size_t)3 * C * C);
+        k.wo1 = bf(p + ".attn1.to_out.0.weight", (size_t)C * C); k.bo1 = f32(p + ".attn1.to_out.0.bias", C);
+        k.ln2g = f32(p + ".norm2.weight", C); k.ln2b = f32(p + ".norm2.bias", C);
+        k.wq2 = bf(p + ".attn2.to_q.weight", (size_t)C * C);
+        k.wo2 = bf(p + ".attn2.to_out.0.weight", (size_t)C * C); k.bo2 = f32(p + ".attn2.to_out.0.bias", C);
+        k.ln3g = f32(p + ".norm3.weight", C); k.ln3b = f32(p + ".norm3.bias", C);
+        k.wff1 = mf.add("geglu_w", p + ".ff.net.0.proj.weight", (size_t)8 * C * C * 2);
+        k.bff1 = mf.add("geglu_b", p + ".ff.net.0.proj.bias", (size_t)8 * C * 4);
+        k.wff2 = bf(p + ".ff.net.2.weight", (size_t)C * 4 * C); k.bff2 = f32(p + ".ff.net.2.bias", C);
+        if (!kv_srcs.empty()) kv_srcs += ",";
+        kv_srcs += p + ".attn2.to_k.weight," + p + ".attn2.to_v.weight";
+        m.blk.push_back(k);
+    }
+    m.kv_total = c.depth * 2 * C;
+    m.kvw = mf.add("bf16", kv_srcs, (size_t)m.kv_total * c.context_dim * 2);      // the neighbours' K/V of ALL layers: one GEMM per sampling call
+    m.wpo = bf("proj_out.weight", (size_t)c.vocab_out * C); m.bpo = f32("proj_out.bias", c.vocab_out);
+}
+
 // ------------------------------------------------------------------------------------ context
 struct rdm_ctx {
     int device = 0; hipStream_t stream = nullptr; char err[512] = {0};
     void* zero_page = nullptr;
-    UNet unet; VqModel vq; ClipModel clip; KnnDb db;
+    UNet unet; VqModel vq; ClipModel clip; RarmModel rarm; KnnDb db;
     float* gn_partial = nullptr; size_t gn_partial_bytes = 0;
     char* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;   // fp32 partial planes of the K-split halo convs
     char* samp = nullptr; size_t samp_bytes = 0;     // sampler scratch
@@ -655,19 +713,10 @@ static int load_blob(rdm_ctx* c, M& m, const Manifest& mf, const void* packed, s
 }
 
 // ------------------------------------------------------------------------------------ VQ decode
-static void vq_body(Ops& o, VqModel& v, const float* z, int B, int force_not_quantize, float* img, int* idx_out) {
+// decoder trunk shared by the VQ-f4 (ldm) and VQGAN-f16 (taming) first stages: ResnetBlocks, AttnBlocks, nearest-2x upsample convs
+static void vq_trunk(Ops& o, VqModel& v, bf16_t* h, int B, int H, int W, float* img) {
     const rdm_vq_cfg& c = v.cfg;
-    const int zr = c.resolution >> (c.n_ch_mult - 1);
-    const int HW0 = zr * zr;
-    float* zq = o.af32((size_t)B * c.z_channels * HW0);
-    const int quant = (!c.kl && !force_not_quantize) ? 1 : 0;
-    if (!o.plan)
-        o.check(launch_vq_quantize(z, c.kl ? nullptr : o.w<float>(v.codebook), c.kl ? 0 : c.n_embed, o.w<float>(v.pqw), o.w<float>(v.pqb),
-                                   zq, idx_out, B, HW0, quant, o.c->stream), "vq_quantize");
     int bin = c.ch * c.ch_mult[c.n_ch_mult - 1];
-    int H = zr, W = zr;
-    bf16_t* h = o.abf((size_t)B * HW0 * bin);
-    if (!o.plan) o.check(launch_conv_in(zq, o.w<float>(v.cinw), o.w<float>(v.cinb), h, B, c.z_channels, H, W, bin, o.c->stream), "vq conv_in");
     auto res = [&](const VqRes& r, bf16_t* x) -> bf16_t* {
         const int HW = H * W, M = B * HW;
         bf16_t* n1 = o.abf((size_t)M * r.cin);
@@ -682,11 +731,10 @@ static void vq_body(Ops& o, VqModel& v, const float* z, int B, int force_not_qua
         o.conv3(n2, nullptr, r.cout, 0, r.w2, r.b2, B, H, W, r.cout, 1, 0, nullptr, 0, rs, out);
         return out;
     };
-    h = res(v.mid1, h);
-    if (c.mid_attn) {   // ldm AttnBlock: single head over H*W tokens, scale C^-1/2
-        const VqAttn& a = v.attn; const int C = a.c, n = H * W, M = B * n;
+    auto attn = [&](const VqAttn& a, bf16_t* x) -> bf16_t* {   // ldm / taming AttnBlock: single head over H*W tokens, scale C^-1/2
+        const int C = a.c, n = H * W, M = B * n;
         bf16_t* hn = o.abf((size_t)M * C);
-        o.groupnorm(h, nullptr, C, 0, B, n, a.ng, a.nb, 1e-6f, 0, hn);
+        o.groupnorm(x, nullptr, C, 0, B, n, a.ng, a.nb, 1e-6f, 0, hn);
         bf16_t* q = o.abf((size_t)M * C); bf16_t* kk = o.abf((size_t)M * C); bf16_t* vt = o.abf((size_t)M * C);
         o.linear(hn, nullptr, C, 0, a.wq, a.bq, true, M, C, ACT_NONE, nullptr, q);
         o.linear(hn, nullptr, C, 0, a.wk, a.bk, true, M, C, ACT_NONE, nullptr, kk);
@@ -706,12 +754,17 @@ static void vq_body(Ops& o, VqModel& v, const float* z, int B, int force_not_qua
             o.check(launch_igemm(pv, false, B, o.c->stream), "vq pv");
         }
         bf16_t* out = o.abf((size_t)M * C);
-        o.linear(ao, nullptr, C, 0, a.wo, a.bo, true, M, C, ACT_NONE, h, out);
-        h = out;
-    }
+        o.linear(ao, nullptr, C, 0, a.wo, a.bo, true, M, C, ACT_NONE, x, out);
+        return out;
+    };
+    h = res(v.mid1, h);
+    if (c.mid_attn) h = attn(v.attn, h);
     h = res(v.mid2, h);
     for (int lvl = c.n_ch_mult - 1; lvl >= 0; lvl--) {
-        for (const VqRes& r : v.up_blocks[lvl]) { h = res(r, h); bin = r.cout; }
+        for (size_t i = 0; i < v.up_blocks[lvl].size(); i++) {
+            h = res(v.up_blocks[lvl][i], h); bin = v.up_blocks[lvl][i].cout;
+            if (i < v.up_attn[lvl].size()) h = attn(v.up_attn[lvl][i], h);
+        }
         if (lvl != 0) {
             const ConvW& u = v.upsample[lvl];
             bf16_t* out = o.abf((size_t)B * (H * 2) * (W * 2) * u.c);
@@ -722,6 +775,38 @@ static void vq_body(Ops& o, VqModel& v, const float* z, int B, int force_not_qua
     bf16_t* no = o.abf((size_t)B * H * W * bin);
     o.groupnorm(h, nullptr, bin, 0, B, H * W, v.noutg, v.noutb, 1e-6f, 1, no);
     if (!o.plan) o.check(launch_conv_out(no, o.w<float>(v.coutw), o.w<float>(v.coutb), img, B, H, W, bin, c.out_ch, o.c->stream), "vq conv_out");
+}
+
+// VQ-f4 (3-channel latent): quantise (or not) + post_quant_conv + conv_in as tiny fp32 stem kernels, then the trunk
+static void vq_body(Ops& o, VqModel& v, const float* z, int B, int force_not_quantize, float* img, int* idx_out) {
+    const rdm_vq_cfg& c = v.cfg;
+    const int zr = c.resolution >> (c.n_ch_mult - 1);
+    const int HW0 = zr * zr;
+    float* zq = o.af32((size_t)B * c.z_channels * HW0);
+    const int quant = (!c.kl && !force_not_quantize) ? 1 : 0;
+    if (!o.plan)
+        o.check(launch_vq_quantize(z, c.kl ? nullptr : o.w<float>(v.codebook), c.kl ? 0 : c.n_embed, o.w<float>(v.pqw), o.w<float>(v.pqb),
+                                   zq, idx_out, B, HW0, quant, o.c->stream), "vq_quantize");
+    const int bin = c.ch * c.ch_mult[c.n_ch_mult - 1];
+    bf16_t* h = o.abf((size_t)B * HW0 * bin);
+    if (!o.plan) o.check(launch_conv_in(zq, o.w<float>(v.cinw), o.w<float>(v.cinb), h, B, c.z_channels, zr, zr, bin, o.c->stream), "vq conv_in");
+    vq_trunk(o, v, h, B, zr, zr, img);
+}
+
+// VQGAN-f16 (wide latent): decode_to_img from code indices (taming Net2NetTransformer.decode_to_img -> quantize.get_codebook_entry ->
+// VQModel.decode = post_quant_conv + Decoder; reached from transformer.py:296-312): codebook rows gathered straight into bf16
+// NHWC tokens, post_quant_conv (1x1) as a GEMM, conv_in as a 3x3 halo conv.
+static void vq_wide_body(Ops& o, VqModel& v, const long long* indices, int B, float* img) {
+    const rdm_vq_cfg& c = v.cfg;
+    const int zr = c.resolution >> (c.n_ch_mult - 1), HW0 = zr * zr, M = B * HW0;
+    bf16_t* zq = o.abf((size_t)M * c.embed_dim);
+    if (!o.plan) o.check(launch_codebook_gather(indices, o.w<float>(v.codebook), c.n_embed, c.embed_dim, M, zq, o.c->stream), "codebook gather");
+    bf16_t* h0 = o.abf((size_t)M * c.z_channels);
+    o.linear(zq, nullptr, c.embed_dim, 0, v.pqw, v.pqb, true, M, c.z_channels, ACT_NONE, nullptr, h0);
+    const int bin = c.ch * c.ch_mult[c.n_ch_mult - 1];
+    bf16_t* h = o.abf((size_t)M * bin);
+    o.conv3(h0, nullptr, c.z_channels, 0, v.cinw, v.cinb, B, zr, zr, bin, 1, 0, nullptr, 0, nullptr, h);
+    vq_trunk(o, v, h, B, zr, zr, img);
 }
 
 // ------------------------------------------------------------------------------------ CLIP
@@ -753,11 +838,16 @@ static void clip_text_body(Ops& o, ClipModel& m, const long long* tokens, int B,
     o.layernorm(eot, 1, m.lnfg, m.lnfb, ln, 0, B, Wd);
     o.linear(ln, nullptr, Wd, 0, m.tproj, 0, false, B, c.embed_dim, ACT_NONE, nullptr, nullptr, out);
 }
-static void clip_image_body(Ops& o, ClipModel& m, const float* img, int B, float* out) {
+// raw_h > 0: `img` is the un-preprocessed [B,3,raw_h,raw_w] image in [-1,1]; the bicubic resize + normalisation of
+// ClipImageRetriever.preprocess (rdm/modules/retrievers.py:83-91) is fused into the patch gather
+static void clip_image_body(Ops& o, ClipModel& m, const float* img, int B, float* out, int raw_h = 0, int raw_w = 0) {
     const rdm_clip_cfg& c = m.cfg; const int P = c.vision_patch_size, G = c.image_resolution / P, Wd = c.vision_width;
     const int K = 3 * P * P, L = G * G + 1;
     bf16_t* patches = o.abf((size_t)B * G * G * K); float* pe = o.af32((size_t)B * G * G * Wd);
-    if (!o.plan) o.check(launch_clip_patchify(img, patches, B, c.image_resolution, P, o.c->stream), "patchify");
+    if (!o.plan) {
+        if (raw_h > 0) o.check(launch_clip_preprocess(img, B, raw_h, raw_w, c.image_resolution, P, nullptr, patches, o.c->stream), "preprocess+patchify");
+        else o.check(launch_clip_patchify(img, patches, B, c.image_resolution, P, o.c->stream), "patchify");
+    }
     o.linear(patches, nullptr, K, 0, m.conv1, 0, false, B * G * G, Wd, ACT_NONE, nullptr, nullptr, pe);
     float* x0 = o.af32((size_t)B * L * Wd); float* x = o.af32((size_t)B * L * Wd);
     if (!o.plan) o.check(launch_clip_vit_assemble(pe, o.w<float>(m.cls), o.w<float>(m.vpos), x0, B, G * G, Wd, o.c->stream), "vit assemble");
@@ -798,7 +888,8 @@ void rdm_ctx_destroy(rdm_ctx* c) {
     DevGuard guard(c->device);
     hipDeviceSynchronize();
     void* ptrs[] = {c->zero_page, c->unet.blob, c->unet.arena.base, c->unet.kv_cache, c->vq.blob, c->vq.arena.base,
-                    c->clip.blob, c->clip.arena.base, c->gn_partial, c->samp, c->splitk_ws, c->unet.xa_cache};
+                    c->clip.blob, c->clip.arena.base, c->gn_partial, c->samp, c->splitk_ws, c->unet.xa_cache,
+                    c->rarm.blob, c->rarm.arena.base, c->rarm.cache, c->rarm.ctxkv, c->rarm.state};
     for (void* p : ptrs) if (p) hipFree(p);
     knn_free(c->db);
     delete c;
@@ -813,7 +904,7 @@ long long rdm_unet_manifest(const rdm_unet_cfg* cfg, char* buf, size_t buflen, s
     return write_manifest(mf, buf, buflen, blob_bytes);
 }
 long long rdm_vq_manifest(const rdm_vq_cfg* cfg, char* buf, size_t buflen, size_t* blob_bytes) {
-    if (!cfg || cfg->n_ch_mult < 1 || cfg->n_ch_mult > RDM_MAX_LEVELS) return -1;
+    if (!cfg || cfg->n_ch_mult < 1 || cfg->n_ch_mult > RDM_MAX_LEVELS || cfg->n_attn_resolutions < 0 || cfg->n_attn_resolutions > RDM_MAX_LEVELS) return -1;
     VqModel v; Manifest mf; build_vq(v, *cfg, mf);
     return write_manifest(mf, buf, buflen, blob_bytes);
 }
@@ -833,8 +924,9 @@ int rdm_load_unet(rdm_ctx* c, const rdm_unet_cfg* cfg, const void* packed, size_
 int rdm_load_vq(rdm_ctx* c, const rdm_vq_cfg* cfg, const void* packed, size_t nbytes) {
     RDM_ENTER(c);
     if (!c || !cfg) return -1;
-    if (cfg->embed_dim != 3 || cfg->z_channels != 3 || cfg->ch % 64 || cfg->out_ch > 4)
-        return c->fail(-1, "unsupported vq cfg: embed_dim == z_channels == 3, ch %% 64 == 0 required");
+    if (cfg->ch % 64 || cfg->out_ch > 4 || cfg->n_attn_resolutions < 0 || cfg->n_attn_resolutions > RDM_MAX_LEVELS ||
+        !((cfg->embed_dim == 3 && cfg->z_channels == 3) || (cfg->embed_dim % 64 == 0 && cfg->z_channels % 64 == 0 && !cfg->kl)))
+        return c->fail(-1, "unsupported vq cfg: ch %% 64 == 0 and either embed_dim == z_channels == 3 (VQ-f4 / KL-f4) or both multiples of 64 (VQGAN-f16)");
     Manifest mf; build_vq(c->vq, *cfg, mf);
     return load_blob(c, c->vq, mf, packed, nbytes);
 }
@@ -1012,8 +1104,17 @@ int rdm_vq_decode(rdm_ctx* c, const float* z, int b, int force_not_quantize, flo
     RDM_ENTER(c);
     if (!c || !z || !img_out) return c ? c->fail(-1, "null argument") : -1;
     if (!c->vq.loaded) return c->fail(-1, "vq weights not loaded");
+    if (c->vq.wide) return c->fail(-1, "this first stage has a wide latent (VQGAN-f16): decode from code indices with rdm_vq_decode_indices");
     RDM_TRY(ensure_gn_partial(c, b));
     return run_with_arena(c, c->vq.arena, c->vq.blob, [&](Ops& o) { vq_body(o, c->vq, z, b, force_not_quantize, img_out, indices_out); });
+}
+int rdm_vq_decode_indices(rdm_ctx* c, const int64_t* indices, int b, float* img_out) {
+    RDM_ENTER(c);
+    if (!indices || !img_out || b < 1) return c->fail(-1, "bad argument");
+    if (!c->vq.loaded) return c->fail(-1, "vq weights not loaded");
+    if (!c->vq.wide || c->vq.cfg.kl) return c->fail(-1, "rdm_vq_decode_indices needs a VQGAN first stage with a wide latent (z_channels %% 64 == 0)");
+    RDM_TRY(ensure_gn_partial(c, b));
+    return run_with_arena(c, c->vq.arena, c->vq.blob, [&](Ops& o) { vq_wide_body(o, c->vq, (const long long*)indices, b, img_out); });
 }
 
 int rdm_to_uint8(rdm_ctx* c, const float* img, int b, int ch, int h, int w, uint8_t* out) {
@@ -1034,6 +1135,149 @@ int rdm_clip_encode_image(rdm_ctx* c, const float* image, int b, float* out) {
     if (!c || !image || !out) return c ? c->fail(-1, "null argument") : -1;
     if (!c->clip.loaded) return c->fail(-1, "clip weights not loaded");
     return run_with_arena(c, c->clip.arena, c->clip.blob, [&](Ops& o) { clip_image_body(o, c->clip, image, b, out); });
+}
+
+int rdm_clip_preprocess(rdm_ctx* c, const float* image, int b, int h, int w, float* out) {
+    RDM_ENTER(c);
+    if (!image || !out || b < 1 || h < 1 || w < 1) return c->fail(-1, "bad argument");
+    if (!c->clip.loaded) return c->fail(-1, "clip weights not loaded (the target resolution comes from the clip cfg)");
+    RDM_CHECK_HIP(c, launch_clip_preprocess(image, b, h, w, c->clip.cfg.image_resolution, c->clip.cfg.vision_patch_size, out, nullptr, c->stream));
+    return 0;
+}
+int rdm_clip_encode_image_raw(rdm_ctx* c, const float* image, int b, int h, int w, float* out) {
+    RDM_ENTER(c);
+    if (!image || !out || b < 1 || h < 1 || w < 1) return c->fail(-1, "bad argument");
+    if (!c->clip.loaded) return c->fail(-1, "clip weights not loaded");
+    return run_with_arena(c, c->clip.arena, c->clip.blob, [&](Ops& o) { clip_image_body(o, c->clip, image, b, out, h, w); });
+}
+
+// ---- RARM (kernels in rarm.hip)
+struct RarmState { int* pos; int* done; long long* tokens; float* logits; };
+static RarmState rarm_state(RarmModel& m, int B2) {
+    RarmState st{};
+    st.pos = (int*)m.state; st.done = (int*)(m.state + 64); st.tokens = (long long*)(m.state + 256);
+    st.logits = (float*)(m.state + 256 + (((size_t)B2 * 8 + 255) & ~(size_t)255));
+    return st;
+}
+static int rarm_prepare(rdm_ctx* c, int B2, int k, const float* context /*[B,k,cd] dev*/, int B, bool cfg) {
+    RarmModel& m = c->rarm; const rdm_rarm_cfg& g = m.cfg; const int C = m.C, L = g.sequence_length;
+    RDM_TRY(ensure_bytes(c, &m.cache, &m.cache_bytes, (size_t)g.depth * 2 * B2 * L * C * 2));
+    RDM_TRY(ensure_bytes(c, &m.ctxkv, &m.ctxkv_bytes, (size_t)B2 * k * m.kv_total * 2));
+    RDM_TRY(ensure_bytes(c, &m.state, &m.state_bytes, 256 + (((size_t)B2 * 8 + 255) & ~(size_t)255) + (size_t)B2 * g.vocab_out * 4));
+    RDM_CHECK_HIP(c, hipMemsetAsync(m.state, 0, 256, c->stream));
+    // neighbours' keys / values of every layer in one GEMM; the unconditional half of a guided batch attends to ZERO neighbours
+    // (transformer.py:237-239), whose projections are zero (to_k / to_v have no bias)
+    RDM_CHECK_HIP(c, hipMemsetAsync(m.ctxkv, 0, (size_t)B2 * k * m.kv_total * 2, c->stream));
+    return run_with_arena(c, m.arena, m.blob, [&](Ops& o) {
+        bf16_t* cb = o.abf((size_t)B * k * g.context_dim);
+        if (!o.plan) o.check(launch_cast_f32_bf16(context, cb, (long long)B * k * g.context_dim, c->stream), "cast ctx");
+        o.linear(cb, nullptr, g.context_dim, 0, m.kvw, 0, false, B * k, m.kv_total, ACT_NONE, nullptr, (bf16_t*)m.ctxkv);
+    });
+}
+// one decode step for B2 sequences: token at position *pos -> logits of the next token
+static int rarm_step(rdm_ctx* c, int B2, int k) {
+    RarmModel& m = c->rarm; const rdm_rarm_cfg& g = m.cfg; const int C = m.C, L = g.sequence_length;
+    RarmState st = rarm_state(m, B2);
+    return run_with_arena(c, m.arena, m.blob, [&](Ops& o) {
+        float* x = o.af32((size_t)B2 * C);
+        bf16_t* ln = o.abf((size_t)B2 * C); bf16_t* qkv = o.abf((size_t)B2 * 3 * C); bf16_t* ao = o.abf((size_t)B2 * C);
+        bf16_t* q2 = o.abf((size_t)B2 * C); bf16_t* ff = o.abf((size_t)B2 * 4 * C);
+        if (!o.plan) o.check(launch_rarm_embed(st.tokens, o.w<float>(m.emb), o.w<float>(m.pos), st.pos, x, B2, C, g.vocab_in, c->stream), "rarm embed");
+        const float scale = 1.0f / sqrtf((float)g.d_head);
+        for (int l = 0; l < g.depth; l++) {
+            const RarmBlk& b = m.blk[l];
+            o.layernorm(x, 1, b.ln1g, b.ln1b, ln, 0, B2, C);
+            o.linear(ln, nullptr, C, 0, b.wqkv, 0, false, B2, 3 * C, ACT_NONE, nullptr, qkv);
+            if (!o.plan) {
+                RarmAttnParams p{}; p.q = qkv; p.ldq = 3 * C; p.k_new = qkv + C; p.v_new = qkv + 2 * C;
+                p.Kc = (bf16_t*)m.cache + ((size_t)l * 2) * B2 * L * C; p.Vc = (bf16_t*)m.cache + ((size_t)l * 2 + 1) * B2 * L * C;
+                p.batch_stride = (long long)L * C; p.row_stride = C; p.nkv = L; p.pos = st.pos; p.scale = scale; p.out = ao; p.ldo = C;
+                o.check(launch_rarm_decode_attention(p, g.n_heads, B2, c->stream), "rarm self attention");
+            }
+            o.linear(ao, nullptr, C, 0, b.wo1, b.bo1, true, B2, C, ACT_NONE, nullptr, nullptr, x, x);
+            o.layernorm(x, 1, b.ln2g, b.ln2b, ln, 0, B2, C);
+            o.linear(ln, nullptr, C, 0, b.wq2, 0, false, B2, C, ACT_NONE, nullptr, q2);
+            if (!o.plan) {
+                RarmAttnParams p{}; p.q = q2; p.ldq = C; p.Kc = (bf16_t*)m.ctxkv + (size_t)l * 2 * C; p.Vc = (bf16_t*)m.ctxkv + (size_t)l * 2 * C + C;
+                p.batch_stride = (long long)k * m.kv_total; p.row_stride = m.kv_total; p.nkv = k; p.scale = scale; p.out = ao; p.ldo = C;
+                o.check(launch_rarm_decode_attention(p, g.n_heads, B2, c->stream), "rarm cross attention");
+            }
+            o.linear(ao, nullptr, C, 0, b.wo2, b.bo2, true, B2, C, ACT_NONE, nullptr, nullptr, x, x);
+            o.layernorm(x, 1, b.ln3g, b.ln3b, ln, 0, B2, C);
+            o.linear(ln, nullptr, C, 0, b.wff1, b.bff1, true, B2, 8 * C, ACT_GEGLU, nullptr, ff);
+            o.linear(ff, nullptr, 4 * C, 0, b.wff2, b.bff2, true, B2, C, ACT_NONE, nullptr, nullptr, x, x);
+        }
+        if (!o.plan) o.check(launch_cast_f32_bf16(x, ln, (long long)B2 * C, c->stream), "cast x");
+        o.linear(ln, nullptr, C, 0, m.wpo, m.bpo, true, B2, g.vocab_out, ACT_NONE, nullptr, nullptr, st.logits);
+    });
+}
+static int rarm_check(rdm_ctx* c, int b, int k, int positions) {
+    RarmModel& m = c->rarm;
+    if (!m.loaded) return c->fail(-1, "rarm weights not loaded");
+    if (b < 1 || k < 1 || k > 1024) return c->fail(-1, "bad rarm shape b=%d k=%d", b, k);
+    if (positions < 1 || positions > m.cfg.sequence_length)
+        return c->fail(-1, "%d positions exceed the positional encoding (sequence_length %d)", positions, m.cfg.sequence_length);
+    return 0;
+}
+// column i of a [b, t] int64 token matrix -> the current-token buffer (optionally duplicated for the unconditional half)
+static int rarm_set_tokens(rdm_ctx* c, RarmState& st, const int64_t* tokens, int b, int t, int i, bool dup) {
+    RDM_CHECK_HIP(c, hipMemcpy2DAsync(st.tokens, 8, tokens + i, (size_t)t * 8, 8, b, hipMemcpyDeviceToDevice, c->stream));
+    if (dup) RDM_CHECK_HIP(c, hipMemcpy2DAsync(st.tokens + b, 8, tokens + i, (size_t)t * 8, 8, b, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+long long rdm_rarm_manifest(const rdm_rarm_cfg* cfg, char* buf, size_t buflen, size_t* blob_bytes) {
+    if (!cfg || cfg->depth < 1 || cfg->n_heads < 1) return -1;
+    RarmModel m; Manifest mf; build_rarm(m, *cfg, mf);
+    return write_manifest(mf, buf, buflen, blob_bytes);
+}
+int rdm_load_rarm(rdm_ctx* c, const rdm_rarm_cfg* cfg, const void* packed, size_t nbytes) {
+    RDM_ENTER(c);
+    if (!cfg) return c->fail(-1, "null cfg");
+    if (cfg->d_head != 64 || cfg->context_dim % 64 || cfg->sequence_length > 1024 || cfg->vocab_out % 2 || cfg->depth < 1)
+        return c->fail(-1, "unsupported rarm cfg: d_head == 64, context_dim %% 64 == 0, sequence_length <= 1024, even vocab_out required");
+    Manifest mf; build_rarm(c->rarm, *cfg, mf);
+    return load_blob(c, c->rarm, mf, packed, nbytes);
+}
+int rdm_rarm_forward(rdm_ctx* c, const int64_t* tokens, int b, int t, const float* context, int k, float* logits_out) {
+    RDM_ENTER(c);
+    if (!tokens || !context || !logits_out) return c->fail(-1, "null argument");
+    RDM_TRY(rarm_check(c, b, k, t));
+    RarmModel& m = c->rarm;
+    RDM_TRY(rarm_prepare(c, b, k, context, b, false));
+    RarmState st = rarm_state(m, b);
+    const size_t V = m.cfg.vocab_out;
+    for (int i = 0; i < t; i++) {
+        RDM_TRY(rarm_set_tokens(c, st, tokens, b, t, i, false));
+        RDM_CHECK_HIP(c, launch_set_int(st.pos, i, c->stream));
+        RDM_TRY(rarm_step(c, b, k));
+        RDM_CHECK_HIP(c, hipMemcpy2DAsync(logits_out + (size_t)i * V, (size_t)t * V * 4, st.logits, V * 4, V * 4, b, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return 0;
+}
+int rdm_rarm_sample(rdm_ctx* c, const rdm_rarm_sample_args* a, const int64_t* cond_tokens, const float* context, const float* uniforms,
+                    int64_t* tokens_out) {
+    RDM_ENTER(c);
+    if (!a || !cond_tokens || !context || !uniforms || !tokens_out) return c->fail(-1, "null argument");
+    if (a->cond_len < 1 || a->steps < 1 || a->temperature <= 0.f) return c->fail(-1, "bad sampling arguments");
+    RDM_TRY(rarm_check(c, a->batch, a->k, a->cond_len + a->steps - 1));
+    RarmModel& m = c->rarm;
+    const bool cfg = a->guidance_scale > 1.0f;
+    const int B = a->batch, B2 = cfg ? 2 * B : B, k = a->k;
+    RDM_TRY(rarm_prepare(c, B2, k, context, B, cfg));
+    RarmState st = rarm_state(m, B2);
+    for (int i = 0; i < a->cond_len; i++) {                    // prefill the conditioning tokens (the sos token)
+        RDM_TRY(rarm_set_tokens(c, st, cond_tokens, B, a->cond_len, i, cfg));
+        RDM_CHECK_HIP(c, launch_set_int(st.pos, i, c->stream));
+        if (i + 1 < a->cond_len) RDM_TRY(rarm_step(c, B2, k));
+    }
+    RarmSampleParams sp{}; sp.logits = st.logits; sp.vocab = m.cfg.vocab_out; sp.B = B; sp.cfg = cfg ? 1 : 0; sp.scale = a->guidance_scale;
+    sp.temperature = a->temperature; sp.top_k = a->top_k > 0 ? a->top_k : m.cfg.vocab_out; sp.uniforms = uniforms; sp.pos = st.pos;
+    sp.pos0 = a->cond_len - 1; sp.steps = a->steps; sp.tokens_out = (long long*)tokens_out; sp.next_tokens = st.tokens; sp.done = st.done;
+    for (int s_ = 0; s_ < a->steps; s_++) {                    // every step: the same launches (the step counter lives on the device)
+        RDM_TRY(rarm_step(c, B2, k));
+        RDM_CHECK_HIP(c, launch_rarm_sample(sp, c->stream));
+    }
+    return 0;
 }
 
 // ---- retrieval (kernels in knn.hip)
@@ -1057,6 +1301,7 @@ int rdm_knn(rdm_ctx* c, const float* q, int b, int k, uint32_t* idx_out, float* 
     if (prof) hipEventRecord(c->prof_recs.back().b, c->stream);
     return msg ? c->fail(-5, "rdm_knn: %s", msg) : 0;
 }
+int rdm_knn_last_fallback(rdm_ctx* c) { return c ? c->db.last_fallbacks : -1; }
 int rdm_db_gather(rdm_ctx* c, const uint32_t* idx, long long n_idx, float* out) {
     RDM_ENTER(c);
     if (!c || !idx || !out) return -1;

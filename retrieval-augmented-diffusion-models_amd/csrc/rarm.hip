@@ -1,0 +1,185 @@
+// Kernels of the RARM (retrieval-augmented autoregressive) sampling path on gfx950:
+//   LatentImageRETRO.sample              rdm/models/autoregression/transformer.py:224-294
+//   RetrievalPatchTransformer.forward    rdm/modules/attention.py:199-272 (continuous=False: token embedding + positional
+//                                        encoding, 18 causal BasicTransformerBlocks with cross-attention to the k neighbours)
+//   top_k_logits / softmax / multinomial transformer.py:256-270 (taming Net2NetTransformer.top_k_logits)
+// The reference re-runs the transformer over the WHOLE prefix for each of the 256 new tokens (:241-248, 32 896 token-forwards
+// per image); here every step processes one token per sequence against a K/V cache.  A decode step is M = B' (<= 128) rows, so
+// the linear layers are weight-bandwidth-bound launches of the shared GEMM (igemm.hip); what is new is below.
+//
+// The step index lives in DEVICE memory (`pos`): every kernel of a step reads it, the sampler increments it — so the launches
+// of all steps are identical and nothing on the host depends on the step.
+#include "kernels.h"
+
+// ---------------------------------------------------------------- token embedding + positional encoding
+// x[b, :] = proj_in.weight[token[b]] + positional_encoding[:, pos]   (attention.py:252-258), fp32 residual stream
+__global__ __launch_bounds__(256) void rarm_embed_kernel(const long long* tokens, const float* emb, const float* pos_t /*[L][C]*/,
+                                                         const int* pos, float* x, int B, int C, int vocab) {
+    const int b = blockIdx.x, t = *pos;
+    long long tok = tokens[b];
+    if (tok < 0 || tok >= vocab) tok = 0;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) x[(long long)b * C + c] = emb[tok * C + c] + pos_t[(long long)t * C + c];
+}
+hipError_t launch_rarm_embed(const long long* tokens, const float* emb, const float* pos_t, const int* pos, float* x, int B, int C,
+                             int vocab, hipStream_t st) {
+    rarm_embed_kernel<<<B, 256, 0, st>>>(tokens, emb, pos_t, pos, x, B, C, vocab);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- decode-step attention against a K/V cache (d_head = 64)
+// One wave per (head, sequence).  Self-attention (attn1, causal): the new token's k / v rows are appended to the cache at
+// position *pos and the query attends to rows 0..*pos.  Cross-attention (attn2): k_new == null, the cache holds the
+// projected neighbours and all nkv rows are attended.  Phase 1: lane j scores keys j, j+64, ...; phase 2: lane d
+// accumulates sum_j p_j V[j][d] with coalesced 128-byte row reads.  CrossAttention.forward, attention.py:42-74.
+__global__ __launch_bounds__(64) void rarm_decode_attention_kernel(RarmAttnParams p) {
+    constexpr int D = 64;
+    __shared__ float sc[1024];
+    __shared__ float qs[D];
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int t = p.pos ? *p.pos : 0;
+    const int n = p.k_new ? t + 1 : p.nkv;
+    bf16_t* Kc = p.Kc + (long long)b * p.batch_stride + h * D;
+    bf16_t* Vc = p.Vc + (long long)b * p.batch_stride + h * D;
+    qs[lane] = bf2f(p.q[(long long)b * p.ldq + h * D + lane]) * p.scale;
+    if (p.k_new) {       // append the new row (visible to this wave only through the registers below; other waves own other heads)
+        Kc[(long long)t * p.row_stride + lane] = p.k_new[(long long)b * p.ldq + h * D + lane];
+        Vc[(long long)t * p.row_stride + lane] = p.v_new[(long long)b * p.ldq + h * D + lane];
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = lane; j < n; j += 64) {
+        const bf16_t* kr = (p.k_new && j == t) ? p.k_new + (long long)b * p.ldq + h * D : Kc + (long long)j * p.row_stride;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; c += 8) {
+            const bf16x8 kk = *(const bf16x8*)(kr + c);
+#pragma unroll
+            for (int e = 0; e < 8; e++) s += qs[c + e] * bf2f((bf16_t)kk[e]);
+        }
+        sc[j] = s; m = fmaxf(m, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float l = 0.f;
+    for (int j = lane; j < n; j += 64) { const float e = __expf(sc[j] - m); sc[j] = e; l += e; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+    __syncthreads();
+    float acc = 0.f;
+    for (int j = 0; j < n; j++) {
+        const bf16_t* vr = (p.k_new && j == t) ? p.v_new + (long long)b * p.ldq + h * D : Vc + (long long)j * p.row_stride;
+        acc += sc[j] * bf2f(vr[lane]);
+    }
+    p.out[(long long)b * p.ldo + h * D + lane] = f2bf(acc / l);
+}
+hipError_t launch_rarm_decode_attention(const RarmAttnParams& p, int heads, int batch, hipStream_t st) {
+    if (p.nkv > 1024) return hipErrorInvalidValue;
+    rarm_decode_attention_kernel<<<dim3(heads, batch), 64, 0, st>>>(p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- CFG + temperature + top-k filter + softmax + multinomial
+// transformer.py:250-270.  One block per sequence: logits = l_u + s (l_c - l_u) (rows b and b + B of the doubled batch),
+// / temperature, values below the k-th largest -> -inf (taming top_k_logits keeps ties with the k-th), softmax, then ONE draw by
+// inverse CDF with the caller's uniform u in [0,1): the smallest index whose cumulative probability exceeds u * total, in
+// vocabulary order (torch.multinomial's device-specific random stream has no cross-device definition; the uniform is an input
+// so that the draw is reproducible and checkable).  The k-th largest value is found by a 4-pass radix select on the
+// order-preserving integer image of the floats.  Writes the token to out[b, *pos], to the next-step token buffer (both CFG
+// halves), and — last block — advances *pos.
+__device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+
+__global__ __launch_bounds__(256) void rarm_sample_kernel(RarmSampleParams p) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sel_prefix; __shared__ int sel_remaining;
+    __shared__ float red[256];
+    __shared__ int chosen;
+    const int b = blockIdx.x, tid = threadIdx.x, V = p.vocab;
+    const int t = *p.pos;
+    const float* lc = p.logits + (long long)b * V;
+    const float* lu = p.cfg ? p.logits + (long long)(b + p.B) * V : nullptr;
+    const float inv_t = 1.0f / p.temperature;
+    auto logit = [&](int i) { const float c = lc[i]; return (lu ? lu[i] + p.scale * (c - lu[i]) : c) * inv_t; };
+    // ---- radix select of the top_k-th largest value
+    uint32_t prefix = 0; int remaining = p.top_k < V ? p.top_k : V;
+    for (int pass = 3; pass >= 0; pass--) {
+        hist[tid] = 0;
+        __syncthreads();
+        const uint32_t mask = pass == 3 ? 0u : (0xffffffffu << ((pass + 1) * 8));
+        for (int i = tid; i < V; i += 256) {
+            const uint32_t o = f2ord(logit(i));
+            if ((o & mask) == (prefix & mask)) atomicAdd(&hist[(o >> (pass * 8)) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int rem = remaining; int d = 255;
+            for (; d > 0; d--) { if ((int)hist[d] >= rem) break; rem -= (int)hist[d]; }
+            sel_prefix = prefix | ((uint32_t)d << (pass * 8)); sel_remaining = rem;
+        }
+        __syncthreads();
+        prefix = sel_prefix; remaining = sel_remaining;
+        __syncthreads();
+    }
+    const uint32_t kth = prefix;                          // order image of the k-th largest logit: keep o >= kth
+    // ---- max, then per-thread partial sums over a CONTIGUOUS chunk (vocabulary order), block scan, locate the draw
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 256) { const float v = logit(i); if (f2ord(v) >= kth) mx = fmaxf(mx, v); }
+    red[tid] = mx; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+    mx = red[0]; __syncthreads();
+    const int chunk = (V + 255) / 256, i0 = tid * chunk, i1 = min(V, i0 + chunk);
+    float part = 0.f;
+    for (int i = i0; i < i1; i++) { const float v = logit(i); if (f2ord(v) >= kth) part += __expf(v - mx); }
+    red[tid] = part; __syncthreads();
+    if (tid == 0) {
+        float total = 0.f;
+        for (int j = 0; j < 256; j++) total += red[j];
+        const float target = p.uniforms[(long long)(t - p.pos0) * p.B + b] * total;
+        float run = 0.f; int c = 255;
+        for (int j = 0; j < 256; j++) { if (run + red[j] > target) { c = j; break; } run += red[j]; }
+        // (if rounding pushed the target past the total, fall into the last non-empty chunk)
+        while (c > 0 && red[c] == 0.f) c--;
+        chosen = c; red[0] = run; red[1] = target;
+    }
+    __syncthreads();
+    if (tid == chosen) {
+        float run = red[0]; const float target = red[1];
+        int pick = -1, last = -1;
+        for (int i = i0; i < i1; i++) {
+            const float v = logit(i);
+            if (f2ord(v) < kth) continue;
+            last = i; run += __expf(v - mx);
+            if (run > target) { pick = i; break; }
+        }
+        if (pick < 0) pick = last;
+        p.tokens_out[(long long)b * p.steps + (t - p.pos0)] = pick;
+        p.next_tokens[b] = pick;
+        if (p.cfg) p.next_tokens[b + p.B] = pick;
+        __threadfence();
+        if (atomicAdd(p.done, 1) == p.B - 1) { *p.done = 0; *p.pos = t + 1; }     // last sequence of the step advances the clock
+    }
+}
+hipError_t launch_rarm_sample(const RarmSampleParams& p, hipStream_t st) {
+    rarm_sample_kernel<<<p.B, 256, 0, st>>>(p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- VQGAN codebook lookup (taming VectorQuantizer2.get_codebook_entry)
+// indices [B*HW] -> bf16 token-major [B*HW, E] (== NHWC), the layout post_quant_conv (1x1) reads as a GEMM operand
+__global__ __launch_bounds__(256) void codebook_gather_kernel(const long long* idx, const float* codebook, int n_embed, int E, long long n,
+                                                              bf16_t* out) {
+    const long long total = n * E;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / E; const int c = (int)(i - r * E);
+        long long id = idx[r]; if (id < 0 || id >= n_embed) id = 0;
+        out[i] = f2bf(codebook[id * E + c]);
+    }
+}
+hipError_t launch_codebook_gather(const long long* idx, const float* codebook, int n_embed, int E, long long n, bf16_t* out, hipStream_t st) {
+    const long long total = n * E;
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+    codebook_gather_kernel<<<grid, 256, 0, st>>>(idx, codebook, n_embed, E, n, out);
+    return hipGetLastError();
+}
+// f32 [rows, C] += nothing; bf16 copy of the fp32 residual stream for the logits GEMM is launch_cast_f32_bf16 (misc.hip)
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
+hipError_t launch_set_int(int* p, int v, hipStream_t st) { set_int_kernel<<<1, 1, 0, st>>>(p, v); return hipGetLastError(); }

@@ -5,7 +5,6 @@ reference's call surface: `retriever(x)` on images in [-1, 1], `.model.encode_te
 return UN-normalised embeddings (callers do `.cpu().numpy()`, dsetbuilder.py:473).
 """
 import torch
-import torch.nn.functional as F
 
 from .. import _lib, packing
 from .custom_clip.tokenizer import tokenize
@@ -22,6 +21,9 @@ class _NativeClip:
 
     def encode_image(self, image):
         return self.ctx.clip_encode_image(image)
+
+    def encode_image_raw(self, image):
+        return self.ctx.clip_encode_image_raw(image)
 
 
 def load_clip(name="ViT-B/32", device=0, jit=False, state_dict=None, ctx=None, clip_cfg=None):
@@ -41,6 +43,8 @@ def load_clip(name="ViT-B/32", device=0, jit=False, state_dict=None, ctx=None, c
 class ClipImageRetriever(object):
     def __init__(self, model="ViT-B/32", jit=False, device=0, antialias=False, state_dict=None, ctx=None, clip_cfg=None):
         self.model, _ = load_clip(name=model, device=device, jit=jit, state_dict=state_dict, ctx=ctx, clip_cfg=clip_cfg)
+        if antialias:
+            raise NotImplementedError("antialias=True (kornia's gaussian pre-blur): no shipped config sets it (retrievers.py:73)")
         self.antialias = antialias
         self.device = self.model.ctx.device
         self.mean = torch.tensor([0.48145466, 0.4578275, 0.40821073], device=self.device)
@@ -51,16 +55,13 @@ class ClipImageRetriever(object):
 
     def preprocess(self, x):
         """retrievers.py:83-91: bicubic resize to the tower resolution (align_corners=True), [-1,1] -> [0,1], CLIP
-        mean/std.  (kornia 0.6.2 is un-vendored; torch's bicubic with align_corners=True is the same kernel.)"""
-        r = self.model.cfg.image_resolution
-        x = x.to(self.device, torch.float32)
-        if x.shape[-2:] != (r, r):
-            x = F.interpolate(x, size=(r, r), mode="bicubic", align_corners=True, antialias=self.antialias)
-        x = (x + 1.) / 2.
-        return (x - self.mean[None, :, None, None]) / self.std[None, :, None, None]
+        mean/std — one HIP kernel (rdm_clip_preprocess).  kornia 0.6.2's resize is `F.interpolate(mode='bicubic',
+        align_corners=True)`, i.e. cubic convolution with A = -0.75 and clamped borders; that is what the kernel computes."""
+        return self.model.ctx.clip_preprocess(x)
 
     def forward(self, x):
-        return self.model.encode_image(self.preprocess(x).contiguous())
+        """retrievers.py:93-95.  The resized image is not materialised: the resize feeds the patch-embedding GEMM directly."""
+        return self.model.encode_image_raw(x)
 
     __call__ = forward
 

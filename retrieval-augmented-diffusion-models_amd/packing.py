@@ -46,6 +46,9 @@ def pack(kind: str, cfg, sd: Dict[str, torch.Tensor]) -> np.ndarray:
         elif kd == "bf16_t":
             assert len(ts) == 1 and ts[0].ndim == 2
             data = _bf16_bytes(ts[0].t())
+        elif kd == "f32_t":
+            assert len(ts) == 1 and ts[0].ndim == 2
+            data = _f32_bytes(ts[0].t())
         elif kd == "conv3":
             assert len(ts) == 1 and ts[0].ndim == 4 and ts[0].shape[2:] == (3, 3)
             data = _bf16_bytes(ts[0].permute(0, 2, 3, 1))            # [N][ky][kx][C]  (K = tap*C + c)

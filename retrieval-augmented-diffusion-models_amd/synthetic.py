@@ -106,21 +106,28 @@ def vq_param_shapes(cfg) -> Dict[str, tuple]:
         if cin != cout:
             p[pre + ".nin_shortcut.weight"] = (cout, cin, 1, 1); p[pre + ".nin_shortcut.bias"] = (cout,)
 
+    def attn(a, ch):
+        p[a + ".norm.weight"] = (ch,); p[a + ".norm.bias"] = (ch,)
+        for n in ("q", "k", "v", "proj_out"):
+            p[f"{a}.{n}.weight"] = (ch, ch, 1, 1); p[f"{a}.{n}.bias"] = (ch,)
+
     bin_ = cfg.ch * mults[-1]
     p["decoder.conv_in.weight"] = (bin_, cfg.z_channels, 3, 3); p["decoder.conv_in.bias"] = (bin_,)
     res("decoder.mid.block_1", bin_, bin_)
     if cfg.mid_attn:
-        a = "decoder.mid.attn_1"
-        p[a + ".norm.weight"] = (bin_,); p[a + ".norm.bias"] = (bin_,)
-        for n in ("q", "k", "v", "proj_out"):
-            p[f"{a}.{n}.weight"] = (bin_, bin_, 1, 1); p[f"{a}.{n}.bias"] = (bin_,)
+        attn("decoder.mid.attn_1", bin_)
     res("decoder.mid.block_2", bin_, bin_)
+    attn_res = {cfg.attn_resolutions[i] for i in range(cfg.n_attn_resolutions)}
+    curr_res = cfg.resolution >> (len(mults) - 1)
     for lvl in reversed(range(len(mults))):
         bout = cfg.ch * mults[lvl]
         for i in range(cfg.num_res_blocks + 1):
             res(f"decoder.up.{lvl}.block.{i}", bin_, bout); bin_ = bout
+            if curr_res in attn_res:
+                attn(f"decoder.up.{lvl}.attn.{i}", bin_)
         if lvl != 0:
             p[f"decoder.up.{lvl}.upsample.conv.weight"] = (bin_, bin_, 3, 3); p[f"decoder.up.{lvl}.upsample.conv.bias"] = (bin_,)
+            curr_res *= 2
     p["decoder.norm_out.weight"] = (bin_,); p["decoder.norm_out.bias"] = (bin_,)
     p["decoder.conv_out.weight"] = (cfg.out_ch, bin_, 3, 3); p["decoder.conv_out.bias"] = (cfg.out_ch,)
     return p
@@ -156,7 +163,28 @@ def clip_param_shapes(cfg) -> Dict[str, tuple]:
     return p
 
 
-UNET_SEED, VQ_SEED, CLIP_SEED = 1234, 4321, 99       # the seeds the committed golden fixtures were generated with
+def rarm_param_shapes(cfg) -> Dict[str, tuple]:
+    """RetrievalPatchTransformer(continuous=False, positional_encodings=True, cross_attend=True) — rdm/modules/attention.py:206-249."""
+    C = cfg.n_heads * cfg.d_head
+    p: Dict[str, tuple] = {"proj_in.weight": (cfg.vocab_in, C), "positional_encoding": (C, cfg.sequence_length),
+                           "proj_out.weight": (cfg.vocab_out, C, 1), "proj_out.bias": (cfg.vocab_out,)}
+    for i in range(cfg.depth):
+        tb = f"transformer_blocks.{i}"
+        for a, d in (("attn1", C), ("attn2", cfg.context_dim)):
+            p[f"{tb}.{a}.to_q.weight"] = (C, C); p[f"{tb}.{a}.to_k.weight"] = (C, d); p[f"{tb}.{a}.to_v.weight"] = (C, d)
+            p[f"{tb}.{a}.to_out.0.weight"] = (C, C); p[f"{tb}.{a}.to_out.0.bias"] = (C,)
+        p[f"{tb}.ff.net.0.proj.weight"] = (8 * C, C); p[f"{tb}.ff.net.0.proj.bias"] = (8 * C,)
+        p[f"{tb}.ff.net.2.weight"] = (C, 4 * C); p[f"{tb}.ff.net.2.bias"] = (C,)
+        for n in ("norm1", "norm2", "norm3"):
+            p[f"{tb}.{n}.weight"] = (C,); p[f"{tb}.{n}.bias"] = (C,)
+    return p
+
+
+UNET_SEED, VQ_SEED, CLIP_SEED, RARM_SEED, VQGAN_SEED = 1234, 4321, 99, 777, 888   # seeds of the committed golden fixtures
+
+
+def rarm_state_dict(cfg, seed=RARM_SEED):
+    return synth_state_dict(rarm_param_shapes(cfg), seed)
 
 
 def unet_state_dict(cfg, seed=UNET_SEED):

@@ -256,3 +256,39 @@ def test_knn_planted_neighbours_large(ctx):
     assert np.array_equal(idx[2:, 0], want[2:])
     assert np.abs(sc[:, 0] - 1.0).max() <= 1e-3                   # fp16 rows: |x|^2 of the stored row, fp64-accumulated
     assert (np.diff(sc, axis=1) <= 0).all()
+
+
+@pytest.mark.parametrize("k,n_copies", [(4, 64), (4, 256), (16, 200), (28, 256)])
+def test_knn_adversarial_near_duplicates(ctx, k, n_copies):
+    """Near-duplicate patches (real in OpenImages): n_copies rows that differ from the query's best match by one fp16 ulp in a few
+    coordinates, i.e. scores within ~1e-6 of each other -- far inside the MFMA scan's score error.  Half of them are packed into the
+    rows ONE lane of the scan sees (same block, same 16-row phase), the rest are spread.  The approximate candidate lists cannot
+    order such a cluster; the certificate must detect it and the exact fallback must return the oracle's answer bit for bit."""
+    N, B = 300_000, 5
+    rng = np.random.default_rng(100 + k)
+    db = (rng.standard_normal((N, 512), dtype=np.float32) * 0.45).astype(np.float16)
+    base = db[1234].copy()
+    rows_lane = [t * 256 + g * 16 + r for t in range(0, 4 * 256, 256) for g in range(8) for r in range(4)]   # tiles of block 0, phase 0
+    rows = (rows_lane[:n_copies // 2] + list(rng.choice(np.arange(2000, N), n_copies - n_copies // 2, replace=False)))
+    for j, r in enumerate(rows):
+        v = base.copy()
+        for c in rng.choice(512, 1 + j % 3, replace=False):
+            v[c] = np.nextafter(v[c], np.float16(np.inf if j % 2 else -np.inf), dtype=np.float16)
+        db[r] = v
+    q = (np.random.default_rng(11).standard_normal((B, 512)) * 0.45).astype(np.float32)
+    q[0] = base.astype(np.float32)                                 # sits in the middle of the cluster
+    q[3] = db[rows[5]].astype(np.float32)
+    ctx.db_load(db)
+    idx, sc = ctx.knn(torch.from_numpy(q), k)
+    torch.cuda.synchronize()
+    ref_i, ref_s = oret.exact_topk(oret.normalize_db(db), oret.normalize_queries(q), k)
+    got = idx.cpu().numpy().view(np.uint32)
+    assert ctx.knn_last_fallback() == 1                            # the cluster cannot be certified from the approximate lists
+    assert np.array_equal(got, ref_i), f"top-k indices differ in {(got != ref_i).sum()} places"
+    assert np.abs(sc.cpu().numpy() - ref_s).max() <= 1e-6
+    # an ordinary batch afterwards: certified, no fallback
+    q2 = (np.random.default_rng(12).standard_normal((B, 512)) * 0.45).astype(np.float32)
+    idx2, _ = ctx.knn(torch.from_numpy(q2), k)
+    torch.cuda.synchronize()
+    assert ctx.knn_last_fallback() == 0
+    assert np.array_equal(idx2.cpu().numpy().view(np.uint32), oret.exact_topk(oret.normalize_db(db), oret.normalize_queries(q2), k)[0])

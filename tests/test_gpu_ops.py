@@ -187,3 +187,33 @@ def test_small_attention(ctx, B, nq, nkv, heads, D, causal):
     ref = (s.softmax(-1) @ sp(v)).permute(0, 2, 1, 3).reshape(B, nq, C)
     out = ctx.op_small_attention(q.to(d, torch.bfloat16), k.to(d, torch.bfloat16), v.to(d, torch.bfloat16), heads, D, causal, D ** -0.5)
     _close(out, ref, what="small attention")
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 96, 80), (1, 256, 256), (3, 224, 224), (1, 37, 501), (2, 1200, 900)])
+def test_clip_preprocess_bicubic(ctx, B, H, W):
+    """ClipImageRetriever.preprocess (rdm/modules/retrievers.py:83-91): bicubic resize with align_corners=True (kornia 0.6.2 ->
+    F.interpolate; un-vendored, so the fp32 torch CPU op is the reference), (x+1)/2, CLIP mean/std.  Non-identity sizes, up- and
+    down-scaling, and the identity size."""
+    from oracle import clip as oclip, unet as ounet
+    from rdm_amd import packing
+    from _util import spec_to_clip_cfg
+    spec = oclip.ClipSpec(embed_dim=64, image_resolution=224, vision_layers=1, vision_width=128, vision_patch_size=32,
+                          context_length=77, vocab_size=1000, transformer_width=128, transformer_heads=2, transformer_layers=1)
+    cfg = spec_to_clip_cfg(spec)
+    sd = ounet.synth_state_dict(oclip.clip_param_shapes(spec), seed=3)
+    ctx.load_clip(cfg, packing.pack("clip", cfg, sd))
+    x = torch.from_numpy(np.random.default_rng(H * 7 + W).uniform(-1, 1, (B, 3, H, W)).astype(np.float32))
+    got = ctx.clip_preprocess(x)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.interpolate(x, size=(224, 224), mode="bicubic", align_corners=True)
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073])[None, :, None, None]
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711])[None, :, None, None]
+    ref = ((ref + 1.) / 2. - mean) / std
+    err = float((got.cpu() - ref).abs().max())
+    print(f"bicubic {H}x{W} -> 224x224: max |err| {err:.2e}")
+    assert got.shape == (B, 3, 224, 224) and err <= 1e-4                 # fp32 on both sides; different summation order, amplified 1/std = 3.8x (values reach +-5)
+    # fused variant (resize feeds the patch-embedding GEMM directly) == tower on the materialised preprocess output
+    a = ctx.clip_encode_image_raw(x)
+    b = ctx.clip_encode_image(got)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)

@@ -312,6 +312,9 @@ def test_synthetic_weights_match_oracle_recipe():
     assert synthetic.unet_param_shapes(_lib.make_unet_cfg()) == ounet.param_shapes(ounet.shipped_spec())
     assert synthetic.vq_param_shapes(_lib.make_vq_cfg()) == ovq.vq_param_shapes(ovq.shipped_vq_spec())
     assert synthetic.clip_param_shapes(_lib.make_clip_cfg()) == oclip.clip_param_shapes(oclip.vitb32_spec())
+    from oracle import rarm as orarm
+    assert synthetic.rarm_param_shapes(_lib.make_rarm_cfg()) == orarm.rarm_param_shapes(orarm.shipped_rarm_spec())
+    assert synthetic.vq_param_shapes(_lib.make_vqgan_f16_cfg()) == ovq.vq_param_shapes(ovq.vqgan_f16_spec())
     t = ounet.tiny_spec()
     cfg = _lib.make_unet_cfg(model_channels=t.model_channels, num_res_blocks=t.num_res_blocks, attention_resolutions=t.attention_resolutions,
                              channel_mult=t.channel_mult)

@@ -168,3 +168,23 @@ def test_full_ddim_golden_first_step_reproduces():
     x, px0 = odiff.p_sample_ddim(lambda x, t, c: ounet.unet_forward(sd, spec, x, t, c), x_T, cond, t, 49, sch, scale=2.0, uc=torch.zeros_like(cond))
     assert np.abs(x.numpy() - g["x_0"]).max() <= 1e-4 * np.abs(g["x_0"]).max()
     assert np.abs(px0.numpy() - g["px0_0"]).max() <= 1e-4 * np.abs(g["px0_0"]).max()
+
+
+def test_rarm_oracle_matches_reference_golden():
+    from oracle import rarm as orarm
+    g = golden("rarm_tiny.npz")
+    spec = orarm.tiny_rarm_spec()
+    sd = ounet.synth_state_dict(orarm.rarm_param_shapes(spec), seed=int(g["seed"]))
+    y = orarm.rarm_forward(sd, spec, torch.from_numpy(g["tokens"]), torch.from_numpy(g["ctx"]))
+    assert np.abs(y.numpy() - g["logits"]).max() <= 5e-5 * np.abs(g["logits"]).max() + 5e-5
+    cond = torch.full((3, 1), spec.vocab_in - 1, dtype=torch.long)
+    out, lg = orarm.rarm_sample(sd, spec, cond, torch.from_numpy(g["ctx"]), g["uniforms"].shape[0], torch.from_numpy(g["uniforms"]),
+                                temperature=float(g["temperature"]), top_k=int(g["top_k"]), guidance_scale=float(g["guidance_scale"]))
+    assert np.array_equal(out.numpy(), g["sampled"])
+
+
+def test_vqgan_oracle_shapes():
+    spec = ovq.vqgan_f16_spec()
+    shapes = ovq.vq_param_shapes(spec)
+    assert "decoder.up.4.attn.2.q.weight" in shapes and "decoder.up.3.attn.0.q.weight" not in shapes
+    assert shapes["decoder.conv_in.weight"] == (512, 256, 3, 3) and shapes["quantize.embedding.weight"] == (16384, 256)

@@ -134,6 +134,54 @@ def gen_tokenizer():
     np.savez_compressed(os.path.join(OUT, "tokenizer.npz"), captions=np.array(caps), tokens=rows)
 
 
+def gen_rarm():
+    """RARM backbone: the in-tree RetrievalPatchTransformer class (rdm/modules/attention.py:199-272) with the shipped switches
+    (continuous=False, causal, cross_attend, positional encodings).  tiny: full forward + a guided, top-k sampled sequence through
+    the oracle's sampling loop with the REFERENCE class as the transformer; shipped (--full): logits of an 8-token prefix."""
+    from rdm.modules.attention import RetrievalPatchTransformer
+    from oracle import rarm as orarm
+
+    def build(spec, seed):
+        m = RetrievalPatchTransformer(in_channels=spec.vocab_in, n_heads=spec.n_heads, d_head=spec.d_head, depth=spec.depth,
+                                      context_dim=spec.context_dim, positional_encodings=True, sequence_length=spec.sequence_length,
+                                      out_channels=spec.vocab_out, cross_attend=True, causal=True, continuous=False).eval()
+        shapes = {n: tuple(v.shape) for n, v in m.state_dict().items()}
+        assert shapes == orarm.rarm_param_shapes(spec), set(shapes) ^ set(orarm.rarm_param_shapes(spec))
+        sd = ounet.synth_state_dict(shapes, seed=seed)
+        m.load_state_dict(sd)
+        return m, sd
+
+    spec = orarm.tiny_rarm_spec()
+    m, sd = build(spec, 777)
+    rng = np.random.default_rng(778)
+    tokens = torch.from_numpy(rng.integers(0, spec.vocab_out, size=(3, 12)).astype(np.int64))
+    tokens[:, 0] = spec.vocab_in - 1                                   # sos
+    ctx = torch.from_numpy((rng.standard_normal((3, 4, 512)) * 0.45).astype(np.float32))
+    y_ref = m(tokens, context=ctx)
+    check("rarm/tiny forward", orarm.rarm_forward(sd, spec, tokens, ctx), y_ref, atol=5e-5, rtol=5e-5)
+    steps = 16
+    u = torch.from_numpy(rng.random((steps, 3)).astype(np.float32))
+    cond = torch.full((3, 1), spec.vocab_in - 1, dtype=torch.long)
+    out_ref, lg_ref = orarm.rarm_sample(sd, spec, cond, ctx, steps, u, temperature=0.9, top_k=50, guidance_scale=2.0,
+                                        forward=lambda t_, c_: m(t_, context=c_))
+    out_or, lg_or = orarm.rarm_sample(sd, spec, cond, ctx, steps, u, temperature=0.9, top_k=50, guidance_scale=2.0)
+    assert torch.equal(out_ref, out_or)
+    check("rarm/tiny sampled logits", lg_or, lg_ref, atol=1e-4, rtol=1e-4)
+    np.savez_compressed(os.path.join(OUT, "rarm_tiny.npz"), tokens=tokens.numpy(), ctx=ctx.numpy(), logits=y_ref.numpy(), uniforms=u.numpy(),
+                        sampled=out_ref.numpy(), sampled_logits=lg_ref.numpy(), seed=np.int64(777), temperature=np.float32(0.9),
+                        top_k=np.int64(50), guidance_scale=np.float32(2.0))
+    if "--full" in sys.argv:
+        spec = orarm.shipped_rarm_spec()
+        m, sd = build(spec, 777)
+        tokens = torch.from_numpy(rng.integers(0, spec.vocab_out, size=(2, 8)).astype(np.int64))
+        tokens[:, 0] = spec.vocab_in - 1
+        ctx = torch.from_numpy((rng.standard_normal((2, 8, 512)) * 0.45).astype(np.float32))
+        y_ref = m(tokens, context=ctx)
+        check("rarm/shipped forward", orarm.rarm_forward(sd, spec, tokens, ctx), y_ref, atol=1e-4, rtol=1e-4)
+        np.savez_compressed(os.path.join(OUT, "rarm_shipped.npz"), tokens=tokens.numpy(), ctx=ctx.numpy(),
+                            logits_last=y_ref[:, -2:].numpy().astype(np.float32), seed=np.int64(777))
+
+
 def gen_script_flags():
     """Flag table of the reference CLI (scripts/rdm_sample.py:22-143), read from its argparse calls with `ast` (the script
     itself cannot be imported: torchvision / clip / omegaconf are absent).  Stored as data: option strings, type name,
@@ -159,6 +207,7 @@ def gen_script_flags():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_script_flags()
+    gen_rarm()
     gen_attention()
     gen_unet("tiny", ounet.tiny_spec(), B=2, k=4, hw=16, seed=1234)
     gen_clip()

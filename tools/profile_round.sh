@@ -9,15 +9,15 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/stats -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $OUT/stats.log 2>&1
 python3 $REPO/tools/pmc_sum.py stats $OUT/stats.csv $OUT/stats
 SHORT="--steps 1 --warmup 0 --ddim-steps 4 --no-cpu-baseline --no-extras"
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM GRBM_GUI_ACTIVE -d $OUT/sq1 -- python3 $REPO/bench.py $SHORT > $OUT/sq1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_WAVES -d $OUT/sq2 -- python3 $REPO/bench.py $SHORT > $OUT/sq2.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM GRBM_GUI_ACTIVE -d $OUT/sq1 -- python3 $REPO/bench.py $SHORT > $OUT/sq1.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_WAVES -d $OUT/sq2 -- python3 $REPO/bench.py $SHORT > $OUT/sq2.log 2>&1
 python3 $REPO/tools/pmc_sum.py counters $OUT/sq.csv $OUT/sq1 $OUT/sq2
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- python3 $REPO/bench.py $SHORT > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -- python3 $REPO/bench.py $SHORT > $OUT/fetch.log 2>&1
 python3 $REPO/tools/pmc_sum.py counters $OUT/fetch.csv $OUT/fetch
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -- python3 $REPO/bench.py $SHORT > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/write -- python3 $REPO/bench.py $SHORT > $OUT/write.log 2>&1
 python3 $REPO/tools/pmc_sum.py counters $OUT/write.csv $OUT/write
 # durations of the counter passes' kernels (kernel-trace of the SQ pass) for per-launch cycle/time cross-checks
 python3 - <<PY
