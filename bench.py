@@ -12,6 +12,8 @@ A "step" is one pass of the whole hot path over one batch of synthetic inputs th
       50-step DDIM + decode.
   --config 4: k=16 retrieval, 250 ancestral DDPM steps (ldm p_sample_loop(timesteps=250): no CFG on this path, as in the
       reference), B=64 per GPU (512 over 8 GPUs).
+  --config 5: RARM (scripts/rarm_sample.py path): k=8 retrieval -> 256 autoregressive tokens (18-layer RetrievalPatchTransformer with a
+      K/V cache, top-k 256 multinomial, guidance scale 1.0 = the script's default) -> VQGAN-f16 decode, B=64 per GPU.
 Weights are seeded random tensors of the shipped architectures (no checkpoints are reachable), DB / queries / captions
 are synthetic.
 
@@ -45,7 +47,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=None, help="timed steps (default 3; 1 for --config 4)")
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--config", type=int, default=3, choices=(2, 3, 4), help="BASELINE.json config number")
+    p.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5), help="BASELINE.json config number")
     p.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     p.add_argument("--ddim-steps", type=int, default=None, help="sampler steps (default 50; 250 for --config 4)")
     p.add_argument("--k", type=int, default=None, help="neighbours (default 4; 1 for --config 2; 16 for --config 4)")
@@ -54,7 +56,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the untimed extras (per-class roofline step, guidance-scale-1.0 step)")
     a = p.parse_args()
-    a.k = a.k if a.k is not None else {2: 1, 3: 4, 4: 16}[a.config]
+    a.k = a.k if a.k is not None else {2: 1, 3: 4, 4: 16, 5: 8}[a.config]
     a.ddim_steps = a.ddim_steps if a.ddim_steps is not None else (250 if a.config == 4 else 50)
     a.steps = a.steps if a.steps is not None else (1 if a.config == 4 else 3)
     return a
@@ -125,8 +127,14 @@ def main():
 
     # ---- model: shipped architecture, seeded random weights; schedule from the product's register_schedule
     model = MinimalRETRODiffusion(unet_config={"params": {}}, first_stage_config={"params": {"ddconfig": {}}}, k_nn=a.k, ctx=ctx)
-    model.load_unet_state_dict(synthetic.unet_state_dict(model.unet_cfg))
-    model.load_first_stage_state_dict(synthetic.vq_state_dict(model.vq_cfg))
+    if a.config == 5:
+        rcfg, vcfg = _lib.make_rarm_cfg(), _lib.make_vqgan_f16_cfg()
+        ctx.load_rarm(rcfg, packing.pack("rarm", rcfg, synthetic.rarm_state_dict(rcfg)))
+        ctx.load_vq(vcfg, packing.pack("vq", vcfg, synthetic.vq_state_dict(vcfg, synthetic.VQGAN_SEED)))
+        a.ddim_steps = 256                             # tokens per image (16 x 16 codes)
+    else:
+        model.load_unet_state_dict(synthetic.unet_state_dict(model.unet_cfg))
+        model.load_first_stage_state_dict(synthetic.vq_state_dict(model.vq_cfg))
     sched_ddpm = {n: getattr(model, n).numpy() for n in ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
                                                          "posterior_mean_coef2", "posterior_log_variance_clipped")}
     N, D, B, k = a.db_rows, 512, a.batch, a.k
@@ -168,6 +176,13 @@ def main():
             idx, _ = ctx.knn(q, k)
             nbrs = ctx.db_gather(idx, D)                                              # [B,k,512] raw neighbour embeddings
             cond = torch.cat([q[:, None], nbrs[:, :k - 1]], dim=1).contiguous()       # ddpm.py:775 (query first)
+        if a.config == 5:
+            u = parallel.per_sample_noise(7000 + i, range(lo, hi), (a.ddim_steps,), device=dev)          # N(0,1) -> uniform via the normal CDF
+            u = (0.5 * (1.0 + torch.erf(u * 0.7071067811865476))).clamp(0.0, 0.99999994).t().contiguous()
+            sos = torch.full((B, 1), 16385, dtype=torch.long, device=dev)
+            tok = ctx.rarm_sample(sos, nbrs, a.ddim_steps, u, temperature=1.0, top_k=256, guidance_scale=1.0)   # RARM: query NOT prepended
+            img = ctx.vq_decode_indices(tok)
+            return parallel.all_gather_images(img, world * B)
         if a.config == 4:
             noise = parallel.per_sample_noise(5000 + i, range(lo, hi), (a.ddim_steps, 3, 64, 64), device=dev).transpose(0, 1).contiguous()
             z = ctx.ddpm_sample(a.ddim_steps, x_Ts[i], cond, noise, sched_ddpm, clip_denoised=True)
@@ -216,7 +231,7 @@ def main():
             n_, ms_, w_ = ctx.prof_collect(kind)
             classes[name] = (n_, ms_, w_)
         extras["untimed_profiled_step_ms"] = t_prof_step * 1e3
-        if world == 1 and a.config != 4:      # single-process only (step() holds the collective when world > 1)
+        if world == 1 and a.config in (2, 3):      # single-process only (step() holds the collective when world > 1)
             torch.cuda.synchronize(); t1 = time.perf_counter()
             step(0, scale=1.0)
             torch.cuda.synchronize()
@@ -237,6 +252,7 @@ def main():
         images = world * B * a.steps
         achieved = fl_conv / (ms_conv * 1e-3) / 1e12 if ms_conv > 0 else 0.0
         sampler = (f"{a.ddim_steps}-step ancestral DDPM (p_sample_loop, no CFG)" if a.config == 4
+                   else "256 autoregressive tokens (RARM transformer 18 x 768 with K/V cache, top-k 256, guidance 1.0)" if a.config == 5
                    else f"{a.ddim_steps}-step DDIM (eta 0, CFG scale {a.scale:.1f})")
         front = ("CLIP ViT-B/32 text tower on 64 captions (no retrieval, k=1)" if a.config == 2
                  else f"exact kNN (k={k}) over a synthetic {N} x 512 fp16 CLIP DB")
@@ -260,10 +276,11 @@ def main():
             "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"BASELINE config #{a.config}: RDM sampling, {front} -> {sampler} over the shipped-config UNet "
-                                   "(400.9M params, random weights) -> VQ-f4 decode to 256x256",
+            "config": {"workload": (f"BASELINE config #5: RARM sampling, {front} -> {sampler} -> VQGAN-f16 decode to 256x256 (random weights)" if a.config == 5 else
+                                    f"BASELINE config #{a.config}: RDM sampling, {front} -> {sampler} over the shipped-config UNet "
+                                    "(400.9M params, random weights) -> VQ-f4 decode to 256x256"),
                        "baseline_config": a.config, "batch_per_gpu": B, "global_batch": world * B, "sampler_steps": a.ddim_steps, "k": k,
-                       "guidance_scale": None if a.config == 4 else a.scale, "db_rows": None if a.config == 2 else N,
+                       "guidance_scale": None if a.config == 4 else (1.0 if a.config == 5 else a.scale), "db_rows": None if a.config == 2 else N,
                        "parallelism": f"dp{world} (batch-sharded, weights + DB replicated, all-gather of images only)"},
             "roofline": roof,
         }

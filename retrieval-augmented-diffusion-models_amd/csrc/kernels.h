@@ -66,6 +66,13 @@ hipError_t launch_rarm_sample(const RarmSampleParams& p, hipStream_t st);
 hipError_t launch_codebook_gather(const long long* idx, const float* codebook, int n_embed, int E, long long n, bf16_t* out, hipStream_t st);
 hipError_t launch_set_int(int* p, int v, hipStream_t st);
 
+// skinny GEMM, M <= 128 rows (sgemm.hip): out[M, N(/2 for GEGLU)] = act(A W^T + bias) (+ res)
+struct SgemmParams {
+    const bf16_t* A; int lda; const bf16_t* W; int M, N, K;     // W [N][K]; GEGLU: N = 2 x outputs, rows interleaved in blocks of 32
+    const float* bias; int act; const float* res_f32; const bf16_t* res_bf16; float* out_f32; bf16_t* out_bf16; int ldo;
+};
+bool sgemm_supported(const SgemmParams& p);
+hipError_t launch_sgemm(const SgemmParams& p, hipStream_t st);
 hipError_t launch_igemm(const IgemmParams& p, bool conv, int batch, hipStream_t st);
 bool conv_halo_supported(const IgemmParams& p);
 int conv_halo_ksplit(const IgemmParams& p);                // K-split factor worth using for this conv (1 = none); needs p.ws of ksplit*M*N floats

@@ -422,7 +422,9 @@ __global__ __launch_bounds__(256) void clip_preprocess_kernel(PreprocParams p, f
     const long long n = (long long)p.B * 3 * p.R * p.R;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int ox = (int)(i % p.R), oy = (int)((i / p.R) % p.R), c = (int)((i / ((long long)p.R * p.R)) % 3), b = (int)(i / ((long long)3 * p.R * p.R));
-        const float ry = p.sy * oy, rx = p.sx * ox;
+        // rounded products (no fma contraction into the subtraction below): the fractional position must be the one
+        // torch's area_pixel_compute_source_index produces, or a 1200-px source shifts the taps by ~1e-4 px
+        const float ry = __fmul_rn(p.sy, (float)oy), rx = __fmul_rn(p.sx, (float)ox);
         const float fy = floorf(ry), fx = floorf(rx);
         const int iy = (int)fy, ix = (int)fx;
         float wy[4], wx[4];

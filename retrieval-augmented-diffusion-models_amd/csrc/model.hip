@@ -410,6 +410,16 @@ struct Ops {
     void linear(const bf16_t* A0, const bf16_t* A1, int C0, int C1, size_t woff, size_t boff, bool has_bias, int M, int N,
                 int act, const bf16_t* res, bf16_t* out, float* out_f32 = nullptr, const float* res_f32 = nullptr) {
         if (plan) return;
+        if (M <= 128 && !A1 && C1 == 0) {       // decode-sized batch: weight-streaming kernel with N/32 blocks (sgemm.hip)
+            SgemmParams q{}; q.A = A0; q.lda = C0; q.W = w<bf16_t>(woff); q.M = M; q.N = N; q.K = C0; q.bias = has_bias ? w<float>(boff) : nullptr;
+            q.act = act; q.res_f32 = res_f32; q.res_bf16 = res; q.out_f32 = out_f32; q.out_bf16 = out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
+            if (sgemm_supported(q)) {
+                prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)C0);
+                check(launch_sgemm(q, c->stream), "skinny linear");
+                prof_end();
+                return;
+            }
+        }
         IgemmParams p = base(M, N, C0 + C1);
         p.A0 = A0; p.A1 = A1; p.C0 = C0; p.C1 = C1; p.W = w<bf16_t>(woff); p.bias = has_bias ? w<float>(boff) : nullptr;
         p.act = act; p.res_bf16 = res; p.res_f32 = res_f32; p.out_bf16 = out; p.out_f32 = out_f32;
@@ -1342,6 +1352,11 @@ int rdm_op_linear(rdm_ctx* c, const void* a, const void* w, const float* bias, c
                   int M, int N, int K, int act, float alpha) {
     RDM_ENTER(c);
     if (!c) return -1;
+    if (M <= 128 && alpha == 1.0f) {       // same dispatch as the executors (Ops::linear): decode-sized batches take the skinny kernel
+        SgemmParams q{}; q.A = (const bf16_t*)a; q.lda = K; q.W = (const bf16_t*)w; q.M = M; q.N = N; q.K = K; q.bias = bias; q.act = act;
+        q.res_bf16 = (const bf16_t*)res; q.out_f32 = out_f32; q.out_bf16 = (bf16_t*)out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
+        if (sgemm_supported(q)) { RDM_CHECK_HIP(c, launch_sgemm(q, c->stream)); return 0; }
+    }
     IgemmParams p{}; p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.ldo = (act == ACT_GEGLU) ? N / 2 : N; p.zero_page = c->zero_page;
     p.Hin = p.Win = p.Hout = p.Wout = 1; p.stride = 1; p.rows_per_sample = 1;
     p.A0 = (const bf16_t*)a; p.C0 = K; p.W = (const bf16_t*)w; p.bias = bias; p.res_bf16 = (const bf16_t*)res;
