@@ -156,3 +156,27 @@ class StreamingTopK:
 
     def result(self):
         return (np.stack(self.best_i).astype(np.uint32), np.stack(self.best_s).astype(np.float32))
+
+
+def exact_topk_bulk(dbn: np.ndarray, qn: np.ndarray, k: int, qblock: int = 1024, chunk: int = 131072, slack: int = 8):
+    """exact_topk for dataset-scale query batches (same definition; vectorised: fp64 GEMM blocks, per-block top-(k+slack), one
+    final (score desc, index asc) sort of the merged candidates).  Exact as long as fewer than `slack` rows tie with a query's
+    k-th score inside one chunk (test databases plant at most a few duplicates)."""
+    import torch
+    B = qn.shape[0]
+    out_i = np.zeros((B, k), dtype=np.uint32); out_s = np.zeros((B, k), dtype=np.float32)
+    d = torch.from_numpy(np.ascontiguousarray(dbn))
+    for q0 in range(0, B, qblock):
+        q64 = torch.from_numpy(np.ascontiguousarray(qn[q0:q0 + qblock])).double()
+        cs, ci = [], []
+        for r0 in range(0, d.shape[0], chunk):
+            blk = d[r0:r0 + chunk].double()
+            sc = q64 @ blk.t()
+            kk = min(k + slack, sc.shape[1])
+            v, i = torch.topk(sc, kk, dim=1)
+            cs.append(v); ci.append(i + r0)
+        cs = torch.cat(cs, dim=1).numpy(); ci = torch.cat(ci, dim=1).numpy()
+        order = np.lexsort((ci, -cs), axis=1)[:, :k]
+        out_s[q0:q0 + qblock] = np.take_along_axis(cs, order, 1).astype(np.float32)
+        out_i[q0:q0 + qblock] = np.take_along_axis(ci, order, 1).astype(np.uint32)
+    return out_i, out_s

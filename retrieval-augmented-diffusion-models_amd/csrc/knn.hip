@@ -29,7 +29,8 @@
 #include "knn.h"
 
 #define KNN_ROWS 256           // rows per tile
-#define KNN_Q 64               // queries per pass
+#define KNN_Q 64               // queries per pass (online search)
+#define KNN_QMAX 256           // queries per launch of the bulk scan (2 groups of 128): size of the per-query scratch arrays
 #define KNN_BK 64              // K slice per stage
 
 constexpr float KNN_EPS = 2.0e-4f;   // bound on |approximate - exact| score (derivation above)
@@ -388,6 +389,114 @@ __global__ __launch_bounds__(512, 2) void knn_scan512w8_kernel(ScanParams p) {
     for (int j = 0; j < KSEL; j++) { p.cand_s[base + j] = ls[j]; p.cand_i[base + j] = li[j]; }
 }
 
+
+// ---------------------------------------------------------------- bulk scan: 128 queries per walker, two query groups per database pass
+// Offline neighbour pre-computation (scripts/search_neighbors.py:380-450: 1.28 M ImageNet queries against the 20.9 M-row database) is
+// the same top-k at dataset scale.  One database pass per 64 queries (above) is HBM-bound there; this kernel scores 128 queries per
+// block against each 256-row tile -- 8 waves = 2 row halves x 4 query groups of 32, a lane still owns ONE query and one private
+// top-KSEL list -- and a launch carries TWO query groups whose walkers sit pairwise on the same XCD and walk the same tiles, so
+// the second reads the tile from that XCD's L2: HBM streams the database once per 256 queries, 1024 MFMA FLOP per database byte
+// (hi/lo split included), past the 460 FLOP/B balance point of the chip: MFMA-bound.  Query slices are staged through LDS with
+// the database slice (128 queries x 512 dims x hi/lo do not fit the register file).
+struct BulkParams { ScanParams s; int groups; };      // s.qh / s.ql: [groups*128][dim]; s.cand_*: [groups*128][nlists][KSEL]
+
+template <int KSEL>
+__global__ __launch_bounds__(512, 1) void knn_scan_bulk_kernel(BulkParams bp) {
+    const ScanParams& p = bp.s;
+    constexpr int QB = 128, DB_BYTES = KNN_ROWS * 128, Q_BYTES = QB * 128, STAGE = DB_BYTES + 2 * Q_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = tid >> 3, pchunk = tid & 7;              // loader: 64 rows x 8 chunks per piece
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int rg = wave >> 2, qg = wave & 3;
+    const int nkc = p.dim / KNN_BK;
+    const char* zero = (const char*)p.zero_page;
+    // block -> (walker, query group): blocks b and b + 8 share an XCD
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int grp = slot % bp.groups;
+    const int walkers = (int)(gridDim.x / bp.groups);
+    const int wk = ((slot / bp.groups) << 3) | xcd;
+    if (wk >= walkers) return;
+    const _Float16* qh = p.qh + (long long)grp * QB * p.dim;
+    const _Float16* ql = p.ql + (long long)grp * QB * p.dim;
+
+    float ls[KSEL]; uint32_t li[KSEL];
+#pragma unroll
+    for (int j = 0; j < KSEL; j++) { ls[j] = -INFINITY; li[j] = 0xffffffffu; }
+
+    const long long my_tiles = (p.ntiles - wk + walkers - 1) / walkers;
+    const long long iters = my_tiles * nkc;
+    auto stage = [&](long long it, int buf) {
+        const long long tl = it / nkc; const int kc = (int)(it - tl * nkc);
+        const long long tile = wk + tl * walkers;
+        char* Ds = smem + buf * STAGE; char* Qh = Ds + DB_BYTES; char* Ql = Qh + Q_BYTES;
+#pragma unroll
+        for (int i = 0; i < KNN_ROWS / 64; i++) {
+            const int r = i * 64 + lrow;
+            const long long row = tile * KNN_ROWS + r;
+            const int c = pchunk ^ ((r >> 1) & 7);
+            const void* g = (row < p.n) ? (const void*)(p.dbn + row * p.dim + kc * KNN_BK + c * 8) : (const void*)zero;
+            glds16(g, Ds + (i * 64 + wave * 8) * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < QB / 64; i++) {
+            const int r = i * 64 + lrow;
+            const int c = pchunk ^ ((r >> 1) & 7);
+            glds16(qh + (long long)r * p.dim + kc * KNN_BK + c * 8, Qh + (i * 64 + wave * 8) * 128);
+            glds16(ql + (long long)r * p.dim + kc * KNN_BK + c * 8, Ql + (i * 64 + wave * 8) * 128);
+        }
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
+
+    if (iters > 0) stage(0, 0);
+    for (long long it = 0; it < iters; it++) {
+        const int cur = (int)(it & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it + 1 < iters) stage(it + 1, cur ^ 1);
+        const char* Ds = smem + cur * STAGE; const char* Qh = Ds + DB_BYTES; const char* Ql = Qh + Q_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int chunk = kk * 2 + fhalf;
+            f16x8 a[4];
+#pragma unroll
+            for (int rf = 0; rf < 4; rf++) {
+                const int row = rg * 128 + rf * 32 + frow;
+                a[rf] = *(const f16x8*)(Ds + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+            const int qrow = qg * 32 + frow;
+            const int qoff = qrow * 128 + ((chunk ^ ((qrow >> 1) & 7)) << 4);
+            const f16x8 bh = *(const f16x8*)(Qh + qoff), bl = *(const f16x8*)(Ql + qoff);
+#pragma unroll
+            for (int rf = 0; rf < 4; rf++) {
+                acc[rf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rf], bl, acc[rf], 0, 0, 0);
+                acc[rf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rf], bh, acc[rf], 0, 0, 0);
+            }
+        }
+        const long long tl = it / nkc; const int kc = (int)(it - tl * nkc);
+        if (kc == nkc - 1) {
+            const long long tile = wk + tl * walkers;
+            const long long rbase = tile * KNN_ROWS + rg * 128 + 4 * fhalf;
+#pragma unroll
+            for (int rf = 0; rf < 4; rf++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const long long row = rbase + rf * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < p.n) list_insert<KSEL>(ls, li, acc[rf][r], (uint32_t)row);
+                    acc[rf][r] = 0.f;
+                }
+        }
+    }
+    const int list_id = wk * 4 + rg * 2 + fhalf;
+    const long long base = ((long long)(grp * QB + qg * 32 + frow) * p.nlists + list_id) * KSEL;
+#pragma unroll
+    for (int j = 0; j < KSEL; j++) { p.cand_s[base + j] = ls[j]; p.cand_i[base + j] = li[j]; }
+}
+
 // ---------------------------------------------------------------- merge + exact re-score
 struct Certify {
     int* flag;                          // [64] 1 = candidate set not provably sufficient -> exact fallback for this query
@@ -485,7 +594,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(MergeParams p) {
 // One wave per row: exact fp64 score against every flagged query; rows that beat-or-tie the query's current k-th candidate
 // under (score desc, index asc) are appended.  The true top k all do (the current k-th is the k-th best of a SUBSET).
 __global__ __launch_bounds__(256) void knn_exact_collect_kernel(Certify c, const _Float16* dbn, const float* qn, long long n, int dim, int nq) {
-    __shared__ int fq[KNN_Q]; __shared__ int nf;
+    __shared__ int fq[KNN_QMAX]; __shared__ int nf;
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) { int m = 0; for (int q = 0; q < nq; q++) if (c.flag[q]) fq[m++] = q; nf = m; }
     __syncthreads();
@@ -600,10 +709,12 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
     const bool d512 = db.dim == 512;                 // register-resident queries (4 lists per block and query instead of 8)
     const int nlists = grid * (d512 ? 4 : 8);
     const int nlists_cap = grid * 8;
-    const size_t qn_b = (size_t)KNN_Q * db.dim * 4, qh_b = (size_t)KNN_Q * db.dim * 2;
-    const size_t cand_b = (size_t)KNN_Q * nlists_cap * KSEL * 4;
+    const bool bulk = b >= 128 && db.dim % KNN_BK == 0 && ntiles >= 16;       // dataset-scale query batches: 128-query walkers, 2 groups per database pass
+    const int QS = bulk ? KNN_QMAX : KNN_Q;                    // queries the scratch is sized for
+    const size_t qn_b = (size_t)QS * db.dim * 4, qh_b = (size_t)QS * db.dim * 2;
+    const size_t cand_b = (size_t)QS * nlists_cap * KSEL * 4;
     const size_t cert_off = (qn_b + 2 * qh_b + 2 * cand_b + 255) & ~(size_t)255;
-    const size_t cert_b = 256 /*status*/ + KNN_Q * (4 + 8 + 4 + 4) + 256 + (size_t)KNN_Q * KNN_FB_CAP * 12;
+    const size_t cert_b = 256 /*status*/ + KNN_QMAX * (4 + 8 + 4 + 4) + 256 + (size_t)KNN_QMAX * KNN_FB_CAP * 12;
     const size_t need = cert_off + cert_b + 1024;
     if (db.scratch_bytes < need) {
         if (db.scratch) { KNN_TRY(hipStreamSynchronize(st)); KNN_TRY(hipFree(db.scratch)); db.scratch = nullptr; db.scratch_bytes = 0; }
@@ -616,11 +727,11 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
     {
         char* cb = s + cert_off;
         cert.status = (int*)cb; cb += 256;
-        cert.tau = (double*)cb; cb += KNN_Q * 8;
-        cert.fb_s = (double*)cb; cb += (size_t)KNN_Q * KNN_FB_CAP * 8;
-        cert.fb_i = (uint32_t*)cb; cb += (size_t)KNN_Q * KNN_FB_CAP * 4;
-        cert.tau_idx = (uint32_t*)cb; cb += KNN_Q * 4;
-        cert.flag = (int*)cb; cb += KNN_Q * 4;
+        cert.tau = (double*)cb; cb += KNN_QMAX * 8;
+        cert.fb_s = (double*)cb; cb += (size_t)KNN_QMAX * KNN_FB_CAP * 8;
+        cert.fb_i = (uint32_t*)cb; cb += (size_t)KNN_QMAX * KNN_FB_CAP * 4;
+        cert.tau_idx = (uint32_t*)cb; cb += KNN_QMAX * 4;
+        cert.flag = (int*)cb; cb += KNN_QMAX * 4;
         cert.fb_count = (int*)cb;
     }
     KNN_TRY(hipMemsetAsync(cert.status, 0, 4, st));
@@ -637,6 +748,36 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
         KNN_TRY(hipFuncSetAttribute((const void*)knn_merge_kernel<KSEL>, hipFuncAttributeMaxDynamicSharedMemorySize, merge_smem));
         attr = true;
     }
+    if (bulk) {
+        constexpr int bulk_smem = 2 * (KNN_ROWS * 128 + 2 * 128 * 128);
+        static bool battr_dev[RDM_MAX_DEVICES] = {false};
+        bool& battr = battr_dev[rdm_cur_device()];
+        if (!battr) { KNN_TRY(hipFuncSetAttribute((const void*)knn_scan_bulk_kernel<KSEL>, hipFuncAttributeMaxDynamicSharedMemorySize, bulk_smem)); battr = true; }
+        const int bgrid = (ncu / 16) * 16;                                  // a multiple of 8 XCDs x 2 groups
+        for (int q0 = 0; q0 < b; q0 += KNN_QMAX) {
+            const int bq = (b - q0 < KNN_QMAX) ? b - q0 : KNN_QMAX;
+            const int groups = bq > 128 ? 2 : 1;
+            knn_prep_queries_kernel<<<groups * 128, 64, 0, st>>>(q + (size_t)q0 * db.dim, bq, db.dim, qn, qh, ql);
+            KNN_TRY(hipGetLastError());
+            BulkParams bp{}; bp.groups = groups;
+            bp.s.dbn = (const _Float16*)db.dbn; bp.s.n = db.n; bp.s.dim = db.dim; bp.s.ntiles = ntiles; bp.s.qh = qh; bp.s.ql = ql;
+            bp.s.cand_s = cs; bp.s.cand_i = ci; bp.s.zero_page = zero_page;
+            int walkers = bgrid / groups; if ((long long)walkers > ntiles) walkers = (int)ntiles;
+            walkers = (walkers / 8) * 8;                                    // >= 8 (ntiles >= 16): every walker owns a tile and writes its lists
+            const int g2 = walkers * groups;
+            bp.s.nlists = walkers * 4;
+            knn_scan_bulk_kernel<KSEL><<<g2, 512, bulk_smem, st>>>(bp);
+            KNN_TRY(hipGetLastError());
+            MergeParams mp{}; mp.cand_s = cs; mp.cand_i = ci; mp.nlists = bp.s.nlists; mp.dbn = (const _Float16*)db.dbn; mp.qn = qn;
+            mp.dim = db.dim; mp.n = db.n; mp.k = k; mp.idx_out = idx_out; mp.score_out = score_out; mp.qbase = q0; mp.cert = cert;
+            knn_merge_kernel<KSEL><<<bq, 256, merge_smem, st>>>(mp);
+            KNN_TRY(hipGetLastError());
+            knn_exact_collect_kernel<<<ncu * 4, 256, 0, st>>>(cert, (const _Float16*)db.dbn, qn, db.n, db.dim, bq);
+            KNN_TRY(hipGetLastError());
+            knn_exact_finish_kernel<<<bq, 256, 0, st>>>(cert, k, idx_out, score_out, q0);
+            KNN_TRY(hipGetLastError());
+        }
+    } else
     for (int q0 = 0; q0 < b; q0 += KNN_Q) {
         const int bq = (b - q0 < KNN_Q) ? b - q0 : KNN_Q;
         knn_prep_queries_kernel<<<KNN_Q, 64, 0, st>>>(q + (size_t)q0 * db.dim, bq, db.dim, qn, qh, ql);

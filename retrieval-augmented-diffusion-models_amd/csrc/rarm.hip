@@ -65,11 +65,21 @@ __global__ __launch_bounds__(64) void rarm_decode_attention_kernel(RarmAttnParam
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
     __syncthreads();
-    float acc = 0.f;
-    for (int j = 0; j < n; j++) {
-        const bf16_t* vr = (p.k_new && j == t) ? p.v_new + (long long)b * p.ldq + h * D : Vc + (long long)j * p.row_stride;
-        acc += sc[j] * bf2f(vr[lane]);
+    // cached rows (8 independent loads in flight per lane: the loop is a chain of dependent 128-byte row reads otherwise),
+    // then the new token's row straight from the projection output (never through the cache it was just stored to)
+    float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int nc = p.k_new ? t : n;
+    int j = 0;
+    for (; j + 8 <= nc; j += 8) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = bf2f(Vc[(long long)(j + e) * p.row_stride + lane]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc8[e] += sc[j + e] * v[e];
     }
+    for (; j < nc; j++) acc8[0] += sc[j] * bf2f(Vc[(long long)j * p.row_stride + lane]);
+    if (p.k_new) acc8[1] += sc[t] * bf2f(p.v_new[(long long)b * p.ldq + h * D + lane]);
+    const float acc = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
     p.out[(long long)b * p.ldo + h * D + lane] = f2bf(acc / l);
 }
 hipError_t launch_rarm_decode_attention(const RarmAttnParams& p, int heads, int batch, hipStream_t st) {

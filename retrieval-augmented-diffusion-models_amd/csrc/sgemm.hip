@@ -9,7 +9,7 @@
 // 32 gate rows (packing._geglu_perm), so a block owns a 64-row strip and emits x * gelu(gate) for 32 outputs.
 #include "kernels.h"
 
-template <int MF, int NF>      // MF: 32-row fragments of M (1..4); NF: 1 plain, 2 GEGLU (x strip + gate strip)
+template <int MF, int NF, int U>   // MF: 32-row fragments of M (1..4); NF: 1 plain, 2 GEGLU (x strip + gate strip); U: k-steps of 16 per batch of loads
 __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
     extern __shared__ float part[];                       // [4 waves][MF][NF][32 rows][32 cols]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -29,17 +29,19 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
         for (int j = 0; j < NF; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    for (int k = 0; k < kq; k += 64) {                    // 4 k-steps of 16 per iteration: 4 * (MF + NF) loads in flight per lane
-        bf16x8 fa[4][MF], fb[4][NF];
+    // U k-steps per iteration: U * (MF + NF) 16-byte loads in flight per lane.  The launch is one or two DEPENDENT round trips to
+    // HBM long (a 768-deep K quarter is 12 k-steps: U = 12 fetches a wave's whole operand set at once), so depth = latency.
+    for (int k = 0; k < kq; k += U * 16) {
+        bf16x8 fa[U][MF], fb[U][NF];
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
+        for (int s = 0; s < U; s++) {
 #pragma unroll
             for (int j = 0; j < NF; j++) fb[s][j] = *(const bf16x8*)(wp[j] + k + s * 16);
 #pragma unroll
             for (int i = 0; i < MF; i++) fa[s][i] = *(const bf16x8*)(ap[i] + k + s * 16);
         }
 #pragma unroll
-        for (int s = 0; s < 4; s++)
+        for (int s = 0; s < U; s++)
 #pragma unroll
             for (int i = 0; i < MF; i++)
 #pragma unroll
@@ -85,26 +87,29 @@ bool sgemm_supported(const SgemmParams& p) {
     return p.N % 32 == 0 && (p.act == ACT_NONE || p.act == ACT_SILU || p.act == ACT_QUICKGELU);
 }
 
+template <int MF, int NF, int U>
+static hipError_t launch_one(const SgemmParams& p, int grid, hipStream_t st) {
+    constexpr size_t sm = (size_t)4 * MF * NF * 1024 * sizeof(float);
+    static bool attr_dev[RDM_MAX_DEVICES] = {false};
+    bool& attr = attr_dev[rdm_cur_device()];
+    if (!attr && sm > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)sgemm_kernel<MF, NF, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    sgemm_kernel<MF, NF, U><<<grid, 256, sm, st>>>(p);
+    return hipGetLastError();
+}
 template <int NF>
 static hipError_t launch_nf(const SgemmParams& p, int grid, hipStream_t st) {
     const int mf = (p.M + 31) / 32;
-    const size_t sm = (size_t)4 * mf * NF * 1024 * sizeof(float);
-    static bool attr_dev[RDM_MAX_DEVICES] = {false};
-    bool& attr = attr_dev[rdm_cur_device()];
-    if (!attr) {
-        hipError_t e;
-        if ((e = hipFuncSetAttribute((const void*)sgemm_kernel<3, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * NF * 4096)) != hipSuccess) return e;
-        if ((e = hipFuncSetAttribute((const void*)sgemm_kernel<4, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4 * NF * 4096)) != hipSuccess) return e;
-        if ((e = hipFuncSetAttribute((const void*)sgemm_kernel<2, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * NF * 4096)) != hipSuccess) return e;
-        attr = true;
-    }
+    const bool deep = ((p.K >> 2) % 192) == 0;            // K quarter is a multiple of 12 k-steps (K = 768, 1536, 3072 ...)
     switch (mf) {
-        case 1: sgemm_kernel<1, NF><<<grid, 256, sm, st>>>(p); break;
-        case 2: sgemm_kernel<2, NF><<<grid, 256, sm, st>>>(p); break;
-        case 3: sgemm_kernel<3, NF><<<grid, 256, sm, st>>>(p); break;
-        default: sgemm_kernel<4, NF><<<grid, 256, sm, st>>>(p); break;
+        case 1: return deep ? launch_one<1, NF, 12>(p, grid, st) : launch_one<1, NF, 4>(p, grid, st);
+        case 2: return deep ? launch_one<2, NF, 12>(p, grid, st) : launch_one<2, NF, 4>(p, grid, st);
+        case 3: return deep ? launch_one<3, NF, 6>(p, grid, st) : launch_one<3, NF, 4>(p, grid, st);
+        default: return deep ? launch_one<4, NF, 6>(p, grid, st) : launch_one<4, NF, 4>(p, grid, st);
     }
-    return hipGetLastError();
 }
 
 hipError_t launch_sgemm(const SgemmParams& p, hipStream_t st) {

@@ -292,3 +292,59 @@ def test_knn_adversarial_near_duplicates(ctx, k, n_copies):
     torch.cuda.synchronize()
     assert ctx.knn_last_fallback() == 0
     assert np.array_equal(idx2.cpu().numpy().view(np.uint32), oret.exact_topk(oret.normalize_db(db), oret.normalize_queries(q2), k)[0])
+
+
+def test_knn_bulk_bit_exact(ctx):
+    """Bulk neighbour search: 10 000 queries x 1 000 003 rows, k = 20 (DatasetBuilder's default k) through the
+    query-tiled scan (128 queries per walker, 2 groups per database pass), bit-exact against the fp64 oracle; ragged last query
+    group, duplicates, a query batch that mixes planted rows."""
+    N, B, k = 1_000_003, 10_000, 20
+    d = ctx.device
+    gen = torch.Generator(device=d).manual_seed(3)
+    db = (torch.randn((N, 512), device=d, generator=gen) * 0.45).half()
+    q = torch.randn((B, 512), device=d, generator=gen) * 0.45
+    q[5] = db[999_999].float(); q[9_999] = db[17].float()
+    db[N - 1] = db[17]                                            # duplicate pair (index tie-break)
+    ctx.db_load(db)
+    import time
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    idx, sc = ctx.knn(q, k)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"bulk kNN {B} x {N}, k={k}: {dt * 1e3:.1f} ms = {2.0 * 2 * B * N * 512 / dt / 1e12:.0f} TFLOP/s (hi/lo), "
+          f"{N * 1024 * ((B + 255) // 256) / dt / 1e12:.2f} TB/s of database")
+    dbn = oret.normalize_db(db.cpu().numpy())
+    qn = oret.normalize_queries(q.cpu().numpy())
+    ref_i, ref_s = oret.exact_topk_bulk(dbn, qn, k)
+    got = idx.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, ref_i), f"top-k indices differ in {(got != ref_i).sum()} places"
+    assert np.abs(sc.cpu().numpy() - ref_s).max() <= 1e-6
+    assert got[9_999, 0] == 17 and got[9_999, 1] == N - 1
+    # the same queries through the online path (64 per pass) give the same answer
+    i64, _ = ctx.knn(q[:64], k)
+    assert np.array_equal(i64.cpu().numpy().view(np.uint32), ref_i[:64])
+
+
+def test_search_nns_on_device(ctx, tmp_path):
+    """search_nns end to end on the GPU: pre-computed query embeddings -> bulk search -> per-image pickles + nn_memory."""
+    import pickle
+    from rdm_amd.data.retrieval_dataset.dsetbuilder import DatasetBuilder
+    from rdm_amd.data.retrieval_dataset.search_neighbors import build_nn_memory, search_nns
+    rng = np.random.default_rng(5)
+    N = 20_000
+    pool = {"embedding": (rng.standard_normal((N, 512)) * 0.45).astype(np.float16), "img_id": np.arange(N), "patch_coords": np.zeros((N, 4), np.int64)}
+    dbb = DatasetBuilder(data_pool=pool, k=20, ctx=ctx)
+    dbb.train_searcher()
+    qs = (rng.standard_normal((3, 200, 1, 512)) * 0.45).astype(np.float32)                       # 3 batches of 200 images, 1 patch each
+    paths = search_nns(dbb, [{"embeddings": b} for b in qs], mode="embedded", save=True, npatches_perside=1, base_savedir=str(tmp_path), batch_size=200)
+    assert len(paths) == 600
+    ref_i, _ = oret.exact_topk(oret.normalize_db(pool["embedding"]), oret.normalize_queries(qs.reshape(600, 512)), 20)
+    for idx_ in (0, 199, 200, 599):
+        with open(tmp_path / paths[idx_], "rb") as f:
+            dct = pickle.load(f)[1]
+        assert np.array_equal(dct["nn_ids"][0], ref_i[idx_])
+        assert np.array_equal(dct["embeddings"][0], pool["embedding"][ref_i[idx_]])
+    counts = search_nns(dbb, [{"embeddings": b} for b in qs], mode="embedded", save=False)
+    ids, cnt = np.unique(ref_i, return_counts=True)
+    assert counts == {int(i): int(c) for i, c in zip(ids, cnt)}
+    mem = build_nn_memory(counts)
+    assert mem["nn_memory"].shape[0] == len(ids) and mem["id_count"][int(mem["nn_memory"][0])] == cnt.max()

@@ -320,3 +320,42 @@ def test_synthetic_weights_match_oracle_recipe():
                              channel_mult=t.channel_mult)
     a, b = synthetic.unet_state_dict(cfg, 1234), ounet.synth_state_dict(ounet.param_shapes(t), 1234)
     assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_search_nns_files_and_nn_memory(tmp_path):
+    """Bulk neighbour pre-computation (scripts/search_neighbors.py:380-450): per-image pickle format, nn_paths index, frequency
+    counting and the nn_memory pickle — host logic around a stand-in searcher (no GPU)."""
+    import pickle
+    from rdm_amd.data.retrieval_dataset.dsetbuilder import DatasetBuilder
+    from rdm_amd.data.retrieval_dataset.search_neighbors import build_nn_memory, search_nns
+    rng = np.random.default_rng(0)
+    pool = {"embedding": rng.standard_normal((50, 16)).astype(np.float16), "img_id": np.arange(50) * 2, "patch_coords": rng.integers(0, 9, (50, 4))}
+    db = DatasetBuilder(data_pool=pool, k=3)
+
+    class Searcher:
+        def search_batched(self, q, final_num_neighbors=None):
+            sc = np.asarray(q, np.float32) @ pool["embedding"].astype(np.float32).T
+            idx = np.argsort(-sc, axis=1, kind="stable")[:, :final_num_neighbors]
+            return idx.astype(np.uint32), np.take_along_axis(sc, idx, 1)
+    db.searcher = Searcher()
+    batches = [{"embeddings": rng.standard_normal((4, 2, 16)).astype(np.float32)} for _ in range(3)]     # 4 images x 2 patches per batch
+    paths = search_nns(db, batches, mode="embedded", save=True, npatches_perside=2, base_savedir=str(tmp_path), start_id=100, batch_size=4)
+    assert sorted(paths) == list(range(100, 112)) and paths[105] == "embeddings/3_nns-img000000105.p"
+    with open(tmp_path / paths[105], "rb") as f:
+        d = pickle.load(f)
+    assert set(d) == {2} and set(d[2]) == {"embeddings", "img_ids", "patch_coords", "nn_ids"}
+    assert d[2]["embeddings"].shape == (2, 3, 16) and d[2]["nn_ids"].shape == (2, 3) and d[2]["patch_coords"].shape == (2, 3, 4)
+    want, _ = Searcher().search_batched(batches[1]["embeddings"][1], 3)
+    assert np.array_equal(d[2]["nn_ids"], want) and np.array_equal(d[2]["img_ids"], pool["img_id"][want])
+    # a second pass with another patch grid merges into the same files
+    search_nns(db, [{"embeddings": b["embeddings"][:, :1]} for b in batches], mode="embedded", save=True, npatches_perside=1,
+               base_savedir=str(tmp_path), start_id=100, batch_size=4)
+    with open(tmp_path / paths[105], "rb") as f:
+        assert set(pickle.load(f)) == {1, 2}
+    counts = search_nns(db, batches, mode="embedded", save=False)
+    assert sum(counts.values()) == 3 * 4 * 2 * 3
+    mem = build_nn_memory(counts, str(tmp_path / "nn_memory" / "m.p"))
+    assert list(mem["nn_memory"]) == sorted(counts, key=lambda i: (-counts[i], i)) and mem["id_count"] == counts
+    with open(tmp_path / "nn_memory" / "m.p", "rb") as f:
+        again = pickle.load(f)
+    assert np.array_equal(again["nn_memory"], mem["nn_memory"])

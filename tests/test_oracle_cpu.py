@@ -188,3 +188,13 @@ def test_vqgan_oracle_shapes():
     shapes = ovq.vq_param_shapes(spec)
     assert "decoder.up.4.attn.2.q.weight" in shapes and "decoder.up.3.attn.0.q.weight" not in shapes
     assert shapes["decoder.conv_in.weight"] == (512, 256, 3, 3) and shapes["quantize.embedding.weight"] == (16384, 256)
+
+
+def test_bulk_topk_oracle_equals_exact_topk():
+    rng = np.random.default_rng(1)
+    db = (rng.standard_normal((6000, 64)) * 0.45).astype(np.float16); db[5000] = db[7]; db[5999] = db[7]
+    q = (rng.standard_normal((300, 64)) * 0.45).astype(np.float32); q[3] = db[7].astype(np.float32)
+    dbn, qn = oret.normalize_db(db), oret.normalize_queries(q)
+    a = oret.exact_topk(dbn, qn, 20)
+    b = oret.exact_topk_bulk(dbn, qn, 20, qblock=128, chunk=2048)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
