@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(MergeParams p) {
         }
     }
     // exact re-score of the best R candidates: fp64 accumulation of exact products
-    constexpr int R = (2 * KSEL > 64) ? 64 : 2 * KSEL;
+    constexpr int R = (KSEL == 8) ? 16 : 64;              // re-scored prefix: >= k (k <= 4 with KSEL 8, k <= 28 otherwise)
     __shared__ double ex[R]; __shared__ uint32_t exi[R];
     const int lane = tid & 63, wave = tid >> 6;
     for (int r = wave; r < R; r += 4) {
@@ -816,10 +816,14 @@ const char* knn_search(KnnDb& db, const float* q, int b, int k, uint32_t* idx_ou
     if (!db.dbn) return "no database loaded (rdm_db_load)";
     if (b < 1 || k < 1) return "b and k must be positive";
     if (k > db.n) return "k exceeds database size";
-    if (k + 4 <= 8) return search_impl<8>(db, q, b, k, idx_out, score_out, st);
-    if (k + 4 <= 16) return search_impl<16>(db, q, b, k, idx_out, score_out, st);
-    if (k + 4 <= 32) return search_impl<32>(db, q, b, k, idx_out, score_out, st);
-    return "k > 28 is not supported by the register top-k lists";
+    // List length per lane: 8 for k <= 4, 16 up to k = 28.  The length is a SPEED choice, not a correctness margin: whatever a list
+    // drops is covered by the certificate (and the exact fallback) in the merge.  A lane sees 1/2048 of the rows (1/512 in the bulk
+    // scan), so a list overflows only when more than 16 of a query's best ~64 rows fall into one lane's rows.  (A 32-entry list made
+    // every candidate of the scan pay a 32-step insertion chain while ANY of the wave's 64 lanes was still filling: k = 16 ran 8x
+    // slower than k = 4, and the 8-wave bulk kernel spilled.)
+    if (k <= 4) return search_impl<8>(db, q, b, k, idx_out, score_out, st);
+    if (k <= 28) return search_impl<16>(db, q, b, k, idx_out, score_out, st);
+    return "k > 28 is not supported (the merge re-scores the best 64 candidates)";
 }
 
 const char* knn_gather(KnnDb& db, const uint32_t* idx, long long n_idx, float* out, hipStream_t st) {
