@@ -94,6 +94,8 @@ hipError_t launch_timestep_embedding(const long long* t, bf16_t* out, int B, int
 hipError_t launch_cast_f32_bf16(const float* x, bf16_t* y, long long n, hipStream_t st);
 hipError_t launch_transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st);       // y[c][r] = x[r][c]
 hipError_t launch_expand_heads(const bf16_t* kv, int ld, int B, int k, int heads, int hd, int NP, float scale, bf16_t* out, hipStream_t st);
+hipError_t launch_add_bias_rows(const bf16_t* x, const float* bias, bf16_t* out, long long rows, int C, hipStream_t st);
+hipError_t launch_row_nonzero(const float* x, int rows, long long n, int* flag, hipStream_t st);   // flag[r] = row r has a non-zero element
 hipError_t launch_ddim_step(const DdimStepParams& p, hipStream_t st);
 hipError_t launch_ddpm_step(const DdpmStepParams& p, hipStream_t st);
 hipError_t launch_vq_quantize(const float* z, const float* codebook, int n_embed, const float* pq_w, const float* pq_b,

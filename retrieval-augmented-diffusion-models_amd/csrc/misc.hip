@@ -241,6 +241,50 @@ hipError_t launch_ddim_step(const DdimStepParams& p, hipStream_t st) {
     return hipGetLastError();
 }
 
+// out[r, :] = x[r, :] + bias[:]   (bf16 rows, 8 columns per thread).  Cross-attention of a sample whose neighbours are all-zero
+// vectors -- the unconditional half of a guided batch, rdm/models/diffusion/ddpm.py:673-680 -- is exactly to_out.bias: K = V = 0
+// gives uniform attention over zero values (rdm/modules/attention.py:52-72), so t2 = t1 + b_o without any GEMM.
+__global__ __launch_bounds__(256) void add_bias_rows_kernel(const bf16_t* x, const float* bias, bf16_t* out, long long rows, int C) {
+    const int cv = C >> 3;
+    const long long nvec = rows * cv;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
+        const int c = (int)(v % cv) * 8;
+        const uint4 u = *(const uint4*)(x + v * 8);
+        const float4 b0 = *(const float4*)(bias + c), b1 = *(const float4*)(bias + c + 4);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            o[e] = cvt_pk_bf16(__uint_as_float(w[e] << 16) + bb[2 * e], __uint_as_float(w[e] & 0xffff0000u) + bb[2 * e + 1]);
+        *(uint4*)(out + v * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+hipError_t launch_add_bias_rows(const bf16_t* x, const float* bias, bf16_t* out, long long rows, int C, hipStream_t st) {
+    if (C % 8) return hipErrorInvalidValue;
+    const long long nvec = rows * (C >> 3);
+    if (nvec <= 0) return hipSuccess;
+    int grid = (int)((nvec + 255) / 256); if (grid > 8192) grid = 8192;
+    add_bias_rows_kernel<<<grid, 256, 0, st>>>(x, bias, out, rows, C);
+    return hipGetLastError();
+}
+// flag[r] = 1 if row r of x [rows, n] has a non-zero element (one block per row)
+__global__ __launch_bounds__(256) void row_nonzero_kernel(const float* x, long long n, int* flag) {
+    __shared__ int any;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    const float* r = x + (long long)blockIdx.x * n;
+    int mine = 0;
+    for (long long i = threadIdx.x; i < n; i += 256) mine |= (r[i] != 0.0f);
+    if (mine) any = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) flag[blockIdx.x] = any;
+}
+hipError_t launch_row_nonzero(const float* x, int rows, long long n, int* flag, hipStream_t st) {
+    row_nonzero_kernel<<<rows, 256, 0, st>>>(x, n, flag);
+    return hipGetLastError();
+}
+
 // ldm LatentDiffusion.p_sample: x0 = c_recip*x - c_recipm1*eps; clamp; mean; + sigma*z
 __global__ void ddpm_step_kernel(DdpmStepParams p) {
     const float sd = p.nonzero ? expf(0.5f * p.log_var) : 0.f;

@@ -100,6 +100,8 @@ struct UNet {
     Arena arena;
     // cached cross-attention K/V for the current conditioning
     bf16_t* kv_cache = nullptr; size_t kv_cache_bytes = 0;
+    int ctx_rows = 0;            // samples [ctx_rows, B') of the cached conditioning have ALL-ZERO neighbours (the unconditional half of
+                                 // a guided batch): their cross-attention is the output bias, no GEMM runs for them
 };
 
 static std::string key(const std::string& pre, const char* s) { return pre + s; }
@@ -524,7 +526,7 @@ static void unet_compute_xattn(Ops& o, UNet& u, const bf16_t* kv, int B, int k, 
 }
 
 static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const bf16_t* kv, const bf16_t* xa, int B, int k, int H, int W,
-                      float* eps_out) {
+                      float* eps_out, int Bx /* samples [Bx, B) have all-zero context */) {
     const rdm_unet_cfg& c = u.cfg;
     const int mc = c.model_channels, ted = mc * 4;
     // time embedding (openaimodel.py:352-353); emb is only ever consumed through SiLU (ResBlock.emb_layers[0])
@@ -596,37 +598,41 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         }
         bf16_t* t1 = o.abf((size_t)M * C);
         o.linear(ao, nullptr, C, 0, s.wo1, s.bo1, true, M, C, ACT_NONE, t0, t1);
-        // --- attn2 (cross over the k neighbours)
+        // --- attn2 (cross over the k neighbours); samples >= Bx have all-zero neighbours: t2 = t1 + b_o exactly (see add_bias_rows_kernel)
+        const int Mx = Bx * n;
         bf16_t* l2 = o.abf((size_t)M * C);
-        o.layernorm(t1, 0, s.ln2g, s.ln2b, l2, 0, M, C);
+        if (Mx > 0) o.layernorm(t1, 0, s.ln2g, s.ln2b, l2, 0, Mx, C);
         bf16_t* t2 = o.abf((size_t)M * C);
-        if (xa) {       // two skinny per-sample GEMMs (see unet_compute_xattn)
+        if (Bx < B && !o.plan)
+            o.check(launch_add_bias_rows(t1 + (size_t)Mx * C, o.w<float>(s.bo2), t2 + (size_t)Mx * C, (long long)(M - Mx), C, o.c->stream), "zero-context cross attention");
+        if (Mx == 0) {
+        } else if (xa) {       // two skinny per-sample GEMMs (see unet_compute_xattn)
             bf16_t* P = o.abf((size_t)M * XA_NP);
             if (!o.plan) {
                 const bf16_t* G = xa + (size_t)B * s.xa_unit; const bf16_t* U = G + (size_t)B * XA_NP * C;
                 IgemmParams p = o.base(n, XA_NP, C);
                 p.A0 = l2; p.C0 = C; p.sA = (long long)n * C; p.W = G; p.sW = (long long)XA_NP * C; p.out_bf16 = P; p.sO = (long long)n * XA_NP;
                 p.act = ACT_SOFTMAXG; p.sm_group = k;
-                o.prof_begin(RDM_PROF_LINEAR, 2.0 * M * XA_NP * (double)C);
-                o.check(launch_igemm(p, false, B, o.c->stream), "xattn scores");
+                o.prof_begin(RDM_PROF_LINEAR, 2.0 * Mx * XA_NP * (double)C);
+                o.check(launch_igemm(p, false, Bx, o.c->stream), "xattn scores");
                 o.prof_end();
                 IgemmParams q = o.base(n, C, XA_NP);
                 q.A0 = P; q.C0 = XA_NP; q.sA = (long long)n * XA_NP; q.W = U; q.sW = (long long)C * XA_NP; q.bias = o.w<float>(s.bo2);
                 q.res_bf16 = t1; q.out_bf16 = t2; q.sO = (long long)n * C;
-                o.prof_begin(RDM_PROF_LINEAR, 2.0 * M * C * (double)XA_NP);
-                o.check(launch_igemm(q, false, B, o.c->stream), "xattn out");
+                o.prof_begin(RDM_PROF_LINEAR, 2.0 * Mx * C * (double)XA_NP);
+                o.check(launch_igemm(q, false, Bx, o.c->stream), "xattn out");
                 o.prof_end();
             }
         } else {
             bf16_t* q2 = o.abf((size_t)M * C);
-            o.linear(l2, nullptr, C, 0, s.wq2, 0, false, M, C, ACT_NONE, nullptr, q2);
+            o.linear(l2, nullptr, C, 0, s.wq2, 0, false, Mx, C, ACT_NONE, nullptr, q2);
             bf16_t* ao2 = o.abf((size_t)M * C);
             if (!o.plan) {
                 SmallAttnParams p{}; p.q = q2; p.ldq = C; p.k = kv + s.kv_off; p.ldk = u.kv_total; p.v = kv + s.kv_off + C;
                 p.ldv = u.kv_total; p.out = ao2; p.ldo = C; p.nq = n; p.nkv = k; p.causal = 0; p.scale = 1.0f / sqrtf(32.f);
-                o.check(launch_small_attention(p, 32, s.heads, B, o.c->stream), "cross attention");
+                o.check(launch_small_attention(p, 32, s.heads, Bx, o.c->stream), "cross attention");
             }
-            o.linear(ao2, nullptr, C, 0, s.wo2, s.bo2, true, M, C, ACT_NONE, t1, t2);
+            o.linear(ao2, nullptr, C, 0, s.wo2, s.bo2, true, Mx, C, ACT_NONE, t1, t2);
         }
         // --- GEGLU feed-forward
         bf16_t* l3 = o.abf((size_t)M * C);
@@ -951,7 +957,7 @@ int rdm_load_clip(rdm_ctx* c, const rdm_clip_cfg* cfg, const void* packed, size_
 }
 
 static int unet_forward_impl(rdm_ctx* c, const float* x, const int64_t* t, const float* context, const bf16_t* kv_cached,
-                             int b, int k, int H, int W, float* eps_out) {
+                             int b, int k, int H, int W, float* eps_out, int ctx_rows = -1) {
     UNet& u = c->unet;
     if (!u.loaded) return c->fail(-1, "unet weights not loaded");
     const int down = 1 << (u.cfg.n_channel_mult - 1);
@@ -971,7 +977,7 @@ static int unet_forward_impl(rdm_ctx* c, const float* x, const int64_t* t, const
                 xa = xab;
             }
         }
-        unet_body(o, u, x, (const long long*)t, kv, xa, b, k, H, W, eps_out);
+        unet_body(o, u, x, (const long long*)t, kv, xa, b, k, H, W, eps_out, (ctx_rows >= 0 && ctx_rows <= b) ? ctx_rows : b);
     });
 }
 
@@ -1002,6 +1008,20 @@ static int prepare_kv(rdm_ctx* c, const float* cond, const float* uncond, int B,
     if (uncond) RDM_CHECK_HIP(c, hipMemcpyAsync(cat + (size_t)B * k * cd, uncond, (size_t)B * k * cd * 4, hipMemcpyDeviceToDevice, c->stream));
     const bool skinny = xattn_skinny_ok(u, k);
     if (skinny) RDM_TRY(ensure_bytes(c, (char**)&u.xa_cache, &u.xa_cache_bytes, (size_t)nb * u.xa_total * 2));
+    u.ctx_rows = nb;
+    if (uncond) {      // how many trailing samples have all-zero neighbours?  (one small kernel + one 4*nb-byte read per sampling call)
+        static const int off = getenv("RDM_NO_ZEROCTX") ? atoi(getenv("RDM_NO_ZEROCTX")) : 0;
+        std::vector<int> flags(nb, 1);
+        int* dflags = (int*)c->gn_partial;             // scratch: >= 16 KB once any forward ran; make sure it exists
+        RDM_TRY(ensure_gn_partial(c, nb));
+        dflags = (int*)c->gn_partial;
+        RDM_CHECK_HIP(c, launch_row_nonzero(cat, nb, (long long)k * cd, dflags, c->stream));
+        RDM_CHECK_HIP(c, hipMemcpyAsync(flags.data(), dflags, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+        RDM_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        int rows = nb;
+        while (rows > 0 && flags[rows - 1] == 0) rows--;
+        if (!off) u.ctx_rows = rows;
+    }
     return run_with_arena(c, u.arena, u.blob, [&](Ops& o) {
         unet_compute_kv(o, u, cat, nb, k, u.kv_cache);
         if (skinny) unet_compute_xattn(o, u, u.kv_cache, nb, k, u.xa_cache);
@@ -1057,7 +1077,7 @@ int rdm_ddim_sample(rdm_ctx* c, const rdm_ddim_args* a, const float* x_T, const 
     for (int i = 0; i < total; i++) {
         const int index = total - i - 1;
         if (cfg && i == 0) RDM_CHECK_HIP(c, hipMemcpyAsync(x2 + n1, x2, n1 * 4, hipMemcpyDeviceToDevice, c->stream));   // later steps: ddim_step writes both halves
-        RDM_TRY(unet_forward_impl(c, x2, (const int64_t*)(tdev + (size_t)index * nb), nullptr, u.kv_cache, nb, k, a->height, a->width, eps));
+        RDM_TRY(unet_forward_impl(c, x2, (const int64_t*)(tdev + (size_t)index * nb), nullptr, u.kv_cache, nb, k, a->height, a->width, eps, u.ctx_rows));
         const bool log = (index % a->log_every_t == 0) || (index == total - 1);
         DdimStepParams p{};
         p.x = x2; p.eps = eps; p.noise = (noise && a->eta != 0.f) ? noise + (size_t)i * n1 : nullptr;
@@ -1098,7 +1118,7 @@ int rdm_ddpm_sample(rdm_ctx* c, const rdm_ddpm_args* a, const float* x_T, const 
     }
     RDM_CHECK_HIP(c, hipMemcpyAsync(x, x_T, n1 * 4, hipMemcpyDeviceToDevice, c->stream));
     for (int n = 0, i = T - 1; i >= 0; i--, n++) {
-        RDM_TRY(unet_forward_impl(c, x, (const int64_t*)(tdev + (size_t)i * B), nullptr, u.kv_cache, B, k, a->height, a->width, eps));
+        RDM_TRY(unet_forward_impl(c, x, (const int64_t*)(tdev + (size_t)i * B), nullptr, u.kv_cache, B, k, a->height, a->width, eps, B));
         DdpmStepParams p{};
         p.x = x; p.eps = eps; p.noise = noise + (size_t)n * n1; p.x_prev = x; p.n = n1;
         p.sqrt_recip = a->sqrt_recip_alphas_cumprod[i]; p.sqrt_recipm1 = a->sqrt_recipm1_alphas_cumprod[i];

@@ -27,6 +27,7 @@ def instantiate_from_config(config):
         "rdm.data.retrieval_dataset.dsetbuilder.DatasetBuilder": "rdm_amd.data.retrieval_dataset.dsetbuilder.DatasetBuilder",
         "rdm.modules.retrievers.ClipImageRetriever": "rdm_amd.modules.retrievers.ClipImageRetriever",
         "rdm.modules.retrievers.CLIPTextEmbedder": "rdm_amd.modules.retrievers.CLIPTextEmbedder",
+        "rdm.models.autoregression.transformer.LatentImageRETRO": "rdm_amd.models.autoregression.transformer.LatentImageRETRO",
     }
     target = redirect.get(target, target)
     mod, cls = target.rsplit(".", 1)

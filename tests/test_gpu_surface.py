@@ -233,7 +233,7 @@ def test_rdm_sample_script_synthetic(tmp_path):
         assert np.array_equal(px[f"{stamp}-query_samples-run1-sample{i}.png"], u8[i])
     assert len(np.unique(u8)) > 16                                   # not a constant image
     # unconditional branch (caption == ""): pseudo-queries from the database, keep_qids
-    opt2 = mod.parse_args(["--synthetic", "--gpu", "0", "-bs", "2", "-n", "1", "--steps", "3", "--keep_qids", "--top_m", "100", "-s", str(tmp_path / "u")])
+    opt2 = mod.parse_args(["--synthetic", "--gpu", "0", "-bs", "2", "-n", "1", "--steps", "4", "--keep_qids", "--top_m", "100", "-s", str(tmp_path / "u")])
     (tmp_path / "u").mkdir()
     mod.sample_unconditional(model, opt2)
     assert len(list((tmp_path / "u").iterdir())) == 2

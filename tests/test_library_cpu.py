@@ -86,6 +86,28 @@ def test_vq_and_clip_manifests():
     _check_manifest("clip", spec_to_clip_cfg(oclip.tiny_clip_spec()), oclip.clip_param_shapes(oclip.tiny_clip_spec()))
 
 
+def test_rarm_and_vqgan_manifests():
+    """RARM transformer (rdm/modules/attention.py:206-249 keys) and the taming VQGAN-f16 decoder (per-level AttnBlocks, wide latent)."""
+    import rdm_amd  # noqa: F401
+    from oracle import rarm as orarm
+    from rdm_amd import _lib
+    spec = orarm.tiny_rarm_spec()
+    cfg = _lib.make_rarm_cfg(in_channels=spec.vocab_in, out_channels=spec.vocab_out, n_heads=spec.n_heads, depth=spec.depth,
+                             sequence_length=spec.sequence_length)
+    entries, blob, sd = _check_manifest("rarm", cfg, orarm.rarm_param_shapes(spec))
+    off, nb, kd, srcs = next(e for e in entries if e[2] == "f32_t")      # positional_encoding [C, L] stored as [L][C]
+    got = torch.from_numpy(blob[off:off + nb].view(np.float32).copy()).reshape(spec.sequence_length, spec.inner_dim)
+    assert torch.equal(got, sd["positional_encoding"].t())
+    vs = ovq.tiny_vqgan_spec()
+    vcfg = _lib.make_vq_cfg(embed_dim=vs.embed_dim, n_embed=vs.n_embed, z_channels=vs.z_channels, ch=vs.ch, ch_mult=vs.ch_mult,
+                            num_res_blocks=vs.num_res_blocks, resolution=vs.resolution, attn_resolutions=vs.attn_resolutions)
+    e2, _, _ = _check_manifest("vq", vcfg, ovq.vq_param_shapes(vs))
+    assert any(e[2] == "conv3" and e[3] == ["decoder.conv_in.weight"] for e in e2)          # wide latent: conv_in is a GEMM-class conv
+    full = _lib.make_vqgan_f16_cfg()
+    e3, nbytes = _lib.manifest("vq", full)
+    assert sorted(s for e in e3 for s in e[3]) == sorted(ovq.vq_param_shapes(ovq.vqgan_f16_spec()))
+
+
 def test_ema_key_mapping():
     import rdm_amd  # noqa: F401
     from rdm_amd import packing
