@@ -525,8 +525,9 @@ static void unet_compute_xattn(Ops& o, UNet& u, const bf16_t* kv, int B, int k, 
     }
 }
 
-static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const bf16_t* kv, const bf16_t* xa, int B, int k, int H, int W,
-                      float* eps_out, int Bx /* samples [Bx, B) have all-zero context */) {
+static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const bf16_t* kv, const bf16_t* xa, const int Bfull, int k, int H, int W,
+                      float* eps_out, int Bx /* samples [Bx, Bfull) have all-zero context */, int Bshared /* Bfull, or Bfull/2: see below */) {
+    int B = Bfull;               // the batch the CURRENT layer runs on (Bshared inside the guidance prefix)
     const rdm_unet_cfg& c = u.cfg;
     const int mc = c.model_channels, ted = mc * 4;
     // time embedding (openaimodel.py:352-353); emb is only ever consumed through SiLU (ResBlock.emb_layers[0])
@@ -542,6 +543,21 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
     struct Act { bf16_t* p; int C, H, W; };
     std::vector<Act> hs;
     Act h{nullptr, 0, H, W};
+    // Shared guidance prefix: with classifier-free guidance the batch is [x | x] with the SAME x and t in both halves and different
+    // contexts (ddim.py:229-234), so every layer before the first SpatialTransformer (conv_in, the 64x64 ResBlocks, the first
+    // Downsample, the first 32x32 ResBlock: 12 % of the conv FLOPs, 17 % of the GroupNorm bytes) computes identical values for the two
+    // halves.  They run once on Bfull/2 samples; the activations (and the skip tensors already pushed) are duplicated right before the
+    // first context-dependent layer.  B below is the batch the CURRENT layer runs on.
+    B = (Bshared > 0 && Bshared * 2 == Bfull) ? Bshared : Bfull;
+    auto expand = [&](Act& a) {        // [B, H, W, C] -> [2B, H, W, C] (second half = copy of the first)
+        const size_t n = (size_t)B * a.H * a.W * a.C;
+        bf16_t* d = o.abf(2 * n);
+        if (!o.plan) {
+            o.check(hipMemcpyAsync(d, a.p, n * 2, hipMemcpyDeviceToDevice, o.c->stream), "expand prefix");
+            o.check(hipMemcpyAsync(d + n, a.p, n * 2, hipMemcpyDeviceToDevice, o.c->stream), "expand prefix");
+        }
+        a.p = d;
+    };
 
     auto resblock = [&](const ResW& r, const Act& a, const Act* skip) -> Act {
         const int C0 = a.C, C1 = skip ? skip->C : 0, HW = a.H * a.W, M = B * HW;
@@ -665,7 +681,9 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                     h = Act{out, mc, H, W};
                 } break;
                 case 1: h = resblock(u.res[L.idx], h, (first && skip) ? skip : nullptr); break;
-                case 2: h = transformer(u.st[L.idx], h); break;
+                case 2:
+                    if (B < Bfull) { expand(h); for (Act& a : hs) expand(a); B = Bfull; }     // first context-dependent layer: leave the shared prefix
+                    h = transformer(u.st[L.idx], h); break;
                 case 3: {
                     const ConvW& d = u.down[L.idx];
                     bf16_t* out = o.abf((size_t)B * (h.H / 2) * (h.W / 2) * d.c);
@@ -683,6 +701,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         }
         if (blk.where == 0) hs.push_back(h);
     }
+    if (B < Bfull) { expand(h); B = Bfull; }          // (a UNet without attention: the whole network was shared)
     bf16_t* no = o.abf((size_t)B * H * W * mc);
     o.groupnorm(h.p, nullptr, mc, 0, B, H * W, u.outg, u.outb, 1e-5f, 1, no);
     if (!o.plan) o.check(launch_conv_out(no, o.w<float>(u.outw), o.w<float>(u.outbias), eps_out, B, H, W, mc, c.out_channels, o.c->stream), "conv_out");
@@ -957,7 +976,7 @@ int rdm_load_clip(rdm_ctx* c, const rdm_clip_cfg* cfg, const void* packed, size_
 }
 
 static int unet_forward_impl(rdm_ctx* c, const float* x, const int64_t* t, const float* context, const bf16_t* kv_cached,
-                             int b, int k, int H, int W, float* eps_out, int ctx_rows = -1) {
+                             int b, int k, int H, int W, float* eps_out, int ctx_rows = -1, int shared_half = 0) {
     UNet& u = c->unet;
     if (!u.loaded) return c->fail(-1, "unet weights not loaded");
     const int down = 1 << (u.cfg.n_channel_mult - 1);
@@ -977,7 +996,7 @@ static int unet_forward_impl(rdm_ctx* c, const float* x, const int64_t* t, const
                 xa = xab;
             }
         }
-        unet_body(o, u, x, (const long long*)t, kv, xa, b, k, H, W, eps_out, (ctx_rows >= 0 && ctx_rows <= b) ? ctx_rows : b);
+        unet_body(o, u, x, (const long long*)t, kv, xa, b, k, H, W, eps_out, (ctx_rows >= 0 && ctx_rows <= b) ? ctx_rows : b, shared_half);
     });
 }
 
@@ -1074,10 +1093,12 @@ int rdm_ddim_sample(rdm_ctx* c, const rdm_ddim_args* a, const float* x_T, const 
     }
     RDM_CHECK_HIP(c, hipMemcpyAsync(x2, x_T, n1 * 4, hipMemcpyDeviceToDevice, c->stream));
     int n_logged = 0;
+    static const int share_prefix = getenv("RDM_NO_SHARED_PREFIX") ? !atoi(getenv("RDM_NO_SHARED_PREFIX")) : 1;
     for (int i = 0; i < total; i++) {
         const int index = total - i - 1;
         if (cfg && i == 0) RDM_CHECK_HIP(c, hipMemcpyAsync(x2 + n1, x2, n1 * 4, hipMemcpyDeviceToDevice, c->stream));   // later steps: ddim_step writes both halves
-        RDM_TRY(unet_forward_impl(c, x2, (const int64_t*)(tdev + (size_t)index * nb), nullptr, u.kv_cache, nb, k, a->height, a->width, eps, u.ctx_rows));
+        RDM_TRY(unet_forward_impl(c, x2, (const int64_t*)(tdev + (size_t)index * nb), nullptr, u.kv_cache, nb, k, a->height, a->width, eps, u.ctx_rows,
+                                  share_prefix && cfg ? B : 0));     // [x | x], same t: the context-independent prefix runs once
         const bool log = (index % a->log_every_t == 0) || (index == total - 1);
         DdimStepParams p{};
         p.x = x2; p.eps = eps; p.noise = (noise && a->eta != 0.f) ? noise + (size_t)i * n1 : nullptr;

@@ -361,9 +361,9 @@ def test_zero_context_shortcut_matches_gemm_path(ctx, k):
     x_T = torch.from_numpy(rng.standard_normal((3, 3, 16, 16)).astype(np.float32))
     cond = torch.from_numpy((rng.standard_normal((3, k, 512)) * 0.45).astype(np.float32))
     sched = odiff.Schedule()
-    z0, _, _ = ctx.ddim_sample(3, x_T, cond, torch.zeros_like(cond), sched.alphas_cumprod, scale=2.0)
-    z1, _, _ = ctx.ddim_sample(3, x_T, cond, torch.full_like(cond, 1e-30), sched.alphas_cumprod, scale=2.0)
+    z0, _, _ = ctx.ddim_sample(4, x_T, cond, torch.zeros_like(cond), sched.alphas_cumprod, scale=2.0)
+    z1, _, _ = ctx.ddim_sample(4, x_T, cond, torch.full_like(cond, 1e-30), sched.alphas_cumprod, scale=2.0)
     torch.cuda.synchronize()
-    ref, _ = odiff.ddim_sample(lambda x, t, c: ounet.unet_forward(sd, spec, x, t, c), sched, 3, x_T, cond, scale=2.0, uncond=torch.zeros_like(cond))
+    ref, _ = odiff.ddim_sample(lambda x, t, c: ounet.unet_forward(sd, spec, x, t, c), sched, 4, x_T, cond, scale=2.0, uncond=torch.zeros_like(cond))
     print(f"zero-context shortcut (k={k}): vs GEMM path {rel_l2(z0, z1):.3e}, vs oracle {rel_l2(z0, ref):.3e} / {rel_l2(z1, ref):.3e}")
     assert rel_l2(z0, z1) <= 1e-2 and rel_l2(z0, ref) <= 4e-2 and rel_l2(z1, ref) <= 4e-2
