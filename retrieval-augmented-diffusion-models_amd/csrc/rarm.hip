@@ -115,9 +115,22 @@ __global__ __launch_bounds__(256) void rarm_sample_kernel(RarmSampleParams p) {
         hist[tid] = 0;
         __syncthreads();
         const uint32_t mask = pass == 3 ? 0u : (0xffffffffu << ((pass + 1) * 8));
-        for (int i = tid; i < V; i += 256) {
-            const uint32_t o = f2ord(logit(i));
-            if ((o & mask) == (prefix & mask)) atomicAdd(&hist[(o >> (pass * 8)) & 255u], 1u);
+        for (int i0 = 0; i0 < V; i0 += 256) {
+            // wave-aggregated histogram update: logits share their leading bytes, so nearly all 64 lanes of a wave hit the SAME bucket
+            // (a plain per-lane LDS atomic serialised 16 384 adds on one address: 117 us per step); one atomic per distinct bucket
+            const int i = i0 + tid;
+            const uint32_t o = i < V ? f2ord(logit(i)) : 0u;
+            bool active = i < V && (o & mask) == (prefix & mask);
+            const uint32_t bucket = (o >> (pass * 8)) & 255u;
+            unsigned long long todo = __ballot(active);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const uint32_t b0 = __shfl(bucket, leader);
+                const unsigned long long same = __ballot(active && bucket == b0);
+                if ((tid & 63) == leader) atomicAdd(&hist[b0], (uint32_t)__popcll(same));
+                todo &= ~same;
+                if (bucket == b0) active = false;
+            }
         }
         __syncthreads();
         if (tid == 0) {
