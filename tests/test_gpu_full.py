@@ -93,6 +93,46 @@ def test_ddim_50_steps_shipped(shipped, tag):
         assert e1 <= 2.5e-2 and e2 <= 2.5e-2
 
 
+def test_ddim_50_steps_shipped_batch64(shipped):
+    """The benchmark's own batch geometry (config #3: B = 64, CFG => UNet batch 128): tall tiles, K-split, wide GEGLU tiles, the shared
+    guidance prefix on 64 samples and the zero-context shortcut only run at this size.  Row 0 carries the golden trajectory's inputs,
+    rows 1..63 are random; samples are independent, so row 0 must track the reference trajectory within the same flat bound."""
+    ctx = shipped
+    g = golden("full_ddim_k4.npz")
+    gen = torch.Generator().manual_seed(77)
+    x_T = torch.cat([torch.from_numpy(g["x_T"]), torch.randn(63, 3, 64, 64, generator=gen)])
+    cond = torch.cat([torch.from_numpy(g["cond"]), torch.randn(63, 4, 512, generator=gen) * 0.45])
+    sched = odiff.Schedule()
+    z, xi, pi = ctx.ddim_sample(50, x_T, cond, torch.zeros_like(cond), sched.alphas_cumprod, eta=0.0, scale=float(g["scale"]), log_every_t=1,
+                                want_intermediates=True)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(z).all())
+    errs = {int(i): rel_l2(xi[int(i), :1], torch.from_numpy(g[f"x_{int(i)}"])) for i in g["steps"]}
+    ez = rel_l2(z[:1], torch.from_numpy(g["z"]))
+    print("[ddim_k4, batch 64] row 0 vs reference trajectory:", {i: f"{e:.3e}" for i, e in errs.items()}, f"final {ez:.3e}")
+    assert all(e <= DDIM_E0 for e in errs.values()) and ez <= DDIM_E0
+
+
+def test_ddpm_250_steps_shipped_k16_batch64(shipped):
+    """Config #4 per-GPU geometry: B = 64, k = 16, 250 ancestral steps; row 0 = the golden trajectory's inputs and noise."""
+    ctx = shipped
+    g = golden("full_ddpm_k16.npz")
+    T = int(g["timesteps"])
+    gen = torch.Generator().manual_seed(78)
+    x_T = torch.cat([torch.from_numpy(g["x_T"]), torch.randn(63, 3, 64, 64, generator=gen)])
+    cond = torch.cat([torch.from_numpy(g["cond"]), torch.randn(63, 16, 512, generator=gen) * 0.45])
+    n0 = torch.from_numpy(np.random.default_rng(int(g["noise_seed"])).standard_normal((T, 1, 3, 64, 64)).astype(np.float32))
+    noise = torch.cat([n0, torch.randn(T, 63, 3, 64, 64, generator=gen)], dim=1)
+    s = odiff.Schedule()
+    sched = {n: getattr(s, n).numpy() for n in ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
+                                                "posterior_mean_coef2", "posterior_log_variance_clipped")}
+    z = ctx.ddpm_sample(T, x_T, cond, noise, sched, clip_denoised=True)
+    torch.cuda.synchronize()
+    ez = rel_l2(z[:1], torch.from_numpy(g["z"]))
+    print(f"[ddpm_k16, batch 64] row 0 final rel L2 {ez:.3e}")
+    assert bool(torch.isfinite(z).all()) and ez <= DDPM_FINAL
+
+
 def test_ddpm_250_steps_shipped_k16(shipped):
     """Config #4: ldm p_sample_loop(timesteps=250) (reached from rdm/models/diffusion/ddpm.py:1007-1009), k = 16 neighbours
     (attention-kernel cross-attention path), no CFG, clip_denoised; the per-step noise is default_rng(noise_seed)."""
