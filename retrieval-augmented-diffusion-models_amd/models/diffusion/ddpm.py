@@ -233,7 +233,9 @@ class MinimalRETRODiffusion(object):
         """ddpm.py:689-844 (nn_encoder is None, retrieval_encoder = Identity — every shipped config)."""
         if cond is not None or example_maps is not None or return_nns:
             raise NotImplementedError("cond / example_maps / return_nns are not part of the native sampling path")
-        if not query_embedded:
+        # (the reference asserts `query.ndim` first, which makes its own `isinstance(query, str)` branch unreachable: a caption only
+        #  works pre-embedded there, scripts/rdm_sample.py:275-277; here str / list-of-str queries take the CLIP text tower)
+        if not query_embedded and not isinstance(query, (str, list)):
             assert query.ndim in [3, 4], 'User defined query for sampling has to be an image or of batch of images'
         if self.retriever is not None and self.retriever.searcher is None:
             self.train_searcher()
@@ -241,10 +243,14 @@ class MinimalRETRODiffusion(object):
             bs = 1
         if isinstance(query, str):
             query = [query] * bs
+        elif isinstance(query, list):
+            pass
         elif query_embedded and query.shape[0] == 1:
             query = query.repeat(bs, 1) if isinstance(query, torch.Tensor) else np.repeat(query, bs, axis=0)
-        elif not query_embedded and not isinstance(query, list) and query.ndim == 3:
+        elif not query_embedded and query.ndim == 3:
             query = torch.stack([torch.as_tensor(query)] * bs, dim=0)
+        elif not query_embedded and query.ndim == 4 and query.shape[0] == 1:
+            query = torch.as_tensor(query).repeat(bs, 1, 1, 1)
         is_caption = isinstance(query, list)
         assert is_caption or query_embedded or ischannellastimage(query)
         if k_nn is None:

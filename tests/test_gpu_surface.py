@@ -299,3 +299,35 @@ def test_single_rank_distributed_mode_is_deterministic(ctx):
     a = _dist_sample(0)
     b = _dist_sample(0)
     assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+
+
+def test_sample_with_query_image_and_caption_queries(model, ctx):
+    """sample_with_query with raw queries (ddpm.py:689-777): a channel-last image batch goes through ClipImageRetriever
+    (bicubic preprocess + image tower), a caption through BPE + the text tower; both must equal the query_embedded=True call on the
+    embeddings the retriever computes for them."""
+    from rdm_amd.data.retrieval_dataset.dsetbuilder import DatasetBuilder
+    from rdm_amd.modules.retrievers import ClipImageRetriever
+    spec = oclip.ClipSpec(embed_dim=512, image_resolution=64, vision_layers=1, vision_width=128, vision_patch_size=32,
+                          context_length=77, vocab_size=49408, transformer_width=128, transformer_heads=2, transformer_layers=1)
+    sd = ounet.synth_state_dict(oclip.clip_param_shapes(spec), seed=3)
+    sd["positional_embedding"] = sd["positional_embedding"] * 0.1
+    r = ClipImageRetriever(state_dict=sd, ctx=ctx, clip_cfg=spec_to_clip_cfg(spec))
+    rng = np.random.default_rng(31)
+    pool = {"embedding": (rng.standard_normal((4000, 512)) * 0.45).astype(np.float16), "img_id": np.arange(4000), "patch_coords": np.zeros((4000, 4), np.int64)}
+    db = DatasetBuilder(data_pool=pool, k=20, retriever=r, ctx=ctx)
+    db.train_searcher()
+    model.retriever = db
+    x_T = torch.from_numpy(rng.standard_normal((2, 3, 16, 16)).astype(np.float32))
+    kw = dict(k_nn=4, ddim=True, ddim_steps=4, x_T=x_T, unconditional_guidance_scale=2.0, unconditional_retro_guidance_label=0.)
+    img = torch.from_numpy(rng.uniform(-1, 1, (2, 48, 40, 3)).astype(np.float32))            # b h w c in [-1, 1]
+    a = model.sample_with_query(query=img, **kw)["query_samples"]
+    emb = db.embed(img)
+    b = model.sample_with_query(query=torch.from_numpy(emb), query_embedded=True, **kw)["query_samples"]
+    assert a.shape == (2, 3, 64, 64) and torch.equal(a, b)
+    c = model.sample_with_query(query="a happy bear reading a newspaper", bs=2, **kw)["query_samples"]
+    emb_t = db.embed(["a happy bear reading a newspaper"] * 2, is_caption=True)
+    d = model.sample_with_query(query=torch.from_numpy(emb_t), query_embedded=True, **kw)["query_samples"]
+    assert torch.equal(c, d) and not torch.equal(a, c)
+    # omit_query / n_reps / normalize switches (ddpm.py:762-777)
+    e = model.sample_with_query(query=torch.from_numpy(emb), query_embedded=True, omit_query=True, normalize=True, n_reps=2, **kw)["query_samples"]
+    assert e.shape == (2, 3, 64, 64) and bool(torch.isfinite(e).all())
