@@ -549,14 +549,11 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
     // halves.  They run once on Bfull/2 samples; the activations (and the skip tensors already pushed) are duplicated right before the
     // first context-dependent layer.  B below is the batch the CURRENT layer runs on.
     B = (Bshared > 0 && Bshared * 2 == Bfull) ? Bshared : Bfull;
-    auto expand = [&](Act& a) {        // [B, H, W, C] -> [2B, H, W, C] (second half = copy of the first)
+    // (block outputs produced inside the prefix are allocated for Bfull samples and written into the first half, so leaving the
+    //  prefix costs one copy of B samples per tensor: first half -> second half)
+    auto expand = [&](Act& a) {        // [B, H, W, C] in a [2B, H, W, C] allocation -> second half = copy of the first
         const size_t n = (size_t)B * a.H * a.W * a.C;
-        bf16_t* d = o.abf(2 * n);
-        if (!o.plan) {
-            o.check(hipMemcpyAsync(d, a.p, n * 2, hipMemcpyDeviceToDevice, o.c->stream), "expand prefix");
-            o.check(hipMemcpyAsync(d + n, a.p, n * 2, hipMemcpyDeviceToDevice, o.c->stream), "expand prefix");
-        }
-        a.p = d;
+        if (!o.plan) o.check(hipMemcpyAsync(a.p + n, a.p, n * 2, hipMemcpyDeviceToDevice, o.c->stream), "expand prefix");
     };
 
     auto resblock = [&](const ResW& r, const Act& a, const Act* skip) -> Act {
@@ -574,7 +571,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
             o.linear(a.p, x1, C0, C1, r.wsk, r.bsk, true, M, r.cout, ACT_NONE, nullptr, s);
             res = s;
         }
-        bf16_t* out = o.abf((size_t)M * r.cout);
+        bf16_t* out = o.abf((size_t)Bfull * HW * r.cout);           // Bfull: see expand()
         o.conv3(n2, nullptr, r.cout, 0, r.w2, r.b2, B, a.H, a.W, r.cout, 1, 0, nullptr, 0, res, out);
         return Act{out, r.cout, a.H, a.W};
     };
@@ -676,7 +673,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         for (const ULayer& L : blk.layers) {
             switch (L.kind) {
                 case 0: {
-                    bf16_t* out = o.abf((size_t)B * H * W * mc);
+                    bf16_t* out = o.abf((size_t)Bfull * H * W * mc);
                     if (!o.plan) o.check(launch_conv_in(x, o.w<float>(u.cinw), o.w<float>(u.cinb), out, B, c.in_channels, H, W, mc, o.c->stream), "conv_in");
                     h = Act{out, mc, H, W};
                 } break;
@@ -686,13 +683,13 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                     h = transformer(u.st[L.idx], h); break;
                 case 3: {
                     const ConvW& d = u.down[L.idx];
-                    bf16_t* out = o.abf((size_t)B * (h.H / 2) * (h.W / 2) * d.c);
+                    bf16_t* out = o.abf((size_t)Bfull * (h.H / 2) * (h.W / 2) * d.c);
                     o.conv3(h.p, nullptr, d.c, 0, d.w, d.b, B, h.H, h.W, d.c, 2, 0, nullptr, 0, nullptr, out);
                     h = Act{out, d.c, h.H / 2, h.W / 2};
                 } break;
                 case 4: {
                     const ConvW& d = u.up[L.idx];
-                    bf16_t* out = o.abf((size_t)B * (h.H * 2) * (h.W * 2) * d.c);
+                    bf16_t* out = o.abf((size_t)Bfull * (h.H * 2) * (h.W * 2) * d.c);
                     o.conv3(h.p, nullptr, d.c, 0, d.w, d.b, B, h.H, h.W, d.c, 1, 1, nullptr, 0, nullptr, out);
                     h = Act{out, d.c, h.H * 2, h.W * 2};
                 } break;
