@@ -534,7 +534,7 @@ __device__ __forceinline__ double exact_score(const float* qn_row, const _Float1
     return acc;
 }
 
-template <int KSEL>
+template <int KSEL, int R>       // R: re-scored prefix of the merged candidates, >= k (16 for k <= 4, 64 up to k = 28)
 __global__ __launch_bounds__(256) void knn_merge_kernel(MergeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NS = 256 * KSEL;
@@ -571,7 +571,6 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(MergeParams p) {
         }
     }
     // exact re-score of the best R candidates: fp64 accumulation of exact products
-    constexpr int R = (KSEL == 8) ? 16 : 64;              // re-scored prefix: >= k (k <= 4 with KSEL 8, k <= 28 otherwise)
     __shared__ double ex[R]; __shared__ uint32_t exi[R];
     const int lane = tid & 63, wave = tid >> 6;
     for (int r = wave; r < R; r += 4) {
@@ -711,7 +710,7 @@ const char* knn_load(KnnDb& db, const void* emb, long long n, int dim, int dtype
     return msg;
 }
 
-template <int KSEL>
+template <int KSEL, int R>
 static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t* idx_out, float* score_out, hipStream_t st) {
     int dev = 0, ncu = 256;
     hipGetDevice(&dev);
@@ -757,7 +756,7 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
     if (!attr) {
         KNN_TRY(hipFuncSetAttribute((const void*)knn_scan_kernel<KSEL>, hipFuncAttributeMaxDynamicSharedMemorySize, scan_smem));
         KNN_TRY(hipFuncSetAttribute((const void*)knn_scan512_kernel<KSEL>, hipFuncAttributeMaxDynamicSharedMemorySize, scan512_smem));
-        KNN_TRY(hipFuncSetAttribute((const void*)knn_merge_kernel<KSEL>, hipFuncAttributeMaxDynamicSharedMemorySize, merge_smem));
+        KNN_TRY(hipFuncSetAttribute((const void*)knn_merge_kernel<KSEL, R>, hipFuncAttributeMaxDynamicSharedMemorySize, merge_smem));
         attr = true;
     }
     if (bulk) {
@@ -782,7 +781,7 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
             KNN_TRY(hipGetLastError());
             MergeParams mp{}; mp.cand_s = cs; mp.cand_i = ci; mp.nlists = bp.s.nlists; mp.dbn = (const _Float16*)db.dbn; mp.qn = qn;
             mp.dim = db.dim; mp.n = db.n; mp.k = k; mp.idx_out = idx_out; mp.score_out = score_out; mp.qbase = q0; mp.cert = cert; mp.eps = KNN_EPS_BULK;
-            knn_merge_kernel<KSEL><<<bq, 256, merge_smem, st>>>(mp);
+            knn_merge_kernel<KSEL, R><<<bq, 256, merge_smem, st>>>(mp);
             KNN_TRY(hipGetLastError());
             knn_exact_collect_kernel<<<ncu * 4, 256, 0, st>>>(cert, (const _Float16*)db.dbn, qn, db.n, db.dim, bq);
             KNN_TRY(hipGetLastError());
@@ -815,7 +814,7 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
         KNN_TRY(hipGetLastError());
         MergeParams mp{}; mp.cand_s = cs; mp.cand_i = ci; mp.nlists = sp.nlists; mp.dbn = (const _Float16*)db.dbn; mp.qn = qn;
         mp.dim = db.dim; mp.n = db.n; mp.k = k; mp.idx_out = idx_out; mp.score_out = score_out; mp.qbase = q0; mp.cert = cert; mp.eps = sp.hi_only ? KNN_EPS_BULK : KNN_EPS;
-        knn_merge_kernel<KSEL><<<bq, 256, merge_smem, st>>>(mp);
+        knn_merge_kernel<KSEL, R><<<bq, 256, merge_smem, st>>>(mp);
         KNN_TRY(hipGetLastError());
         // exact fallback for the flagged queries of this group (both kernels return at once when nothing is flagged)
         knn_exact_collect_kernel<<<ncu * 4, 256, 0, st>>>(cert, (const _Float16*)db.dbn, qn, db.n, db.dim, bq);
@@ -835,13 +834,14 @@ const char* knn_search(KnnDb& db, const float* q, int b, int k, uint32_t* idx_ou
     if (!db.dbn) return "no database loaded (rdm_db_load)";
     if (b < 1 || k < 1) return "b and k must be positive";
     if (k > db.n) return "k exceeds database size";
-    // List length per lane: 8 for k <= 4, 16 up to k = 28.  The length is a SPEED choice, not a correctness margin: whatever a list
-    // drops is covered by the certificate (and the exact fallback) in the merge.  A lane sees 1/2048 of the rows (1/512 in the bulk
-    // scan), so a list overflows only when more than 16 of a query's best ~64 rows fall into one lane's rows.  (A 32-entry list made
-    // every candidate of the scan pay a 32-step insertion chain while ANY of the wave's 64 lanes was still filling: k = 16 ran 8x
-    // slower than k = 4, and the 8-wave bulk kernel spilled.)
-    if (k <= 4) return search_impl<8>(db, q, b, k, idx_out, score_out, st);
-    if (k <= 28) return search_impl<16>(db, q, b, k, idx_out, score_out, st);
+    // List length per lane: 8 for every k; the merge re-scores the best 16 (k <= 4) or 64 (k <= 28) of the merged candidates.  The
+    // length is a SPEED choice, not a correctness margin: whatever a list drops is covered by the certificate (and the exact
+    // fallback) in the merge.  A lane sees 1/2048 of the rows (1/1024 in the bulk scan), so a list overflows only when more than 8
+    // of a query's best ~64 rows fall into one lane's rows.  (The insertion chain runs for a candidate when ANY of the wave's 64
+    // lanes accepts it, so its cost grows with the list length times the acceptance rate: 16-entry lists made k = 16 take 8.8 ms
+    // per 64 queries against 4.4 ms for k = 4, 32-entry lists 8x and the 8-wave bulk kernel spilled.)
+    if (k <= 4) return search_impl<8, 16>(db, q, b, k, idx_out, score_out, st);
+    if (k <= 28) return search_impl<8, 64>(db, q, b, k, idx_out, score_out, st);
     return "k > 28 is not supported (the merge re-scores the best 64 candidates)";
 }
 
