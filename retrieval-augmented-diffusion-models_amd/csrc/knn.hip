@@ -48,6 +48,22 @@ __device__ __forceinline__ void list_insert(float (&ls)[KSEL], uint32_t (&li)[KS
     }
 }
 
+// Scan-side insertion: a lane visits its rows in ASCENDING index order, so a new candidate loses every score tie against what the
+// list already holds -- better() collapses to one strict compare, and the insert is a one-pass shift (2 compares + 4 selects per
+// entry) instead of the compare-and-swap bubble.  Same resulting list as list_insert for such a stream.
+template <int KSEL>
+__device__ __forceinline__ void list_insert_ascending(float (&ls)[KSEL], uint32_t (&li)[KSEL], float s, uint32_t i) {
+    if (!(s > ls[KSEL - 1])) return;
+#pragma unroll
+    for (int j = KSEL - 1; j >= 1; j--) {
+        const bool up = s > ls[j - 1];                  // entry j-1 moves down into j
+        const bool here = !up && s > ls[j];
+        ls[j] = up ? ls[j - 1] : (here ? s : ls[j]);
+        li[j] = up ? li[j - 1] : (here ? i : li[j]);
+    }
+    if (s > ls[0]) { ls[0] = s; li[0] = i; }
+}
+
 // ---------------------------------------------------------------- database / query preparation
 // one wave per row: n = fp32(sqrt(sum x^2 in fp64)); out = fp16(x / n)
 template <typename TIN>
@@ -379,14 +395,22 @@ __global__ __launch_bounds__(512, 2) void knn_scan512w8_kernel(ScanParams p) {
         }
         const long long tile = blockIdx.x + tl * gridDim.x;
         const long long rbase = tile * KNN_ROWS + rh * 128 + kq * 4;
+        if ((tile + 1) * KNN_ROWS <= p.n) {                   // full tile (all but the last): no per-row bound check
+            const uint32_t rb = (uint32_t)rbase;
 #pragma unroll
-        for (int rf = 0; rf < 8; rf++)
+            for (int rf = 0; rf < 8; rf++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const long long row = rbase + rf * 16 + r;
-                if (row < p.n) list_insert<KSEL>(ls, li, acc[rf][r], (uint32_t)row);
-                acc[rf][r] = 0.f;
-            }
+                for (int r = 0; r < 4; r++) { list_insert_ascending<KSEL>(ls, li, acc[rf][r], rb + rf * 16 + r); acc[rf][r] = 0.f; }
+        } else {
+#pragma unroll
+            for (int rf = 0; rf < 8; rf++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const long long row = rbase + rf * 16 + r;
+                    if (row < p.n) list_insert_ascending<KSEL>(ls, li, acc[rf][r], (uint32_t)row);
+                    acc[rf][r] = 0.f;
+                }
+        }
     }
     const int list_id = blockIdx.x * 8 + rh * 4 + kq;
     const long long base = ((long long)(qg * 16 + l15) * p.nlists + list_id) * KSEL;
@@ -403,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void knn_scan512w8_kernel(ScanParams p) {
 // the second reads the tile from that XCD's L2: HBM streams the database once per 256 queries, 1024 MFMA FLOP per database byte
 // (hi/lo split included), past the 460 FLOP/B balance point of the chip: MFMA-bound.  Query slices are staged through LDS with
 // the database slice (128 queries x 512 dims x hi/lo do not fit the register file).
-struct BulkParams { ScanParams s; int groups; };      // s.qh / s.ql: [groups*128][dim]; s.cand_*: [groups*128][nlists][KSEL]
+struct BulkParams { ScanParams s; int groups; int rot_off; int dbg; };      // s.qh / s.ql: [groups*128][dim]; s.cand_*: [groups*128][nlists][KSEL]
 
 template <int KSEL>
 __global__ __launch_bounds__(512, 1) void knn_scan_bulk_kernel(BulkParams bp) {
@@ -443,11 +467,17 @@ __global__ __launch_bounds__(512, 1) void knn_scan_bulk_kernel(BulkParams bp) {
     auto tile_rows = [&](long long tile) { const long long left = p.n - tile * KNN_ROWS; return (int)(left > KNN_ROWS ? KNN_ROWS : (left < 0 ? 0 : left)); };
     const char* st_ptr = tile_ptr(wk); int st_rows = tile_rows(wk); int st_kc = 0, st_slot = 0; long long st_tile = wk;
     const char* q_ptr = (const char*)qh + (long long)lrow * row_bytes + csw;
+    // The blocks of one XCD that walk the same tiles request its four 64-row pieces in rotated order: a CU's outstanding-request
+    // window bounds its ingest to ~(window / latency), so every block takes the HBM latency on its own share of the tile and finds
+    // the rest in L2 (fetched by its partners) instead of one block of the pair paying it for the whole tile.
+    static_assert(KNN_ROWS / 64 == 4, "rotation below");
+    const int rot = (bp.rot_off ? 0 : (grp * 4) / bp.groups);
     auto stage_next = [&]() {
         char* Ds = smem + st_slot * STAGE; char* Qh = Ds + DB_BYTES;
         const char* src = st_ptr + st_kc * (KNN_BK * 2);
 #pragma unroll
-        for (int i = 0; i < KNN_ROWS / 64; i++) {
+        for (int i0 = 0; i0 < KNN_ROWS / 64; i0++) {
+            const int i = (i0 + rot) & 3;                       // request order rotated per group (see `rot`)
             const void* g = (i * 64 + lrow < st_rows) ? (const void*)(src + (long long)i * 64 * row_bytes) : (const void*)zero;
             glds16(g, Ds + (i * 64 + wave * 8) * 128);
         }
@@ -472,9 +502,10 @@ __global__ __launch_bounds__(512, 1) void knn_scan_bulk_kernel(BulkParams bp) {
         if (it + 1 < iters) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                 // raw: landed for all waves; everyone is done reading the slot of stage it-1
-        if (it + 2 < iters) stage_next();
+        if (it + 2 < iters && !(bp.dbg & 1)) stage_next();
         const char* Ds = smem + cslot * STAGE; const char* Qh = Ds + DB_BYTES;
         cslot = cslot == NSLOT - 1 ? 0 : cslot + 1;
+        if (!(bp.dbg & 2))
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             const int chunk = kk * 2 + fhalf;
@@ -492,15 +523,29 @@ __global__ __launch_bounds__(512, 1) void knn_scan_bulk_kernel(BulkParams bp) {
         if (++ckc == nkc) {
             ckc = 0;
             const long long rbase = ctile * KNN_ROWS + rg * 128 + 4 * fhalf;
+            const bool full = (ctile + 1) * KNN_ROWS <= p.n;      // all but the last tile: no per-row bound check
             ctile += walkers;
+            if (bp.dbg & 4) {
 #pragma unroll
-            for (int rf = 0; rf < 4; rf++)
+                for (int rf = 0; rf < 4; rf++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const long long row = rbase + rf * 32 + (r & 3) + 8 * (r >> 2);
-                    if (row < p.n) list_insert<KSEL>(ls, li, acc[rf][r], (uint32_t)row);
-                    acc[rf][r] = 0.f;
-                }
+                    for (int r = 0; r < 16; r++) acc[rf][r] = 0.f;
+            } else if (full) {
+                const uint32_t rb = (uint32_t)rbase;
+#pragma unroll
+                for (int rf = 0; rf < 4; rf++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) { list_insert_ascending<KSEL>(ls, li, acc[rf][r], rb + rf * 32 + (r & 3) + 8 * (r >> 2)); acc[rf][r] = 0.f; }
+            } else {
+#pragma unroll
+                for (int rf = 0; rf < 4; rf++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const long long row = rbase + rf * 32 + (r & 3) + 8 * (r >> 2);
+                        if (row < p.n) list_insert_ascending<KSEL>(ls, li, acc[rf][r], (uint32_t)row);
+                        acc[rf][r] = 0.f;
+                    }
+            }
         }
     }
     const int list_id = wk * 4 + rg * 2 + fhalf;
@@ -771,6 +816,8 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
             knn_prep_queries_kernel<<<groups * 128, 64, 0, st>>>(q + (size_t)q0 * db.dim, bq, db.dim, qn, qh, ql);
             KNN_TRY(hipGetLastError());
             BulkParams bp{}; bp.groups = groups;
+            static const int rot_off = getenv("RDM_KNN_NO_ROT") ? 1 : 0; bp.rot_off = rot_off;
+            static const int bdbg = getenv("RDM_KNN_BULK_DBG") ? atoi(getenv("RDM_KNN_BULK_DBG")) : 0; bp.dbg = bdbg;
             bp.s.dbn = (const _Float16*)db.dbn; bp.s.n = db.n; bp.s.dim = db.dim; bp.s.ntiles = ntiles; bp.s.qh = qh; bp.s.ql = ql;
             bp.s.cand_s = cs; bp.s.cand_i = ci; bp.s.zero_page = zero_page;
             int walkers = bgrid / groups; if ((long long)walkers > ntiles) walkers = (int)ntiles;
@@ -781,6 +828,7 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
             KNN_TRY(hipGetLastError());
             MergeParams mp{}; mp.cand_s = cs; mp.cand_i = ci; mp.nlists = bp.s.nlists; mp.dbn = (const _Float16*)db.dbn; mp.qn = qn;
             mp.dim = db.dim; mp.n = db.n; mp.k = k; mp.idx_out = idx_out; mp.score_out = score_out; mp.qbase = q0; mp.cert = cert; mp.eps = KNN_EPS_BULK;
+            if (bdbg) continue;                                            // ablation timing of the scan alone: results are garbage
             knn_merge_kernel<KSEL, R><<<bq, 256, merge_smem, st>>>(mp);
             KNN_TRY(hipGetLastError());
             knn_exact_collect_kernel<<<ncu * 4, 256, 0, st>>>(cert, (const _Float16*)db.dbn, qn, db.n, db.dim, bq);
