@@ -25,12 +25,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include "kernels.h"
 #include "knn.h"
 
 #define KNN_ROWS 256           // rows per tile
 #define KNN_Q 64               // queries per pass (online search)
-#define KNN_QMAX 256           // queries per launch of the bulk scan (2 groups of 128): size of the per-query scratch arrays
+#define KNN_QMAX 512           // queries per launch of the bulk scan (4 groups of 128): size of the per-query scratch arrays
 #define KNN_BK 64              // K slice per stage
 
 constexpr float KNN_EPS = 2.0e-4f;   // bound on |approximate - exact| score (derivation above)
@@ -419,139 +420,196 @@ __global__ __launch_bounds__(512, 2) void knn_scan512w8_kernel(ScanParams p) {
 }
 
 
-// ---------------------------------------------------------------- bulk scan: 128 queries per walker, two query groups per database pass
+// ---------------------------------------------------------------- bulk scan: 128 queries per walker, four query groups per database pass
 // Offline neighbour pre-computation (scripts/search_neighbors.py:380-450: 1.28 M ImageNet queries against the 20.9 M-row database) is
 // the same top-k at dataset scale.  One database pass per 64 queries (above) is HBM-bound there; this kernel scores 128 queries per
-// block against each 256-row tile -- 8 waves = 2 row halves x 4 query groups of 32, a lane still owns ONE query and one private
-// top-KSEL list -- and a launch carries TWO query groups whose walkers sit pairwise on the same XCD and walk the same tiles, so
-// the second reads the tile from that XCD's L2: HBM streams the database once per 256 queries, 1024 MFMA FLOP per database byte
-// (hi/lo split included), past the 460 FLOP/B balance point of the chip: MFMA-bound.  Query slices are staged through LDS with
-// the database slice (128 queries x 512 dims x hi/lo do not fit the register file).
-struct BulkParams { ScanParams s; int groups; int rot_off; int dbg; };      // s.qh / s.ql: [groups*128][dim]; s.cand_*: [groups*128][nlists][KSEL]
+// block against each 256-row tile, and a launch carries up to FOUR query groups whose walkers sit on the same XCD and walk the same
+// tiles, so three of them read the tile from that XCD's L2: HBM streams the database once per 512 queries.  Scores come from the hi
+// word of the query only: |q - fp16(q)| <= 2^-12 |q| per element moves a score by at most 2^-12 sum |q_j d_j| <= 2.4e-4 (unit
+// vectors) -- the certificate in the merge runs with KNN_EPS_BULK and the exact fallback absorbs the (rare) failures.  A stage is 256
+// database rows + 128 query rows x 64 dims = 48 KB, three stages in an LDS ring requested two ahead.
+//
+// The block is cut into producer and consumer waves.  The first version (eight waves of 128 rows x 32 queries that also issued the
+// LDS-DMA requests) was measured with ablation bits and counters at 4096 x 20.9 M: requests alone 54 ms, LDS reads + MFMA alone 54 ms,
+// both together 108 ms -- nothing overlapped: every wave issued its requests right after the stage barrier (a wave whose request
+// meets a full queue is parked), and the eight waves read 160 KB of LDS per stage for 16 MFMAs each.  Here
+//   * waves 0-3 score: one per SIMD, 128 rows x 64 queries each (2 row halves x 2 query halves), 32 MFMAs per stage from 24 LDS
+//     reads (96 KB per stage for the block); they never issue a memory request;
+//   * waves 4-7 load: one per SIMD, each owns a quarter of every 64-row piece (12 requests per stage, counted vmcnt), waits for
+//     its share of stage `it` and meets the scoring waves at the barrier.
+// A lane owns TWO queries (one per query fragment), i.e. two private lists.  294 ms -> 110 ms for 4096 x 20.9 M, k = 20 (with the
+// 8-entry lists, the ascending insertion and the 16-candidate pre-compare below); an idle sleep in place of the MFMAs hides completely
+// behind the requests (62 ms), the real MFMA + LDS-read stream does not (96 ms without insertion): what is left is contention between
+// the LDS-DMA stream (48 KB per stage and block at ~26 B/clk) and the scoring waves, not the ring depth.
+struct BulkParams { ScanParams s; int groups; int dbg; };      // s.qh: [groups*128][dim]; s.cand_*: [groups*128][nlists][KSEL]; dbg: ablation bits (RDM_KNN_BULK_DBG)
 
 template <int KSEL>
 __global__ __launch_bounds__(512, 1) void knn_scan_bulk_kernel(BulkParams bp) {
     const ScanParams& p = bp.s;
-    // Scores from the hi word of the query only: |q - fp16(q)| <= 2^-12 |q| per element, so the score moves by at most
-    // 2^-12 sum |q_j d_j| <= 2.4e-4 (unit vectors) -- the certificate in the merge runs with KNN_EPS_BULK and the exact fallback absorbs
-    // the (rare) failures.  That halves the MFMA work and the query staging, and lets THREE stages (256 database rows + 128 query
-    // rows x 64 dims = 48 KB) fit in LDS: a ring requested two stages ahead with counted vmcnt across raw barriers, like the online
-    // scan -- with one 64 KB stage in flight the loop sat on the memory latency (9.2 k cycles per stage against 2 k cycles of MFMA).
-    constexpr int QB = 128, DB_BYTES = KNN_ROWS * 128, Q_BYTES = QB * 128, STAGE = DB_BYTES + Q_BYTES, NSLOT = 3, PIECES = KNN_ROWS / 64 + QB / 64;
+    constexpr int QB = 128, DB_BYTES = KNN_ROWS * 128, Q_BYTES = QB * 128, STAGE = DB_BYTES + Q_BYTES, NSLOT = 3;
+    constexpr int NP = KNN_ROWS / 64 + QB / 64;               // 64-row pieces per stage (4 database + 2 query)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lrow = tid >> 3, pchunk = tid & 7;              // loader: 64 rows x 8 chunks per piece
+    const bool loader = wave >= 4;
     const int frow = lane & 31, fhalf = lane >> 5;
-    const int rg = wave >> 2, qg = wave & 3;
+    const int rg = (wave >> 1) & 1, qh2 = wave & 1;            // scoring wave: row half, query half
     const int nkc = p.dim / KNN_BK;
     const char* zero = (const char*)p.zero_page;
-    // block -> (walker, query group): blocks b and b + 8 share an XCD
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int grp = slot % bp.groups;
     const int walkers = (int)(gridDim.x / bp.groups);
     const int wk = ((slot / bp.groups) << 3) | xcd;
     if (wk >= walkers) return;
     const _Float16* qh = p.qh + (long long)grp * QB * p.dim;
-
-    float ls[KSEL]; uint32_t li[KSEL];
-#pragma unroll
-    for (int j = 0; j < KSEL; j++) { ls[j] = -INFINITY; li[j] = 0xffffffffu; }
-
     const long long my_tiles = (p.ntiles - wk + walkers - 1) / walkers;
     const long long iters = my_tiles * nkc;
-    // loader state advanced incrementally (no 64-bit division / row*dim products per stage: they cost more than the requests):
-    // one lane pointer per TILE, K slices and pieces are constant byte offsets from it (the swizzle term is piece-invariant: 64 | 128 rows)
-    const long long row_bytes = (long long)p.dim * 2;
-    const int csw = (pchunk ^ ((lrow >> 1) & 7)) * 16;
-    auto tile_ptr = [&](long long tile) { return (const char*)p.dbn + (tile * KNN_ROWS + lrow) * row_bytes + csw; };
-    auto tile_rows = [&](long long tile) { const long long left = p.n - tile * KNN_ROWS; return (int)(left > KNN_ROWS ? KNN_ROWS : (left < 0 ? 0 : left)); };
-    const char* st_ptr = tile_ptr(wk); int st_rows = tile_rows(wk); int st_kc = 0, st_slot = 0; long long st_tile = wk;
-    const char* q_ptr = (const char*)qh + (long long)lrow * row_bytes + csw;
-    // The blocks of one XCD that walk the same tiles request its four 64-row pieces in rotated order: a CU's outstanding-request
-    // window bounds its ingest to ~(window / latency), so every block takes the HBM latency on its own share of the tile and finds
-    // the rest in L2 (fetched by its partners) instead of one block of the pair paying it for the whole tile.
-    static_assert(KNN_ROWS / 64 == 4, "rotation below");
-    const int rot = (bp.rot_off ? 0 : (grp * 4) / bp.groups);
-    auto stage_next = [&]() {
-        char* Ds = smem + st_slot * STAGE; char* Qh = Ds + DB_BYTES;
-        const char* src = st_ptr + st_kc * (KNN_BK * 2);
+
+    if (loader) {
+        // loader wave lw requests sub-pieces 2 lw and 2 lw + 1 (8 rows x 128 B each) of every 64-row piece
+        const int lw = wave - 4;
+        const int r0 = lw * 16 + (lane >> 3), r1 = r0 + 8;    // my two rows inside a piece
+        const int pchunk = lane & 7;
+        const long long row_bytes = (long long)p.dim * 2;
+        const int csw0 = (pchunk ^ ((r0 >> 1) & 7)) * 16, csw1 = (pchunk ^ ((r1 >> 1) & 7)) * 16;
+        auto tile_rows = [&](long long tile) { const long long left = p.n - tile * KNN_ROWS; return (int)(left > KNN_ROWS ? KNN_ROWS : (left < 0 ? 0 : left)); };
+        const char* dbase = (const char*)p.dbn + ((long long)wk * KNN_ROWS + r0) * row_bytes;   // row r0 of my current tile
+        const long long tile_step = (long long)walkers * KNN_ROWS * row_bytes;
+        const char* qbase = (const char*)qh + (long long)r0 * row_bytes;
+        int st_rows = tile_rows(wk), st_kc = 0, st_slot = 0; long long st_tile = wk;
+        auto stage_next = [&]() {
+            char* Ds = smem + st_slot * STAGE; char* Qs = Ds + DB_BYTES;
+            const char* src = dbase + st_kc * (KNN_BK * 2);
 #pragma unroll
-        for (int i0 = 0; i0 < KNN_ROWS / 64; i0++) {
-            const int i = (i0 + rot) & 3;                       // request order rotated per group (see `rot`)
-            const void* g = (i * 64 + lrow < st_rows) ? (const void*)(src + (long long)i * 64 * row_bytes) : (const void*)zero;
-            glds16(g, Ds + (i * 64 + wave * 8) * 128);
+            for (int i = 0; i < KNN_ROWS / 64; i++) {
+                const char* s0 = src + (long long)i * 64 * row_bytes;
+                const void* g0 = (i * 64 + r0 < st_rows) ? (const void*)(s0 + csw0) : (const void*)zero;
+                const void* g1 = (i * 64 + r1 < st_rows) ? (const void*)(s0 + 8 * row_bytes + csw1) : (const void*)zero;
+                glds16(g0, Ds + (i * 64 + lw * 16) * 128);
+                glds16(g1, Ds + (i * 64 + lw * 16 + 8) * 128);
+            }
+            const char* qsrc = qbase + st_kc * (KNN_BK * 2);
+#pragma unroll
+            for (int i = 0; i < QB / 64; i++) {
+                const char* s0 = qsrc + (long long)i * 64 * row_bytes;
+                glds16(s0 + csw0, Qs + (i * 64 + lw * 16) * 128);
+                glds16(s0 + 8 * row_bytes + csw1, Qs + (i * 64 + lw * 16 + 8) * 128);
+            }
+            st_slot = st_slot == NSLOT - 1 ? 0 : st_slot + 1;
+            if (++st_kc == nkc) { st_kc = 0; st_tile += walkers; dbase += tile_step; st_rows = tile_rows(st_tile); }
+        };
+        static_assert(NP * 2 == 12, "counted vmcnt below");
+        if (iters > 0) stage_next();
+        if (iters > 1) stage_next();
+        for (long long it = 0; it < iters; it++) {
+            if (it + 1 < iters) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // stage `it` landed; the 12 requests of stage it+1 may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                 // everyone is done reading the slot of stage it-1
+            if (it + 2 < iters && !(bp.dbg & 1)) stage_next();
         }
-        const char* qsrc = q_ptr + st_kc * (KNN_BK * 2);
+        return;
+    }
+
+    float ls[2][KSEL]; uint32_t li[2][KSEL];
 #pragma unroll
-        for (int i = 0; i < QB / 64; i++) glds16(qsrc + (long long)i * 64 * row_bytes, Qh + (i * 64 + wave * 8) * 128);
-        st_slot = st_slot == NSLOT - 1 ? 0 : st_slot + 1;
-        if (++st_kc == nkc) { st_kc = 0; st_tile += walkers; st_ptr = tile_ptr(st_tile); st_rows = tile_rows(st_tile); }
-    };
-    f32x16 acc[4];
+    for (int f = 0; f < 2; f++)
+#pragma unroll
+        for (int j = 0; j < KSEL; j++) { ls[f][j] = -INFINITY; li[f][j] = 0xffffffffu; }
+    f32x16 acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
-
-    static_assert(PIECES == 6, "counted vmcnt below");
-    if (iters > 0) stage_next();
-    if (iters > 1) stage_next();
+        for (int f = 0; f < 2; f++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][f][r] = 0.f;
     int cslot = 0, ckc = 0; long long ctile = wk;
+    // LDS byte addresses of my fragment rows for the four k-steps of a stage (slot base added per stage).  (row >> 1) & 7 of every
+    // fragment row equals (frow >> 1) & 7: the row / query offsets are multiples of 32 rows, applied as immediates.
+    const unsigned lds0 = (unsigned)(uintptr_t)(LDS_AS char*)smem;
+    unsigned la[4], lb[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        const unsigned o = (unsigned)(frow * 128 + (((kk * 2 + fhalf) ^ ((frow >> 1) & 7)) << 4));
+        la[kk] = lds0 + o + (unsigned)(rg * 128 * 128);
+        lb[kk] = lds0 + o + (unsigned)(DB_BYTES + qh2 * 64 * 128);
+    }
+#define KNN_LDS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
     for (long long it = 0; it < iters; it++) {
-        // stage `it` landed (this wave's 6 pieces); the 6 pieces of stage it+1 may stay in flight
-        if (it + 1 < iters) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                 // raw: landed for all waves; everyone is done reading the slot of stage it-1
-        if (it + 2 < iters && !(bp.dbg & 1)) stage_next();
-        const char* Ds = smem + cslot * STAGE; const char* Qh = Ds + DB_BYTES;
+        __builtin_amdgcn_s_barrier();                     // stage `it` landed (the loader waves waited for it before arriving here)
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned sb = (unsigned)(cslot * STAGE);
         cslot = cslot == NSLOT - 1 ? 0 : cslot + 1;
-        if (!(bp.dbg & 2))
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            const int chunk = kk * 2 + fhalf;
-            f16x8 a[4];
-#pragma unroll
-            for (int rf = 0; rf < 4; rf++) {
-                const int row = rg * 128 + rf * 32 + frow;
-                a[rf] = *(const f16x8*)(Ds + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        if (bp.dbg & 16) __builtin_amdgcn_s_sleep(16);    // ~1024 idle cycles per stage in place of the MFMAs (with bit 2)
+        if (!(bp.dbg & 2)) {
+            // One scoring wave per SIMD: nobody else hides its LDS latency, so the fragments of k-step kk+1 are requested before the
+            // MFMAs of k-step kk are issued.  Left to the scheduler the loop came out as read-6 / wait / 8 MFMAs (2.1 k cycles per
+            // stage for 1 k cycles of MFMA), hence explicit reads with counted lgkmcnt waits.
+            f16x8 fa[2][4], fb[2][2];
+            {
+                const unsigned xa = la[0] + sb, xb = lb[0] + sb;
+                KNN_LDS_READ(fa[0][0], xa, 0); KNN_LDS_READ(fa[0][1], xa, 4096); KNN_LDS_READ(fa[0][2], xa, 8192); KNN_LDS_READ(fa[0][3], xa, 12288);
+                KNN_LDS_READ(fb[0][0], xb, 0); KNN_LDS_READ(fb[0][1], xb, 4096);
             }
-            const int qrow = qg * 32 + frow;
-            const f16x8 bh = *(const f16x8*)(Qh + qrow * 128 + ((chunk ^ ((qrow >> 1) & 7)) << 4));
 #pragma unroll
-            for (int rf = 0; rf < 4; rf++) acc[rf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rf], bh, acc[rf], 0, 0, 0);
+            for (int kk = 0; kk < 4; kk++) {
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk < 3) {
+                    const unsigned xa = la[kk + 1] + sb, xb = lb[kk + 1] + sb;
+                    KNN_LDS_READ(fa[nxt][0], xa, 0); KNN_LDS_READ(fa[nxt][1], xa, 4096); KNN_LDS_READ(fa[nxt][2], xa, 8192); KNN_LDS_READ(fa[nxt][3], xa, 12288);
+                    KNN_LDS_READ(fb[nxt][0], xb, 0); KNN_LDS_READ(fb[nxt][1], xb, 4096);
+                    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                } else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rf = 0; rf < 4; rf++)
+#pragma unroll
+                    for (int f = 0; f < 2; f++) acc[rf][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][rf], fb[cur][f], acc[rf][f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (++ckc == nkc) {
             ckc = 0;
             const long long rbase = ctile * KNN_ROWS + rg * 128 + 4 * fhalf;
             const bool full = (ctile + 1) * KNN_ROWS <= p.n;      // all but the last tile: no per-row bound check
             ctile += walkers;
-            if (bp.dbg & 4) {
-#pragma unroll
-                for (int rf = 0; rf < 4; rf++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc[rf][r] = 0.f;
-            } else if (full) {
-                const uint32_t rb = (uint32_t)rbase;
-#pragma unroll
-                for (int rf = 0; rf < 4; rf++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) { list_insert_ascending<KSEL>(ls, li, acc[rf][r], rb + rf * 32 + (r & 3) + 8 * (r >> 2)); acc[rf][r] = 0.f; }
-            } else {
+            if (!full) {                                   // last tile: rows past the end (zero page) must lose
 #pragma unroll
                 for (int rf = 0; rf < 4; rf++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const long long row = rbase + rf * 32 + (r & 3) + 8 * (r >> 2);
-                        if (row < p.n) list_insert_ascending<KSEL>(ls, li, acc[rf][r], (uint32_t)row);
-                        acc[rf][r] = 0.f;
+                        const bool dead = rbase + rf * 32 + (r & 3) + 8 * (r >> 2) >= p.n;
+                        acc[rf][0][r] = dead ? -INFINITY : acc[rf][0][r];
+                        acc[rf][1][r] = dead ? -INFINITY : acc[rf][1][r];
                     }
             }
+            const uint32_t rb = (uint32_t)rbase;
+            const bool ins = !(bp.dbg & 4);
+            auto insert_half = [&](auto F) {               // compile-time query fragment: the lists must stay in registers
+                constexpr int f = decltype(F)::value;
+#pragma unroll
+                for (int rf = 0; rf < 4; rf++) {
+                    // one compare per 16 candidates: late in the scan hardly any 32 x 32 block holds a row that enters a list
+                    float m = acc[rf][f][0];
+#pragma unroll
+                    for (int r = 1; r < 16; r++) m = fmaxf(m, acc[rf][f][r]);
+                    if (ins && m > ls[f][KSEL - 1]) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) list_insert_ascending<KSEL>(ls[f], li[f], acc[rf][f][r], rb + rf * 32 + (r & 3) + 8 * (r >> 2));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[rf][f][r] = 0.f;
+                }
+            };
+            insert_half(std::integral_constant<int, 0>{});
+            insert_half(std::integral_constant<int, 1>{});
         }
     }
     const int list_id = wk * 4 + rg * 2 + fhalf;
-    const long long base = ((long long)(grp * QB + qg * 32 + frow) * p.nlists + list_id) * KSEL;
 #pragma unroll
-    for (int j = 0; j < KSEL; j++) { p.cand_s[base + j] = ls[j]; p.cand_i[base + j] = li[j]; }
+    for (int f = 0; f < 2; f++) {
+        const long long base = ((long long)(grp * QB + qh2 * 64 + f * 32 + frow) * p.nlists + list_id) * KSEL;
+#pragma unroll
+        for (int j = 0; j < KSEL; j++) { p.cand_s[base + j] = ls[f][j]; p.cand_i[base + j] = li[f][j]; }
+    }
 }
 
 // ---------------------------------------------------------------- merge + exact re-score
@@ -765,7 +823,7 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
     const bool d512 = db.dim == 512;                 // register-resident queries (4 lists per block and query instead of 8)
     const int nlists = grid * (d512 ? 4 : 8);
     const int nlists_cap = grid * 8;
-    const bool bulk = b >= 128 && db.dim % KNN_BK == 0 && ntiles >= 16;       // dataset-scale query batches: 128-query walkers, 2 groups per database pass
+    const bool bulk = b >= 128 && db.dim % KNN_BK == 0 && ntiles >= 16;       // dataset-scale query batches: 128-query walkers, up to 4 groups per database pass
     const int QS = bulk ? KNN_QMAX : KNN_Q;                    // queries the scratch is sized for
     const size_t qn_b = (size_t)QS * db.dim * 4, qh_b = (size_t)QS * db.dim * 2;
     const size_t cand_b = (size_t)QS * nlists_cap * KSEL * 4;
@@ -809,14 +867,13 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
         static bool battr_dev[RDM_MAX_DEVICES] = {false};
         bool& battr = battr_dev[rdm_cur_device()];
         if (!battr) { KNN_TRY(hipFuncSetAttribute((const void*)knn_scan_bulk_kernel<KSEL>, hipFuncAttributeMaxDynamicSharedMemorySize, bulk_smem)); battr = true; }
-        const int bgrid = (ncu / 16) * 16;                                  // a multiple of 8 XCDs x 2 groups
+        const int bgrid = (ncu / 32) * 32;                                  // a multiple of 8 XCDs x 4 groups
         for (int q0 = 0; q0 < b; q0 += KNN_QMAX) {
             const int bq = (b - q0 < KNN_QMAX) ? b - q0 : KNN_QMAX;
-            const int groups = bq > 128 ? 2 : 1;
+            const int groups = (bq + 127) / 128;                        // 1 .. 4 query groups share every database pass
             knn_prep_queries_kernel<<<groups * 128, 64, 0, st>>>(q + (size_t)q0 * db.dim, bq, db.dim, qn, qh, ql);
             KNN_TRY(hipGetLastError());
             BulkParams bp{}; bp.groups = groups;
-            static const int rot_off = getenv("RDM_KNN_NO_ROT") ? 1 : 0; bp.rot_off = rot_off;
             static const int bdbg = getenv("RDM_KNN_BULK_DBG") ? atoi(getenv("RDM_KNN_BULK_DBG")) : 0; bp.dbg = bdbg;
             bp.s.dbn = (const _Float16*)db.dbn; bp.s.n = db.n; bp.s.dim = db.dim; bp.s.ntiles = ntiles; bp.s.qh = qh; bp.s.ql = ql;
             bp.s.cand_s = cs; bp.s.cand_i = ci; bp.s.zero_page = zero_page;
@@ -884,7 +941,7 @@ const char* knn_search(KnnDb& db, const float* q, int b, int k, uint32_t* idx_ou
     if (k > db.n) return "k exceeds database size";
     // List length per lane: 8 for every k; the merge re-scores the best 16 (k <= 4) or 64 (k <= 28) of the merged candidates.  The
     // length is a SPEED choice, not a correctness margin: whatever a list drops is covered by the certificate (and the exact
-    // fallback) in the merge.  A lane sees 1/2048 of the rows (1/1024 in the bulk scan), so a list overflows only when more than 8
+    // fallback) in the merge.  A lane sees 1/2048 of the rows (1/256 in the bulk scan), so a list overflows only when more than 8
     // of a query's best ~64 rows fall into one lane's rows.  (The insertion chain runs for a candidate when ANY of the wave's 64
     // lanes accepts it, so its cost grows with the list length times the acceptance rate: 16-entry lists made k = 16 take 8.8 ms
     // per 64 queries against 4.4 ms for k = 4, 32-entry lists 8x and the 8-wave bulk kernel spilled.)

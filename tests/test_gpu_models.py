@@ -296,7 +296,7 @@ def test_knn_adversarial_near_duplicates(ctx, k, n_copies):
 
 def test_knn_bulk_bit_exact(ctx):
     """Bulk neighbour search: 10 000 queries x 1 000 003 rows, k = 20 (DatasetBuilder's default k) through the
-    query-tiled scan (128 queries per walker, 2 groups per database pass), bit-exact against the fp64 oracle; ragged last query
+    query-tiled scan (128 queries per walker, up to 4 groups per database pass), bit-exact against the fp64 oracle; ragged last query
     group, duplicates, a query batch that mixes planted rows."""
     N, B, k = 1_000_003, 10_000, 20
     d = ctx.device
@@ -322,6 +322,10 @@ def test_knn_bulk_bit_exact(ctx):
     # the same queries through the online path (64 per pass) give the same answer
     i64, _ = ctx.knn(q[:64], k)
     assert np.array_equal(i64.cpu().numpy().view(np.uint32), ref_i[:64])
+    # 1, 2, 3 and 4 query groups per launch, ragged last group
+    for bsz in (128, 129, 257, 400, 512, 513):
+        ib, _ = ctx.knn(q[:bsz], k)
+        assert np.array_equal(ib.cpu().numpy().view(np.uint32), ref_i[:bsz]), bsz
 
 
 def test_search_nns_on_device(ctx, tmp_path):
