@@ -92,23 +92,62 @@ def p_sample_ddim(apply_model, x, c, t, index, sch, *, scale=1.0, uc=None, noise
 
 
 def ddim_sample(apply_model, sched: Schedule, S, x_T, cond, *, eta=0.0, scale=1.0, uncond=None,
-                noise=None, log_every_t=100, temperature=1.0):
-    """ddim.py:142-215. `noise` is an optional [S,B,...] stack consumed in loop order."""
+                noise=None, log_every_t=100, temperature=1.0, mask=None, x0=None, q_noise=None, content_cond=None,
+                style_cond=None, timesteps=None, score_corrector=None):
+    """ddim.py:142-215. `noise` is an optional [S,B,...] stack consumed in loop order.  Optional loop-body options of the
+    reference: inpainting (`mask`, `x0`; `q_noise` = explicit stack for the q_sample draw at :187), style / content conditioning
+    by SNR band (:179-184), timestep subset (:158-160), score corrector (:239-241; a callable e_t, x, t, c -> e_t)."""
     sch = ddim_schedule(sched, S, eta)
     ts = sch[0]
+    if timesteps is not None:
+        subset_end = int(min(timesteps / ts.shape[0], 1) * ts.shape[0]) - 1
+        ts = ts[:subset_end]
     img = x_T
     inter = {"x_inter": [img], "pred_x0": [img]}
     total = ts.shape[0]
+    a_t = sch[1]
     for i, step in enumerate(np.flip(ts)):
         index = total - i - 1
         t = torch.full((x_T.shape[0],), int(step), dtype=torch.long)
         nz = None if noise is None else noise[i]
-        img, pred_x0 = p_sample_ddim(apply_model, img, cond, t, index, sch, scale=scale, uc=uncond,
-                                     noise=nz, temperature=temperature)
+        snr = float(a_t[index]) / (1.0 - float(a_t[index]))
+        c_in = cond
+        if style_cond is not None and snr < 5.e-2:
+            c_in = style_cond
+        if content_cond is not None and snr >= 5.e-2 and snr < 1.:
+            c_in = content_cond
+        if mask is not None:
+            qn = torch.zeros_like(x0) if q_noise is None else q_noise[i]
+            ac = sched.alphas_cumprod[t].reshape(-1, 1, 1, 1)
+            img_orig = ac.sqrt() * x0 + (1.0 - ac).sqrt() * qn       # ldm q_sample with sqrt_alphas_cumprod buffers
+            img = img_orig * mask + (1. - mask) * img
+        am = apply_model
+        if score_corrector is not None:                               # corrector sees the guided e_t: wrap p_sample_ddim's pieces
+            img, pred_x0 = _p_sample_ddim_corrected(apply_model, img, c_in, t, index, sch, scale, uncond, nz, temperature, score_corrector)
+        else:
+            img, pred_x0 = p_sample_ddim(am, img, c_in, t, index, sch, scale=scale, uc=uncond, noise=nz, temperature=temperature)
         if index % log_every_t == 0 or index == total - 1:
             inter["x_inter"].append(img)
             inter["pred_x0"].append(pred_x0)
     return img, inter
+
+
+def _p_sample_ddim_corrected(apply_model, x, c, t, index, sch, scale, uc, noise, temperature, corrector):
+    ts, a_t, a_prev, sigma, sqrt_1m = sch
+    b = x.shape[0]
+    if noise is None:
+        noise = torch.zeros_like(x)
+    if scale > 1.0:
+        out = apply_model(torch.cat([x] * 2), torch.cat([t] * 2), torch.cat([c, uc]))
+        e_t = out[b:] + scale * (out[:b] - out[b:])
+    else:
+        e_t = apply_model(x, t, c)
+    e_t = corrector(e_t, x, t, c)
+    at = torch.full_like(e_t, float(a_t[index])); ap = torch.full_like(e_t, float(a_prev[index]))
+    sg = torch.full_like(e_t, float(sigma[index])); s1m = torch.full_like(e_t, float(sqrt_1m[index]))
+    pred_x0 = (x - s1m * e_t) / at.sqrt()
+    x_prev = ap.sqrt() * pred_x0 + (1.0 - ap - sg ** 2).sqrt() * e_t + sg * noise * temperature
+    return x_prev, pred_x0
 
 
 def p_sample_ddpm(apply_model, sched: Schedule, x, c, t, noise, clip_denoised=True, temperature=1.0):

@@ -2,8 +2,10 @@
 
 Same constructor, `make_schedule`, `sample`, `ddim_sampling`, `p_sample_ddim` signatures and return values; the
 S-step loop itself runs inside librdm_hip (rdm_ddim_sample): UNet forward with CFG batch doubling + fused update
-per step, K/V of the neighbours projected once per call.  Options the native loop does not implement raise
-NotImplementedError instead of being silently ignored.  Unlike the reference, nothing is forced
+per step, K/V of the neighbours projected once per call.  Options that change the loop body per step (callbacks, mask / x0
+inpainting, style_cond / content_cond by SNR band, timestep subset, noise_dropout, score_corrector) take the per-step path:
+native UNet forward, torch elementwise update.  quantize_x0 and ddim_use_original_steps raise NotImplementedError instead of
+being silently ignored.  Unlike the reference, nothing is forced
 onto a "cuda" device string (ddim.py:21-25) and `--seed` style RNG comes from the caller's torch generator.
 """
 import numpy as np
@@ -64,11 +66,12 @@ class DDIMSampler(object):
         size = (batch_size,) + tuple(shape)
         return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback,
                                   quantize_denoised=quantize_x0, mask=mask, x0=x0, noise_dropout=noise_dropout,
-                                  temperature=temperature, score_corrector=score_corrector, x_T=x_T,
+                                  temperature=temperature, score_corrector=score_corrector, corrector_kwargs=corrector_kwargs, x_T=x_T,
                                   log_every_t=log_every_t, unconditional_guidance_scale=unconditional_guidance_scale,
                                   unconditional_conditioning=unconditional_conditioning, random_guiding=random_guiding,
                                   content_cond=content_cond, style_cond=style_cond,
-                                  intermediates_to_cpu=intermediates_to_cpu, S=S, eta=eta, noise=kwargs.get("noise"))
+                                  intermediates_to_cpu=intermediates_to_cpu, S=S, eta=eta, noise=kwargs.get("noise"),
+                                  q_noise=kwargs.get("q_noise"))
 
     @torch.no_grad()
     def ddim_sampling(self, cond, shape, x_T=None, ddim_use_original_steps=False, callback=None, timesteps=None,
@@ -76,14 +79,13 @@ class DDIMSampler(object):
                       noise_dropout=0., score_corrector=None, corrector_kwargs=None, unconditional_guidance_scale=1.,
                       unconditional_conditioning=None, random_guiding='none', content_cond=None, style_cond=None,
                       intermediates_to_cpu=False, S=None, eta=0., **kwargs):
-        unsupported = {"mask/x0 inpainting": mask is not None or x0 is not None, "quantize_x0": quantize_denoised,
-                       "noise_dropout": noise_dropout > 0., "score_corrector": score_corrector is not None,
-                       "style/content conditioning": content_cond is not None or style_cond is not None,
-                       "random_guiding": random_guiding != 'none', "ddim_use_original_steps": ddim_use_original_steps,
-                       "timesteps subset": timesteps is not None}
+        unsupported = {"quantize_x0": quantize_denoised, "ddim_use_original_steps": ddim_use_original_steps}
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError("native DDIM loop does not implement: " + ", ".join(bad))
+        # options that change the loop body step by step run through the per-step path (native UNet forward per step)
+        per_step = (mask is not None or x0 is not None or noise_dropout > 0. or score_corrector is not None or
+                    content_cond is not None or style_cond is not None or random_guiding != 'none' or timesteps is not None)
         if isinstance(cond, dict):
             cond = cond[list(cond.keys())[0]]
         if isinstance(cond, list):
@@ -99,9 +101,15 @@ class DDIMSampler(object):
         img = torch.randn(shape, device=device) if x_T is None else x_T.to(device)
         total_steps = self.ddim_timesteps.shape[0]
         print(f"Running DDIM Sampling with {total_steps} timesteps")
-        if callback is not None or img_callback is not None:
+        if callback is not None or img_callback is not None or per_step:
+            unwrap = lambda c: c[0] if isinstance(c, (list, tuple)) else (c[list(c.keys())[0]] if isinstance(c, dict) else c)
             return self._python_loop(cond, img, callback, img_callback, log_every_t, temperature, eta,
-                                     unconditional_guidance_scale, unconditional_conditioning, intermediates_to_cpu)
+                                     unconditional_guidance_scale, unconditional_conditioning, intermediates_to_cpu,
+                                     mask=mask, x0=x0, noise_dropout=noise_dropout, score_corrector=score_corrector,
+                                     corrector_kwargs=corrector_kwargs, random_guiding=random_guiding, timesteps=timesteps,
+                                     content_cond=None if content_cond is None else unwrap(content_cond),
+                                     style_cond=None if style_cond is None else unwrap(style_cond),
+                                     noise=kwargs.get("noise"), q_noise=kwargs.get("q_noise"))
         noise = kwargs.get("noise")             # [native] optional explicit per-step noise stack [S, B, C, H, W] (consumed in loop order)
         if eta != 0. and noise is None:
             noise = torch.randn((total_steps,) + tuple(shape), device=device)
@@ -112,16 +120,42 @@ class DDIMSampler(object):
         intermediates = {'x_inter': [img] + [mv(t) for t in xi], 'pred_x0': [img] + [mv(t) for t in pi]}
         return z.detach(), intermediates
 
-    def _python_loop(self, cond, img, callback, img_callback, log_every_t, temperature, eta, scale, uc, to_cpu):
-        """Per-step path (only when the caller wants callbacks): native UNet forward, torch elementwise update."""
-        total_steps = self.ddim_timesteps.shape[0]
+    def _python_loop(self, cond, img, callback, img_callback, log_every_t, temperature, eta, scale, uc, to_cpu, mask=None,
+                     x0=None, noise_dropout=0., score_corrector=None, corrector_kwargs=None, random_guiding='none',
+                     timesteps=None, content_cond=None, style_cond=None, noise=None, q_noise=None):
+        """Per-step path of ddim.py:143-209 (callbacks, inpainting mask, style / content conditioning by SNR band, timestep
+        subset, noise dropout, score corrector): native UNet forward per step, torch elementwise update.  `noise` / `q_noise`
+        [native]: optional explicit stacks [steps, B, C, H, W] for the update noise and for q_sample of the masked region."""
+        ts_all = self.ddim_timesteps
+        if timesteps is not None:                                   # ddim.py:158-160
+            subset_end = int(min(timesteps / ts_all.shape[0], 1) * ts_all.shape[0]) - 1
+            ts_all = ts_all[:subset_end]
+        total_steps = ts_all.shape[0]
         intermediates = {'x_inter': [img], 'pred_x0': [img]}
         b = img.shape[0]
-        for i, step in enumerate(np.flip(self.ddim_timesteps)):
+        random_guider = None
+        if random_guiding != 'none':                                # drawn (RNG parity) but unused, as in the reference (:228)
+            random_guider = torch.clamp(torch.randn(img.shape, device=img.device), -1., 1.)
+        for i, step in enumerate(np.flip(ts_all)):
             index = total_steps - i - 1
             ts = torch.full((b,), int(step), device=img.device, dtype=torch.long)
-            img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, temperature=temperature,
-                                              unconditional_guidance_scale=scale, unconditional_conditioning=uc)
+            snr = self.ddim_alphas[index] / (1 - self.ddim_alphas[index])
+            input_cond = cond
+            if style_cond is not None and snr < 5.e-2:
+                input_cond = style_cond
+            if content_cond is not None and snr >= 5.e-2 and snr < 1.:
+                input_cond = content_cond
+            if mask is not None:
+                assert x0 is not None
+                img_orig = self.model.q_sample(x0, ts, noise=None if q_noise is None else q_noise[i])
+                img = img_orig * mask + (1. - mask) * img
+            if random_guiding == 'sampled':
+                random_guider = torch.clamp(torch.randn(img.shape, device=img.device), -1., 1.)
+            img, pred_x0 = self.p_sample_ddim(img, input_cond, ts, index=index, temperature=temperature,
+                                              noise_dropout=noise_dropout, score_corrector=score_corrector,
+                                              corrector_kwargs=corrector_kwargs, unconditional_guidance_scale=scale,
+                                              unconditional_conditioning=uc, noise=None if noise is None else noise[i],
+                                              random_guider=random_guider)
             if callback: callback(i)
             if img_callback: img_callback(pred_x0, i)
             if index % log_every_t == 0 or index == total_steps - 1:
@@ -135,7 +169,7 @@ class DDIMSampler(object):
                       unconditional_conditioning=None, noise=None, random_guider=None):
         b = x.shape[0]
         assert unconditional_guidance_scale >= 1.
-        if use_original_steps or quantize_denoised or noise_dropout > 0. or score_corrector is not None:
+        if use_original_steps or quantize_denoised:
             raise NotImplementedError
         if noise is None:
             noise = torch.randn(x.shape, device=x.device)
@@ -146,11 +180,17 @@ class DDIMSampler(object):
             e_t = e_u + unconditional_guidance_scale * (e_t - e_u)
         else:
             e_t = self.model.apply_model(x, t, c)
+        if score_corrector is not None:
+            assert getattr(self.model, "parameterization", "eps") == "eps"
+            e_t = score_corrector.modify_score(self.model, e_t, x, t, c, **(corrector_kwargs or {}))
         a_t = torch.full_like(e_t, float(self.ddim_alphas[index]))
         a_prev = torch.full_like(e_t, float(self.ddim_alphas_prev[index]))
         sigma_t = torch.full_like(e_t, float(self.ddim_sigmas[index]))
         sqrt_one_minus_at = torch.full_like(e_t, float(self.ddim_sqrt_one_minus_alphas[index]))
         pred_x0 = (x - sqrt_one_minus_at * e_t) / a_t.sqrt()
         dir_xt = (1. - a_prev - sigma_t ** 2).sqrt() * e_t
-        x_prev = a_prev.sqrt() * pred_x0 + dir_xt + sigma_t * noise * temperature
+        noise = sigma_t * noise * temperature
+        if noise_dropout > 0.:
+            noise = torch.nn.functional.dropout(noise, p=noise_dropout)
+        x_prev = a_prev.sqrt() * pred_x0 + dir_xt + noise
         return x_prev, pred_x0

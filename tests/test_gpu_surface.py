@@ -84,6 +84,31 @@ def test_ddim_sampler_surface(model):
     assert torch.equal(e1, e2) and torch.equal(e1, e3)
 
 
+def test_ddim_inpainting_and_style_content_conditioning(model):
+    """ddim.py:179-189: mask / x0 inpainting blend and the style / content conditioning switch by SNR band, through the per-step
+    path on the native UNet forward, against the oracle's loop on the oracle UNet."""
+    from rdm_amd.models.diffusion.ddim import DDIMSampler
+    rng = np.random.default_rng(6)
+    B, S = 2, 10
+    f = lambda *shape, s=1.0: torch.from_numpy((rng.standard_normal(shape) * s).astype(np.float32)).to(model.device)
+    x_T, x0 = f(B, 3, 16, 16), f(B, 3, 16, 16)
+    cond, cs, cc = f(B, 4, 512, s=0.45), f(B, 4, 512, s=0.45), f(B, 4, 512, s=0.45)
+    uc = torch.zeros_like(cond)
+    mask = torch.from_numpy((rng.random((B, 1, 16, 16)) > 0.5).astype(np.float32)).to(model.device)
+    qn = f(S, B, 3, 16, 16)
+    sampler = DDIMSampler(model)
+    z, inter = sampler.sample(S, B, (3, 16, 16), conditioning=cond, eta=0., x_T=x_T, verbose=False, unconditional_guidance_scale=2.0,
+                              unconditional_conditioning=uc, mask=mask, x0=x0, q_noise=qn, style_cond=cs, content_cond=cc, log_every_t=3)
+    apply = lambda x, t, c: ounet.unet_forward(model.sd_unet, model.spec, x, t, c)
+    zr, ir = odiff.ddim_sample(apply, odiff.Schedule(), S, x_T.cpu(), cond.cpu(), scale=2.0, uncond=uc.cpu(), mask=mask.cpu(), x0=x0.cpu(),
+                               q_noise=qn.cpu(), style_cond=cs.cpu(), content_cond=cc.cpu(), log_every_t=3)
+    assert len(inter["x_inter"]) == len(ir["x_inter"])
+    assert rel_l2(z, zr) <= 4e-2
+    # the SNR bands were actually exercised at S = 10 (alphas from 0.999 down to ~0.005: all three bands occur)
+    a = np.asarray(sampler.ddim_alphas); snr = a / (1 - a)
+    assert (snr < 5e-2).any() and ((snr >= 5e-2) & (snr < 1.)).any() and (snr >= 1.).any()
+
+
 def test_search_k_nearest_surface(retriever):
     rng = np.random.default_rng(22)
     q = (rng.standard_normal((5, 512)) * 0.45).astype(np.float32)

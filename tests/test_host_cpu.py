@@ -50,9 +50,69 @@ def test_ddim_sampler_rejects_unsupported_options():
     from rdm_amd.models.diffusion.ddim import DDIMSampler
     s = DDIMSampler(_DummyModel())
     with pytest.raises(NotImplementedError):
-        s.sample(5, 1, (3, 8, 8), conditioning=torch.zeros(1, 4, 512), mask=torch.ones(1, 3, 8, 8), x0=torch.zeros(1, 3, 8, 8), verbose=False)
+        s.sample(5, 1, (3, 8, 8), conditioning=torch.zeros(1, 4, 512), quantize_x0=True, verbose=False)
     with pytest.raises(AssertionError):
         s.sample(5, 1, (3, 8, 8), conditioning=torch.zeros(1, 4, 512), unconditional_guidance_scale=0.5, verbose=False)
+
+
+class _ToyModel(_DummyModel):
+    """apply_model stand-in (a fixed nonlinear map of x, t and the context) for the host-side loop logic."""
+    parameterization = "eps"
+    def __init__(self):
+        super().__init__()
+        self.sqrt_ac = self.alphas_cumprod.sqrt(); self.sqrt_1mac = (1.0 - self.alphas_cumprod).sqrt()
+    def apply_model(self, x, t, c):
+        return torch.tanh(x * 0.7 + c.mean(dim=(1, 2)).reshape(-1, 1, 1, 1)) * (1.0 + t.reshape(-1, 1, 1, 1).float() / 1000.0)
+    def q_sample(self, x0, t, noise=None):
+        noise = torch.zeros_like(x0) if noise is None else noise
+        return self.sqrt_ac[t].reshape(-1, 1, 1, 1) * x0 + self.sqrt_1mac[t].reshape(-1, 1, 1, 1) * noise
+
+
+@pytest.mark.parametrize("case", ["callback", "mask", "style_content", "subset", "corrector", "all"])
+def test_ddim_per_step_options_match_oracle(case):
+    """ddim.py:143-209 loop-body options (inpainting mask, style / content conditioning by SNR band, timestep subset, score
+    corrector, callbacks) through the mirror's per-step path == the oracle's restatement, bit for bit on CPU."""
+    from rdm_amd.models.diffusion.ddim import DDIMSampler
+    g = torch.Generator().manual_seed(5)
+    B, S, eta, scale = 3, 20, 0.4, 2.0
+    m = _ToyModel()
+    x_T = torch.randn(B, 3, 8, 8, generator=g)
+    c = torch.randn(B, 4, 16, generator=g); uc = torch.zeros(B, 4, 16)
+    cs = torch.randn(B, 4, 16, generator=g); cc = torch.randn(B, 4, 16, generator=g)
+    noise = torch.randn(S, B, 3, 8, 8, generator=g); qn = torch.randn(S, B, 3, 8, 8, generator=g)
+    x0 = torch.randn(B, 3, 8, 8, generator=g); mask = (torch.rand(B, 1, 8, 8, generator=g) > 0.5).float()
+    kw, okw = {}, {}
+    seen = []
+    if case in ("callback", "all"):
+        kw.update(img_callback=lambda px0, i: seen.append(i))
+    if case in ("mask", "all"):
+        kw.update(mask=mask, x0=x0, q_noise=qn); okw.update(mask=mask, x0=x0, q_noise=qn)
+    if case in ("style_content", "all"):
+        kw.update(style_cond=[cs], content_cond={"c_crossattn": cc}); okw.update(style_cond=cs, content_cond=cc)
+    if case in ("subset", "all"):
+        kw.update(timesteps=12); okw.update(timesteps=12)
+    if case in ("corrector", "all"):
+        class Corr:
+            def modify_score(self, model, e_t, x, t, c, gain=1.0):
+                return e_t * gain + 0.1 * x
+        kw.update(score_corrector=Corr(), corrector_kwargs={"gain": 0.9})
+        okw.update(score_corrector=lambda e, x, t, c_: e * 0.9 + 0.1 * x)
+    smp = DDIMSampler(m)
+    if "timesteps" in kw:        # like the reference, `sample` does not forward a timestep subset: ddim_sampling is the entry for it
+        smp.make_schedule(S, ddim_eta=eta, verbose=False)
+        z, inter = smp.ddim_sampling([c], (B, 3, 8, 8), x_T=x_T, unconditional_guidance_scale=scale, unconditional_conditioning=uc,
+                                     log_every_t=5, noise=noise, S=S, eta=eta, **kw)
+    else:
+        z, inter = smp.sample(S, B, (3, 8, 8), conditioning=[c], eta=eta, x_T=x_T, unconditional_guidance_scale=scale,
+                              unconditional_conditioning=uc, log_every_t=5, verbose=False, noise=noise, **kw)
+    rz, rinter = odiff.ddim_sample(m.apply_model, odiff.Schedule(), S, x_T, c, eta=eta, scale=scale, uncond=uc, noise=noise,
+                                   log_every_t=5, **okw)
+    assert torch.equal(z, rz)
+    assert len(inter["x_inter"]) == len(rinter["x_inter"])
+    for a, b_ in zip(inter["pred_x0"], rinter["pred_x0"]):
+        assert torch.equal(a, b_)
+    if case in ("callback", "all"):
+        assert seen == list(range(11 if case == "all" else 20))
 
 
 def test_tokenizer_matches_reference_golden():
