@@ -287,6 +287,7 @@ class Context:
     def vq_decode_indices(self, indices):
         """decode_to_img: code indices int64 [b, h*w] -> image f32 [b,out_ch,R,R] (VQGAN first stage with a wide latent)."""
         indices = self._dev(indices, torch.int64)
+        self._need("vq_decode_indices", "vq")
         zr = self.vq_cfg.resolution >> (self.vq_cfg.n_ch_mult - 1)
         if indices.ndim != 2 or indices.shape[1] != zr * zr:
             raise RdmError(f"vq_decode_indices: indices must be [b,{zr * zr}], got {tuple(indices.shape)}")
@@ -297,6 +298,13 @@ class Context:
     # ---- model calls (torch CUDA tensors in / out)
     def _dev(self, t, dtype):
         return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def _need(self, what, name):
+        """The binding sizes its outputs from the loaded configuration: fail like the C ABI does (a message, not an AttributeError)."""
+        cfg = getattr(self, name + "_cfg")
+        if cfg is None:
+            raise RdmError(f"{what}: {name} weights not loaded (load_{name})")
+        return cfg
 
     def _check_sampler_shapes(self, what, x, cond, uncond=None, noise=None, steps=None):
         """The C ABI takes raw pointers: reject every shape it would silently mis-read (the reference raises a torch
@@ -369,6 +377,10 @@ class Context:
 
     def vq_decode(self, z, force_not_quantize=False, return_indices=False):
         z = self._dev(z, torch.float32)
+        cfg = self._need("vq_decode", "vq")
+        zr = cfg.resolution >> (cfg.n_ch_mult - 1)
+        if z.ndim != 4 or tuple(z.shape[1:]) != (cfg.embed_dim, zr, zr):
+            raise RdmError(f"vq_decode: latent must be [b,{cfg.embed_dim},{zr},{zr}], got {tuple(z.shape)}")
         b = z.shape[0]; r = self.vq_cfg.resolution
         img = torch.empty((b, self.vq_cfg.out_ch, r, r), device=self.device, dtype=torch.float32)
         idx = torch.empty((b * z.shape[2] * z.shape[3],), device=self.device, dtype=torch.int32) if return_indices else None
@@ -384,12 +396,18 @@ class Context:
 
     def clip_encode_text(self, tokens):
         tokens = self._dev(tokens, torch.int64)
+        cfg = self._need("clip_encode_text", "clip")
+        if tokens.ndim != 2 or tokens.shape[1] != cfg.context_length:
+            raise RdmError(f"clip_encode_text: tokens must be [b,{cfg.context_length}], got {tuple(tokens.shape)}")
         out = torch.empty((tokens.shape[0], self.clip_cfg.embed_dim), device=self.device, dtype=torch.float32)
         self._check(lib.rdm_clip_encode_text(self._h, _ptr(tokens), tokens.shape[0], _ptr(out)))
         return out
 
     def clip_encode_image(self, image):
         image = self._dev(image, torch.float32)
+        cfg = self._need("clip_encode_image", "clip")
+        if image.ndim != 4 or tuple(image.shape[1:]) != (3, cfg.image_resolution, cfg.image_resolution):
+            raise RdmError(f"clip_encode_image: image must be [b,3,{cfg.image_resolution},{cfg.image_resolution}] (already resized / normalised), got {tuple(image.shape)}")
         out = torch.empty((image.shape[0], self.clip_cfg.embed_dim), device=self.device, dtype=torch.float32)
         self._check(lib.rdm_clip_encode_image(self._h, _ptr(image), image.shape[0], _ptr(out)))
         return out
@@ -399,7 +417,7 @@ class Context:
         image = self._dev(image, torch.float32)
         if image.ndim != 4 or image.shape[1] != 3:
             raise RdmError(f"clip_preprocess: image must be [b,3,h,w], got {tuple(image.shape)}")
-        r = self.clip_cfg.image_resolution
+        r = self._need("clip_preprocess", "clip").image_resolution
         out = torch.empty((image.shape[0], 3, r, r), device=self.device, dtype=torch.float32)
         self._check(lib.rdm_clip_preprocess(self._h, _ptr(image), image.shape[0], image.shape[2], image.shape[3], _ptr(out)))
         return out
@@ -409,6 +427,7 @@ class Context:
         image = self._dev(image, torch.float32)
         if image.ndim != 4 or image.shape[1] != 3:
             raise RdmError(f"clip_encode_image_raw: image must be [b,3,h,w], got {tuple(image.shape)}")
+        self._need("clip_encode_image_raw", "clip")
         out = torch.empty((image.shape[0], self.clip_cfg.embed_dim), device=self.device, dtype=torch.float32)
         self._check(lib.rdm_clip_encode_image_raw(self._h, _ptr(image), image.shape[0], image.shape[2], image.shape[3], _ptr(out)))
         return out

@@ -1,0 +1,82 @@
+"""Error behaviour of the C ABI (include/rdm_hip.h: every entry returns 0 or a negative code and leaves a message in rdm_last_error)
+and of the ctypes binding's argument checks: calls before weights / database are loaded, wrong shapes, out-of-range k / S / positions,
+blobs that do not match the manifest -- and the context stays usable after every one of them."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet as ounet
+
+from _util import spec_to_unet_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def fresh():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import rdm_amd  # noqa: F401
+    from rdm_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _err(fn):
+    from rdm_amd._lib import RdmError
+    with pytest.raises(RdmError) as e:
+        fn()
+    msg = str(e.value)
+    assert len(msg) > 20, msg                   # code + a real message, not an empty string
+    return msg
+
+
+def test_calls_before_load_fail_with_a_message(fresh):
+    d = fresh.device
+    x = torch.zeros(1, 3, 16, 16, device=d); t = torch.zeros(1, dtype=torch.long, device=d); c = torch.zeros(1, 4, 512, device=d)
+    assert "not loaded" in _err(lambda: fresh.unet_forward(x, t, c))
+    assert "not loaded" in _err(lambda: fresh.vq_decode(x))
+    assert "no database" in _err(lambda: fresh.knn(torch.zeros(2, 512, device=d), 4))
+    assert "no database" in _err(lambda: fresh.db_gather(torch.zeros(2, 4, dtype=torch.int32, device=d), 512))
+    _err(lambda: fresh.clip_encode_text(torch.zeros(1, 77, dtype=torch.long, device=d)))
+    _err(lambda: fresh.rarm_forward(torch.zeros(1, 4, dtype=torch.long, device=d), torch.zeros(1, 2, 512, device=d)))
+
+
+def test_knn_argument_checks(fresh):
+    d = fresh.device
+    g = torch.Generator(device=d).manual_seed(1)
+    db = torch.randn(1000, 512, device=d, generator=g).half()
+    fresh.db_load(db)
+    q = torch.randn(3, 512, device=d, generator=g)
+    assert "k > 28" in _err(lambda: fresh.knn(q, 29))
+    small = torch.randn(5, 512, device=d, generator=g).half()
+    fresh.db_load(small)
+    assert "exceeds" in _err(lambda: fresh.knn(q, 6))
+    # still usable, and exact
+    idx, sc = fresh.knn(q, 5)
+    ref = (torch.nn.functional.normalize(q.double(), dim=1) @ torch.nn.functional.normalize(small.double(), dim=1).T).argsort(dim=1, descending=True)
+    assert torch.equal(idx.cpu().long() & 0xffffffff, ref.cpu())
+
+
+def test_blob_and_shape_mismatches(fresh):
+    from rdm_amd import _lib, packing
+    spec = ounet.tiny_spec()
+    cfg = spec_to_unet_cfg(spec)
+    sd = ounet.synth_state_dict(ounet.param_shapes(spec), seed=3)
+    blob = packing.pack("unet", cfg, sd)
+    assert "manifest" in _err(lambda: fresh.load_unet(cfg, blob[:-256]))
+    fresh.load_unet(cfg, blob)
+    d = fresh.device
+    B, k = 2, 4
+    x = torch.zeros(B, spec.in_channels, 16, 16, device=d); t = torch.zeros(B, dtype=torch.long, device=d)
+    c = torch.zeros(B, k, spec.context_dim, device=d)
+    fresh.unet_forward(x, t, c)                                            # fine
+    _err(lambda: fresh.unet_forward(x, t, c[:, 0]))                        # [B, 512] instead of [B, k, 512]
+    _err(lambda: fresh.unet_forward(x, t[:1], c))                          # timestep vector of the wrong length
+    _err(lambda: fresh.unet_forward(x, t, c[:1]))                          # conditioning for a different batch
+    ac = torch.linspace(0.999, 0.005, 1000)
+    _err(lambda: fresh.ddim_sample(4, x, c, c[:, :2], ac, scale=2.0))      # unconditional conditioning with another k
+    _err(lambda: fresh.ddim_sample(4, x, c, None, ac, eta=1.0, noise=torch.zeros(3, B, 3, 16, 16, device=d)))   # noise stack shorter than the loop
+    z, _, _ = fresh.ddim_sample(4, x, c, None, ac)                         # and the context is still alive
+    assert torch.isfinite(z).all()
