@@ -102,10 +102,10 @@ class MinimalRETRODiffusion(object):
     def set_distributed(self, enabled=True, group=None):
         """Shard every `sample_with_query` / `sample_from_rdata` batch contiguously over the ranks of the initialised
         torch.distributed group (one process per GPU): each rank retrieves, samples and decodes only its rows, the
-        starting noise of row i is a function of (shared seed, GLOBAL index i) — so the result does not depend on the
-        number of ranks — and the finished images are all-gathered (the only collective).  Weights and the database are
-        replicated.  With a single process the same per-row noise streams are used, which is what makes
-        "N ranks == 1 rank" checkable bit for bit."""
+        starting noise of row i is a function of (shared seed, GLOBAL index i) — so what is fed to the kernels does not depend
+        on the number of ranks — and the finished images are all-gathered (the only collective).  Weights and the database are
+        replicated.  With a single process the same per-row noise streams are used.  (The kernels pick tiles / split-K by local
+        batch size, so latents of different rank counts agree to rounding, not bit for bit: tests/test_gpu_surface.py.)"""
         self.distributed, self._group = bool(enabled), group
         return self
 

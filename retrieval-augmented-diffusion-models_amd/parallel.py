@@ -77,6 +77,8 @@ def all_gather_images(local: torch.Tensor, n_total: int = None, group=None) -> t
     if not dist.is_available() or not dist.is_initialized():
         return local
     world = dist.get_world_size(group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":        # gloo has no device all-gather: stage through the host
+        return all_gather_images(local.cpu(), n_total, group).to(local.device)
     if n_total is None:
         n_total = local.shape[0] * world
     counts = [shard_range(n_total, world, r)[1] - shard_range(n_total, world, r)[0] for r in range(world)]

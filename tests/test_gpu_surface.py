@@ -265,20 +265,37 @@ def test_rdm_sample_script_synthetic(tmp_path):
     model.ctx.close()
 
 
-def _two_rank_worker(rank, world, port, q):
+def _two_rank_worker(rank, world, port, q, backend="nccl", one_gpu=False):
     import os
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0" if one_gpu else str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from rdm_amd import parallel
-    r, local = parallel.init_distributed("nccl")
+    r, local = parallel.init_distributed(backend)
     out = _dist_sample(local)
+    lat = _dist_sample(local, latents=True)
     if r == 0:
-        q.put(out.cpu().numpy())
+        q.put((out.cpu().numpy(), lat.cpu().numpy()))
     parallel.shutdown()
 
 
-def _dist_sample(device_index):
-    """Tiny UNet / first stage, 5 000-row database, B = 6 (ragged over 4 ranks, even over 2), eta = 1 (per-step noise streams)."""
+# Sharding changes the per-rank batch, and the executor picks tiles / split-K by problem size (unet_forward on 12 rows is not bit-equal to
+# 6 + 6 rows: rel L2 7.7e-3 on the tiny model, measured): what IS identical per global row is everything fed to the kernels -- neighbours,
+# conditioning, x_T, per-step noise (bit for bit in tests/test_host_cpu.py::test_batch_sharding_world2_gloo).  So latents must agree to
+# bf16 kernel-selection rounding, images after VQ quantisation (code flips) to a looser bound.
+RANK_LATENT_TOL, RANK_IMAGE_TOL = 3e-2, 0.2
+
+
+def _check_rank_invariance(got, ref):
+    (gi, gl), (ri, rl) = got, ref
+    assert gi.shape == ri.shape == (6, 3, 64, 64) and gl.shape == rl.shape == (6, 3, 16, 16)
+    e_lat, e_img = rel_l2(torch.from_numpy(gl), torch.from_numpy(rl)), rel_l2(torch.from_numpy(gi), torch.from_numpy(ri))
+    print(f"sharded vs single rank: latents rel L2 {e_lat:.3e}, images {e_img:.3e}")
+    assert e_lat <= RANK_LATENT_TOL and e_img <= RANK_IMAGE_TOL
+
+
+def _dist_sample(device_index, latents=False):
+    """Tiny UNet / first stage, 5 000-row database, B = 6 (ragged over 4 ranks, even over 2), eta = 1 (per-step noise streams).
+    latents=True: the first-stage decode is skipped, the gathered tensor is the DDIM latent."""
     from rdm_amd import _lib
     from rdm_amd.data.retrieval_dataset.dsetbuilder import DatasetBuilder
     from rdm_amd.models.diffusion.ddpm import MinimalRETRODiffusion
@@ -293,6 +310,8 @@ def _dist_sample(device_index):
     pool = {"embedding": (rng.standard_normal((5000, 512)) * 0.45).astype(np.float16), "img_id": np.arange(5000), "patch_coords": np.zeros((5000, 4), np.int64)}
     m.retriever = DatasetBuilder(data_pool=pool, ctx=ctx)
     m.set_distributed(True)
+    if latents:
+        m.decode_first_stage = lambda z, **kw: z
     torch.manual_seed(11); np.random.seed(11)
     qv = (np.random.default_rng(2).standard_normal((6, 512)) * 0.45).astype(np.float32)
     out = m.sample_with_query(query=torch.from_numpy(qv), query_embedded=True, k_nn=4, ddim=True, ddim_steps=4, eta=1.0,
@@ -303,7 +322,7 @@ def _dist_sample(device_index):
 
 
 def test_two_rank_sampling_matches_single_rank():
-    """Row (e): the rank-gathered batch of a 2-GPU run (RCCL all-gather) equals the single-rank result bit for bit."""
+    """Row (e): the rank-gathered batch of a 2-GPU run (RCCL all-gather) against the single-rank result (see RANK_*_TOL)."""
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs")
     import torch.multiprocessing as mp
@@ -313,9 +332,23 @@ def test_two_rank_sampling_matches_single_rank():
     for p in procs: p.start()
     got = q.get(timeout=600)
     for p in procs: p.join(timeout=120)
-    ref = _dist_sample(0).cpu().numpy()
-    assert got.shape == ref.shape == (6, 3, 64, 64)
-    assert np.array_equal(got, ref)
+    _check_rank_invariance(got, (_dist_sample(0).cpu().numpy(), _dist_sample(0, latents=True).cpu().numpy()))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_sharing_one_gpu_match_single_rank(world):
+    """Row (e) on a one-GPU box: 2 and 4 processes (gloo group, every rank on cuda:0, each with its own library context) shard the
+    batch (B = 6: even over 2, ragged over 4), sample their rows on the HIP path and all-gather the images -- against the
+    single-rank result (see RANK_*_TOL).  Everything of the multi-GPU path except RCCL itself."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_two_rank_worker, args=(r, world, 29660 + world, q, "gloo", True)) for r in range(world)]
+    for p in procs: p.start()
+    got = q.get(timeout=600)
+    for p in procs: p.join(timeout=120)
+    assert all(p.exitcode == 0 for p in procs)
+    _check_rank_invariance(got, (_dist_sample(0).cpu().numpy(), _dist_sample(0, latents=True).cpu().numpy()))
 
 
 def test_single_rank_distributed_mode_is_deterministic(ctx):
