@@ -185,6 +185,11 @@ int rdm_clip_encode_image_raw(rdm_ctx* ctx, const float* image, int b, int h, in
 int rdm_db_load(rdm_ctx* ctx, const void* emb, long long n, int dim, int dtype, int is_device);
 long long rdm_db_size(rdm_ctx* ctx);
 int rdm_knn(rdm_ctx* ctx, const float* q, int b, int k, uint32_t* idx_out, float* score_out);
+/* The same search with the scores as the fp64 values the ranking was made on (score_out [dev] f64 [b,k]).  For a database whose ROWS are
+ * sharded over GPUs ("when memory matters"): every rank searches its rows, the per-rank lists are exchanged (one
+ * all-gather of [b,k] (index, score) pairs) and merged under the same total order (score desc, global index asc) -- on the fp32
+ * scores two rows whose fp64 scores differ could tie and swap. */
+int rdm_knn_f64(rdm_ctx* ctx, const float* q, int b, int k, uint32_t* idx_out, double* score_out);
 /* 1 if the last rdm_knn could not certify its MFMA-scored candidate set for some query (a cluster of near-duplicates within the
  * score error bound around the k-th neighbour) and answered it by the exact fp64 pass instead; 0 otherwise.  Diagnostic only:
  * the result is exact either way. */

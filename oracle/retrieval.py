@@ -36,9 +36,9 @@ def normalize_queries(q: np.ndarray) -> np.ndarray:
     return q / n
 
 
-def exact_topk(dbn: np.ndarray, qn: np.ndarray, k: int, chunk: int = 262144):
+def exact_topk(dbn: np.ndarray, qn: np.ndarray, k: int, chunk: int = 262144, f64: bool = False):
     """Exact MIPS top-k. dbn fp16 [N,D] (normalised), qn f32 [B,D] (normalised).
-    Returns (idx uint32 [B,k], score f32 [B,k]); ties -> lower index."""
+    Returns (idx uint32 [B,k], score f32 [B,k] -- or the fp64 scores themselves with f64=True); ties -> lower index."""
     B = qn.shape[0]
     q64 = qn.astype(np.float64)
     best_s = np.full((B, 0), 0.0)
@@ -52,7 +52,7 @@ def exact_topk(dbn: np.ndarray, qn: np.ndarray, k: int, chunk: int = 262144):
         order = np.lexsort((ci, -cs), axis=1)[:, :k]            # score desc, then index asc
         best_s = np.take_along_axis(cs, order, 1)
         best_i = np.take_along_axis(ci, order, 1)
-    return best_i.astype(np.uint32), best_s.astype(np.float32)
+    return best_i.astype(np.uint32), (best_s if f64 else best_s.astype(np.float32))
 
 
 def search_k_nearest(data_pool: dict, dbn: np.ndarray, queries: np.ndarray, k: int):

@@ -95,6 +95,7 @@ SIGNATURES = {
     "rdm_db_load": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, C.c_int]),
     "rdm_db_size": (C.c_longlong, [_P]),
     "rdm_knn": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "rdm_knn_f64": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "rdm_knn_last_fallback": (C.c_int, [_P]),
     "rdm_db_gather": (C.c_int, [_P, _P, C.c_longlong, _P]),
     "rdm_prof_enable": (C.c_int, [_P, C.c_int]),
@@ -447,11 +448,15 @@ class Context:
     def db_size(self):
         return int(lib.rdm_db_size(self._h))
 
-    def knn(self, q, k):
+    def knn(self, q, k, f64=False):
+        """-> (idx int32 holding uint32 bits [b,k], score f32 [b,k]); f64=True: the fp64 scores the ranking was made on (shard merges)."""
         q = self._dev(q, torch.float32)
+        if q.ndim != 2:
+            raise RdmError(f"knn: queries must be [b,dim], got {tuple(q.shape)}")
         idx = torch.empty((q.shape[0], k), device=self.device, dtype=torch.int32)   # uint32 bits
-        sc = torch.empty((q.shape[0], k), device=self.device, dtype=torch.float32)
-        self._check(lib.rdm_knn(self._h, _ptr(q), q.shape[0], k, _ptr(idx), _ptr(sc)))
+        sc = torch.empty((q.shape[0], k), device=self.device, dtype=torch.float64 if f64 else torch.float32)
+        fn = lib.rdm_knn_f64 if f64 else lib.rdm_knn
+        self._check(fn(self._h, _ptr(q), q.shape[0], k, _ptr(idx), _ptr(sc)))
         return idx, sc
 
     def knn_last_fallback(self):

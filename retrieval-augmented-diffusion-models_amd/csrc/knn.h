@@ -16,6 +16,6 @@ struct KnnDb {
 
 // all return nullptr on success, or a static error string
 const char* knn_load(KnnDb& db, const void* emb, long long n, int dim, int dtype, int is_device, hipStream_t st);
-const char* knn_search(KnnDb& db, const float* q, int b, int k, uint32_t* idx_out, float* score_out, hipStream_t st);
+const char* knn_search(KnnDb& db, const float* q, int b, int k, uint32_t* idx_out, float* score_out, double* score64_out, hipStream_t st);
 const char* knn_gather(KnnDb& db, const uint32_t* idx, long long n_idx, float* out, hipStream_t st);
 void knn_free(KnnDb& db);

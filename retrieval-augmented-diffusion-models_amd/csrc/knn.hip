@@ -623,7 +623,7 @@ struct Certify {
 struct MergeParams {
     const float* cand_s; const uint32_t* cand_i; int nlists;
     const _Float16* dbn; const float* qn; int dim; long long n;
-    int k; uint32_t* idx_out; float* score_out; int qbase;   // output row = qbase + blockIdx.x
+    int k; uint32_t* idx_out; float* score_out; double* score64_out; int qbase;   // output row = qbase + blockIdx.x; score64_out: the fp64 scores themselves (shard merges)
     Certify cert; float eps;
 };
 
@@ -692,6 +692,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(MergeParams p) {
         for (int j = 0; j < p.k; j++) {
             p.idx_out[(long long)(p.qbase + q) * p.k + j] = exi[j];
             if (p.score_out) p.score_out[(long long)(p.qbase + q) * p.k + j] = (float)ex[j];
+            if (p.score64_out) p.score64_out[(long long)(p.qbase + q) * p.k + j] = ex[j];
         }
         // certificate: nothing that was dropped can reach the k-th exact score
         float th = (si[R] != 0xffffffffu) ? ss[R] : -INFINITY;          // first candidate after the re-scored prefix
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(256) void knn_exact_collect_kernel(Certify c, const
     }
 }
 // top k of the collected rows by k rounds of block-wide arg-best (k <= 28, <= KNN_FB_CAP entries)
-__global__ __launch_bounds__(256) void knn_exact_finish_kernel(Certify c, int k, uint32_t* idx_out, float* score_out, int qbase) {
+__global__ __launch_bounds__(256) void knn_exact_finish_kernel(Certify c, int k, uint32_t* idx_out, float* score_out, double* score64_out, int qbase) {
     const int q = blockIdx.x, tid = threadIdx.x;
     if (!c.flag[q]) return;
     int cnt = c.fb_count[q];
@@ -751,6 +752,7 @@ __global__ __launch_bounds__(256) void knn_exact_finish_kernel(Certify c, int k,
         if (tid == 0 && bp[0] >= 0) {
             idx_out[(long long)(qbase + q) * k + j] = bi[0];
             if (score_out) score_out[(long long)(qbase + q) * k + j] = (float)bs[0];
+            if (score64_out) score64_out[(long long)(qbase + q) * k + j] = bs[0];
             fi[bp[0]] = 0xffffffffu;                      // taken
         }
         __syncthreads();
@@ -814,7 +816,7 @@ const char* knn_load(KnnDb& db, const void* emb, long long n, int dim, int dtype
 }
 
 template <int KSEL, int R>
-static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t* idx_out, float* score_out, hipStream_t st) {
+static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t* idx_out, float* score_out, double* score64_out, hipStream_t st) {
     int dev = 0, ncu = 256;
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -884,13 +886,13 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
             knn_scan_bulk_kernel<KSEL><<<g2, 512, bulk_smem, st>>>(bp);
             KNN_TRY(hipGetLastError());
             MergeParams mp{}; mp.cand_s = cs; mp.cand_i = ci; mp.nlists = bp.s.nlists; mp.dbn = (const _Float16*)db.dbn; mp.qn = qn;
-            mp.dim = db.dim; mp.n = db.n; mp.k = k; mp.idx_out = idx_out; mp.score_out = score_out; mp.qbase = q0; mp.cert = cert; mp.eps = KNN_EPS_BULK;
+            mp.dim = db.dim; mp.n = db.n; mp.k = k; mp.idx_out = idx_out; mp.score_out = score_out; mp.score64_out = score64_out; mp.qbase = q0; mp.cert = cert; mp.eps = KNN_EPS_BULK;
             if (bdbg) continue;                                            // ablation timing of the scan alone: results are garbage
             knn_merge_kernel<KSEL, R><<<bq, 256, merge_smem, st>>>(mp);
             KNN_TRY(hipGetLastError());
             knn_exact_collect_kernel<<<ncu * 4, 256, 0, st>>>(cert, (const _Float16*)db.dbn, qn, db.n, db.dim, bq);
             KNN_TRY(hipGetLastError());
-            knn_exact_finish_kernel<<<bq, 256, 0, st>>>(cert, k, idx_out, score_out, q0);
+            knn_exact_finish_kernel<<<bq, 256, 0, st>>>(cert, k, idx_out, score_out, score64_out, q0);
             KNN_TRY(hipGetLastError());
         }
     } else
@@ -918,13 +920,13 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
         else knn_scan_kernel<KSEL><<<grid, 256, scan_smem, st>>>(sp);
         KNN_TRY(hipGetLastError());
         MergeParams mp{}; mp.cand_s = cs; mp.cand_i = ci; mp.nlists = sp.nlists; mp.dbn = (const _Float16*)db.dbn; mp.qn = qn;
-        mp.dim = db.dim; mp.n = db.n; mp.k = k; mp.idx_out = idx_out; mp.score_out = score_out; mp.qbase = q0; mp.cert = cert; mp.eps = sp.hi_only ? KNN_EPS_BULK : KNN_EPS;
+        mp.dim = db.dim; mp.n = db.n; mp.k = k; mp.idx_out = idx_out; mp.score_out = score_out; mp.score64_out = score64_out; mp.qbase = q0; mp.cert = cert; mp.eps = sp.hi_only ? KNN_EPS_BULK : KNN_EPS;
         knn_merge_kernel<KSEL, R><<<bq, 256, merge_smem, st>>>(mp);
         KNN_TRY(hipGetLastError());
         // exact fallback for the flagged queries of this group (both kernels return at once when nothing is flagged)
         knn_exact_collect_kernel<<<ncu * 4, 256, 0, st>>>(cert, (const _Float16*)db.dbn, qn, db.n, db.dim, bq);
         KNN_TRY(hipGetLastError());
-        knn_exact_finish_kernel<<<bq, 256, 0, st>>>(cert, k, idx_out, score_out, q0);
+        knn_exact_finish_kernel<<<bq, 256, 0, st>>>(cert, k, idx_out, score_out, score64_out, q0);
         KNN_TRY(hipGetLastError());
     }
     int status = 0;
@@ -935,7 +937,7 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
     return nullptr;
 }
 
-const char* knn_search(KnnDb& db, const float* q, int b, int k, uint32_t* idx_out, float* score_out, hipStream_t st) {
+const char* knn_search(KnnDb& db, const float* q, int b, int k, uint32_t* idx_out, float* score_out, double* score64_out, hipStream_t st) {
     if (!db.dbn) return "no database loaded (rdm_db_load)";
     if (b < 1 || k < 1) return "b and k must be positive";
     if (k > db.n) return "k exceeds database size";
@@ -945,8 +947,8 @@ const char* knn_search(KnnDb& db, const float* q, int b, int k, uint32_t* idx_ou
     // of a query's best ~64 rows fall into one lane's rows.  (The insertion chain runs for a candidate when ANY of the wave's 64
     // lanes accepts it, so its cost grows with the list length times the acceptance rate: 16-entry lists made k = 16 take 8.8 ms
     // per 64 queries against 4.4 ms for k = 4, 32-entry lists 8x and the 8-wave bulk kernel spilled.)
-    if (k <= 4) return search_impl<8, 16>(db, q, b, k, idx_out, score_out, st);
-    if (k <= 28) return search_impl<8, 64>(db, q, b, k, idx_out, score_out, st);
+    if (k <= 4) return search_impl<8, 16>(db, q, b, k, idx_out, score_out, score64_out, st);
+    if (k <= 28) return search_impl<8, 64>(db, q, b, k, idx_out, score_out, score64_out, st);
     return "k > 28 is not supported (the merge re-scores the best 64 candidates)";
 }
 

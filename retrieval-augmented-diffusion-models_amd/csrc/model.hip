@@ -1336,7 +1336,10 @@ int rdm_db_load(rdm_ctx* c, const void* emb, long long n, int dim, int dtype, in
     return msg ? c->fail(-5, "rdm_db_load: %s", msg) : 0;
 }
 long long rdm_db_size(rdm_ctx* c) { return c ? c->db.n : -1; }
-int rdm_knn(rdm_ctx* c, const float* q, int b, int k, uint32_t* idx_out, float* score_out) {
+static int knn_entry(rdm_ctx* c, const float* q, int b, int k, uint32_t* idx_out, float* score_out, double* score64_out);
+int rdm_knn(rdm_ctx* c, const float* q, int b, int k, uint32_t* idx_out, float* score_out) { return knn_entry(c, q, b, k, idx_out, score_out, nullptr); }
+int rdm_knn_f64(rdm_ctx* c, const float* q, int b, int k, uint32_t* idx_out, double* score_out) { return knn_entry(c, q, b, k, idx_out, nullptr, score_out); }
+static int knn_entry(rdm_ctx* c, const float* q, int b, int k, uint32_t* idx_out, float* score_out, double* score64_out) {
     RDM_ENTER(c);
     if (!c || !q || !idx_out) return c ? c->fail(-1, "null argument") : -1;
     const bool prof = (c->prof >> RDM_PROF_KNN) & 1u;
@@ -1345,7 +1348,7 @@ int rdm_knn(rdm_ctx* c, const float* q, int b, int k, uint32_t* idx_out, float* 
         r.flops = (double)((b + 63) / 64) * (double)c->db.n * c->db.dim * 2.0;
         hipEventRecord(r.a, c->stream); c->prof_recs.push_back(r);
     }
-    const char* msg = knn_search(c->db, q, b, k, idx_out, score_out, c->stream);
+    const char* msg = knn_search(c->db, q, b, k, idx_out, score_out, score64_out, c->stream);
     if (prof) hipEventRecord(c->prof_recs.back().b, c->stream);
     return msg ? c->fail(-5, "rdm_knn: %s", msg) : 0;
 }

@@ -19,19 +19,35 @@ from ... import _lib
 
 
 class HipSearcher(object):
-    """Drop-in for the scann searcher object."""
+    """Drop-in for the scann searcher object.  With `row0` / `group` the context holds only rows [row0, row0 + n_local) of the
+    database (one shard per rank): every search runs on the local rows, the per-rank lists are merged in one exchange
+    (parallel.merge_sharded_topk) and the answer -- global row ids -- is the same on every rank and the same as an unsharded search."""
 
-    def __init__(self, ctx, dim):
-        self.ctx, self.dim = ctx, dim
+    def __init__(self, ctx, dim, row0=0, group=None, sharded=False, n_local=None):
+        self.ctx, self.dim, self.row0, self.group, self.sharded, self.n_local = ctx, dim, int(row0), group, bool(sharded), n_local
+
+    def _search(self, q: torch.Tensor, k: int):
+        if not self.sharded:
+            return self.ctx.knn(q, k)
+        from ... import parallel
+        kl = min(k, self.n_local)
+        idx, sc = self.ctx.knn(q, kl, f64=True)
+        gid = (idx.to(torch.int64) & 0xffffffff) + self.row0
+        if kl < k:                                                  # a shard shorter than k: pad with "no row"
+            pad = k - kl
+            gid = torch.cat([gid, torch.full((gid.shape[0], pad), 2 ** 62, dtype=torch.int64, device=gid.device)], dim=1)
+            sc = torch.cat([sc, torch.full((sc.shape[0], pad), float("-inf"), dtype=torch.float64, device=sc.device)], dim=1)
+        gi, gs = parallel.merge_sharded_topk(gid, sc, k, self.group)
+        return gi.to(torch.int32), gs.to(torch.float32)             # uint32 bits, like the unsharded call
 
     def search_batched(self, queries, final_num_neighbors=None, **kw):
         q = torch.as_tensor(np.ascontiguousarray(queries, dtype=np.float32))
-        idx, dist = self.ctx.knn(q, int(final_num_neighbors))
+        idx, dist = self._search(q, int(final_num_neighbors))
         return idx.cpu().numpy().view(np.uint32), dist.cpu().numpy()
 
     def search_batched_device(self, queries: torch.Tensor, k: int):
         """Device-resident variant (no host round trip): -> (idx int32-bits-of-uint32 [B,k], score f32 [B,k])."""
-        return self.ctx.knn(queries, k)
+        return self._search(queries, k)
 
     def search(self, query, final_num_neighbors=None, **kw):
         i, d = self.search_batched(np.asarray(query)[None], final_num_neighbors)
@@ -95,12 +111,26 @@ class DatasetBuilder(object):
         print(f'Finished loading of patch embeddings ({self.data_pool["embedding"].shape[0]} rows) in {time.time() - t0:.1f} s')
 
     # ---- dsetbuilder.py:534-619: "training" = upload + normalise on device
+    def shard_rows(self, enabled=True, group=None):
+        """[native] Hold only this rank's contiguous share of the database rows in HBM (for databases beyond one GPU's memory,
+        SURVEY.md 8e); the host-side data_pool stays whole, like the reference's.  Takes effect at the next train_searcher()."""
+        self._shard_rows, self._shard_group = bool(enabled), group
+        self.searcher = None
+        return self
+
     def train_searcher(self, k=None, metric=None, **ignored):
-        emb = np.ascontiguousarray(self.data_pool['embedding'])
+        emb = self.data_pool['embedding']
+        row0, sharded, group = 0, bool(getattr(self, "_shard_rows", False)), getattr(self, "_shard_group", None)
+        if sharded:
+            from ... import parallel
+            world, rank = parallel.world_rank(group)
+            row0, row1 = parallel.shard_range(len(emb), world, rank)
+            emb = emb[row0:row1]
+        emb = np.ascontiguousarray(emb)
         if emb.dtype not in (np.float16, np.float32):
             emb = emb.astype(np.float32)
         self.ctx.db_load(emb)
-        self.searcher = HipSearcher(self.ctx, emb.shape[1])
+        self.searcher = HipSearcher(self.ctx, emb.shape[1], row0=row0, group=group, sharded=sharded, n_local=emb.shape[0])
         return self.searcher
 
     # ---- dsetbuilder.py:461-473

@@ -99,15 +99,28 @@ class MinimalRETRODiffusion(object):
     def to(self, device): return self
 
     # ---- multi-GPU (new functionality; the reference samples on one GPU, scripts/rdm_sample.py:31-36, 181-185)
-    def set_distributed(self, enabled=True, group=None):
+    def set_distributed(self, enabled=True, group=None, shard_db=False):
         """Shard every `sample_with_query` / `sample_from_rdata` batch contiguously over the ranks of the initialised
         torch.distributed group (one process per GPU): each rank retrieves, samples and decodes only its rows, the
         starting noise of row i is a function of (shared seed, GLOBAL index i) — so what is fed to the kernels does not depend
         on the number of ranks — and the finished images are all-gathered (the only collective).  Weights and the database are
         replicated.  With a single process the same per-row noise streams are used.  (The kernels pick tiles / split-K by local
-        batch size, so latents of different rank counts agree to rounding, not bit for bit: tests/test_gpu_surface.py.)"""
+        batch size, so latents of different rank counts agree to rounding, not bit for bit: tests/test_gpu_surface.py.)
+        shard_db=True: the database ROWS are sharded over the ranks instead of replicated (for databases beyond one GPU's HBM):
+        every rank searches its rows for the whole query batch and the per-rank top-k lists are merged in one exchange."""
         self.distributed, self._group = bool(enabled), group
+        self.shard_db = bool(shard_db) and self.distributed
+        if self.retriever is not None and hasattr(self.retriever, "shard_rows") and \
+                bool(getattr(self.retriever, "_shard_rows", False)) != self.shard_db:
+            self.retriever.shard_rows(self.shard_db, group)          # takes effect at the next train_searcher()
         return self
+
+    def _sync_retriever_sharding(self):
+        """A retriever attached after set_distributed() still has to learn whether it holds the whole database or a row shard."""
+        want = self.distributed and getattr(self, "shard_db", False)
+        r = self.retriever
+        if r is not None and hasattr(r, "shard_rows") and bool(getattr(r, "_shard_rows", False)) != want:
+            r.shard_rows(want, getattr(self, "_group", None))
 
     def _shard(self, n_total):
         world, rank = parallel.world_rank(getattr(self, "_group", None))
@@ -237,6 +250,7 @@ class MinimalRETRODiffusion(object):
         #  works pre-embedded there, scripts/rdm_sample.py:275-277; here str / list-of-str queries take the CLIP text tower)
         if not query_embedded and not isinstance(query, (str, list)):
             assert query.ndim in [3, 4], 'User defined query for sampling has to be an image or of batch of images'
+        self._sync_retriever_sharding()
         if self.retriever is not None and self.retriever.searcher is None:
             self.train_searcher()
         if bs is None:
@@ -257,12 +271,15 @@ class MinimalRETRODiffusion(object):
             k_nn = self.k_nn
         n_total = len(query)
         lo, hi = self._shard(n_total) if self.distributed else (0, n_total)
-        if self.distributed:
+        shard_db = self.distributed and getattr(self, "shard_db", False)
+        if self.distributed and not shard_db:
             query = query[lo:hi]            # every rank retrieves for its own rows only (the database is replicated)
         nn_dict = self.retriever.search_k_nearest(query, visualize=False, k=k_nn, is_caption=is_caption,
                                                   query_embedded=query_embedded)
         q_emb = torch.as_tensor(nn_dict['q_embeddings']).float()
         r_emb = torch.as_tensor(nn_dict['embeddings']).float()
+        if shard_db:                        # row-sharded database: every rank searched ALL queries on its rows; keep this rank's samples
+            q_emb, r_emb = q_emb[lo:hi], r_emb[lo:hi]
         if normalize:
             q_emb = q_emb / q_emb.norm(dim=-1, keepdim=True)
             r_emb = r_emb / r_emb.norm(dim=-1, keepdim=True)
@@ -313,19 +330,24 @@ class MinimalRETRODiffusion(object):
         """ddpm.py:878-984: pseudo-queries drawn from the DB; the query itself is NOT prepended (:921)."""
         if cond is not None or return_nns or pre_loaded_patches is not None:
             raise NotImplementedError("cond / return_nns / pre_loaded_patches are not part of the native sampling path")
+        self._sync_retriever_sharding()
         if self.retriever.searcher is None:
             self.train_searcher()
         if k_nn is None:
             k_nn = self.k_nn
         qids = self.get_qids(memsize, N, qids=qids, use_weights=use_weights, verbose=verbose)   # numpy global RNG: same draw on every rank
         lo, hi = self._shard(N) if self.distributed else (0, N)
+        shard_db = self.distributed and getattr(self, "shard_db", False) and nn_embeddings is None
         if self.distributed:
-            qids = np.asarray(qids)[lo:hi]
+            if not shard_db:
+                qids = np.asarray(qids)[lo:hi]
             if nn_embeddings is not None:
                 nn_embeddings = nn_embeddings[lo:hi]
         query_embeddings = self.retriever.data_pool['embedding'][qids]
         if nn_embeddings is None:
             nns, _ = self.retriever.searcher.search_batched(query_embeddings, final_num_neighbors=k_nn)   # normalises internally
+            if shard_db:                    # row-sharded database: all pseudo-queries were searched on this rank's rows and merged
+                nns = nns[lo:hi]
             retro_cond = torch.from_numpy(np.asarray(self.retriever.data_pool['embedding'][nns])).to(self.device).to(torch.float)
         else:
             retro_cond = nn_embeddings

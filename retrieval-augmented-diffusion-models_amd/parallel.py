@@ -18,6 +18,10 @@ def init_distributed(backend: str = None):
     -> (rank, local_rank).  Backend: RCCL ("nccl") when a HIP device is visible, else gloo.  Must be called before
     the library context is created so that each rank binds its own device."""
     rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    # test switches for a one-GPU box: every rank on one device, gloo group (RCCL refuses two ranks on one GPU)
+    backend = backend or os.environ.get("RDM_DIST_BACKEND") or None
+    if os.environ.get("RDM_DIST_DEVICE") is not None:
+        local = int(os.environ["RDM_DIST_DEVICE"])
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
@@ -92,3 +96,31 @@ def all_gather_images(local: torch.Tensor, n_total: int = None, group=None) -> t
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+
+
+def all_gather_tensor(local: torch.Tensor, group=None) -> torch.Tensor:
+    """[...] on every rank (same shape) -> [world, ...]; a gloo group takes device tensors through the host."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local[None]
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        return all_gather_tensor(local.cpu(), group).to(local.device)
+    world = dist.get_world_size(group)
+    flat = local.contiguous().reshape(1, -1)
+    out = torch.empty((world, flat.shape[1]), device=local.device, dtype=local.dtype)      # concatenation along dim 0 (gloo and RCCL)
+    dist.all_gather_into_tensor(out, flat, group=group)
+    return out.reshape((world,) + tuple(local.shape))
+
+
+def merge_sharded_topk(idx_global: torch.Tensor, score: torch.Tensor, k: int, group=None):
+    """Row-sharded database ("when memory matters"): every rank holds the exact top-k_l of ITS rows for all queries
+    -- idx_global int64 [B,k_l] (already offset by the shard's first row; padding = 2^62), score fp64 [B,k_l] (padding = -inf).
+    ONE exchange (all-gather of the pairs), then the same total order as the single-GPU search: score descending, ties to the
+    lower global index.  -> (idx int64 [B,k], score fp64 [B,k]) identical on every rank."""
+    pairs = torch.stack([idx_global.to(torch.float64), score.to(torch.float64)], dim=0)      # indices < 2^53: exact in fp64
+    allp = all_gather_tensor(pairs, group)                                                  # [world, 2, B, k_l]
+    idx = allp[:, 0].permute(1, 0, 2).reshape(idx_global.shape[0], -1).to(torch.int64)
+    sc = allp[:, 1].permute(1, 0, 2).reshape(idx_global.shape[0], -1)
+    o1 = torch.argsort(idx, dim=1, stable=True)                                             # secondary key first ...
+    idx, sc = torch.gather(idx, 1, o1), torch.gather(sc, 1, o1)
+    o2 = torch.argsort(sc, dim=1, descending=True, stable=True)                             # ... then the stable primary sort
+    return torch.gather(idx, 1, o2)[:, :k].contiguous(), torch.gather(sc, 1, o2)[:, :k].contiguous()

@@ -60,6 +60,8 @@ def build_parser() -> argparse.ArgumentParser:
                         help="[native] seeded random weights + synthetic database instead of checkpoint files")
     parser.add_argument("--synthetic_db_rows", type=int, default=200_000, help="[native] rows of the --synthetic database")
     parser.add_argument("--gpus", type=int, default=1, help="[native] shard each batch over this many GPUs (RCCL)")
+    parser.add_argument("--shard_db", action="store_true", help="[native] with --gpus N: shard the database ROWS over the GPUs instead of "
+                        "replicating them (databases beyond one GPU's memory); neighbours are merged in one exchange per search")
     return parser
 
 
@@ -236,7 +238,7 @@ def main(argv=None):
         is_writer = rank == 0
     model = load_model(opt)
     if world > 1:
-        model.set_distributed(seed=opt.seed if opt.seed is not None else 0)
+        model.set_distributed(True, shard_db=opt.shard_db)       # noise streams: f(shared seed drawn after seed_everything, global row)
     if opt.caption == "":
         sample_unconditional(model, opt, is_writer)
     else:

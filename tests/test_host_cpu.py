@@ -419,3 +419,52 @@ def test_search_nns_files_and_nn_memory(tmp_path):
     with open(tmp_path / "nn_memory" / "m.p", "rb") as f:
         again = pickle.load(f)
     assert np.array_equal(again["nn_memory"], mem["nn_memory"])
+
+
+def _merge_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from rdm_amd import parallel
+    parallel.init_distributed("gloo")
+    q.put((rank, _sharded_search(rank, world)))
+    parallel.shutdown()
+
+
+def _sharded_db():
+    rng = np.random.default_rng(77)
+    db = (rng.standard_normal((1003, 64)) * 0.45).astype(np.float16)
+    db[900] = db[17]; db[333] = db[17]                     # one row three times: ties across shards -> global index order
+    db[1002] = db[5]
+    qs = (rng.standard_normal((9, 64)) * 0.45).astype(np.float32)
+    qs[0] = db[17].astype(np.float32); qs[1] = db[5].astype(np.float32)
+    return db, qs
+
+
+def _sharded_search(rank, world, k=7):
+    """Every rank: exact fp64 top-k of ITS rows (what rdm_knn_f64 returns), then the product's merge."""
+    from rdm_amd import parallel
+    db, qs = _sharded_db()
+    r0, r1 = parallel.shard_range(len(db), world, rank)
+    dbn, qn = oret.normalize_db(db), oret.normalize_queries(qs)
+    li, ls = oret.exact_topk(dbn[r0:r1], qn, min(k, r1 - r0), f64=True)
+    gi, gs = parallel.merge_sharded_topk(torch.from_numpy(li.astype(np.int64)) + r0, torch.from_numpy(ls.astype(np.float64)), k)
+    return gi.numpy(), gs.numpy()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_row_sharded_topk_merge_equals_unsharded(world):
+    """SURVEY 8e alternative: database rows sharded over ranks, one all-gather of (index, fp64 score) pairs, merge under the single
+    total order (score desc, global index asc) == the exact search over the whole database, ties across shards included."""
+    db, qs = _sharded_db()
+    ref_i, ref_s = oret.exact_topk(oret.normalize_db(db), oret.normalize_queries(qs), 7, f64=True)
+    if world == 1:
+        outs = [(0, _sharded_search(0, 1))]
+    else:
+        ctx = mp.get_context("spawn"); q = ctx.Queue()
+        procs = [ctx.Process(target=_merge_worker, args=(r, world, 29570 + world, q)) for r in range(world)]
+        for p in procs: p.start()
+        outs = [q.get(timeout=300) for _ in range(world)]
+        for p in procs: p.join(timeout=60)
+    for rank, (gi, gs) in outs:
+        assert np.array_equal(gi, ref_i.astype(np.int64)), rank
+        assert np.abs(gs - ref_s).max() <= 1e-15, rank            # the oracle's BLAS may block a shard differently from the whole
+    assert list(ref_i[0][:3]) == [17, 333, 900]            # the planted triple, in index order
