@@ -317,6 +317,17 @@ def test_rdm_sample_flags_match_reference():
     mod.parse_args(["--seed", "3"])                               # the reference crashes here (opt.r_runs, :141)
 
 
+def test_rdm_sample_documented_deviations():
+    """The script's docstring lists its deviations from the reference: --gpu -1 (the reference's CPU default) is refused because
+    there is no CPU path, --save_nns needs the raw OpenImages patches."""
+    mod = _script()
+    with pytest.raises(NotImplementedError):
+        mod.load_model(mod.parse_args(["--save_nns", "--gpu", "0", "--synthetic"]))
+    with pytest.raises(SystemExit) as e:
+        mod.load_model(mod.parse_args(["--synthetic"]))            # --gpu defaults to -1
+    assert "gpu" in str(e.value).lower()
+
+
 def test_rdm_sample_run_loops_follow_reference(tmp_path, monkeypatch):
     """Run-loop semantics of scripts/rdm_sample.py:225-315 on a stand-in model: per-run seeding, k_nn = 1 with --only_caption,
     omit_query masked by only_caption, no eta override, --increase_guidance, --keep_qids, file naming, uint8 truncation."""
