@@ -268,6 +268,93 @@ def test_rdm_sample_script_synthetic(tmp_path):
     model.ctx.close()
 
 
+def test_rdm_sample_script_from_checkpoint_directory(tmp_path):
+    """`scripts/rdm_sample.py --model_path DIR` on a checkpoint directory in the reference's own on-disk formats (scripts/rdm_sample.py:
+    146-185, models/rdm/*/config.yaml): config.yaml (model.params.{unet_config, first_stage_config, retrieval_cfg, nn_memory, ...}),
+    model.ckpt (pytorch-lightning `state_dict` with live `model.diffusion_model.*`, LitEma `model_ema.*` and `first_stage_model.*`
+    entries), the database as `<rows>x512-part_<i>.npz` shards, the nn_memory pickle, a ViT-B/32 state_dict.  The images the script
+    writes must be the ones the library produces from the EMA weights (NOT the live ones) through the API."""
+    import pickle
+    import yaml
+    from PIL import Image
+    from rdm_amd import _lib, synthetic
+    from rdm_amd.data.retrieval_dataset.dsetbuilder import DatasetBuilder
+    from rdm_amd.models.diffusion.ddpm import MinimalRETRODiffusion
+    from rdm_amd.modules.retrievers import ClipImageRetriever
+    from rdm_amd.modules.custom_clip.tokenizer import tokenize
+    mod = _script()
+    spec, vspec = ounet.tiny_spec(), ovq.tiny_vq_spec()
+    mdir = tmp_path / "models" / "rdm" / "toy"; mdir.mkdir(parents=True)
+    dbdir = tmp_path / "database" / "toy"; dbdir.mkdir(parents=True)
+    rng = np.random.default_rng(8)
+    N = 6000
+    emb = (rng.standard_normal((N, 512)) * 0.45).astype(np.float16)
+    for i, (a, b) in enumerate(((0, 2500), (2500, 6000))):          # two shards, like scripts/download_databases.sh unpacks them
+        np.savez(dbdir / f"{b - a}x512-part_{i + 1}.npz", embedding=emb[a:b], img_id=np.arange(a, b), patch_coords=np.zeros((b - a, 4), np.int64))
+    mem = {"nn_memory": np.arange(100, 600), "id_count": {int(i): 1 + int(i) % 3 for i in range(100, 600)}}
+    with open(tmp_path / "nn_memory.p", "wb") as f:
+        pickle.dump(mem, f)
+    cfg = {"model": {"target": "rdm.models.diffusion.ddpm.MinimalRETRODiffusion", "params": {
+        "k_nn": 4, "linear_start": 0.0015, "linear_end": 0.0195, "log_every_t": 200, "timesteps": 1000, "image_size": 16, "channels": 3,
+        "nn_memory": str(tmp_path / "nn_memory.p"), "conditioning_key": "retro_only",
+        "unet_config": {"target": "rdm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(
+            _unet_params(spec), image_size=16, use_spatial_transformer=True, transformer_depth=1, use_checkpoint=True,
+            attention_resolutions=list(spec.attention_resolutions), channel_mult=list(spec.channel_mult))},
+        "first_stage_config": {"target": "ldm.models.autoencoder.VQModelInterface", "params": {"embed_dim": 3, "n_embed": vspec.n_embed, "ddconfig": {
+            "double_z": False, "z_channels": 3, "resolution": vspec.resolution, "in_channels": 3, "out_ch": 3, "ch": vspec.ch,
+            "ch_mult": list(vspec.ch_mult), "num_res_blocks": vspec.num_res_blocks, "attn_resolutions": [], "dropout": 0.0},
+            "lossconfig": {"target": "torch.nn.Identity"}}},
+        "retrieval_cfg": {"target": "rdm.data.retrieval_dataset.dsetbuilder.DatasetBuilder", "params": {
+            "k": 20, "saved_embeddings": str(dbdir), "load_patch_dataset": True,
+            "retriever_config": {"target": "rdm.modules.retrievers.ClipImageRetriever", "params": {"model": "ViT-B/32"}}}},
+        "retrieval_encoder_cfg": {"target": "torch.nn.Identity"}, "cond_stage_config": "__is_unconditional__"}}}
+    with open(mdir / "config.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    live = ounet.synth_state_dict(ounet.param_shapes(spec), seed=77)                 # what training last wrote ...
+    ema = ounet.synth_state_dict(ounet.param_shapes(spec), seed=1234)                # ... and the EMA copies sampling must use
+    vq = ounet.synth_state_dict(ovq.vq_param_shapes(vspec), seed=5)
+    sd = {"betas": torch.zeros(1000), "model_ema.decay": torch.tensor(0.9999), "model_ema.num_updates": torch.tensor(1)}
+    for k, v in live.items():
+        sd["model.diffusion_model." + k] = v
+        sd["model_ema." + ("diffusion_model." + k).replace(".", "")] = ema[k]
+    for k, v in vq.items():
+        sd["first_stage_model." + k] = v
+    torch.save({"state_dict": sd, "global_step": 1}, mdir / "model.ckpt")
+    clip_cfg = _lib.make_clip_cfg()
+    clip_sd = synthetic.clip_state_dict(clip_cfg)
+    torch.save(clip_sd, tmp_path / "vit_b32.pt")
+    out = tmp_path / "out"
+    cap = "a red fox in the snow"
+    argv = ["--model_path", str(mdir), "--clip_ckpt", str(tmp_path / "vit_b32.pt"), "--gpu", "0", "-bs", "2", "-n", "1", "--steps", "4", "--seed", "5",
+            "-c", cap, "-s", str(out)]
+    mod.main(argv)
+    files = sorted(out.glob("*.png"))
+    assert len(files) == 2
+    px = [np.asarray(Image.open(f)) for f in files]
+    # the same thing through the API, from the EMA weights
+    ctx = _lib.Context(0)
+    fs = {"params": {"embed_dim": 3, "n_embed": vspec.n_embed, "ddconfig": {"z_channels": 3, "ch": vspec.ch, "ch_mult": vspec.ch_mult,
+                                                                          "num_res_blocks": vspec.num_res_blocks, "resolution": vspec.resolution}}}
+    m = MinimalRETRODiffusion(unet_config={"params": _unet_params(spec)}, first_stage_config=fs, k_nn=4, image_size=16, ctx=ctx)
+    m.load_unet_state_dict(ema); m.load_first_stage_state_dict(vq)
+    retr = ClipImageRetriever(state_dict=clip_sd, ctx=ctx)
+    m.retriever = DatasetBuilder(data_pool={"embedding": emb, "img_id": np.arange(N), "patch_coords": np.zeros((N, 4), np.int64)}, retriever=retr, ctx=ctx)
+    q = retr.model.encode_text(torch.from_numpy(tokenize([cap] * 2))).cpu()
+    mod.seed_everything(5)
+    ref = m.sample_with_query(query=q, query_embedded=True, k_nn=4, unconditional_guidance_scale=2.0, ddim_steps=4, ddim=True,
+                              unconditional_retro_guidance_label=0.)["query_samples"]
+    u8 = ctx.to_uint8(ref).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(px[i], u8[i]), i
+    # and NOT the live weights
+    m.load_unet_state_dict(live)
+    mod.seed_everything(5)
+    other = ctx.to_uint8(m.sample_with_query(query=q, query_embedded=True, k_nn=4, unconditional_guidance_scale=2.0, ddim_steps=4, ddim=True,
+                                             unconditional_retro_guidance_label=0.)["query_samples"]).cpu().numpy()
+    assert not np.array_equal(other[0], px[0])
+    ctx.close()
+
+
 @pytest.mark.parametrize("shard_db", [False, True])
 def test_rdm_sample_script_two_processes(tmp_path, shard_db):
     """`scripts/rdm_sample.py` as torchrun runs it for --gpus 2 (world 2; here both ranks on the box's one GPU over gloo:
