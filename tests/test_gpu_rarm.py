@@ -177,3 +177,98 @@ def test_latent_image_retro_surface(ctx):
     # explicit neighbours (the --only_caption / --unconditional branches of scripts/rarm_sample.py:236-241)
     o2 = m.sample_from_rdata(2, nn_embeddings=torch.zeros(2, 1, 512), code_side_len=8, z_dimensionality=64, top_k=10)
     assert o2["samples_with_sampled_nns"].shape == (2, 3, 32, 32)
+
+
+def _rarm_script():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "rarm_sample.py")
+    spec = importlib.util.spec_from_file_location("rarm_sample_native", path)
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod
+
+
+def test_rarm_sample_script_synthetic(tmp_path):
+    """scripts/rarm_sample.py end to end on the shipped architecture (18 x 768 transformer, VQGAN-f16; seeded random weights and
+    database): caption -> CLIP text tower -> retrieval -> 256 sampled tokens -> decode -> PNG; a seeded second run repeats."""
+    from PIL import Image
+    mod = _rarm_script()
+    opt = mod.parse_args(["--synthetic", "--synthetic_db_rows", "20000", "--gpu", "0", "-bs", "2", "-n", "2", "--seed", "7", "--k_nn", "8",
+                          "-c", "a photo of a corgi", "-s", str(tmp_path)])
+    model = mod.load_model(opt)
+    stamp = mod.sample(model, opt)
+    files = sorted(p.name for p in tmp_path.iterdir())
+    assert files == sorted(f"{stamp}-samples_with_sampled_nns-run{n}-sample{i}.png" for n in range(2) for i in range(2))
+    px = {f: np.asarray(Image.open(tmp_path / f)) for f in files}
+    assert all(v.shape == (256, 256, 3) and v.dtype == np.uint8 for v in px.values())
+    for i in range(2):                                         # same --seed every run -> same images
+        assert np.array_equal(px[f"{stamp}-samples_with_sampled_nns-run0-sample{i}.png"], px[f"{stamp}-samples_with_sampled_nns-run1-sample{i}.png"])
+    assert len(np.unique(px[files[0]])) > 16
+    # --unconditional (zero neighbour) and --only_caption branches (rarm_sample.py:236-241)
+    for extra in (["--unconditional"], ["--only_caption", "-c", "a photo of a corgi"]):
+        d = tmp_path / extra[0].strip("-"); d.mkdir()
+        o2 = mod.parse_args(["--synthetic", "--gpu", "0", "-bs", "2", "-n", "1", "-s", str(d)] + extra)
+        mod.sample(model, o2)
+        assert len(list(d.iterdir())) == 2
+    model.ctx.close()
+
+
+def test_rarm_sample_script_from_checkpoint_directory(tmp_path):
+    """`scripts/rarm_sample.py --model_path DIR` on a checkpoint directory in the reference's formats (models/rarm/*/config.yaml:
+    transformer_config / first_stage_config / retrieval_cfg / nn_memory; model.ckpt with `transformer.*` and `first_stage_model.*`):
+    the images equal the API's on the same weights."""
+    import pickle
+    import yaml
+    from PIL import Image
+    from rdm_amd import _lib, synthetic
+    from rdm_amd.data.retrieval_dataset.dsetbuilder import DatasetBuilder
+    from rdm_amd.models.autoregression.transformer import LatentImageRETRO
+    mod = _rarm_script()
+    spec = orarm.RarmSpec(vocab_in=514, vocab_out=512, n_heads=2, d_head=64, depth=2, context_dim=512, sequence_length=256)
+    vspec = ovq.VQSpec(embed_dim=256, n_embed=512, z_channels=256, ch=64, ch_mult=(1, 2, 4), num_res_blocks=1, resolution=64, attn_resolutions=(16,))
+    mdir = tmp_path / "models" / "rarm" / "toy"; mdir.mkdir(parents=True)
+    dbdir = tmp_path / "database" / "toy"; dbdir.mkdir(parents=True)
+    rng = np.random.default_rng(9)
+    N = 4000
+    emb = (rng.standard_normal((N, 512)) * 0.45).astype(np.float16)
+    np.savez(dbdir / f"{N}x512-part_1.npz", embedding=emb, img_id=np.arange(N), patch_coords=np.zeros((N, 4), np.int64))
+    with open(tmp_path / "nn_memory.p", "wb") as f:
+        pickle.dump({"nn_memory": np.arange(50, 450), "id_count": {int(i): 1 for i in range(50, 450)}}, f)
+    tparams = dict(in_channels=spec.vocab_in, out_channels=spec.vocab_out, n_heads=spec.n_heads, d_head=64, depth=spec.depth, context_dim=512,
+                   sequence_length=spec.sequence_length, continuous=False, causal=True)
+    fparams = {"embed_dim": 256, "n_embed": 512, "ddconfig": {"double_z": False, "z_channels": 256, "resolution": 64, "in_channels": 3, "out_ch": 3, "ch": 64,
+                                                             "ch_mult": [1, 2, 4], "num_res_blocks": 1, "attn_resolutions": [16], "dropout": 0.0}}
+    cfg = {"model": {"target": "rdm.models.autoregression.transformer.LatentImageRETRO", "params": {
+        "k_nn": 4, "mask_token": 512, "sos_token": 513, "nn_memory": str(tmp_path / "nn_memory.p"),
+        "transformer_config": {"target": "rdm.modules.attention.RetrievalPatchTransformer", "params": tparams},
+        "first_stage_config": {"target": "taming.models.vqgan.VQModel", "params": fparams},
+        "retrieval_cfg": {"target": "rdm.data.retrieval_dataset.dsetbuilder.DatasetBuilder", "params": {"k": 20, "saved_embeddings": str(dbdir)}}}}}
+    with open(mdir / "config.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    tsd = ounet.synth_state_dict(orarm.rarm_param_shapes(spec), seed=777)
+    vsd = ounet.synth_state_dict(ovq.vq_param_shapes(vspec), seed=888)
+    sd = {("transformer." + k): v for k, v in tsd.items()}
+    sd.update({("first_stage_model." + k): v for k, v in vsd.items()})
+    torch.save({"state_dict": sd}, mdir / "model.ckpt")
+    clip_sd = synthetic.clip_state_dict(_lib.make_clip_cfg())
+    torch.save(clip_sd, tmp_path / "vit_b32.pt")
+    out = tmp_path / "out"; out.mkdir()
+    opt = mod.parse_args(["--model_path", str(mdir), "--clip_ckpt", str(tmp_path / "vit_b32.pt"), "--gpu", "0", "-bs", "3", "-n", "1", "--seed", "2",
+                          "--top_k", "50", "--top_m", "100", "--guidance_scale", "2.0", "-s", str(out)])
+    model = mod.load_model(opt)
+    mod.sample(model, opt)
+    files = sorted(out.glob("*.png"))
+    assert len(files) == 3
+    px = [np.asarray(Image.open(f)) for f in files]
+    assert px[0].shape == (64, 64, 3)
+    # API on the same weights / database / seed
+    ctx = model.ctx
+    m = LatentImageRETRO({"params": tparams}, {"params": fparams}, mask_token=512, sos_token=513, nn_memory=np.arange(50, 450), k_nn=4, ctx=ctx)
+    m.load_transformer_state_dict(tsd); m.load_first_stage_state_dict(vsd)
+    m.retriever = DatasetBuilder(data_pool={"embedding": emb, "img_id": np.arange(N), "patch_coords": np.zeros((N, 4), np.int64)}, ctx=ctx)
+    mod.seed_everything(2)
+    ref = m.sample_from_rdata(3, k_nn=4, memsize=100, top_k=50, temperature=1.0, guidance_scale=2.0)["samples_with_sampled_nns"]
+    u8 = ctx.to_uint8(ref).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(px[i], u8[i]), i
+    ctx.close()
