@@ -137,7 +137,19 @@ def _ptr(t):
 
 
 def make_unet_cfg(in_channels=3, out_channels=3, model_channels=192, num_res_blocks=2, attention_resolutions=(8, 4, 2),
-                  channel_mult=(1, 2, 3, 5), num_head_channels=32, context_dim=512, **_ignored) -> UNetCfg:
+                  channel_mult=(1, 2, 3, 5), num_head_channels=32, context_dim=512, **other) -> UNetCfg:
+    """UNetModel keyword arguments (openaimodel.py:228-262) -> rdm_unet_cfg.  Arguments that do not change the sampling graph are
+    accepted and dropped; ones that select a graph the library does not build raise instead of being silently ignored."""
+    inert = {"image_size", "use_checkpoint", "use_fp16", "dropout", "legacy", "use_new_attention_order", "num_heads", "num_heads_upsample"}
+    required = {"conv_resample": True, "dims": 2, "num_classes": None, "use_scale_shift_norm": False, "resblock_updown": False,
+                "use_spatial_transformer": True, "transformer_depth": 1, "n_embed": None}
+    for k_, v_ in other.items():
+        if k_ in inert:
+            continue
+        if k_ not in required:
+            raise TypeError(f"make_unet_cfg: unknown UNetModel argument {k_!r}")
+        if v_ != required[k_]:
+            raise NotImplementedError(f"UNetModel({k_}={v_!r}): the native graph is built for {k_}={required[k_]!r} (every shipped RDM config)")
     c = UNetCfg()
     c.in_channels, c.out_channels, c.model_channels, c.num_res_blocks = in_channels, out_channels, model_channels, num_res_blocks
     c.n_attention_resolutions = len(attention_resolutions)
@@ -173,8 +185,18 @@ def make_vqgan_f16_cfg(**kw) -> VqCfg:
 
 
 def make_rarm_cfg(in_channels=16386, out_channels=16384, n_heads=12, d_head=64, depth=18, context_dim=512, sequence_length=256,
-                  **_ignored) -> RarmCfg:
-    """RetrievalPatchTransformer params (models/rarm/imagenet/dogs/config.yaml:14-27)."""
+                  **other) -> RarmCfg:
+    """RetrievalPatchTransformer params (models/rarm/imagenet/dogs/config.yaml:14-27; rdm/modules/attention.py:206-220).  The native
+    graph is the shipped one: token input (continuous=False), learned positions, causal self-attention + cross-attention to the
+    neighbours, no outer residual; anything else raises instead of being silently ignored."""
+    required = {"positional_encodings": True, "cross_attend": True, "causal": True, "continuous": False, "residual": False}
+    for k_, v_ in other.items():
+        if k_ in ("dropout", "checkpoint"):
+            continue
+        if k_ not in required:
+            raise TypeError(f"make_rarm_cfg: unknown RetrievalPatchTransformer argument {k_!r}")
+        if v_ != required[k_]:
+            raise NotImplementedError(f"RetrievalPatchTransformer({k_}={v_!r}): the native graph is built for {k_}={required[k_]!r}")
     return RarmCfg(vocab_in=in_channels, vocab_out=out_channels, n_heads=n_heads, d_head=d_head, depth=depth, context_dim=context_dim,
                    sequence_length=sequence_length)
 

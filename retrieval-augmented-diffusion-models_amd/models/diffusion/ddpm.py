@@ -10,6 +10,9 @@ the reference's `ema_scope` arranges (ddpm.py:836, 977): `load_state_dict` picks
 """
 from contextlib import contextmanager
 
+import os
+import pickle
+
 import numpy as np
 import torch
 
@@ -37,7 +40,8 @@ class MinimalRETRODiffusion(object):
                                            z_channels=dd.get("z_channels", 3), ch=dd.get("ch", 128),
                                            ch_mult=tuple(dd.get("ch_mult", (1, 2, 4))), num_res_blocks=dd.get("num_res_blocks", 2),
                                            out_ch=dd.get("out_ch", 3), resolution=dd.get("resolution", 256),
-                                           mid_attn=fparams.get("mid_attn", True), kl=fparams.get("kl", False))
+                                           mid_attn=fparams.get("mid_attn", True), kl=fparams.get("kl", False),
+                                           attn_resolutions=tuple(dd.get("attn_resolutions", ()) or ()))
         self.k_nn, self.image_size, self.channels = k_nn, image_size, channels
         self.scale_factor, self.clip_denoised, self.log_every_t = scale_factor, clip_denoised, log_every_t
         self.parameterization = parameterization
@@ -46,6 +50,14 @@ class MinimalRETRODiffusion(object):
         self.nn_encoder = None
         self.retrieval_encoder = torch.nn.Identity()           # models/rdm/*/config.yaml:104-105
         self.conditional_retrieval_encoder = False
+        if isinstance(nn_memory, (str, os.PathLike)):          # ddpm.py:168-176: a pickled {'nn_memory', 'id_count'}; a missing file = no memory
+            path, nn_memory = os.fspath(nn_memory), None
+            if os.path.isfile(path):
+                assert path.endswith('.p')
+                print(f'Loading nn_memory from "{path}"')
+                with open(path, 'rb') as f:
+                    nn_data = pickle.load(f)
+                nn_memory, id_count = nn_data['nn_memory'], nn_data.get('id_count', id_count)
         if nn_memory is not None:
             self.nn_memory = torch.as_tensor(np.asarray(nn_memory))
         self.id_count = id_count

@@ -479,3 +479,43 @@ def test_row_sharded_topk_merge_equals_unsharded(world):
         assert np.array_equal(gi, ref_i.astype(np.int64)), rank
         assert np.abs(gs - ref_s).max() <= 1e-15, rank            # the oracle's BLAS may block a shard differently from the whole
     assert list(ref_i[0][:3]) == [17, 333, 900]            # the planted triple, in index order
+
+
+def test_instantiate_from_config_with_the_shipped_config_structure(tmp_path):
+    """INTEGRATION.md path A: `instantiate_from_config(config.model)` on a config with every key of models/rdm/imagenet/config.yaml
+    (targets redirected to rdm_amd.*; constructing needs no GPU): training-only keys are accepted, the nn_memory pickle is loaded like
+    ddpm.py:168-176, and UNet options that would select a graph the library does not build are refused, not ignored."""
+    import pickle
+    from rdm_amd.util import instantiate_from_config
+    from rdm_amd.models.diffusion.ddpm import MinimalRETRODiffusion
+    with open(tmp_path / "mem.p", "wb") as f:
+        pickle.dump({"nn_memory": np.arange(7, 107), "id_count": {i: 2 for i in range(7, 107)}}, f)
+    unet = {"target": "rdm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(
+        image_size=64, in_channels=3, out_channels=3, model_channels=192, attention_resolutions=[8, 4, 2], num_res_blocks=2,
+        channel_mult=[1, 2, 3, 5], use_scale_shift_norm=False, resblock_updown=False, num_head_channels=32, use_spatial_transformer=True,
+        transformer_depth=1, context_dim=512, use_checkpoint=True)}
+    cfg = {"base_learning_rate": 1e-4, "target": "rdm.models.diffusion.ddpm.MinimalRETRODiffusion", "params": {
+        "k_nn": 4, "query_key": "clip_img_emb", "linear_start": 0.0015, "linear_end": 0.0195, "num_timesteps_cond": 1, "log_every_t": 200,
+        "timesteps": 1000, "first_stage_key": "image", "cond_stage_key": "nixda", "image_size": 64, "channels": 3, "cond_stage_trainable": False,
+        "nn_key": "nn_embeddings", "nn_memory": str(tmp_path / "mem.p"), "conditioning_key": "retro_only", "monitor": "val/loss_simple_ema",
+        "scale_by_std": False, "ignore_keys": ["unconditional_guidance_vex"],
+        "scheduler_config": {"target": "ldm.lr_scheduler.LambdaLinearScheduler", "params": {"warm_up_steps": [100]}},
+        "unet_config": unet,
+        "first_stage_config": {"target": "ldm.models.autoencoder.VQModelInterface", "params": {"embed_dim": 3, "n_embed": 8192, "ddconfig": {
+            "double_z": False, "z_channels": 3, "resolution": 256, "in_channels": 3, "out_ch": 3, "ch": 128, "ch_mult": [1, 2, 4],
+            "num_res_blocks": 2, "attn_resolutions": [], "dropout": 0.0}, "lossconfig": {"target": "torch.nn.Identity"}}},
+        "retrieval_cfg": {"target": "rdm.data.retrieval_dataset.dsetbuilder.DatasetBuilder", "params": {"k": 20, "saved_embeddings": "database/openimages"}},
+        "retrieval_encoder_cfg": {"target": "torch.nn.Identity"}, "cond_stage_config": "__is_unconditional__"}}
+    m = instantiate_from_config(cfg)
+    assert isinstance(m, MinimalRETRODiffusion) and m._ctx is None                      # no GPU touched
+    assert (m.k_nn, m.image_size, m.channels, m.num_timesteps) == (4, 64, 3, 1000)
+    assert m.unet_cfg.model_channels == 192 and [m.unet_cfg.channel_mult[i] for i in range(4)] == [1, 2, 3, 5]
+    assert m.vq_cfg.n_embed == 8192 and m.use_memory and m.nn_memory.shape == (100,) and m.id_count[7] == 2
+    cfg["params"]["nn_memory"] = "nn_memory/oi_imagenet.p"                               # file not there: no memory, like the reference
+    assert not instantiate_from_config(cfg).use_memory
+    for bad in ({"use_scale_shift_norm": True}, {"resblock_updown": True}, {"transformer_depth": 2}, {"use_spatial_transformer": False}, {"num_classes": 10}):
+        c2 = {"target": cfg["target"], "params": dict(cfg["params"], unet_config={"params": dict(unet["params"], **bad)})}
+        with pytest.raises(NotImplementedError):
+            instantiate_from_config(c2)
+    with pytest.raises(TypeError):
+        instantiate_from_config({"target": cfg["target"], "params": dict(cfg["params"], unet_config={"params": dict(unet["params"], no_such_option=1)})})
