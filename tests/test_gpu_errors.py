@@ -5,9 +5,11 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import rarm as orarm
 from oracle import unet as ounet
+from oracle import vqdecoder as ovq
 
-from _util import spec_to_unet_cfg
+from _util import spec_to_unet_cfg, spec_to_vq_cfg
 
 pytestmark = pytest.mark.gpu
 
@@ -80,3 +82,46 @@ def test_blob_and_shape_mismatches(fresh):
     _err(lambda: fresh.ddim_sample(4, x, c, None, ac, eta=1.0, noise=torch.zeros(3, B, 3, 16, 16, device=d)))   # noise stack shorter than the loop
     z, _, _ = fresh.ddim_sample(4, x, c, None, ac)                         # and the context is still alive
     assert torch.isfinite(z).all()
+
+
+def test_no_device_memory_growth_across_calls_and_contexts():
+    """hipMemGetInfo at the same point of three context lifetimes and over twelve rounds of every sampling entry (DDIM, VQ decode, online
+    and bulk kNN, RARM sampling): the library's scratch is sized once and reused, and rdm_ctx_destroy gives everything back."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import rdm_amd  # noqa: F401
+    from rdm_amd import _lib, packing
+
+    def free():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    levels = []
+    for rep in range(3):
+        ctx = _lib.Context(0); d = ctx.device
+        spec = ounet.tiny_spec(); cfg = spec_to_unet_cfg(spec)
+        ctx.load_unet(cfg, packing.pack("unet", cfg, ounet.synth_state_dict(ounet.param_shapes(spec), seed=1)))
+        vspec = ovq.tiny_vq_spec(); vcfg = spec_to_vq_cfg(vspec)
+        ctx.load_vq(vcfg, packing.pack("vq", vcfg, ounet.synth_state_dict(ovq.vq_param_shapes(vspec), seed=5)))
+        rs = orarm.RarmSpec(vocab_in=514, vocab_out=512, n_heads=2, d_head=64, depth=2, context_dim=512, sequence_length=64)
+        rcfg = _lib.make_rarm_cfg(in_channels=514, out_channels=512, n_heads=2, d_head=64, depth=2, context_dim=512, sequence_length=64)
+        ctx.load_rarm(rcfg, packing.pack("rarm", rcfg, ounet.synth_state_dict(orarm.rarm_param_shapes(rs), seed=7)))
+        g = torch.Generator(device=d).manual_seed(0)
+        db = torch.randn(50000, 512, device=d, generator=g).half(); ctx.db_load(db); del db
+        x = torch.randn(4, 3, 16, 16, device=d, generator=g); c = torch.randn(4, 4, 512, device=d, generator=g); uc = torch.zeros_like(c)
+        ac = torch.linspace(0.9999, 0.005, 1000)
+        marks = []
+        for it in range(12):
+            z = ctx.ddim_sample(4, x, c, uc, ac, scale=2.0)[0]
+            img = ctx.vq_decode(z)
+            idx, sc = ctx.knn(torch.randn(200 if it % 2 else 7, 512, device=d, generator=g), 20 if it % 2 else 4)
+            toks = ctx.rarm_sample(torch.full((3, 1), 513, device=d, dtype=torch.long), c[:3], 16, torch.rand(16, 3, device=d, generator=g),
+                                   top_k=50, guidance_scale=2.0)
+            del z, img, idx, sc, toks
+            torch.cuda.empty_cache()
+            marks.append(free())
+        assert marks[1] - marks[-1] < (4 << 20), f"device memory grows across calls: {marks}"      # after the second round nothing is allocated
+        levels.append(marks[-1])
+        ctx.close(); del ctx, x, c, uc
+        torch.cuda.empty_cache()
+    assert abs(levels[0] - levels[2]) < (4 << 20), f"a closed context leaves device memory behind: {levels}"
