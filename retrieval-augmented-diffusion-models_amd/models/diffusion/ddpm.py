@@ -256,8 +256,8 @@ class MinimalRETRODiffusion(object):
                           n_reps=None, query_embedded=False, example_maps=None, visualize_nns=True, omit_query=False,
                           normalize=False, **kwargs):
         """ddpm.py:689-844 (nn_encoder is None, retrieval_encoder = Identity — every shipped config)."""
-        if cond is not None or example_maps is not None or return_nns:
-            raise NotImplementedError("cond / example_maps / return_nns are not part of the native sampling path")
+        if cond is not None or return_nns:
+            raise NotImplementedError("cond (a second conditioning) / return_nns (neighbour image grids) are not part of the native sampling path")
         # (the reference asserts `query.ndim` first, which makes its own `isinstance(query, str)` branch unreachable: a caption only
         #  works pre-embedded there, scripts/rdm_sample.py:275-277; here str / list-of-str queries take the CLIP text tower)
         if not query_embedded and not isinstance(query, (str, list)):
@@ -295,12 +295,20 @@ class MinimalRETRODiffusion(object):
         if normalize:
             q_emb = q_emb / q_emb.norm(dim=-1, keepdim=True)
             r_emb = r_emb / r_emb.norm(dim=-1, keepdim=True)
-        if omit_query:
-            retro_cond = r_emb.to(self.device)
+        if example_maps is not None:        # ddpm.py:764-769: the query followed by ONE given embedding in place of the retrieved neighbours
+            em = torch.as_tensor(example_maps).float()
+            if shard_db or self.distributed:
+                em = em[lo:hi]
+            retro_cond = torch.cat([q_emb[:, None], em[:, None].expand(-1, k_nn - 1, -1)], dim=1).to(self.device)
+            if n_reps is not None:
+                retro_cond = torch.stack([q_emb, em], dim=1).repeat_interleave(n_reps // 2, dim=1).to(self.device)      # 'b n c -> b (n r) c'
         else:
-            retro_cond = torch.cat([q_emb[:, None].to(self.device), r_emb[:, :k_nn - 1].to(self.device)], dim=1)
-        if n_reps is not None:
-            retro_cond = torch.cat([retro_cond] * n_reps, dim=1)
+            if omit_query:
+                retro_cond = r_emb.to(self.device)
+            else:
+                retro_cond = torch.cat([q_emb[:, None].to(self.device), r_emb[:, :k_nn - 1].to(self.device)], dim=1)
+            if n_reps is not None:
+                retro_cond = torch.cat([retro_cond] * n_reps, dim=1)
         c = self.retrieval_encoder(retro_cond).float().contiguous()
         bs = c.shape[0]
         c_uncond = self.get_unconditional_conditioning(c.shape, unconditional_guidance_label=unconditional_retro_guidance_label, k_nn=k_nn)

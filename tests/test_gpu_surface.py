@@ -178,6 +178,36 @@ def test_sample_with_query_and_from_rdata(model, retriever):
     model.decode_first_stage = real_decode
 
 
+def test_sample_with_query_example_maps(model, retriever):
+    """ddpm.py:764-769: `example_maps` replaces the retrieved neighbours by one given embedding per sample (query first), with and
+    without n_reps; the conditioning handed to the sampler is checked exactly, the sample is the one that conditioning gives."""
+    model.retriever = retriever
+    rng = np.random.default_rng(31)
+    B, k = 2, 4
+    q = torch.from_numpy((rng.standard_normal((B, 512)) * 0.45).astype(np.float32))
+    em = torch.from_numpy((rng.standard_normal((B, 512)) * 0.45).astype(np.float32))
+    x_T = torch.from_numpy(rng.standard_normal((B, 3, 16, 16)).astype(np.float32))
+    seen = {}
+    real = model.sample_log
+    def spy(cond, batch_size, **kw):
+        seen["c"], seen["uc"] = cond.clone(), kw["unconditional_conditioning"].clone()
+        return real(cond=cond, batch_size=batch_size, **kw)
+    model.sample_log = spy
+    try:
+        out = model.sample_with_query(query=q, query_embedded=True, k_nn=k, example_maps=em, ddim=True, ddim_steps=4, x_T=x_T,
+                                      unconditional_guidance_scale=2.0, unconditional_retro_guidance_label=0.)["query_samples"]
+        want = torch.stack([q, em, em, em], dim=1)
+        assert torch.equal(seen["c"].cpu(), want) and seen["uc"].shape == want.shape and not seen["uc"].any()
+        ref = model.decode_first_stage(model.sample_log(cond=want.to(model.device), batch_size=B, ddim=True, ddim_steps=4, x_T=x_T,
+                                                        unconditional_guidance_scale=2.0, unconditional_conditioning=torch.zeros_like(want).to(model.device))[0])
+        assert torch.equal(out, ref)
+        model.sample_with_query(query=q, query_embedded=True, k_nn=1, n_reps=4, example_maps=em, ddim=True, ddim_steps=4, x_T=x_T,
+                                unconditional_guidance_scale=2.0, unconditional_retro_guidance_label=0.)
+        assert torch.equal(seen["c"].cpu(), torch.stack([q, q, em, em], dim=1))          # 'b n c -> b (n r) c', r = n_reps // 2
+    finally:
+        model.sample_log = real
+
+
 def test_clip_retriever_wrappers(ctx):
     from rdm_amd import _lib
     from rdm_amd.modules.custom_clip.tokenizer import tokenize
