@@ -36,6 +36,11 @@ class Schedule:
         self.posterior_log_variance_clipped = f32(np.log(np.maximum(pv, 1e-20)))
         self.posterior_mean_coef1 = f32(betas * np.sqrt(ac_prev) / (1.0 - ac))
         self.posterior_mean_coef2 = f32((1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac))
+        # [ldm] eps-parameterisation ELBO weights: betas^2 / (2 * posterior_variance * alphas * (1 - alphas_cumprod)), [0] <- [1]
+        pv32, b32, a32 = self.posterior_variance, self.betas, f32(alphas)
+        lv = b32 ** 2 / (2 * pv32 * a32 * (1 - self.alphas_cumprod))
+        lv[0] = lv[1]
+        self.lvlb_weights = lv
 
 
 def make_ddim_timesteps(S, T=1000):
@@ -171,3 +176,27 @@ def ddpm_sample(apply_model, sched: Schedule, x_T, cond, noise, timesteps=None, 
         t = torch.full((x_T.shape[0],), i, dtype=torch.long)
         img = p_sample_ddpm(apply_model, sched, img, cond, t, noise[n], clip_denoised)
     return img
+
+
+def shared_step_loss(apply_model, sched: Schedule, x, nns, t, noise, *, uncond_mask=None, uncond_signal=None, l_simple_weight=1.0,
+                     original_elbo_weight=0.0, prefix="val"):
+    """MinimalRETRODiffusion.shared_step / forward (rdm/models/diffusion/ddpm.py:390-443; shipped configs: nn_encoder None,
+    retrieval_encoder Identity, no second conditioning) + [ldm] LatentDiffusion.p_losses (loss_type l2, eps parameterisation,
+    logvar = 0, learn_logvar False), forward only -- what validation_step logs.  x: latent [B,C,H,W]; nns [B,n,k,D] neighbour
+    embeddings of the batch (ddpm.py:363-365: 'b n k d -> b (n k) d'); uncond_mask [B] bool = the Bernoulli(p_uncond) draw (:393-396)."""
+    r = nns.reshape(nns.shape[0], -1, nns.shape[-1]).float()
+    if uncond_mask is not None:
+        r = torch.where(uncond_mask.reshape(-1, 1, 1), uncond_signal, r)
+    a = sched.sqrt_alphas_cumprod[t].reshape(-1, 1, 1, 1); b = sched.sqrt_one_minus_alphas_cumprod[t].reshape(-1, 1, 1, 1)
+    x_noisy = a * x + b * noise
+    out = apply_model(x_noisy, t, r)
+    loss_simple = ((out - noise) ** 2).mean(dim=(1, 2, 3))
+    d = {f"{prefix}/loss_simple": loss_simple.mean()}
+    logvar_t = torch.zeros_like(loss_simple)
+    loss = (loss_simple / torch.exp(logvar_t) + logvar_t)
+    loss = l_simple_weight * loss.mean()
+    loss_vlb = (sched.lvlb_weights[t] * ((out - noise) ** 2).mean(dim=(1, 2, 3))).mean()
+    d[f"{prefix}/loss_vlb"] = loss_vlb
+    loss = loss + original_elbo_weight * loss_vlb
+    d[f"{prefix}/loss"] = loss
+    return loss, d

@@ -208,6 +208,36 @@ def test_sample_with_query_example_maps(model, retriever):
         model.sample_log = real
 
 
+def test_shared_step_validation_loss(model):
+    """SURVEY 8f-4, forward half: MinimalRETRODiffusion.shared_step (ddpm.py:390-443: neighbour embeddings from the batch, Bernoulli
+    conditioning dropout to the guidance vector) + ldm p_losses (l2, eps) without gradients, against the oracle's restatement on the
+    oracle UNet; explicit t / noise / dropout mask, then the drawn-RNG path."""
+    rng = np.random.default_rng(41)
+    B, k = 4, 4
+    f = lambda *shape, s=1.0: torch.from_numpy((rng.standard_normal(shape) * s).astype(np.float32))
+    z, nns, noise = f(B, 3, 16, 16), f(B, 1, k, 512, s=0.45), f(B, 3, 16, 16)
+    t = torch.tensor([5, 250, 600, 999])
+    mask = torch.tensor([False, True, False, True])
+    model.unconditional_guidance_vex = torch.randn(512, device=model.device)
+    old_p = model.p_uncond
+    try:
+        model.p_uncond = 0.3
+        loss, d = model.shared_step({"image": z, "nn_embeddings": nns}, t=t, noise=noise, uncond_mask=mask, original_elbo_weight=0.1)
+        apply = lambda x, tt, c: ounet.unet_forward(model.sd_unet, model.spec, x, tt, c)
+        sig = model.unconditional_guidance_vex.cpu()[None, None, :].expand(B, k, 512)
+        rl, rd = odiff.shared_step_loss(apply, odiff.Schedule(), z, nns, t, noise, uncond_mask=mask, uncond_signal=sig, original_elbo_weight=0.1)
+        assert set(d) == set(rd) == {"val/loss_simple", "val/loss_vlb", "val/loss"}
+        for key in d:
+            assert abs(float(d[key]) - float(rd[key])) <= 2e-2 * abs(float(rd[key])), (key, float(d[key]), float(rd[key]))
+        assert abs(float(loss) - float(rl)) <= 2e-2 * abs(float(rl))
+        # drawn t / noise / mask: finite, and the schedule weights are the oracle's
+        loss2, d2 = model.shared_step({"image": z, "nn_embeddings": nns})
+        assert bool(torch.isfinite(loss2)) and float(d2["val/loss_vlb"]) >= 0
+        assert torch.allclose(model.lvlb_weights, odiff.Schedule().lvlb_weights, rtol=0, atol=0)
+    finally:
+        model.p_uncond = old_p
+
+
 def test_clip_retriever_wrappers(ctx):
     from rdm_amd import _lib
     from rdm_amd.modules.custom_clip.tokenizer import tokenize
