@@ -326,6 +326,12 @@ def test_knn_bulk_bit_exact(ctx):
     for bsz in (128, 129, 257, 400, 512, 513):
         ib, _ = ctx.knn(q[:bsz], k)
         assert np.array_equal(ib.cpu().numpy().view(np.uint32), ref_i[:bsz]), bsz
+    # rdm_knn_f64 (the scores the ranking was made on, for shard merges) through the bulk and the online scan
+    for bsz in (300, 40):
+        i64b, s64 = ctx.knn(q[:bsz], k, f64=True)
+        assert s64.dtype == torch.float64 and np.array_equal(i64b.cpu().numpy().view(np.uint32), ref_i[:bsz])
+        assert np.array_equal(s64.cpu().numpy().astype(np.float32), sc[:bsz].cpu().numpy())        # the f32 output is the rounded f64 one
+        assert bool((s64[:, :-1] >= s64[:, 1:]).all())
 
 
 def test_search_nns_on_device(ctx, tmp_path):
