@@ -5,6 +5,7 @@
 struct GnParams {
     const bf16_t* x0; const bf16_t* x1;   // [B, HW, C0], [B, HW, C1] (x1 may be null)
     int C0, C1, HW, B, groups;
+    int L0, L1;                           // logical channels of x0 / x1 (<= C0 / C1: the tails are zero padding, build_unet); 0 = C0 / C1
     int nchunk;                           // pixel chunks per sample
     float* partial;                       // [B, nchunk, groups, 2] (sum, sumsq)
     const float* gamma; const float* beta;
@@ -83,14 +84,14 @@ inline hipError_t launch_conv3x3(const IgemmParams& p, hipStream_t st) {
 }
 hipError_t launch_groupnorm(GnParams p, hipStream_t st);
 hipError_t launch_layernorm(const void* x, int in_is_f32, const float* gamma, const float* beta, void* out, int out_is_f32,
-                            int M, int C, float eps, hipStream_t st);
+                            int M, int C, float eps, hipStream_t st, int Clog = -1);   // Clog: logical width of zero-padded rows (statistics over Clog)
 hipError_t launch_flash_d32(const FlashParams& p, int heads, int batch, hipStream_t st);
 hipError_t launch_small_attention(const SmallAttnParams& p, int D, int heads, int batch, hipStream_t st);
 hipError_t launch_conv_in(const float* x, const float* w, const float* bias, bf16_t* out, int B, int Cin, int H, int W,
                           int Cout, hipStream_t st);
 hipError_t launch_conv_out(const bf16_t* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin,
                            int Cout, hipStream_t st);
-hipError_t launch_timestep_embedding(const long long* t, bf16_t* out, int B, int dim, hipStream_t st);
+hipError_t launch_timestep_embedding(const long long* t, bf16_t* out, int B, int dim, int ld, hipStream_t st);   // rows of ld >= dim, tail zeroed
 hipError_t launch_cast_f32_bf16(const float* x, bf16_t* y, long long n, hipStream_t st);
 hipError_t launch_transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st);       // y[c][r] = x[r][c]
 hipError_t launch_expand_heads(const bf16_t* kv, int ld, int B, int k, int heads, int hd, int NP, float scale, bf16_t* out, hipStream_t st);

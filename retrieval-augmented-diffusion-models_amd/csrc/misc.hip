@@ -148,19 +148,26 @@ hipError_t launch_conv_out(const bf16_t* x, const float* w, const float* bias, f
 
 // ------------------------------------------------------------------ timestep embedding
 // ldm timestep_embedding: [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(1e4) * i / half). bf16 out.
-__global__ void timestep_embedding_kernel(const long long* t, bf16_t* out, int B, int dim) {
+__global__ void timestep_embedding_kernel(const long long* t, bf16_t* out, int B, int dim, int ld) {
     const int half = dim / 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * half) return;
-    const int b = i / half, j = i % half;
+    if (i >= B * (ld / 2)) return;
+    const int b = i / (ld / 2), j = i % (ld / 2);
+    if (j >= half) {                        // zero tail of a padded row [dim, ld) (two columns per thread)
+        const int c = dim + (j - half) * 2;
+        if (c < ld) out[(long long)b * ld + c] = 0;
+        if (c + 1 < ld) out[(long long)b * ld + c + 1] = 0;
+        return;
+    }
     const float freq = expf(-9.210340371976184f * (float)j / (float)half);
     const float arg = (float)t[b] * freq;
-    out[(long long)b * dim + j] = f2bf(cosf(arg));
-    out[(long long)b * dim + half + j] = f2bf(sinf(arg));
+    out[(long long)b * ld + j] = f2bf(cosf(arg));
+    out[(long long)b * ld + half + j] = f2bf(sinf(arg));
 }
-hipError_t launch_timestep_embedding(const long long* t, bf16_t* out, int B, int dim, hipStream_t st) {
-    const int n = B * (dim / 2);
-    timestep_embedding_kernel<<<(n + 255) / 256, 256, 0, st>>>(t, out, B, dim);
+hipError_t launch_timestep_embedding(const long long* t, bf16_t* out, int B, int dim, int ld, hipStream_t st) {
+    if (dim % 2 || ld % 2 || ld < dim) return hipErrorInvalidValue;
+    const int n = B * (ld / 2);
+    timestep_embedding_kernel<<<(n + 255) / 256, 256, 0, st>>>(t, out, B, dim, ld);
     return hipGetLastError();
 }
 

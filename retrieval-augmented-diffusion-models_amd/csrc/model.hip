@@ -53,12 +53,10 @@ struct DevGuard {
 struct Manifest {
     std::string text;
     size_t total = 0;
-    size_t add(const char* kind, const std::string& srcs, size_t nbytes) {
+    size_t add(const std::string& kind, const std::string& srcs, size_t nbytes) {      // kind may carry a padding recipe ("|R=..|C=..", build_unet)
         total = (total + 255) & ~(size_t)255;
         const size_t off = total;
-        char line[128];
-        snprintf(line, sizeof line, "%zu %zu %s ", off, nbytes, kind);
-        text += line; text += srcs; text += "\n";
+        text += std::to_string(off) + " " + std::to_string(nbytes) + " " + kind + " "; text += srcs; text += "\n";
         total += nbytes;
         return off;
     }
@@ -78,14 +76,32 @@ struct Arena {
 };
 
 // ------------------------------------------------------------------------------------ UNet description
-struct ResW { int cin, cout; size_t gn1g, gn1b, w1, b1, gn2g, gn2b, w2, b2, wsk, bsk; int emb_off; bool skip; };
+// Channel padding.  Every GEMM / conv K loop advances in 64-channel slices and the skip-concat split points sit on slice boundaries,
+// so an activation with C channels is held with P(C) = C rounded up to 64 of them, the tail zero: models/rdm/ffhq has
+// model_channels 224 (224 / 448 / 672 / 896: multiples of 32 only).  Weights are padded to match by the packer -- the manifest kind
+// carries the recipe, "|R=" row segments and "|C=" channel segments as logical>padded pairs, absent when nothing is padded (the
+// ImageNet models: byte-identical manifests) -- with zero rows / columns / biases / norm affines in the tail, so a padded channel
+// stays exactly zero through every layer.  Only the normalisations must know the LOGICAL counts (group membership and divisor of
+// GroupNorm, mean / variance of LayerNorm); attention simply gains all-zero heads.  cin / cout / c below are PHYSICAL counts.
+static inline int pad64(int c) { return (c + 63) & ~63; }
+struct Seg { int n, p; };
+static std::string seg_spec(const char* tag, std::initializer_list<Seg> segs) {
+    bool any = false; for (const Seg& g : segs) any |= g.n != g.p;
+    if (!any) return "";
+    std::string o = std::string("|") + tag + "=";
+    bool first = true;
+    for (const Seg& g : segs) { char b[48]; snprintf(b, sizeof b, "%s%d>%d", first ? "" : ",", g.n, g.p); o += b; first = false; }
+    return o;
+}
+struct ResW { int cin, cout; size_t gn1g, gn1b, w1, b1, gn2g, gn2b, w2, b2, wsk, bsk; int emb_off; bool skip; int l0, l1, lout, p0, p1; };
 constexpr int XA_NP = 128;        // padded (heads x neighbours) width of the skinny cross-attention operands
 
 struct StW {
     int c, heads; size_t gng, gnb, win, bin, ln1g, ln1b, wqk, wv, wo1, bo1, ln2g, ln2b, wq2, wo2, bo2, ln3g, ln3b, wff1,
         bff1, wff2, bff2, wout, bout, wfo, bfo; int kv_off; long long xa_unit;   // xa_unit: per-sample element offset of this layer's (G, U) pair
+    int lc;                           // logical channels (c is padded)
 };
-struct ConvW { int c; size_t w, b; };
+struct ConvW { int c; size_t w, b; int lc; };
 struct ULayer { int kind; int idx; };            // 0 conv_in, 1 res, 2 st, 3 down, 4 up
 struct UBlock { int where; std::vector<ULayer> layers; };   // where: 0 input, 1 middle, 2 output
 
@@ -108,59 +124,82 @@ static std::string key(const std::string& pre, const char* s) { return pre + s; 
 
 static void build_unet(UNet& u, const rdm_unet_cfg& c, Manifest& mf) {
     u.cfg = c; u.blocks.clear(); u.res.clear(); u.st.clear(); u.down.clear(); u.up.clear();
-    const int mc = c.model_channels, ted = mc * 4;
-    auto f32 = [&](const std::string& n, size_t numel) { return mf.add("f32", n, numel * 4); };
-    auto bf = [&](const std::string& n, size_t numel) { return mf.add("bf16", n, numel * 2); };
-    u.te0w = bf("time_embed.0.weight", (size_t)ted * mc); u.te0b = f32("time_embed.0.bias", ted);
-    u.te2w = bf("time_embed.2.weight", (size_t)ted * ted); u.te2b = f32("time_embed.2.bias", ted);
-    std::string emb_w_srcs, emb_b_srcs, kv_srcs;
+    const int mc = c.model_channels, ted = mc * 4, mcp = pad64(mc);       // ted = 4 mc: a multiple of 64 whenever mc % 32 == 0... (128-aligned)
+    // vec: fp32 vector(s) over channel segments; mat: bf16 [rows][cols]; both padded per segment
+    auto vec = [&](const std::string& n, std::initializer_list<Seg> segs) {
+        size_t tot = 0; for (const Seg& g : segs) tot += g.p;
+        return mf.add("f32" + seg_spec("R", segs), n, tot * 4);
+    };
+    auto mat = [&](const char* kind, const std::string& n, std::initializer_list<Seg> rows, std::initializer_list<Seg> cols, size_t elt = 2, int taps = 1) {
+        size_t r = 0, k = 0; for (const Seg& g : rows) r += g.p; for (const Seg& g : cols) k += g.p;
+        return mf.add((std::string(kind) + seg_spec("R", rows) + seg_spec("C", cols)), n, r * k * taps * elt);
+    };
+    const Seg TED{ted, ted};
+    u.te0w = mat("bf16", "time_embed.0.weight", {TED}, {{mc, mcp}}); u.te0b = vec("time_embed.0.bias", {TED});
+    u.te2w = mat("bf16", "time_embed.2.weight", {TED}, {TED}); u.te2b = vec("time_embed.2.bias", {TED});
+    std::string emb_w_srcs, emb_b_srcs, kv_srcs, emb_rspec, kv_rspec;
+    bool emb_padded = false, kv_padded = false;
     u.emb_total = 0; u.kv_total = 0; u.xa_total = 0;
     auto in_attn = [&](int ds) { for (int i = 0; i < c.n_attention_resolutions; i++) if (c.attention_resolutions[i] == ds) return true; return false; };
-    auto add_res = [&](const std::string& pre, int cin, int cout) {
-        ResW r{}; r.cin = cin; r.cout = cout; r.skip = cin != cout;
-        r.gn1g = f32(pre + ".in_layers.0.weight", cin); r.gn1b = f32(pre + ".in_layers.0.bias", cin);
-        r.w1 = mf.add("conv3", pre + ".in_layers.2.weight", (size_t)cout * cin * 9 * 2); r.b1 = f32(pre + ".in_layers.2.bias", cout);
-        r.gn2g = f32(pre + ".out_layers.0.weight", cout); r.gn2b = f32(pre + ".out_layers.0.bias", cout);
-        r.w2 = mf.add("conv3", pre + ".out_layers.3.weight", (size_t)cout * cout * 9 * 2); r.b2 = f32(pre + ".out_layers.3.bias", cout);
-        if (r.skip) { r.wsk = bf(pre + ".skip_connection.weight", (size_t)cout * cin); r.bsk = f32(pre + ".skip_connection.bias", cout); }
-        r.emb_off = u.emb_total; u.emb_total += cout;
+    auto add_seg = [](std::string& spec, bool& padded, int n, int p) { char b[48]; snprintf(b, sizeof b, "%s%d>%d", spec.empty() ? "" : ",", n, p); spec += b; padded |= n != p; };
+    auto add_res = [&](const std::string& pre, int l0, int l1, int lout) {       // input = [l0 | l1] logical channels (l1: the skip tensor, or 0)
+        ResW r{}; r.l0 = l0; r.l1 = l1; r.lout = lout; r.p0 = pad64(l0); r.p1 = l1 ? pad64(l1) : 0;
+        r.cin = r.p0 + r.p1; r.cout = pad64(lout); r.skip = (l0 + l1) != lout;
+        const Seg S0{l0, r.p0}, S1{l1, r.p1}, SO{lout, r.cout};
+        if (l1) { r.gn1g = vec(pre + ".in_layers.0.weight", {S0, S1}); r.gn1b = vec(pre + ".in_layers.0.bias", {S0, S1}); }
+        else { r.gn1g = vec(pre + ".in_layers.0.weight", {S0}); r.gn1b = vec(pre + ".in_layers.0.bias", {S0}); }
+        r.w1 = l1 ? mat("conv3", pre + ".in_layers.2.weight", {SO}, {S0, S1}, 2, 9) : mat("conv3", pre + ".in_layers.2.weight", {SO}, {S0}, 2, 9);
+        r.b1 = vec(pre + ".in_layers.2.bias", {SO});
+        r.gn2g = vec(pre + ".out_layers.0.weight", {SO}); r.gn2b = vec(pre + ".out_layers.0.bias", {SO});
+        r.w2 = mat("conv3", pre + ".out_layers.3.weight", {SO}, {SO}, 2, 9); r.b2 = vec(pre + ".out_layers.3.bias", {SO});
+        if (r.skip) {
+            r.wsk = l1 ? mat("bf16", pre + ".skip_connection.weight", {SO}, {S0, S1}) : mat("bf16", pre + ".skip_connection.weight", {SO}, {S0});
+            r.bsk = vec(pre + ".skip_connection.bias", {SO});
+        }
+        r.emb_off = u.emb_total; u.emb_total += r.cout;
         if (!emb_w_srcs.empty()) { emb_w_srcs += ","; emb_b_srcs += ","; }
         emb_w_srcs += pre + ".emb_layers.1.weight"; emb_b_srcs += pre + ".emb_layers.1.bias";
+        add_seg(emb_rspec, emb_padded, lout, r.cout);
         u.res.push_back(r); return (int)u.res.size() - 1;
     };
-    auto add_st = [&](const std::string& pre, int ch) {
-        StW s{}; s.c = ch; s.heads = ch / c.num_head_channels;
+    auto add_st = [&](const std::string& pre, int lch) {
+        StW s{}; s.lc = lch; s.c = pad64(lch); s.heads = s.c / c.num_head_channels;
+        const int ch = s.c;
+        const Seg S{lch, ch}, F{4 * lch, 4 * lch};
         const std::string tb = pre + ".transformer_blocks.0";
-        s.gng = f32(pre + ".norm.weight", ch); s.gnb = f32(pre + ".norm.bias", ch);
-        s.win = bf(pre + ".proj_in.weight", (size_t)ch * ch); s.bin = f32(pre + ".proj_in.bias", ch);
-        s.ln1g = f32(tb + ".norm1.weight", ch); s.ln1b = f32(tb + ".norm1.bias", ch);
-        s.wqk = bf(tb + ".attn1.to_q.weight," + tb + ".attn1.to_k.weight", (size_t)2 * ch * ch);
-        s.wv = bf(tb + ".attn1.to_v.weight", (size_t)ch * ch);
-        s.wo1 = bf(tb + ".attn1.to_out.0.weight", (size_t)ch * ch); s.bo1 = f32(tb + ".attn1.to_out.0.bias", ch);
-        s.ln2g = f32(tb + ".norm2.weight", ch); s.ln2b = f32(tb + ".norm2.bias", ch);
-        s.wq2 = bf(tb + ".attn2.to_q.weight", (size_t)ch * ch);
-        s.wo2 = bf(tb + ".attn2.to_out.0.weight", (size_t)ch * ch); s.bo2 = f32(tb + ".attn2.to_out.0.bias", ch);
-        s.ln3g = f32(tb + ".norm3.weight", ch); s.ln3b = f32(tb + ".norm3.bias", ch);
-        s.wff1 = mf.add("geglu_w", tb + ".ff.net.0.proj.weight", (size_t)8 * ch * ch * 2);
-        s.bff1 = mf.add("geglu_b", tb + ".ff.net.0.proj.bias", (size_t)8 * ch * 4);
-        s.wff2 = bf(tb + ".ff.net.2.weight", (size_t)ch * 4 * ch); s.bff2 = f32(tb + ".ff.net.2.bias", ch);
-        s.wout = bf(pre + ".proj_out.weight", (size_t)ch * ch); s.bout = f32(pre + ".proj_out.bias", ch);
+        s.gng = vec(pre + ".norm.weight", {S}); s.gnb = vec(pre + ".norm.bias", {S});
+        s.win = mat("bf16", pre + ".proj_in.weight", {S}, {S}); s.bin = vec(pre + ".proj_in.bias", {S});
+        s.ln1g = vec(tb + ".norm1.weight", {S}); s.ln1b = vec(tb + ".norm1.bias", {S});
+        s.wqk = mat("bf16", tb + ".attn1.to_q.weight," + tb + ".attn1.to_k.weight", {S, S}, {S});
+        s.wv = mat("bf16", tb + ".attn1.to_v.weight", {S}, {S});
+        s.wo1 = mat("bf16", tb + ".attn1.to_out.0.weight", {S}, {S}); s.bo1 = vec(tb + ".attn1.to_out.0.bias", {S});
+        s.ln2g = vec(tb + ".norm2.weight", {S}); s.ln2b = vec(tb + ".norm2.bias", {S});
+        s.wq2 = mat("bf16", tb + ".attn2.to_q.weight", {S}, {S});
+        s.wo2 = mat("bf16", tb + ".attn2.to_out.0.weight", {S}, {S}); s.bo2 = vec(tb + ".attn2.to_out.0.bias", {S});
+        s.ln3g = vec(tb + ".norm3.weight", {S}); s.ln3b = vec(tb + ".norm3.bias", {S});
+        // GEGLU hidden width 4 * lch (a multiple of 128): not padded, only its K side
+        s.wff1 = mat("geglu_w", tb + ".ff.net.0.proj.weight", {{8 * lch, 8 * lch}}, {S});
+        s.bff1 = mf.add("geglu_b", tb + ".ff.net.0.proj.bias", (size_t)8 * lch * 4);
+        s.wff2 = mat("bf16", tb + ".ff.net.2.weight", {S}, {F}); s.bff2 = vec(tb + ".ff.net.2.bias", {S});
+        s.wout = mat("bf16", pre + ".proj_out.weight", {S}, {S}); s.bout = vec(pre + ".proj_out.bias", {S});
         // ff.net.2 followed by proj_out is one linear map of [ff | t2]:  [W_out W_2 | W_out], bias W_out b_2 + b_out (packed in fp32)
-        s.wfo = mf.add("fuse_w", tb + ".ff.net.2.weight," + pre + ".proj_out.weight", (size_t)ch * 5 * ch * 2);
-        s.bfo = mf.add("fuse_b", tb + ".ff.net.2.bias," + pre + ".proj_out.weight," + pre + ".proj_out.bias", (size_t)ch * 4);
+        s.wfo = mat("fuse_w", tb + ".ff.net.2.weight," + pre + ".proj_out.weight", {S}, {F, S});
+        s.bfo = mf.add("fuse_b" + seg_spec("R", {S}), tb + ".ff.net.2.bias," + pre + ".proj_out.weight," + pre + ".proj_out.bias", (size_t)ch * 4);
         s.kv_off = u.kv_total; u.kv_total += 2 * ch;
         s.xa_unit = u.xa_total; u.xa_total += 2LL * XA_NP * ch;
         if (!kv_srcs.empty()) kv_srcs += ",";
         kv_srcs += tb + ".attn2.to_k.weight," + tb + ".attn2.to_v.weight";
+        add_seg(kv_rspec, kv_padded, lch, ch); add_seg(kv_rspec, kv_padded, lch, ch);
         u.st.push_back(s); return (int)u.st.size() - 1;
     };
     auto name_of = [](const char* grp, int i, int j) { char b[64]; snprintf(b, sizeof b, "%s.%d.%d", grp, i, j); return std::string(b); };
 
-    // input blocks (openaimodel.py:144-215)
+    // input blocks (openaimodel.py:144-215); all channel bookkeeping below is LOGICAL
     std::vector<int> chans;
     {
         UBlock b; b.where = 0; b.layers.push_back({0, 0});
-        u.cinw = f32("input_blocks.0.0.weight", (size_t)mc * c.in_channels * 9); u.cinb = f32("input_blocks.0.0.bias", mc);
+        u.cinw = mf.add("f32" + seg_spec("R", {{mc, mcp}}), "input_blocks.0.0.weight", (size_t)mcp * c.in_channels * 9 * 4);     // [mc][in][3][3]: rows padded
+        u.cinb = vec("input_blocks.0.0.bias", {{mc, mcp}});
         u.blocks.push_back(b); chans.push_back(mc);
     }
     int ch = mc, ds = 1, idx = 1;
@@ -168,24 +207,24 @@ static void build_unet(UNet& u, const rdm_unet_cfg& c, Manifest& mf) {
         const int mult = c.channel_mult[level];
         for (int r = 0; r < c.num_res_blocks; r++) {
             UBlock b; b.where = 0;
-            b.layers.push_back({1, add_res(name_of("input_blocks", idx, 0), ch, mult * mc)});
+            b.layers.push_back({1, add_res(name_of("input_blocks", idx, 0), ch, 0, mult * mc)});
             ch = mult * mc;
             if (in_attn(ds)) b.layers.push_back({2, add_st(name_of("input_blocks", idx, 1), ch)});
             u.blocks.push_back(b); idx++; chans.push_back(ch);
         }
         if (level != c.n_channel_mult - 1) {
             UBlock b; b.where = 0;
-            ConvW d{}; d.c = ch; const std::string pre = name_of("input_blocks", idx, 0);
-            d.w = mf.add("conv3", pre + ".op.weight", (size_t)ch * ch * 9 * 2); d.b = f32(pre + ".op.bias", ch);
+            ConvW d{}; d.lc = ch; d.c = pad64(ch); const std::string pre = name_of("input_blocks", idx, 0);
+            d.w = mat("conv3", pre + ".op.weight", {{ch, d.c}}, {{ch, d.c}}, 2, 9); d.b = vec(pre + ".op.bias", {{ch, d.c}});
             u.down.push_back(d); b.layers.push_back({3, (int)u.down.size() - 1});
             u.blocks.push_back(b); idx++; chans.push_back(ch); ds *= 2;
         }
     }
     {   // middle (openaimodel.py:223-249)
         UBlock b; b.where = 1;
-        b.layers.push_back({1, add_res("middle_block.0", ch, ch)});
+        b.layers.push_back({1, add_res("middle_block.0", ch, 0, ch)});
         b.layers.push_back({2, add_st("middle_block.1", ch)});
-        b.layers.push_back({1, add_res("middle_block.2", ch, ch)});
+        b.layers.push_back({1, add_res("middle_block.2", ch, 0, ch)});
         u.blocks.push_back(b);
     }
     int oidx = 0;   // output blocks (openaimodel.py:252-305)
@@ -194,22 +233,24 @@ static void build_unet(UNet& u, const rdm_unet_cfg& c, Manifest& mf) {
         for (int i = 0; i <= c.num_res_blocks; i++) {
             const int ich = chans.back(); chans.pop_back();
             UBlock b; b.where = 2; int j = 0;
-            b.layers.push_back({1, add_res(name_of("output_blocks", oidx, j++), ch + ich, mc * mult)});
+            b.layers.push_back({1, add_res(name_of("output_blocks", oidx, j++), ch, ich, mc * mult)});
             ch = mc * mult;
             if (in_attn(ds)) b.layers.push_back({2, add_st(name_of("output_blocks", oidx, j++), ch)});
             if (level && i == c.num_res_blocks) {
-                ConvW up{}; up.c = ch; const std::string pre = name_of("output_blocks", oidx, j++);
-                up.w = mf.add("conv3", pre + ".conv.weight", (size_t)ch * ch * 9 * 2); up.b = f32(pre + ".conv.bias", ch);
+                ConvW up{}; up.lc = ch; up.c = pad64(ch); const std::string pre = name_of("output_blocks", oidx, j++);
+                up.w = mat("conv3", pre + ".conv.weight", {{ch, up.c}}, {{ch, up.c}}, 2, 9); up.b = vec(pre + ".conv.bias", {{ch, up.c}});
                 u.up.push_back(up); b.layers.push_back({4, (int)u.up.size() - 1}); ds /= 2;
             }
             u.blocks.push_back(b); oidx++;
         }
     }
-    u.outg = f32("out.0.weight", mc); u.outb = f32("out.0.bias", mc);
-    u.outw = f32("out.2.weight", (size_t)c.out_channels * mc * 9); u.outbias = f32("out.2.bias", c.out_channels);
-    u.embw = mf.add("bf16", emb_w_srcs, (size_t)u.emb_total * ted * 2);
-    u.embb = mf.add("f32", emb_b_srcs, (size_t)u.emb_total * 4);
-    u.kvw = mf.add("bf16", kv_srcs, (size_t)u.kv_total * c.context_dim * 2);
+    u.outg = vec("out.0.weight", {{mc, mcp}}); u.outb = vec("out.0.bias", {{mc, mcp}});
+    // out conv weights stay [Cout][Cin][3][3] fp32 (misc.hip conv_out_kernel): the Cin axis is padded
+    u.outw = mf.add(mc == mcp ? std::string("f32") : "f32_cin" + seg_spec("C", {{mc, mcp}}), "out.2.weight", (size_t)c.out_channels * mcp * 9 * 4);
+    u.outbias = mf.add("f32", "out.2.bias", (size_t)c.out_channels * 4);
+    u.embw = mf.add(std::string("bf16") + (emb_padded ? "|R=" + emb_rspec : ""), emb_w_srcs, (size_t)u.emb_total * ted * 2);
+    u.embb = mf.add(std::string("f32") + (emb_padded ? "|R=" + emb_rspec : ""), emb_b_srcs, (size_t)u.emb_total * 4);
+    u.kvw = mf.add(std::string("bf16") + (kv_padded ? "|R=" + kv_rspec : ""), kv_srcs, (size_t)u.kv_total * c.context_dim * 2);
 }
 
 // ------------------------------------------------------------------------------------ VQ decoder description
@@ -453,9 +494,10 @@ struct Ops {
     }
     void prof_end() { if (prof_open) hipEventRecord(c->prof_recs.back().b, c->stream); prof_open = false; }
     void groupnorm(const bf16_t* x0, const bf16_t* x1, int C0, int C1, int B, int HW, size_t g, size_t b, float eps, int silu,
-                   bf16_t* out) {
+                   bf16_t* out, int L0 = -1, int L1 = -1) {      // L0 / L1: logical channels of the (zero-padded) sources, default = all
         if (plan) return;
         GnParams p{}; p.x0 = x0; p.x1 = x1; p.C0 = C0; p.C1 = C1; p.HW = HW; p.B = B; p.groups = 32;
+        p.L0 = L0 < 0 ? C0 : L0; p.L1 = L1 < 0 ? C1 : L1;
         int nchunk = HW / 64; if (nchunk < 1) nchunk = 1; if (nchunk > 32) nchunk = 32;
         p.nchunk = nchunk; p.partial = c->gn_partial; p.gamma = w<float>(g); p.beta = w<float>(b); p.eps = eps; p.silu = silu;
         p.out = out;
@@ -463,10 +505,10 @@ struct Ops {
         check(launch_groupnorm(p, c->stream), "groupnorm");
         prof_end();
     }
-    void layernorm(const void* x, int in_f32, size_t g, size_t b, void* out, int out_f32, int M, int C) {
+    void layernorm(const void* x, int in_f32, size_t g, size_t b, void* out, int out_f32, int M, int C, int Clog = -1) {
         if (plan) return;
         prof_begin(RDM_PROF_LAYERNORM, (double)M * C * ((in_f32 ? 4.0 : 2.0) + (out_f32 ? 4.0 : 2.0)));
-        check(launch_layernorm(x, in_f32, w<float>(g), w<float>(b), out, out_f32, M, C, 1e-5f, c->stream), "layernorm");
+        check(launch_layernorm(x, in_f32, w<float>(g), w<float>(b), out, out_f32, M, C, 1e-5f, c->stream, Clog < 0 ? C : Clog), "layernorm");
         prof_end();
     }
 };
@@ -529,10 +571,10 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                       float* eps_out, int Bx /* samples [Bx, Bfull) have all-zero context */, int Bshared /* Bfull, or Bfull/2: see below */) {
     int B = Bfull;               // the batch the CURRENT layer runs on (Bshared inside the guidance prefix)
     const rdm_unet_cfg& c = u.cfg;
-    const int mc = c.model_channels, ted = mc * 4;
+    const int mcl = c.model_channels, mc = pad64(mcl), ted = mcl * 4;        // mc: padded width of the base level (see build_unet)
     // time embedding (openaimodel.py:352-353); emb is only ever consumed through SiLU (ResBlock.emb_layers[0])
     bf16_t* temb = o.abf((size_t)B * mc);
-    if (!o.plan) o.check(launch_timestep_embedding(t, temb, B, mc, o.c->stream), "timestep_embedding");
+    if (!o.plan) o.check(launch_timestep_embedding(t, temb, B, mcl, mc, o.c->stream), "timestep_embedding");
     bf16_t* e1 = o.abf((size_t)B * ted);
     o.linear(temb, nullptr, mc, 0, u.te0w, u.te0b, true, B, ted, ACT_SILU, nullptr, e1);
     bf16_t* semb = o.abf((size_t)B * ted);
@@ -540,9 +582,9 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
     float* emb_all = o.af32((size_t)B * u.emb_total);     // all 22 emb_layers in one GEMM
     o.linear(semb, nullptr, ted, 0, u.embw, u.embb, true, B, u.emb_total, ACT_NONE, nullptr, nullptr, emb_all);
 
-    struct Act { bf16_t* p; int C, H, W; };
+    struct Act { bf16_t* p; int C, H, W, L; };          // C: padded channels (row stride), L: logical channels
     std::vector<Act> hs;
-    Act h{nullptr, 0, H, W};
+    Act h{nullptr, 0, H, W, 0};
     // Shared guidance prefix: with classifier-free guidance the batch is [x | x] with the SAME x and t in both halves and different
     // contexts (ddim.py:229-234), so every layer before the first SpatialTransformer (conv_in, the 64x64 ResBlocks, the first
     // Downsample, the first 32x32 ResBlock: 12 % of the conv FLOPs, 17 % of the GroupNorm bytes) computes identical values for the two
@@ -560,11 +602,11 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         const int C0 = a.C, C1 = skip ? skip->C : 0, HW = a.H * a.W, M = B * HW;
         const bf16_t* x1 = skip ? skip->p : nullptr;
         bf16_t* n1 = o.abf((size_t)M * r.cin);
-        o.groupnorm(a.p, x1, C0, C1, B, HW, r.gn1g, r.gn1b, 1e-5f, 1, n1);
+        o.groupnorm(a.p, x1, C0, C1, B, HW, r.gn1g, r.gn1b, 1e-5f, 1, n1, a.L, skip ? skip->L : 0);
         bf16_t* h1 = o.abf((size_t)M * r.cout);
         o.conv3(n1, nullptr, r.cin, 0, r.w1, r.b1, B, a.H, a.W, r.cout, 1, 0, emb_all + r.emb_off, u.emb_total, nullptr, h1);
         bf16_t* n2 = o.abf((size_t)M * r.cout);
-        o.groupnorm(h1, nullptr, r.cout, 0, B, HW, r.gn2g, r.gn2b, 1e-5f, 1, n2);
+        o.groupnorm(h1, nullptr, r.cout, 0, B, HW, r.gn2g, r.gn2b, 1e-5f, 1, n2, r.lout, 0);
         const bf16_t* res = a.p;
         if (r.skip) {
             bf16_t* s = o.abf((size_t)M * r.cout);
@@ -573,17 +615,17 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         }
         bf16_t* out = o.abf((size_t)Bfull * HW * r.cout);           // Bfull: see expand()
         o.conv3(n2, nullptr, r.cout, 0, r.w2, r.b2, B, a.H, a.W, r.cout, 1, 0, nullptr, 0, res, out);
-        return Act{out, r.cout, a.H, a.W};
+        return Act{out, r.cout, a.H, a.W, r.lout};
     };
     auto transformer = [&](const StW& s, const Act& a) -> Act {
         const int C = s.c, n = a.H * a.W, M = B * n;
         bf16_t* xn = o.abf((size_t)M * C);
-        o.groupnorm(a.p, nullptr, C, 0, B, n, s.gng, s.gnb, 1e-6f, 0, xn);
+        o.groupnorm(a.p, nullptr, C, 0, B, n, s.gng, s.gnb, 1e-6f, 0, xn, s.lc, 0);
         bf16_t* t0 = o.abf((size_t)M * C);
         o.linear(xn, nullptr, C, 0, s.win, s.bin, true, M, C, ACT_NONE, nullptr, t0);
         // --- attn1 (self)
         bf16_t* l1 = o.abf((size_t)M * C);
-        o.layernorm(t0, 0, s.ln1g, s.ln1b, l1, 0, M, C);
+        o.layernorm(t0, 0, s.ln1g, s.ln1b, l1, 0, M, C, s.lc);
         bf16_t* qk = o.abf((size_t)M * 2 * C);
         o.linear(l1, nullptr, C, 0, s.wqk, 0, false, M, 2 * C, ACT_NONE, nullptr, qk);
         bf16_t* ao = o.abf((size_t)M * C);
@@ -614,7 +656,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         // --- attn2 (cross over the k neighbours); samples >= Bx have all-zero neighbours: t2 = t1 + b_o exactly (see add_bias_rows_kernel)
         const int Mx = Bx * n;
         bf16_t* l2 = o.abf((size_t)M * C);
-        if (Mx > 0) o.layernorm(t1, 0, s.ln2g, s.ln2b, l2, 0, Mx, C);
+        if (Mx > 0) o.layernorm(t1, 0, s.ln2g, s.ln2b, l2, 0, Mx, C, s.lc);
         bf16_t* t2 = o.abf((size_t)M * C);
         if (Bx < B && !o.plan)
             o.check(launch_add_bias_rows(t1 + (size_t)Mx * C, o.w<float>(s.bo2), t2 + (size_t)Mx * C, (long long)(M - Mx), C, o.c->stream), "zero-context cross attention");
@@ -649,21 +691,22 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         }
         // --- GEGLU feed-forward
         bf16_t* l3 = o.abf((size_t)M * C);
-        o.layernorm(t2, 0, s.ln3g, s.ln3b, l3, 0, M, C);
-        bf16_t* ff = o.abf((size_t)M * 4 * C);
-        o.linear(l3, nullptr, C, 0, s.wff1, s.bff1, true, M, 8 * C, ACT_GEGLU, nullptr, ff);
+        o.layernorm(t2, 0, s.ln3g, s.ln3b, l3, 0, M, C, s.lc);
+        const int FI = 4 * s.lc;                     // GEGLU hidden width: 4 x the LOGICAL channels (a multiple of 128, never padded)
+        bf16_t* ff = o.abf((size_t)M * FI);
+        o.linear(l3, nullptr, C, 0, s.wff1, s.bff1, true, M, 2 * FI, ACT_GEGLU, nullptr, ff);
         bf16_t* out = o.abf((size_t)M * C);
         static const int no_ffout = getenv("RDM_NO_FFOUT") ? atoi(getenv("RDM_NO_FFOUT")) : 0;
         if (!no_ffout) {
             // t3 = ff W_2^T + b_2 + t2 and out = t3 W_out^T + b_out + x are one GEMM over the K-concatenated operand [ff | t2]
             // (dual-source A) with the product weights built by the packer: t3 never exists (2 of 9 tensor passes, one launch)
-            o.linear(ff, t2, 4 * C, C, s.wfo, s.bfo, true, M, C, ACT_NONE, a.p, out);
+            o.linear(ff, t2, FI, C, s.wfo, s.bfo, true, M, C, ACT_NONE, a.p, out);
         } else {
             bf16_t* t3 = o.abf((size_t)M * C);
-            o.linear(ff, nullptr, 4 * C, 0, s.wff2, s.bff2, true, M, C, ACT_NONE, t2, t3);
+            o.linear(ff, nullptr, FI, 0, s.wff2, s.bff2, true, M, C, ACT_NONE, t2, t3);
             o.linear(t3, nullptr, C, 0, s.wout, s.bout, true, M, C, ACT_NONE, a.p, out);
         }
-        return Act{out, C, a.H, a.W};
+        return Act{out, C, a.H, a.W, s.lc};
     };
 
     for (const UBlock& blk : u.blocks) {
@@ -675,7 +718,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                 case 0: {
                     bf16_t* out = o.abf((size_t)Bfull * H * W * mc);
                     if (!o.plan) o.check(launch_conv_in(x, o.w<float>(u.cinw), o.w<float>(u.cinb), out, B, c.in_channels, H, W, mc, o.c->stream), "conv_in");
-                    h = Act{out, mc, H, W};
+                    h = Act{out, mc, H, W, mcl};
                 } break;
                 case 1: h = resblock(u.res[L.idx], h, (first && skip) ? skip : nullptr); break;
                 case 2:
@@ -685,13 +728,13 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                     const ConvW& d = u.down[L.idx];
                     bf16_t* out = o.abf((size_t)Bfull * (h.H / 2) * (h.W / 2) * d.c);
                     o.conv3(h.p, nullptr, d.c, 0, d.w, d.b, B, h.H, h.W, d.c, 2, 0, nullptr, 0, nullptr, out);
-                    h = Act{out, d.c, h.H / 2, h.W / 2};
+                    h = Act{out, d.c, h.H / 2, h.W / 2, d.lc};
                 } break;
                 case 4: {
                     const ConvW& d = u.up[L.idx];
                     bf16_t* out = o.abf((size_t)Bfull * (h.H * 2) * (h.W * 2) * d.c);
                     o.conv3(h.p, nullptr, d.c, 0, d.w, d.b, B, h.H, h.W, d.c, 1, 1, nullptr, 0, nullptr, out);
-                    h = Act{out, d.c, h.H * 2, h.W * 2};
+                    h = Act{out, d.c, h.H * 2, h.W * 2, d.lc};
                 } break;
             }
             first = false;
@@ -700,7 +743,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
     }
     if (B < Bfull) { expand(h); B = Bfull; }          // (a UNet without attention: the whole network was shared)
     bf16_t* no = o.abf((size_t)B * H * W * mc);
-    o.groupnorm(h.p, nullptr, mc, 0, B, H * W, u.outg, u.outb, 1e-5f, 1, no);
+    o.groupnorm(h.p, nullptr, mc, 0, B, H * W, u.outg, u.outb, 1e-5f, 1, no, mcl, 0);
     if (!o.plan) o.check(launch_conv_out(no, o.w<float>(u.outw), o.w<float>(u.outbias), eps_out, B, H, W, mc, c.out_channels, o.c->stream), "conv_out");
 }
 
@@ -722,8 +765,8 @@ static int run_with_arena(rdm_ctx* c, Arena& ar, const char* blob, F&& body) {
 static int cfg_check_unet(rdm_ctx* c, const rdm_unet_cfg* g) {
     if (!g || g->n_channel_mult < 1 || g->n_channel_mult > RDM_MAX_LEVELS || g->n_attention_resolutions > RDM_MAX_LEVELS)
         return c ? c->fail(-1, "bad unet cfg") : -1;
-    if (g->model_channels % 64 || g->num_head_channels != 32 || g->context_dim % 64 || g->in_channels > 4 || g->out_channels > 4)
-        return c ? c->fail(-1, "unsupported unet cfg: model_channels %% 64 == 0, num_head_channels == 32, context_dim %% 64 == 0 required") : -1;
+    if (g->model_channels % 32 || g->num_head_channels != 32 || g->context_dim % 64 || g->in_channels > 4 || g->out_channels > 4)
+        return c ? c->fail(-1, "unsupported unet cfg: model_channels %% 32 == 0 (GroupNorm32; widths that are not multiples of 64 run zero-padded), num_head_channels == 32, context_dim %% 64 == 0 required") : -1;
     return 0;
 }
 

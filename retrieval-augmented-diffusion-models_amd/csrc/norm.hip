@@ -14,6 +14,14 @@
 #include "kernels.h"
 
 
+// Zero-padded sources (model.hip build_unet): x0 holds L0 <= C0 real channels, x1 L1 <= C1; groups partition the L0 + L1 logical
+// channels.  gn_logical: physical concat index -> logical index (or -1 for a padding channel); gn_physical: the inverse.
+__device__ __forceinline__ int gn_logical(const GnParams& p, int c) {
+    if (c < p.C0) return c < p.L0 ? c : -1;
+    return (c - p.C0) < p.L1 ? p.L0 + (c - p.C0) : -1;
+}
+__device__ __forceinline__ int gn_physical(const GnParams& p, int l) { return l < p.L0 ? l : p.C0 + (l - p.L0); }
+
 __device__ __forceinline__ const bf16_t* gn_src(const GnParams& p, int b, int row, int c) {
     return (c < p.C0) ? p.x0 + ((long long)(b * p.HW + row) * p.C0 + c)
                       : p.x1 + ((long long)(b * p.HW + row) * p.C1 + (c - p.C0));
@@ -63,10 +71,10 @@ __global__ void gn_stats_kernel(GnParams p) {
         ch[c * 2] = a; ch[c * 2 + 1] = bq;
     }
     __syncthreads();
-    const int cg = C / p.groups;
+    const int cg = (p.L0 + p.L1) / p.groups;
     if (threadIdx.x < p.groups) {
         float a = 0.f, bq = 0.f;
-        for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; c++) { a += ch[c * 2]; bq += ch[c * 2 + 1]; }
+        for (int l = threadIdx.x * cg; l < (threadIdx.x + 1) * cg; l++) { const int c = gn_physical(p, l); a += ch[c * 2]; bq += ch[c * 2 + 1]; }
         float* o = p.partial + (((long long)b * p.nchunk + chunk) * p.groups + threadIdx.x) * 2;
         o[0] = a; o[1] = bq;
     }
@@ -76,7 +84,7 @@ __global__ void gn_stats_kernel(GnParams p) {
 // for the whole launch, so (mean, rstd, gamma, beta) fold into 16 registers and the body is a pure 16-byte stream:
 // no LDS table (a per-channel table read with a 64-byte lane stride is a 16-way bank conflict).
 __global__ void gn_apply_kernel(GnParams p) {
-    const int C = p.C0 + p.C1, VC = C >> 3, cg = C / p.groups;
+    const int C = p.C0 + p.C1, VC = C >> 3, cg = (p.L0 + p.L1) / p.groups;
     const int R = blockDim.x / VC;
     const int v = threadIdx.x % VC, rr = threadIdx.x / VC;
     const int b = blockIdx.y;
@@ -97,7 +105,9 @@ __global__ void gn_apply_kernel(GnParams p) {
     float fa[8], fb[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-        const int c = v * 8 + e, g = c / cg;
+        const int c = v * 8 + e, l = gn_logical(p, c);
+        if (l < 0) { fa[e] = 0.f; fb[e] = 0.f; continue; }           // padding channel: stays zero (SiLU(0) = 0)
+        const int g = l / cg;
         fa[e] = gstat[g][1] * p.gamma[c];
         fb[e] = p.beta[c] - gstat[g][0] * fa[e];
     }
@@ -118,7 +128,10 @@ __global__ void gn_apply_kernel(GnParams p) {
 
 hipError_t launch_groupnorm(GnParams p, hipStream_t st) {
     const int C = p.C0 + p.C1;
-    if (C % 8 || C % p.groups || p.groups > 64 || (p.C0 % 8) || (p.C1 % 8)) return hipErrorInvalidValue;
+    if (p.L0 <= 0) p.L0 = p.C0;
+    if (p.L1 <= 0) p.L1 = p.C1;
+    if (p.L0 > p.C0 || p.L1 > p.C1 || (p.L0 + p.L1) % p.groups) return hipErrorInvalidValue;
+    if (C % 8 || p.groups > 64 || (p.C0 % 8) || (p.C1 % 8)) return hipErrorInvalidValue;
     const int VC = C / 8;
     if (VC > 1024) return hipErrorInvalidValue;
     int R = 256 / VC; if (R < 1) R = 1;
@@ -197,12 +210,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* x, const floa
 // (256 B per instruction ~ 1.9 TB/s chip-wide); this one moves 1 KiB per instruction.
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(const bf16_t* x, const float* gamma, const float* beta,
-                                                               bf16_t* out, int M, int C, float eps) {
+                                                               bf16_t* out, int M, int C, float eps, int Clog) {
+    // Clog <= C: the row's tail [Clog, C) is zero padding (Clog % 8 == 0): statistics over Clog values; the tail's gamma / beta
+    // are zero, so it is written back as zero.
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const bf16_t* xr = x + row * C;
-    const int nvec = C >> 3;
+    const int nvec = C >> 3, nlog = Clog >> 3;
     float v[NV][8];
     float s = 0.f;
 #pragma unroll
@@ -219,17 +234,17 @@ __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(const bf16_t* x, 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s / C;
+    const float mean = s / Clog;             // the padded tail contributed zeros to s
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; j++)
-        if (lane + j * 64 < nvec) {
+        if (lane + j * 64 < nlog) {
 #pragma unroll
             for (int e = 0; e < 8; e++) { const float d = v[j][e] - mean; q += d * d; }
         }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rstd = rsqrtf(q / C + eps);
+    const float rstd = rsqrtf(q / Clog + eps);
 #pragma unroll
     for (int j = 0; j < NV; j++) {
         const int vi = lane + j * 64;
@@ -261,14 +276,17 @@ static void ln_dispatch(const void* x, int in_is_f32, const float* g, const floa
 }
 
 hipError_t launch_layernorm(const void* x, int in_is_f32, const float* gamma, const float* beta, void* out, int out_is_f32,
-                            int M, int C, float eps, hipStream_t st) {
+                            int M, int C, float eps, hipStream_t st, int Clog) {
     if (C % 2 || C > 4096) return hipErrorInvalidValue;
+    if (Clog < 0) Clog = C;
+    if (Clog > C || Clog % 8 || (Clog != C && (in_is_f32 || out_is_f32 || C % 8 || C > 1024))) return hipErrorInvalidValue;   // padded rows: the bf16 vector kernel only
     static const int no_vec = getenv("RDM_LN_NOVEC") ? atoi(getenv("RDM_LN_NOVEC")) : 0;
+    if (Clog != C && (no_vec || ((size_t)x % 16) || ((size_t)out % 16) || ((size_t)gamma % 16) || ((size_t)beta % 16))) return hipErrorInvalidValue;
     if (!no_vec && !in_is_f32 && !out_is_f32 && C % 8 == 0 && C <= 1024 && ((size_t)x % 16 == 0) && ((size_t)out % 16 == 0) &&
         ((size_t)gamma % 16 == 0) && ((size_t)beta % 16 == 0)) {
         const int grid = (M + 3) / 4;
-        if (C <= 512) layernorm_bf16x8_kernel<1><<<grid, 256, 0, st>>>((const bf16_t*)x, gamma, beta, (bf16_t*)out, M, C, eps);
-        else layernorm_bf16x8_kernel<2><<<grid, 256, 0, st>>>((const bf16_t*)x, gamma, beta, (bf16_t*)out, M, C, eps);
+        if (C <= 512) layernorm_bf16x8_kernel<1><<<grid, 256, 0, st>>>((const bf16_t*)x, gamma, beta, (bf16_t*)out, M, C, eps, Clog);
+        else layernorm_bf16x8_kernel<2><<<grid, 256, 0, st>>>((const bf16_t*)x, gamma, beta, (bf16_t*)out, M, C, eps, Clog);
         return hipGetLastError();
     }
     if (C <= 1024) ln_dispatch<8>(x, in_is_f32, gamma, beta, out, out_is_f32, M, C, eps, st);

@@ -30,19 +30,59 @@ def _geglu_perm(n8c: int) -> torch.Tensor:
     return torch.cat([x_rows, g_rows], dim=1).reshape(-1)
 
 
+def _parse_kind(kd: str):
+    """'kind|R=a>b,c>d|C=e>f' -> (kind, row segments, channel segments): the library's channel-padding recipe (model.hip build_unet):
+    a dimension of sum(logical) entries becomes sum(padded) entries, every segment followed by its zero tail."""
+    parts = kd.split("|")
+    rows = cols = None
+    for sp in parts[1:]:
+        segs = [tuple(int(v) for v in g.split(">")) for g in sp[2:].split(",")]
+        if sp.startswith("R="):
+            rows = segs
+        elif sp.startswith("C="):
+            cols = segs
+        else:
+            raise ValueError(f"unknown manifest recipe '{sp}'")
+    return parts[0], rows, cols
+
+
+def _pad_dim(t: torch.Tensor, dim: int, segs) -> torch.Tensor:
+    """Pad dimension `dim` segment by segment (logical n -> padded p, zeros behind each segment)."""
+    if segs is None:
+        return t
+    if sum(n for n, _ in segs) != t.shape[dim]:
+        raise ValueError(f"padding recipe {segs} does not cover a dimension of {t.shape[dim]}")
+    out, pos = [], 0
+    for n, p_ in segs:
+        piece = t.narrow(dim, pos, n); pos += n
+        if p_ > n:
+            shape = list(t.shape); shape[dim] = p_ - n
+            piece = torch.cat([piece, torch.zeros(shape, dtype=t.dtype)], dim=dim)
+        out.append(piece)
+    return torch.cat(out, dim=dim)
+
+
 def pack(kind: str, cfg, sd: Dict[str, torch.Tensor]) -> np.ndarray:
     entries, blob_bytes = _lib.manifest(kind, cfg)
     blob = np.zeros(blob_bytes, dtype=np.uint8)
-    for off, nbytes, kd, srcs in entries:
+    for off, nbytes, kd_full, srcs in entries:
+        kd, rseg, cseg = _parse_kind(kd_full)
         ts = []
         for s in srcs:
             if s not in sd:
                 raise KeyError(f"state_dict is missing '{s}' (needed by the {kind} manifest)")
             ts.append(sd[s].detach().to("cpu", torch.float32))
         if kd == "f32":
-            data = _f32_bytes(torch.cat([t.reshape(-1) for t in ts]))
+            if rseg is not None and ts[0].ndim >= 2:          # [rows, ...] (conv_in weights): pad the rows
+                assert len(ts) == 1
+                data = _f32_bytes(_pad_dim(ts[0].reshape(ts[0].shape[0], -1), 0, rseg))
+            else:
+                data = _f32_bytes(_pad_dim(torch.cat([t.reshape(-1) for t in ts]), 0, rseg))
+        elif kd == "f32_cin":                                 # [Cout][Cin][3][3] fp32 (conv_out_kernel): the Cin axis is padded
+            assert len(ts) == 1 and ts[0].ndim == 4
+            data = _f32_bytes(_pad_dim(ts[0], 1, cseg))
         elif kd == "bf16":
-            data = _bf16_bytes(torch.cat([t.reshape(t.shape[0], -1) for t in ts], dim=0))
+            data = _bf16_bytes(_pad_dim(_pad_dim(torch.cat([t.reshape(t.shape[0], -1) for t in ts], dim=0), 0, rseg), 1, cseg))
         elif kd == "bf16_t":
             assert len(ts) == 1 and ts[0].ndim == 2
             data = _bf16_bytes(ts[0].t())
@@ -51,17 +91,17 @@ def pack(kind: str, cfg, sd: Dict[str, torch.Tensor]) -> np.ndarray:
             data = _f32_bytes(ts[0].t())
         elif kd == "conv3":
             assert len(ts) == 1 and ts[0].ndim == 4 and ts[0].shape[2:] == (3, 3)
-            data = _bf16_bytes(ts[0].permute(0, 2, 3, 1))            # [N][ky][kx][C]  (K = tap*C + c)
+            data = _bf16_bytes(_pad_dim(_pad_dim(ts[0].permute(0, 2, 3, 1), 0, rseg), 3, cseg))     # [N][ky][kx][C]  (K = tap*C + c)
         elif kd == "geglu_w":
-            data = _bf16_bytes(ts[0][_geglu_perm(ts[0].shape[0])])
+            data = _bf16_bytes(_pad_dim(ts[0][_geglu_perm(ts[0].shape[0])], 1, cseg))
         elif kd == "geglu_b":
             data = _f32_bytes(ts[0][_geglu_perm(ts[0].shape[0])])
         elif kd == "fuse_w":      # [W_out W_2 | W_out]: ff.net.2 then proj_out as ONE linear map of [ff | t2] (model.hip transformer())
             w2, wo = ts[0].double(), ts[1].reshape(ts[1].shape[0], -1).double()
-            data = _bf16_bytes(torch.cat([wo @ w2, wo], dim=1).float())
+            data = _bf16_bytes(_pad_dim(_pad_dim(torch.cat([wo @ w2, wo], dim=1).float(), 0, rseg), 1, cseg))
         elif kd == "fuse_b":      # W_out b_2 + b_out
             b2, wo, bo = ts[0].double(), ts[1].reshape(ts[1].shape[0], -1).double(), ts[2].double()
-            data = _f32_bytes((wo @ b2 + bo).float())
+            data = _f32_bytes(_pad_dim((wo @ b2 + bo).float(), 0, rseg))
         else:
             raise ValueError(f"unknown manifest kind {kd}")
         if data.nbytes != nbytes:

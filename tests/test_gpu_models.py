@@ -45,6 +45,60 @@ def test_unet_tiny_golden(ctx):
     assert e <= 2.5e-2
 
 
+@pytest.mark.parametrize("mc,mult", [(96, (1, 2, 3)), (32, (1, 3, 5))])
+def test_unet_channel_widths_that_are_not_multiples_of_64(mc, mult):
+    """models/rdm/ffhq/config.yaml has model_channels 224 (224 / 448 / 672 / 896): widths that are multiples of 32 only.  The
+    library holds such activations zero-padded to the next multiple of 64 (weights padded by the packer from the manifest's
+    recipe, GroupNorm / LayerNorm over the logical channels): forward at batch 2 and 6 (skip-concat of two padded tensors,
+    attention with all-zero heads, shared guidance prefix) and a guided 4-step DDIM against the oracle on the logical model."""
+    from rdm_amd import _lib, packing
+    spec = ounet.UNetSpec(model_channels=mc, num_res_blocks=1, attention_resolutions=(2, 4), channel_mult=mult, num_head_channels=32, context_dim=512)
+    sd = ounet.synth_state_dict(ounet.param_shapes(spec), seed=4242)
+    c2 = _lib.Context(0)
+    try:
+        cfg = spec_to_unet_cfg(spec)
+        kinds = {e[2].split("|")[0] for e in _lib.manifest("unet", cfg)[0]}
+        assert any("|" in e[2] for e in _lib.manifest("unet", cfg)[0]) and kinds <= {"f32", "f32_cin", "bf16", "conv3", "geglu_w", "geglu_b", "fuse_w", "fuse_b"}
+        c2.load_unet(cfg, packing.pack("unet", cfg, sd))
+        g = torch.Generator().manual_seed(3)
+        for B in (2, 6):
+            x = torch.randn(B, 3, 16, 16, generator=g); t = torch.randint(0, 1000, (B,), generator=g); c = torch.randn(B, 4, 512, generator=g) * 0.45
+            eps = c2.unet_forward(x, t, c)
+            ref = ounet.unet_forward(sd, spec, x, t, c)
+            e = rel_l2(eps, ref)
+            print(f"mc={mc} B={B}: rel L2 {e:.3e}")
+            assert e <= 2.5e-2
+        x = torch.randn(3, 3, 16, 16, generator=g); c = torch.randn(3, 4, 512, generator=g) * 0.45; uc = torch.zeros_like(c)
+        z = c2.ddim_sample(4, x, c, uc, odiff.Schedule().alphas_cumprod, scale=2.0)[0]
+        apply = lambda xx, tt, cc: ounet.unet_forward(sd, spec, xx, tt, cc)
+        zr, _ = odiff.ddim_sample(apply, odiff.Schedule(), 4, x, c, scale=2.0, uncond=uc)
+        assert rel_l2(z, zr) <= 4e-2
+    finally:
+        c2.close()
+
+
+def test_unet_ffhq_config():
+    """The UNet of models/rdm/ffhq/config.yaml (model_channels 224, channel_mult 1-2-3-4, otherwise the ImageNet one): forward at the
+    shipped size against the oracle (seeded random weights; 28 heads x k = 4 at the widest level still fits the skinny cross-attention)."""
+    from rdm_amd import _lib, packing
+    spec = ounet.UNetSpec(model_channels=224, channel_mult=(1, 2, 3, 4))
+    sd = ounet.synth_state_dict(ounet.param_shapes(spec), seed=99)
+    c2 = _lib.Context(0)
+    try:
+        cfg = spec_to_unet_cfg(spec)
+        c2.load_unet(cfg, packing.pack("unet", cfg, sd))
+        g = torch.Generator().manual_seed(8)
+        x = torch.randn(2, 3, 64, 64, generator=g); t = torch.tensor([981, 21]); c = torch.randn(2, 4, 512, generator=g) * 0.45
+        c[1] = 0                                              # one zero-context sample (the unconditional half of a guided batch)
+        eps = c2.unet_forward(x, t, c)
+        ref = ounet.unet_forward(sd, spec, x, t, c)
+        e = rel_l2(eps, ref)
+        print("unet ffhq config rel L2 vs oracle:", e)
+        assert e <= 2.5e-2
+    finally:
+        c2.close()
+
+
 def test_unet_shipped_golden(ctx):
     g = golden("unet_shipped.npz")
     spec = ounet.shipped_spec()
