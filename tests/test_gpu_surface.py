@@ -567,8 +567,11 @@ def _shard_db_run(device_index, shard_db):
                               unconditional_guidance_scale=2.0, unconditional_retro_guidance_label=0.)["query_samples"]
     nn = m.retriever.search_k_nearest(qs, k=20, query_embedded=True)
     rows = ctx.db_size()
+    torch.manual_seed(12); np.random.seed(12)
+    lat2 = m.sample_from_rdata(6, qids=np.array([41, 7, 15_500, 29_999, 123, 20_000]), k_nn=4, ddim=True, ddim_steps=4,
+                               unconditional_guidance_scale=2.0, unconditional_retro_guidance_label=0.)["samples_with_sampled_nns"]
     torch.cuda.synchronize(); ctx.close()
-    return lat.cpu().numpy(), nn["nns"], nn["distances"], rows
+    return lat.cpu().numpy(), nn["nns"], nn["distances"], rows, lat2.cpu().numpy()
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -581,7 +584,7 @@ def test_row_sharded_database_matches_replicated(world):
     q = mpc.Queue()
     procs = [mpc.Process(target=_shard_db_worker, args=(r, world, 29670 + world, q)) for r in range(world)]
     for p in procs: p.start()
-    lat, nns, dist, rows = q.get(timeout=600)
+    lat, nns, dist, rows, lat_rd = q.get(timeout=600)
     for p in procs: p.join(timeout=120)
     assert all(p.exitcode == 0 for p in procs)
     pool, qs = _shard_db_pool()
@@ -591,9 +594,10 @@ def test_row_sharded_database_matches_replicated(world):
     assert np.abs(dist - ref_s).max() <= 1e-6
     assert list(nns[0][:3]) == [41, 15_500, 29_000]
     # replicated database, single process, same per-rank batch? no: compare against the replicated mode's neighbours through the latents
-    lat1, nns1, _, rows1 = _shard_db_run(0, False)
+    lat1, nns1, _, rows1, lat_rd1 = _shard_db_run(0, False)
     assert rows1 == len(pool["embedding"]) and np.array_equal(nns1, ref_i)
     assert rel_l2(torch.from_numpy(lat), torch.from_numpy(lat1)) <= RANK_LATENT_TOL
+    assert rel_l2(torch.from_numpy(lat_rd), torch.from_numpy(lat_rd1)) <= RANK_LATENT_TOL        # sample_from_rdata: pseudo-queries drawn from the database
 
 
 def test_single_rank_distributed_mode_is_deterministic(ctx):
