@@ -59,6 +59,31 @@ def _check_manifest(kind, cfg, shapes):
     return entries, blob, sd
 
 
+def test_unet_manifest_padding_recipes():
+    """A UNet whose widths are multiples of 32 only (models/rdm/ffhq: model_channels 224): the manifest's kinds carry the padding
+    recipe and the packer executes it -- every reference tensor is used, padded segments end in zeros, logical values sit where
+    the recipe says (checked on a skip-concat conv: [N][ky][kx][C0 pad | C1 pad]); the ImageNet config has no recipe at all."""
+    from rdm_amd import _lib
+    spec = ounet.UNetSpec(model_channels=96, num_res_blocks=1, attention_resolutions=(2, 4), channel_mult=(1, 2, 3), num_head_channels=32, context_dim=512)
+    entries, blob, sd = _check_manifest("unet", spec_to_unet_cfg(spec), ounet.param_shapes(spec))
+    assert any("|R=" in e[2] or "|C=" in e[2] for e in entries)
+    assert not any("|" in e[2] for e in _lib.manifest("unet", spec_to_unet_cfg(ounet.shipped_spec()))[0])
+    ffhq = ounet.UNetSpec(model_channels=224, channel_mult=(1, 2, 3, 4))
+    e2, nbytes = _lib.manifest("unet", spec_to_unet_cfg(ffhq))
+    assert sorted(s for e in e2 if not e[2].startswith("fuse_") for s in e[3]) == sorted(ounet.param_shapes(ffhq))
+    # a decoder ResBlock conv over [h | skip]: 'conv3|R=n>np|C=c0>p0,c1>p1'
+    off, nb, kd, srcs = next(e for e in entries if e[2].startswith("conv3") and e[2].count(">") == 3)
+    from rdm_amd.packing import _parse_kind
+    _, rows, cols = _parse_kind(kd)
+    (n, npad), ((c0, p0), (c1, p1)) = rows[0], cols
+    w = sd[srcs[0]]
+    assert w.shape == (n, c0 + c1, 3, 3) and nb == npad * 9 * (p0 + p1) * 2
+    got = torch.from_numpy(blob[off:off + nb].view(np.int16).copy()).view(torch.bfloat16).float().reshape(npad, 3, 3, p0 + p1)
+    ref = w.permute(0, 2, 3, 1).to(torch.bfloat16).float()
+    assert torch.equal(got[:n, :, :, :c0], ref[..., :c0]) and torch.equal(got[:n, :, :, p0:p0 + c1], ref[..., c0:])
+    assert not got[n:].any() and not got[:, :, :, c0:p0].any() and not got[:, :, :, p0 + c1:].any()
+
+
 def test_unet_manifest_matches_reference_state_dict():
     spec = ounet.tiny_spec()
     entries, blob, sd = _check_manifest("unet", spec_to_unet_cfg(spec), ounet.param_shapes(spec))
