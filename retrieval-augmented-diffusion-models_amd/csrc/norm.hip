@@ -92,7 +92,15 @@ __global__ void gn_apply_kernel(GnParams p) {
     if (threadIdx.x < p.groups) {
         double a = 0.0, q = 0.0;
         const float* pp = p.partial + ((long long)b * p.nchunk * p.groups + threadIdx.x) * 2;
-        for (int k = 0; k < p.nchunk; k++) { a += pp[(long long)k * p.groups * 2]; q += pp[(long long)k * p.groups * 2 + 1]; }
+        // eight (sum, sumsq) pairs in flight per round trip, summed in chunk order (left to a rolled loop this is up to 32 dependent
+        // L2 round trips in front of the whole block: ~10 us per launch)
+        for (int k0 = 0; k0 < p.nchunk; k0 += 8) {
+            float2 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = (k0 + u < p.nchunk) ? *(const float2*)(pp + (long long)(k0 + u) * p.groups * 2) : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; u++) { a += t[u].x; q += t[u].y; }
+        }
         const double n = (double)cg * p.HW;
         const double mean = a / n;
         double var = q / n - mean * mean;
@@ -103,13 +111,22 @@ __global__ void gn_apply_kernel(GnParams p) {
     __syncthreads();
     if (rr >= R) return;
     float fa[8], fb[8];
+    {   // The thread's 8 channels are all logical or all padding (sources and logical counts are multiples of 8): ONE division finds
+        // the first channel's group, the rest follow by counting.  gamma / beta are read as two 16-byte vectors each, unconditionally
+        // -- the packer zeroes them on padding channels, which therefore come out as exactly 0 whatever group is used for them
+        // (guarding the loads per channel instead serialised 16 scalar loads: +10 us on every launch).
+        const int l0 = gn_logical(p, v * 8);
+        int g = l0 < 0 ? 0 : l0 / cg, r = l0 < 0 ? 0 : l0 - g * cg;
+        const float4 g0 = *(const float4*)(p.gamma + v * 8), g1 = *(const float4*)(p.gamma + v * 8 + 4);
+        const float4 b0 = *(const float4*)(p.beta + v * 8), b1 = *(const float4*)(p.beta + v * 8 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const int c = v * 8 + e, l = gn_logical(p, c);
-        if (l < 0) { fa[e] = 0.f; fb[e] = 0.f; continue; }           // padding channel: stays zero (SiLU(0) = 0)
-        const int g = l / cg;
-        fa[e] = gstat[g][1] * p.gamma[c];
-        fb[e] = p.beta[c] - gstat[g][0] * fa[e];
+        for (int e = 0; e < 8; e++) {
+            fa[e] = gstat[g][1] * gg[e];
+            fb[e] = bb[e] - gstat[g][0] * fa[e];
+            if (++r == cg) { r = 0; g++; }
+        }
     }
     const int rows_per = (p.HW + gridDim.x - 1) / gridDim.x;
     const int r0 = blockIdx.x * rows_per, r1 = min(p.HW, r0 + rows_per);
@@ -130,7 +147,7 @@ hipError_t launch_groupnorm(GnParams p, hipStream_t st) {
     const int C = p.C0 + p.C1;
     if (p.L0 <= 0) p.L0 = p.C0;
     if (p.L1 <= 0) p.L1 = p.C1;
-    if (p.L0 > p.C0 || p.L1 > p.C1 || (p.L0 + p.L1) % p.groups) return hipErrorInvalidValue;
+    if (p.L0 > p.C0 || p.L1 > p.C1 || (p.L0 + p.L1) % p.groups || p.L0 % 8 || p.L1 % 8) return hipErrorInvalidValue;
     if (C % 8 || p.groups > 64 || (p.C0 % 8) || (p.C1 % 8)) return hipErrorInvalidValue;
     const int VC = C / 8;
     if (VC > 1024) return hipErrorInvalidValue;

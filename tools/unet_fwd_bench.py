@@ -7,9 +7,10 @@ sys.path.insert(0, ROOT)
 import torch
 import rdm_amd
 from rdm_amd import _lib, packing, synthetic
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 10
+ffhq = "--ffhq" in sys.argv        # models/rdm/ffhq: model_channels 224, channel_mult 1-2-3-4 (runs zero-padded to 64-channel slices)
 ctx = _lib.Context(0); d = ctx.device
-cfg = _lib.make_unet_cfg()
+cfg = _lib.make_unet_cfg(model_channels=224, channel_mult=(1, 2, 3, 4)) if ffhq else _lib.make_unet_cfg()
 ctx.load_unet(cfg, packing.pack("unet", cfg, synthetic.unet_state_dict(cfg)))
 g = torch.Generator(device=d).manual_seed(0)
 x = torch.randn(128, 3, 64, 64, device=d, generator=g); t = torch.full((128,), 500, device=d, dtype=torch.long)
