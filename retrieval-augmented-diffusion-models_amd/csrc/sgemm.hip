@@ -9,57 +9,83 @@
 // 32 gate rows (packing._geglu_perm), so a block owns a 64-row strip and emits x * gelu(gate) for 32 outputs.
 #include "kernels.h"
 
-template <int MF, int NF, int U>   // MF: 32-row fragments of M (1..4); NF: 1 plain, 2 GEGLU (x strip + gate strip); U: k-steps of 16 per batch of loads
+template <int MF, int NF, int U>   // MF: 32-row blocks of M (1..4); NF: 1 plain, 2 GEGLU (x strip + gate strip); U: k-steps of 32 per batch of loads
 __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
+    // 16x16x32 MFMAs, not 32x32x16: the operands come straight from global memory in fragment order, and what such a launch pays
+    // for is the number of cache LINES its load instructions touch (phase clocks at M = 64, K = 768: 9.1 of the launch's ~12 us are
+    // the load phase).  A 32x32x16 fragment is 32 rows x 32 bytes per instruction -- 32 lines for 1 KB --, a 16x16x32 fragment is
+    // 16 rows x 64 bytes: half the lines for the same bytes and the same FLOPs per cycle.
     extern __shared__ float part[];                       // [4 waves][MF][NF][32 rows][32 cols]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int frow = lane & 31, fhalf = lane >> 5;
+    const int r16 = lane & 15, q4 = lane >> 4;
     const int n0 = blockIdx.x * 32 * NF;                  // first weight row of this block's strip
     const int kq = p.K >> 2, k0 = wave * kq;              // this wave's K quarter
-    const bf16_t* wp[NF];
+    constexpr int MA = 2 * MF, NB = 2 * NF;               // 16-row fragments of M, 16-column fragments of the strip(s)
+    const bf16_t* wp[NB];
 #pragma unroll
-    for (int j = 0; j < NF; j++) wp[j] = p.W + (long long)(n0 + j * 32 + frow) * p.K + k0 + fhalf * 8;
-    const bf16_t* ap[MF];
+    for (int j = 0; j < NB; j++) wp[j] = p.W + (long long)(n0 + j * 16 + r16) * p.K + k0 + q4 * 8;
+    const bf16_t* ap[MA];
 #pragma unroll
-    for (int i = 0; i < MF; i++) { int m = i * 32 + frow; if (m >= p.M) m = p.M - 1; ap[i] = p.A + (long long)m * p.lda + k0 + fhalf * 8; }
-    f32x16 acc[MF][NF];
+    for (int i = 0; i < MA; i++) { int m = i * 16 + r16; if (m >= p.M) m = p.M - 1; ap[i] = p.A + (long long)m * p.lda + k0 + q4 * 8; }
+    f32x4 acc[MA][NB];
 #pragma unroll
-    for (int i = 0; i < MF; i++)
+    for (int i = 0; i < MA; i++)
 #pragma unroll
-        for (int j = 0; j < NF; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    // U k-steps per iteration: U * (MF + NF) 16-byte loads in flight per lane.  The launch is one or two DEPENDENT round trips to
-    // HBM long (a 768-deep K quarter is 12 k-steps: U = 12 fetches a wave's whole operand set at once), so depth = latency.
-    for (int k = 0; k < kq; k += U * 16) {
-        bf16x8 fa[U][MF], fb[U][NF];
+        for (int j = 0; j < NB; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // U k-steps per iteration: U * (MA + NB) 16-byte loads in flight per lane.  The launch is one or two DEPENDENT round trips to
+    // HBM long (a 768-deep K quarter is 6 k-steps of 32: U = 6 fetches a wave's whole operand set at once), so depth = latency.
+    for (int k = 0; k < kq; k += U * 32) {
+        bf16x8 fa[U][MA], fb[U][NB];
 #pragma unroll
         for (int s = 0; s < U; s++) {
 #pragma unroll
-            for (int j = 0; j < NF; j++) fb[s][j] = *(const bf16x8*)(wp[j] + k + s * 16);
+            for (int j = 0; j < NB; j++) fb[s][j] = *(const bf16x8*)(wp[j] + k + s * 32);
 #pragma unroll
-            for (int i = 0; i < MF; i++) fa[s][i] = *(const bf16x8*)(ap[i] + k + s * 16);
+            for (int i = 0; i < MA; i++) fa[s][i] = *(const bf16x8*)(ap[i] + k + s * 32);
         }
+        // all requests first, then the MFMAs: left alone the scheduler interleaves them to save registers (7 loads, wait, MFMA, 2
+        // loads, wait, ...), i.e. a chain of dependent round trips -- the 9 us "load phase" of this kernel
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < U; s++)
 #pragma unroll
-            for (int i = 0; i < MF; i++)
+            for (int i = 0; i < MA; i++)
 #pragma unroll
-                for (int j = 0; j < NF; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NB; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
     }
-    // partial tiles -> LDS (D layout: column = frow, rows (r&3) + 8 (r>>2) + 4 fhalf)
+    // partial tiles -> LDS (D layout 16x16: column = lane & 15, rows (lane >> 4) * 4 + r)
 #pragma unroll
-    for (int i = 0; i < MF; i++)
+    for (int i = 0; i < MA; i++)
 #pragma unroll
-        for (int j = 0; j < NF; j++)
+        for (int j = 0; j < NB; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                part[((((wave * MF + i) * NF + j) * 32) + ((r & 3) + 8 * (r >> 2) + 4 * fhalf)) * 32 + frow] = acc[i][j][r];
+            for (int r = 0; r < 4; r++)
+                part[((((wave * MF + (i >> 1)) * NF + (j >> 1)) * 32) + ((i & 1) * 16 + q4 * 4 + r)) * 32 + (j & 1) * 16 + r16] = acc[i][j][r];
     __syncthreads();
     const int ncol0 = blockIdx.x * 32;                    // first OUTPUT column
-    for (int e = tid; e < MF * 1024; e += 256) {
+    // Two phases: every residual / bias value this thread needs is requested first, THEN the results are formed and stored.  The
+    // decode step accumulates in place (out == residual: x += ...), so inside a single loop no load may move above the previous
+    // iteration's store and the 4 * MF iterations cost one L2 round trip each (~5 of the launch's ~14 us).  A thread reads and
+    // writes the same elements, so hoisting its own loads above its own stores is safe whatever aliases.
+    constexpr int IT = 4 * MF;
+    float acc_[IT], res_[IT]; long long oi_[IT]; bool ok_[IT];
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+        const int e = tid + it * 256;
         const int i = e >> 10, row = (e >> 5) & 31, col = e & 31, m = i * 32 + row;
-        if (m >= p.M) continue;
+        ok_[it] = m < p.M;
+        oi_[it] = (long long)m * p.ldo + ncol0 + col;
+        float r = 0.f;
+        if (ok_[it]) {
+            if (p.res_f32) r += p.res_f32[oi_[it]];
+            if (p.res_bf16) r += bf2f(p.res_bf16[oi_[it]]);
+        }
+        res_[it] = r;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+        const int e = tid + it * 256;
+        const int i = e >> 10, row = (e >> 5) & 31, col = e & 31;
         float v[NF];
 #pragma unroll
         for (int j = 0; j < NF; j++) {
@@ -72,11 +98,13 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
         if (NF == 2) o = v[0] * gelu_erf_f(v[1]);
         else if (p.act == ACT_SILU) o = silu_f(o);
         else if (p.act == ACT_QUICKGELU) o = quickgelu_f(o);
-        const long long oi = (long long)m * p.ldo + ncol0 + col;
-        if (p.res_f32) o += p.res_f32[oi];
-        if (p.res_bf16) o += bf2f(p.res_bf16[oi]);
-        if (p.out_f32) p.out_f32[oi] = o;
-        if (p.out_bf16) p.out_bf16[oi] = f2bf(o);
+        acc_[it] = o + res_[it];
+    }
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+        if (!ok_[it]) continue;
+        if (p.out_f32) p.out_f32[oi_[it]] = acc_[it];
+        if (p.out_bf16) p.out_bf16[oi_[it]] = f2bf(acc_[it]);
     }
 }
 
@@ -103,12 +131,12 @@ static hipError_t launch_one(const SgemmParams& p, int grid, hipStream_t st) {
 template <int NF>
 static hipError_t launch_nf(const SgemmParams& p, int grid, hipStream_t st) {
     const int mf = (p.M + 31) / 32;
-    const bool deep = ((p.K >> 2) % 192) == 0;            // K quarter is a multiple of 12 k-steps (K = 768, 1536, 3072 ...)
+    const bool deep = ((p.K >> 2) % 192) == 0;            // K quarter is a multiple of 6 k-steps of 32 (K = 768, 1536, 3072 ...)
     switch (mf) {
-        case 1: return deep ? launch_one<1, NF, 12>(p, grid, st) : launch_one<1, NF, 4>(p, grid, st);
-        case 2: return deep ? launch_one<2, NF, 12>(p, grid, st) : launch_one<2, NF, 4>(p, grid, st);
-        case 3: return deep ? launch_one<3, NF, 6>(p, grid, st) : launch_one<3, NF, 4>(p, grid, st);
-        default: return deep ? launch_one<4, NF, 6>(p, grid, st) : launch_one<4, NF, 4>(p, grid, st);
+        case 1: return deep ? launch_one<1, NF, 6>(p, grid, st) : launch_one<1, NF, 2>(p, grid, st);
+        case 2: return deep ? launch_one<2, NF, 6>(p, grid, st) : launch_one<2, NF, 2>(p, grid, st);
+        case 3: return deep ? launch_one<3, NF, 3>(p, grid, st) : launch_one<3, NF, 2>(p, grid, st);
+        default: return deep ? launch_one<4, NF, 3>(p, grid, st) : launch_one<4, NF, 2>(p, grid, st);
     }
 }
 
