@@ -32,55 +32,90 @@ hipError_t launch_rarm_embed(const long long* tokens, const float* emb, const fl
 // projected neighbours and all nkv rows are attended.  Phase 1: lane j scores keys j, j+64, ...; phase 2: lane d
 // accumulates sum_j p_j V[j][d] with coalesced 128-byte row reads.  CrossAttention.forward, attention.py:42-74.
 __global__ __launch_bounds__(64) void rarm_decode_attention_kernel(RarmAttnParams p) {
+    // Eight lanes per cache row (16 bytes each), eight rows per load instruction: an instruction touches 8 cache lines.  (One lane
+    // per key row -- 64 rows, 64 lines per instruction -- in the score phase and one 128-byte row per instruction in the value
+    // phase made this launch 11.5 us of mostly address traffic.)
     constexpr int D = 64;
     __shared__ float sc[1024];
-    __shared__ float qs[D];
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int jr = lane >> 3, c8 = (lane & 7) * 8;
     const int t = p.pos ? *p.pos : 0;
     const int n = p.k_new ? t + 1 : p.nkv;
     bf16_t* Kc = p.Kc + (long long)b * p.batch_stride + h * D;
     bf16_t* Vc = p.Vc + (long long)b * p.batch_stride + h * D;
-    qs[lane] = bf2f(p.q[(long long)b * p.ldq + h * D + lane]) * p.scale;
-    if (p.k_new) {       // append the new row (visible to this wave only through the registers below; other waves own other heads)
-        Kc[(long long)t * p.row_stride + lane] = p.k_new[(long long)b * p.ldq + h * D + lane];
-        Vc[(long long)t * p.row_stride + lane] = p.v_new[(long long)b * p.ldq + h * D + lane];
+    const bf16_t* knew = p.k_new ? p.k_new + (long long)b * p.ldq + h * D : nullptr;
+    const bf16_t* vnew = p.k_new ? p.v_new + (long long)b * p.ldq + h * D : nullptr;
+    float qv[8];
+    {
+        const bf16x8 qq = *(const bf16x8*)(p.q + (long long)b * p.ldq + h * D + c8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) qv[e] = bf2f((bf16_t)qq[e]) * p.scale;
     }
-    __syncthreads();
+    if (p.k_new && jr == 0) {       // append the new row (this wave reads it back from the projection output, never through the cache)
+        *(bf16x8*)(Kc + (long long)t * p.row_stride + c8) = *(const bf16x8*)(knew + c8);
+        *(bf16x8*)(Vc + (long long)t * p.row_stride + c8) = *(const bf16x8*)(vnew + c8);
+    }
+    // ---- scores: rows j0 + jr, four row groups (32 rows) in flight
     float m = -INFINITY;
-    for (int j = lane; j < n; j += 64) {
-        const bf16_t* kr = (p.k_new && j == t) ? p.k_new + (long long)b * p.ldq + h * D : Kc + (long long)j * p.row_stride;
-        float s = 0.f;
+    for (int j0 = 0; j0 < n; j0 += 32) {
+        bf16x8 kk[4];
 #pragma unroll
-        for (int c = 0; c < D; c += 8) {
-            const bf16x8 kk = *(const bf16x8*)(kr + c);
-#pragma unroll
-            for (int e = 0; e < 8; e++) s += qs[c + e] * bf2f((bf16_t)kk[e]);
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * 8 + jr;
+            const bf16_t* kr = (p.k_new && j == t) ? knew : Kc + (long long)(j < n ? j : 0) * p.row_stride;
+            kk[u] = *(const bf16x8*)(kr + c8);
         }
-        sc[j] = s; m = fmaxf(m, s);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * 8 + jr;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) s += qv[e] * bf2f((bf16_t)kk[u][e]);
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            if (j < n) { if ((lane & 7) == 0) sc[j] = s; m = fmaxf(m, s); }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __syncthreads();
     float l = 0.f;
     for (int j = lane; j < n; j += 64) { const float e = __expf(sc[j] - m); sc[j] = e; l += e; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
     __syncthreads();
-    // cached rows (8 independent loads in flight per lane: the loop is a chain of dependent 128-byte row reads otherwise),
-    // then the new token's row straight from the projection output (never through the cache it was just stored to)
-    float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // ---- values: cached rows, then the new token's row straight from the projection output
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int nc = p.k_new ? t : n;
-    int j = 0;
-    for (; j + 8 <= nc; j += 8) {
-        float v[8];
+    for (int j0 = 0; j0 < nc; j0 += 32) {
+        bf16x8 vv[4];
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = bf2f(Vc[(long long)(j + e) * p.row_stride + lane]);
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * 8 + jr;
+            vv[u] = *(const bf16x8*)(Vc + (long long)(j < nc ? j : 0) * p.row_stride + c8);
+        }
 #pragma unroll
-        for (int e = 0; e < 8; e++) acc8[e] += sc[j + e] * v[e];
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * 8 + jr;
+            const float pj = j < nc ? sc[j] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] += pj * bf2f((bf16_t)vv[u][e]);
+        }
     }
-    for (; j < nc; j++) acc8[0] += sc[j] * bf2f(Vc[(long long)j * p.row_stride + lane]);
-    if (p.k_new) acc8[1] += sc[t] * bf2f(p.v_new[(long long)b * p.ldq + h * D + lane]);
-    const float acc = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
-    p.out[(long long)b * p.ldo + h * D + lane] = f2bf(acc / l);
+    if (p.k_new && jr == 0) {
+        const bf16x8 vn = *(const bf16x8*)(vnew + c8);
+        const float pt = sc[t];
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] += pt * bf2f((bf16_t)vn[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) { acc[e] += __shfl_xor(acc[e], 8); acc[e] += __shfl_xor(acc[e], 16); acc[e] += __shfl_xor(acc[e], 32); }
+    if (jr == 0) {
+        const float inv = 1.f / l;
+        uint4 w;
+        w.x = pack2bf(acc[0] * inv, acc[1] * inv); w.y = pack2bf(acc[2] * inv, acc[3] * inv);
+        w.z = pack2bf(acc[4] * inv, acc[5] * inv); w.w = pack2bf(acc[6] * inv, acc[7] * inv);
+        *(uint4*)(p.out + (long long)b * p.ldo + h * D + c8) = w;
+    }
 }
 hipError_t launch_rarm_decode_attention(const RarmAttnParams& p, int heads, int batch, hipStream_t st) {
     if (p.nkv > 1024) return hipErrorInvalidValue;
