@@ -143,7 +143,14 @@ __global__ __launch_bounds__(256) void rarm_sample_kernel(RarmSampleParams p) {
     const float* lc = p.logits + (long long)b * V;
     const float* lu = p.cfg ? p.logits + (long long)(b + p.B) * V : nullptr;
     const float inv_t = 1.0f / p.temperature;
-    auto logit = [&](int i) { const float c = lc[i]; return (lu ? lu[i] + p.scale * (c - lu[i]) : c) * inv_t; };
+    auto logit_g = [&](int i) { const float c = lc[i]; return (lu ? lu[i] + p.scale * (c - lu[i]) : c) * inv_t; };
+    // The guided, temperature-scaled logits are formed ONCE (coalesced reads) and kept in LDS: the select's four passes, the max,
+    // the partial sums and the final scan had each gone back to global memory, the last two one strided / dependent element at a
+    // time (117 us per step).  Element i lives at i + (i >> 6): a thread's contiguous 64-element chunk then spreads over the banks.
+    extern __shared__ float lg[];
+    for (int i = tid; i < V; i += 256) lg[i + (i >> 6)] = logit_g(i);
+    __syncthreads();
+    auto logit = [&](int i) { return lg[i + (i >> 6)]; };
     // ---- radix select of the top_k-th largest value
     uint32_t prefix = 0; int remaining = p.top_k < V ? p.top_k : V;
     for (int pass = 3; pass >= 0; pass--) {
@@ -217,7 +224,16 @@ __global__ __launch_bounds__(256) void rarm_sample_kernel(RarmSampleParams p) {
     }
 }
 hipError_t launch_rarm_sample(const RarmSampleParams& p, hipStream_t st) {
-    rarm_sample_kernel<<<p.B, 256, 0, st>>>(p);
+    const size_t sm = ((size_t)p.vocab + (p.vocab >> 6) + 64) * sizeof(float);
+    if (sm > 150 * 1024) return hipErrorInvalidValue;          // vocabulary beyond ~37 k entries: not an RARM configuration
+    static bool attr_dev[RDM_MAX_DEVICES] = {false};
+    bool& attr = attr_dev[rdm_cur_device()];
+    if (!attr && sm > 32 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)rarm_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    rarm_sample_kernel<<<p.B, 256, sm, st>>>(p);
     return hipGetLastError();
 }
 
