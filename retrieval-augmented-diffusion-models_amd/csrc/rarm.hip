@@ -128,14 +128,13 @@ hipError_t launch_rarm_decode_attention(const RarmAttnParams& p, int heads, int 
 // / temperature, values below the k-th largest -> -inf (taming top_k_logits keeps ties with the k-th), softmax, then ONE draw by
 // inverse CDF with the caller's uniform u in [0,1): the smallest index whose cumulative probability exceeds u * total, in
 // vocabulary order (torch.multinomial's device-specific random stream has no cross-device definition; the uniform is an input
-// so that the draw is reproducible and checkable).  The k-th largest value is found by a 4-pass radix select on the
-// order-preserving integer image of the floats.  Writes the token to out[b, *pos], to the next-step token buffer (both CFG
+// so that the draw is reproducible and checkable).  The k-th largest value is found by a 32-round bit-wise threshold search on the
+// order-preserving integer image of the floats (keys in registers).  Writes the token to out[b, *pos], to the next-step token buffer (both CFG
 // halves), and — last block — advances *pos.
 __device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 
 __global__ __launch_bounds__(256) void rarm_sample_kernel(RarmSampleParams p) {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t sel_prefix; __shared__ int sel_remaining;
     __shared__ float red[256];
     __shared__ int chosen;
     const int b = blockIdx.x, tid = threadIdx.x, V = p.vocab;
@@ -148,42 +147,51 @@ __global__ __launch_bounds__(256) void rarm_sample_kernel(RarmSampleParams p) {
     // the partial sums and the final scan had each gone back to global memory, the last two one strided / dependent element at a
     // time (117 us per step).  Element i lives at i + (i >> 6): a thread's contiguous 64-element chunk then spreads over the banks.
     extern __shared__ float lg[];
-    for (int i = tid; i < V; i += 256) lg[i + (i >> 6)] = logit_g(i);
+    for (int i0 = tid; i0 < V; i0 += 256 * 16) {              // sixteen independent (pairs of) loads in flight per thread
+        float tmp[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int i = i0 + u * 256; tmp[u] = i < V ? logit_g(i) : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int i = i0 + u * 256; if (i < V) lg[i + (i >> 6)] = tmp[u]; }
+    }
     __syncthreads();
     auto logit = [&](int i) { return lg[i + (i >> 6)]; };
-    // ---- radix select of the top_k-th largest value
-    uint32_t prefix = 0; int remaining = p.top_k < V ? p.top_k : V;
-    for (int pass = 3; pass >= 0; pass--) {
-        hist[tid] = 0;
-        __syncthreads();
-        const uint32_t mask = pass == 3 ? 0u : (0xffffffffu << ((pass + 1) * 8));
-        for (int i0 = 0; i0 < V; i0 += 256) {
-            // wave-aggregated histogram update: logits share their leading bytes, so nearly all 64 lanes of a wave hit the SAME bucket
-            // (a plain per-lane LDS atomic serialised 16 384 adds on one address: 117 us per step); one atomic per distinct bucket
-            const int i = i0 + tid;
-            const uint32_t o = i < V ? f2ord(logit(i)) : 0u;
-            bool active = i < V && (o & mask) == (prefix & mask);
-            const uint32_t bucket = (o >> (pass * 8)) & 255u;
-            unsigned long long todo = __ballot(active);
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const uint32_t b0 = __shfl(bucket, leader);
-                const unsigned long long same = __ballot(active && bucket == b0);
-                if ((tid & 63) == leader) atomicAdd(&hist[b0], (uint32_t)__popcll(same));
-                todo &= ~same;
-                if (bucket == b0) active = false;
-            }
+    // ---- the top_k-th largest value: bit-by-bit search for the largest threshold that at least top_k keys reach.  Keys (the
+    // order-preserving integer image of the logits) sit in registers, a round is 64 compares per thread + one block-wide count:
+    // 32 rounds.  (The 4-pass radix select it replaces spent its time in wave-aggregated LDS-atomic histogram updates: ~180 us.)
+    const int remaining0 = p.top_k < V ? p.top_k : V;
+    constexpr int KPT = 64;                                   // keys per thread: vocabularies up to 16 384; longer ones loop below
+    uint32_t prefix = 0;
+    if (V <= 256 * KPT) {
+        uint32_t key[KPT];
+#pragma unroll
+        for (int u = 0; u < KPT; u++) { const int i = tid + u * 256; key[u] = i < V ? f2ord(logit(i)) : 0u; }      // 0 is below every real key
+        for (int bit = 31; bit >= 0; bit--) {
+            const uint32_t cand = prefix | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < KPT; u++) cnt += key[u] >= cand ? 1 : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            if ((tid & 63) == 0) hist[(bit & 1) * 4 + (tid >> 6)] = (uint32_t)cnt;       // two alternating slots: one barrier per round
+            __syncthreads();
+            const int tot = (int)(hist[(bit & 1) * 4] + hist[(bit & 1) * 4 + 1] + hist[(bit & 1) * 4 + 2] + hist[(bit & 1) * 4 + 3]);
+            if (tot >= remaining0) prefix = cand;
         }
-        __syncthreads();
-        if (tid == 0) {
-            int rem = remaining; int d = 255;
-            for (; d > 0; d--) { if ((int)hist[d] >= rem) break; rem -= (int)hist[d]; }
-            sel_prefix = prefix | ((uint32_t)d << (pass * 8)); sel_remaining = rem;
+    } else {
+        for (int bit = 31; bit >= 0; bit--) {
+            const uint32_t cand = prefix | (1u << bit);
+            int cnt = 0;
+            for (int i = tid; i < V; i += 256) cnt += f2ord(logit(i)) >= cand ? 1 : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            if ((tid & 63) == 0) hist[(bit & 1) * 4 + (tid >> 6)] = (uint32_t)cnt;
+            __syncthreads();
+            const int tot = (int)(hist[(bit & 1) * 4] + hist[(bit & 1) * 4 + 1] + hist[(bit & 1) * 4 + 2] + hist[(bit & 1) * 4 + 3]);
+            if (tot >= remaining0) prefix = cand;
         }
-        __syncthreads();
-        prefix = sel_prefix; remaining = sel_remaining;
-        __syncthreads();
     }
+    __syncthreads();
     const uint32_t kth = prefix;                          // order image of the k-th largest logit: keep o >= kth
     // ---- max, then per-thread partial sums over a CONTIGUOUS chunk (vocabulary order), block scan, locate the draw
     float mx = -INFINITY;
