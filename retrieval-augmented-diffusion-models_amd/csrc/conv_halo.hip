@@ -444,7 +444,9 @@ int conv_halo_ksplit(const IgemmParams& p) {
 }
 
 hipError_t launch_conv_halo(const IgemmParams& p, hipStream_t st) {
-    hipError_t e = (p.N % 192 == 0) ? launch_halo<192>(p, st) : launch_halo<128>(p, st);
+    hipError_t e;
+    if (conv_halo4_supported(p)) e = launch_conv_halo4(p, st);            // one wave per SIMD (conv_halo4.hip)
+    else e = (p.N % 192 == 0) ? launch_halo<192>(p, st) : launch_halo<128>(p, st);
     if (e != hipSuccess || p.ksplit <= 1) return e;
     const long long nvec = (long long)p.M * (p.N >> 3);
     long long g = (nvec + 255) / 256; if (g > 4096) g = 4096;

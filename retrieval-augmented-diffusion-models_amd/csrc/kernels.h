@@ -78,7 +78,11 @@ hipError_t launch_igemm(const IgemmParams& p, bool conv, int batch, hipStream_t 
 bool conv_halo_supported(const IgemmParams& p);
 int conv_halo_ksplit(const IgemmParams& p);                // K-split factor worth using for this conv (1 = none); needs p.ws of ksplit*M*N floats
 hipError_t launch_conv_halo(const IgemmParams& p, hipStream_t st);
-// 3x3 conv dispatcher: input-stationary halo kernel when the geometry allows, else the generic implicit GEMM
+// one-wave-per-SIMD halo kernel (conv_halo4.hip): needs p.Wfrag, the fragment-ordered weight copy
+bool conv_halo4_supported(const IgemmParams& p);
+hipError_t launch_conv_halo4(const IgemmParams& p, hipStream_t st);
+hipError_t launch_conv_w_fragpack(const bf16_t* W, bf16_t* dst, int N, int Cin, hipStream_t st);   // dst: N*9*Cin elements
+// 3x3 conv dispatcher: input-stationary halo kernels when the geometry allows, else the generic implicit GEMM
 inline hipError_t launch_conv3x3(const IgemmParams& p, hipStream_t st) {
     return conv_halo_supported(p) ? launch_conv_halo(p, st) : launch_igemm(p, true, 1, st);
 }

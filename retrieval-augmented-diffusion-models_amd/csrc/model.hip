@@ -14,10 +14,12 @@
 // once per step per layer.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <cmath>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/rdm_hip.h"
@@ -416,6 +418,20 @@ struct rdm_ctx {
     float* gn_partial = nullptr; size_t gn_partial_bytes = 0;
     char* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;   // fp32 partial planes of the K-split halo convs
     char* samp = nullptr; size_t samp_bytes = 0;     // sampler scratch
+    // fragment-ordered copies of the 3x3 conv weights (conv_halo4.hip), built on first use per weight, dropped when a model is reloaded
+    std::unordered_map<unsigned long long, bf16_t*> wfrag;      // key: weight address mixed with (N, Cin)
+    char* wfrag_tmp = nullptr; size_t wfrag_tmp_bytes = 0;      // rdm_op_conv3x3: caller-owned weights are re-packed per call
+    void drop_frags() { for (auto& kv : wfrag) (void)hipFree(kv.second); wfrag.clear(); }
+    const bf16_t* frag_for(const bf16_t* W, int N, int Cin) {
+        const unsigned long long key = (unsigned long long)(uintptr_t)W ^ ((unsigned long long)N << 48) ^ ((unsigned long long)Cin << 32);
+        auto it = wfrag.find(key);
+        if (it != wfrag.end()) return it->second;
+        bf16_t* d = nullptr;
+        if (hipMalloc((void**)&d, (size_t)N * 9 * Cin * 2) != hipSuccess) return nullptr;
+        if (launch_conv_w_fragpack(W, d, N, Cin, stream) != hipSuccess) { (void)hipFree(d); return nullptr; }
+        wfrag[key] = d;
+        return d;
+    }
     // optional per-launch HIP-event profiler for the GEMM-class kernels (bench.py roofline)
     unsigned prof = 0;           // bit k set: record HIP events around launches of kind k (RDM_PROF_* in rdm_hip.h)
     struct ProfRec { hipEvent_t a, b; int kind; double flops; };
@@ -481,6 +497,7 @@ struct Ops {
         p.rowvec = rowvec; p.rowvec_ld = rowvec_ld; p.rows_per_sample = Hout * Wout; p.res_bf16 = res; p.out_bf16 = out;
         const int ks = conv_halo_ksplit(p);
         if (ks > 1 && ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)ks * p.M * N * 4) == 0) { p.ksplit = ks; p.ws = (float*)c->splitk_ws; }
+        if (conv_halo_supported(p)) p.Wfrag = c->frag_for(p.W, N, C0 + C1);
         prof_begin(RDM_PROF_CONV3X3, 2.0 * p.M * N * (double)p.K);
         check(launch_conv3x3(p, c->stream), "conv3x3");
         prof_end();
@@ -780,6 +797,8 @@ template <typename M>
 static int load_blob(rdm_ctx* c, M& m, const Manifest& mf, const void* packed, size_t nbytes) {
     const size_t need = (mf.total + 255) & ~(size_t)255;
     if (nbytes != need) return c->fail(-1, "packed blob is %zu bytes, manifest needs %zu", nbytes, need);
+    RDM_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    c->drop_frags();                                  // derived weight layouts refer to blob addresses that may be reused
     if (m.blob) { RDM_CHECK_HIP(c, hipFree(m.blob)); m.blob = nullptr; }
     RDM_CHECK_HIP(c, hipMalloc((void**)&m.blob, need));
     RDM_CHECK_HIP(c, hipMemcpy(m.blob, packed, need, hipMemcpyHostToDevice));
@@ -964,8 +983,9 @@ void rdm_ctx_destroy(rdm_ctx* c) {
     hipDeviceSynchronize();
     void* ptrs[] = {c->zero_page, c->unet.blob, c->unet.arena.base, c->unet.kv_cache, c->vq.blob, c->vq.arena.base,
                     c->clip.blob, c->clip.arena.base, c->gn_partial, c->samp, c->splitk_ws, c->unet.xa_cache,
-                    c->rarm.blob, c->rarm.arena.base, c->rarm.cache, c->rarm.ctxkv, c->rarm.state};
+                    c->rarm.blob, c->rarm.arena.base, c->rarm.cache, c->rarm.ctxkv, c->rarm.state, c->wfrag_tmp};
     for (void* p : ptrs) if (p) hipFree(p);
+    c->drop_frags();
     knn_free(c->db);
     delete c;
 }
@@ -1460,6 +1480,13 @@ int rdm_op_conv3x3(rdm_ctx* c, const void* x0, const void* x1, int C0, int C1, c
     p.rowvec = rowvec; p.rowvec_ld = rowvec_ld; p.rows_per_sample = Hout * Wout; p.res_bf16 = (const bf16_t*)res; p.out_bf16 = (bf16_t*)out;
     const int ks = conv_halo_ksplit(p);
     if (ks > 1) { RDM_TRY(ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)ks * p.M * N * 4)); p.ksplit = ks; p.ws = (float*)c->splitk_ws; }
+    static const int op_cache = getenv("RDM_OP_FRAG_CACHE") ? atoi(getenv("RDM_OP_FRAG_CACHE")) : 0;     // dev-only (tools/conv_bench.py): the caller promises constant weights
+    if (conv_halo_supported(p) && op_cache) p.Wfrag = c->frag_for(p.W, N, C0 + C1);
+    else if (conv_halo_supported(p)) {
+        RDM_TRY(ensure_bytes(c, &c->wfrag_tmp, &c->wfrag_tmp_bytes, (size_t)N * p.K * 2));
+        RDM_CHECK_HIP(c, launch_conv_w_fragpack(p.W, (bf16_t*)c->wfrag_tmp, N, C0 + C1, c->stream));
+        p.Wfrag = (const bf16_t*)c->wfrag_tmp;
+    }
     RDM_CHECK_HIP(c, launch_conv3x3(p, c->stream));
     return 0;
 }
