@@ -198,6 +198,19 @@ int rdm_knn_last_fallback(rdm_ctx* ctx);
  * of the RAW (un-normalised) embeddings (rdm_db_load keeps a raw copy in HBM next to the normalised one). */
 int rdm_db_gather(rdm_ctx* ctx, const uint32_t* idx, long long n_idx, float* out);
 
+/* ---- multi-GPU: one process and one context per device; the path has ONE exchange, an all-gather -- of the
+ * decoded images (replicated database) or of the per-shard (index, score) top-k pairs (row-sharded database).  Thin wrappers
+ * around RCCL (loaded with dlopen at rdm_comm_init: single-GPU users never touch it) for callers that bind the C ABI directly;
+ * the Python mirror reaches the same RCCL through torch.distributed (rdm_amd/parallel.py).  The reference has no multi-GPU
+ * sampling (scripts/rdm_sample.py is single-process); the reference-side analogue is DDP's process group in main.py:783-785.
+ *   rdm_comm_unique_id: rank 0 fills a 128-byte id and hands it to the other ranks by any out-of-band means.
+ *   rdm_comm_init:      every rank, same id; binds the communicator to the context's device and stream.
+ *   rdm_comm_all_gather: recv[dev] (world * nbytes) <- send[dev] (nbytes) of every rank, in rank order; enqueued on the stream. */
+int rdm_comm_unique_id(rdm_ctx* ctx, void* id128 /*[host] 128 bytes*/);
+int rdm_comm_init(rdm_ctx* ctx, const void* id128 /*[host]*/, int rank, int world);
+int rdm_comm_all_gather(rdm_ctx* ctx, const void* send /*[dev]*/, void* recv /*[dev]*/, size_t nbytes);
+int rdm_comm_destroy(rdm_ctx* ctx);
+
 /* ---- measurement: optional HIP-event brackets around launches on the context stream, by kernel class.
  * enable: bit mask of (1 << RDM_PROF_*) kinds to record (0 = off).  collect: sums elapsed ms and ALGORITHMIC work of the
  * launches of one kind recorded since the last reset -- FLOPs (2*M*N*K; 4*n^2*d per attention head) for the MFMA-bound

@@ -101,6 +101,10 @@ SIGNATURES = {
     "rdm_prof_enable": (C.c_int, [_P, C.c_int]),
     "rdm_prof_collect": (C.c_int, [_P, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rdm_prof_reset": (C.c_int, [_P]),
+    "rdm_comm_unique_id": (C.c_int, [_P, _P]),
+    "rdm_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "rdm_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "rdm_comm_destroy": (C.c_int, [_P]),
     "rdm_op_linear": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "rdm_op_conv3x3": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int]),
@@ -284,11 +288,20 @@ class Context:
         if context.ndim != 3 or context.shape[0] != b or context.shape[2] != self.rarm_cfg.context_dim:
             raise RdmError(f"{what}: neighbours must be [b={b},k,{self.rarm_cfg.context_dim}], got {tuple(context.shape)}")
 
+    def _check_ids(self, what, ids, n, name):
+        """nn.Embedding / get_codebook_entry raise IndexError on an id outside the table; the kernels would silently read row 0.
+        One tiny reduction + a host read per call (not per token)."""
+        if ids.numel():
+            lo, hi = int(ids.min()), int(ids.max())
+            if lo < 0 or hi >= n:
+                raise RdmError(f"{what}: {name} must lie in [0, {n}), got values in [{lo}, {hi}]")
+
     def rarm_forward(self, tokens, context):
         """RetrievalPatchTransformer.forward: tokens int64 [b,t], context f32 [b,k,ctx] -> logits f32 [b,t,vocab_out]."""
         tokens = self._dev(tokens, torch.int64); context = self._dev(context, torch.float32)
         b, t = tokens.shape
         self._check_rarm("rarm_forward", context, b)
+        self._check_ids("rarm_forward", tokens, self.rarm_cfg.vocab_in, "tokens")
         out = torch.empty((b, t, self.rarm_cfg.vocab_out), device=self.device, dtype=torch.float32)
         self._check(lib.rdm_rarm_forward(self._h, _ptr(tokens), b, t, _ptr(context), context.shape[1], _ptr(out)))
         return out
@@ -299,6 +312,7 @@ class Context:
         uniforms = self._dev(uniforms, torch.float32)
         b, tc = cond_tokens.shape
         self._check_rarm("rarm_sample", context, b)
+        self._check_ids("rarm_sample", cond_tokens, self.rarm_cfg.vocab_in, "cond_tokens")
         if tuple(uniforms.shape) != (steps, b):
             raise RdmError(f"rarm_sample: uniforms must be [{steps},{b}], got {tuple(uniforms.shape)}")
         a = RarmSampleArgs(batch=b, k=context.shape[1], cond_len=tc, steps=steps, temperature=temperature,
@@ -314,6 +328,7 @@ class Context:
         zr = self.vq_cfg.resolution >> (self.vq_cfg.n_ch_mult - 1)
         if indices.ndim != 2 or indices.shape[1] != zr * zr:
             raise RdmError(f"vq_decode_indices: indices must be [b,{zr * zr}], got {tuple(indices.shape)}")
+        self._check_ids("vq_decode_indices", indices, self.vq_cfg.n_embed, "indices")
         img = torch.empty((indices.shape[0], self.vq_cfg.out_ch, self.vq_cfg.resolution, self.vq_cfg.resolution), device=self.device, dtype=torch.float32)
         self._check(lib.rdm_vq_decode_indices(self._h, _ptr(indices), indices.shape[0], _ptr(img)))
         return img
@@ -499,6 +514,26 @@ class Context:
         for k in (kinds or ()):
             mask |= 1 << int(k)
         self._check(lib.rdm_prof_enable(self._h, mask))
+
+    # ---- RCCL through the C ABI (include/rdm_hip.h "multi-GPU"); the package's own multi-GPU path uses torch.distributed
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._check(lib.rdm_comm_unique_id(self._h, buf))
+        return buf.raw
+
+    def comm_init(self, uid: bytes, rank: int, world: int):
+        if len(uid) != 128:
+            raise RdmError(f"comm_init: the unique id is 128 bytes, got {len(uid)}")
+        self._check(lib.rdm_comm_init(self._h, C.create_string_buffer(uid, 128), int(rank), int(world)))
+
+    def comm_all_gather(self, local: torch.Tensor, world: int) -> torch.Tensor:
+        local = local.contiguous()
+        out = torch.empty((world,) + tuple(local.shape), device=self.device, dtype=local.dtype)
+        self._check(lib.rdm_comm_all_gather(self._h, _ptr(local), _ptr(out), local.numel() * local.element_size()))
+        return out
+
+    def comm_destroy(self):
+        self._check(lib.rdm_comm_destroy(self._h))
 
     def prof_reset(self):
         self._check(lib.rdm_prof_reset(self._h))

@@ -876,7 +876,14 @@ static const char* search_impl(KnnDb& db, const float* q, int b, int k, uint32_t
             knn_prep_queries_kernel<<<groups * 128, 64, 0, st>>>(q + (size_t)q0 * db.dim, bq, db.dim, qn, qh, ql);
             KNN_TRY(hipGetLastError());
             BulkParams bp{}; bp.groups = groups;
-            static const int bdbg = getenv("RDM_KNN_BULK_DBG") ? atoi(getenv("RDM_KNN_BULK_DBG")) : 0; bp.dbg = bdbg;
+            // scan-only ablation (tools/bulk_pmc.sh): compiled in only with -DRDM_DEBUG_ABLATION -- a leaked environment variable must
+            // never make the production search return success with uninitialised neighbours
+#ifdef RDM_DEBUG_ABLATION
+            static const int bdbg = getenv("RDM_KNN_BULK_DBG") ? atoi(getenv("RDM_KNN_BULK_DBG")) : 0;
+#else
+            constexpr int bdbg = 0;
+#endif
+            bp.dbg = bdbg;
             bp.s.dbn = (const _Float16*)db.dbn; bp.s.n = db.n; bp.s.dim = db.dim; bp.s.ntiles = ntiles; bp.s.qh = qh; bp.s.ql = ql;
             bp.s.cand_s = cs; bp.s.cand_i = ci; bp.s.zero_page = zero_page;
             int walkers = bgrid / groups; if ((long long)walkers > ntiles) walkers = (int)ntiles;

@@ -12,6 +12,7 @@
 // SiLU), no materialised skip-concat, cross-attention K/V and all 22 emb_layers projections batched
 // into one GEMM each, K/V of the retrieved neighbours computed once per sample() call instead of
 // once per step per layer.
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -432,6 +433,8 @@ struct rdm_ctx {
         wfrag[key] = d;
         return d;
     }
+    // RCCL communicator (rdm_comm_*): library handle from dlopen, function table, communicator
+    void* rccl_lib = nullptr; void* comm = nullptr; int comm_world = 0;
     // optional per-launch HIP-event profiler for the GEMM-class kernels (bench.py roofline)
     unsigned prof = 0;           // bit k set: record HIP events around launches of kind k (RDM_PROF_* in rdm_hip.h)
     struct ProfRec { hipEvent_t a, b; int kind; double flops; };
@@ -979,6 +982,7 @@ int rdm_ctx_create(int device_id, rdm_ctx** out) {
 
 void rdm_ctx_destroy(rdm_ctx* c) {
     if (!c) return;
+    if (c->comm) rdm_comm_destroy(c);
     DevGuard guard(c->device);
     hipDeviceSynchronize();
     void* ptrs[] = {c->zero_page, c->unet.blob, c->unet.arena.base, c->unet.kv_cache, c->vq.blob, c->vq.arena.base,
@@ -1424,6 +1428,67 @@ int rdm_db_gather(rdm_ctx* c, const uint32_t* idx, long long n_idx, float* out) 
 }
 
 // ---- profiler
+// ------------------------------------------------------------------------------------ RCCL wrappers (include/rdm_hip.h, multi-GPU)
+// RCCL is resolved at run time: the ABI types are spelled out here (ncclUniqueId = 128 bytes, ncclComm_t = pointer, ncclInt8 = 0)
+namespace {
+struct RcclId { char b[128]; };
+typedef int (*fn_get_id)(RcclId*);
+typedef int (*fn_init_rank)(void**, int, RcclId, int);
+typedef int (*fn_all_gather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*fn_destroy)(void*);
+typedef const char* (*fn_errstr)(int);
+struct RcclFns { fn_get_id get_id; fn_init_rank init_rank; fn_all_gather all_gather; fn_destroy destroy; fn_errstr errstr; };
+int rccl_load(rdm_ctx* c, RcclFns& f) {
+    if (!c->rccl_lib) {
+        c->rccl_lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!c->rccl_lib) c->rccl_lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!c->rccl_lib) return c->fail(-5, "rdm_comm: cannot load librccl.so (%s)", dlerror());
+    }
+    f.get_id = (fn_get_id)dlsym(c->rccl_lib, "ncclGetUniqueId"); f.init_rank = (fn_init_rank)dlsym(c->rccl_lib, "ncclCommInitRank");
+    f.all_gather = (fn_all_gather)dlsym(c->rccl_lib, "ncclAllGather"); f.destroy = (fn_destroy)dlsym(c->rccl_lib, "ncclCommDestroy");
+    f.errstr = (fn_errstr)dlsym(c->rccl_lib, "ncclGetErrorString");
+    if (!f.get_id || !f.init_rank || !f.all_gather || !f.destroy) return c->fail(-5, "rdm_comm: librccl.so lacks the expected entry points");
+    return 0;
+}
+}  // namespace
+int rdm_comm_unique_id(rdm_ctx* c, void* id128) {
+    RDM_ENTER(c);
+    if (!id128) return c->fail(-1, "rdm_comm_unique_id: null id buffer");
+    RcclFns f{}; RDM_TRY(rccl_load(c, f));
+    RcclId id; const int r = f.get_id(&id);
+    if (r != 0) return c->fail(-5, "ncclGetUniqueId failed: %s", f.errstr ? f.errstr(r) : "?");
+    memcpy(id128, id.b, 128);
+    return 0;
+}
+int rdm_comm_init(rdm_ctx* c, const void* id128, int rank, int world) {
+    RDM_ENTER(c);
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return c->fail(-1, "rdm_comm_init: bad arguments (rank %d of %d)", rank, world);
+    if (c->comm) return c->fail(-1, "rdm_comm_init: communicator already initialised (rdm_comm_destroy first)");
+    RcclFns f{}; RDM_TRY(rccl_load(c, f));
+    RcclId id; memcpy(id.b, id128, 128);
+    void* comm = nullptr; const int r = f.init_rank(&comm, world, id, rank);
+    if (r != 0) return c->fail(-5, "ncclCommInitRank failed: %s", f.errstr ? f.errstr(r) : "?");
+    c->comm = comm; c->comm_world = world;
+    return 0;
+}
+int rdm_comm_all_gather(rdm_ctx* c, const void* send, void* recv, size_t nbytes) {
+    RDM_ENTER(c);
+    if (!c->comm) return c->fail(-1, "rdm_comm_all_gather: no communicator (rdm_comm_init)");
+    if (!send || !recv) return c->fail(-1, "rdm_comm_all_gather: null buffer");
+    RcclFns f{}; RDM_TRY(rccl_load(c, f));
+    const int r = f.all_gather(send, recv, nbytes, /*ncclInt8*/ 0, c->comm, c->stream);
+    if (r != 0) return c->fail(-5, "ncclAllGather failed: %s", f.errstr ? f.errstr(r) : "?");
+    return 0;
+}
+int rdm_comm_destroy(rdm_ctx* c) {
+    RDM_ENTER(c);
+    if (!c->comm) return 0;
+    RcclFns f{}; RDM_TRY(rccl_load(c, f));
+    RDM_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    f.destroy(c->comm); c->comm = nullptr; c->comm_world = 0;
+    return 0;
+}
+
 int rdm_prof_enable(rdm_ctx* c, int kind_mask) {
     if (!c) return -1;
     c->prof = (unsigned)kind_mask;

@@ -381,6 +381,11 @@ class MinimalRETRODiffusion(object):
                 qids = np.random.choice(nn_mem, size=N, p=ps)
             else:
                 qids = np.random.choice(len(self.retriever.data_pool['embedding']), size=N)
+            if getattr(self, "distributed", False):
+                # drawn from numpy's PROCESS-local generator: without a seed every rank would draw different pseudo-queries, and a
+                # row-sharded search would merge the top-k lists of different queries row by row -- rank 0's draw is everyone's
+                from rdm_amd import parallel
+                qids = parallel.broadcast_int_array(qids, src=0, device=self.device)
         else:
             assert qids.shape[0] == N
         return qids
@@ -398,7 +403,7 @@ class MinimalRETRODiffusion(object):
             self.train_searcher()
         if k_nn is None:
             k_nn = self.k_nn
-        qids = self.get_qids(memsize, N, qids=qids, use_weights=use_weights, verbose=verbose)   # numpy global RNG: same draw on every rank
+        qids = self.get_qids(memsize, N, qids=qids, use_weights=use_weights, verbose=verbose)   # rank 0's draw on every rank (get_qids)
         lo, hi = self._shard(N) if self.distributed else (0, N)
         shard_db = self.distributed and getattr(self, "shard_db", False) and nn_embeddings is None
         if self.distributed:

@@ -63,6 +63,44 @@ def shared_seed(device="cpu", group=None) -> int:
     return int(s.item())
 
 
+def broadcast_int_array(arr, src: int = 0, device="cpu", group=None):
+    """numpy integer array -> rank `src`'s copy on every rank (same shape everywhere).  Used for anything drawn from a PROCESS-local
+    generator that all ranks must agree on (pseudo-query ids from numpy's global RNG: without a seed every rank draws differently)."""
+    import numpy as np
+    a = np.asarray(arr)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return a
+    t = torch.from_numpy(a.astype(np.int64)).to(device)
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        t = t.cpu()
+    dist.broadcast(t, src=src, group=group)
+    return t.cpu().numpy().astype(a.dtype)
+
+
+def profiler_attached() -> bool:
+    """True when a profiler / preloaded tool (rocprofv3, LD_PRELOAD) has very likely initialised the GPU before main():
+    starting another program from here would be the exec-after-GPU-init that takes the node down on this pool."""
+    import os
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return True
+    pre = os.environ.get("LD_PRELOAD", "")
+    return any(t in pre for t in ("rocprof", "roctracer", "rocp", "rocm-sdk"))
+
+
+def safe_self_launch(script: str, gpus: int, argv, master_port: str = None) -> int:
+    """One process per GPU through torch.distributed.run, started as a CHILD before anything in this process touches the GPU.
+    Refused under a profiler (profile the per-rank process under torchrun instead).  Returns the child's exit code."""
+    import os, subprocess, sys
+    if profiler_attached():
+        sys.stderr.write("refusing to self-launch torch.distributed.run under a profiler / LD_PRELOAD tool: the preloaded library has "
+                         "initialised the GPU, and starting another program from this process is not allowed on this pool.\n"
+                         "Profile one rank instead:  python -m torch.distributed.run ... rocprofv3 ... -- python3 <script> ...\n")
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", master_port or os.environ.get("MASTER_PORT", "29541"), os.path.abspath(script)] + list(argv)
+    return subprocess.call(cmd)
+
+
 def per_sample_noise(seed: int, global_indices, shape, device="cpu", dtype=torch.float32):
     """Noise for each global sample index from its own generator (created ON `device`, so a GPU rank draws with the device's
     Philox stream and nothing crosses PCIe): a function of (seed, global index) only, hence invariant to the sharding."""

@@ -224,10 +224,12 @@ def main(argv=None):
     opt = parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if opt.gpus > 1 and world == 1:
-        # one process per GPU; launched BEFORE anything in this process touches the GPU (no torch import so far)
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={opt.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", os.environ.get("MASTER_PORT", "29541"), os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else list(argv))
-        sys.exit(subprocess.call(cmd))
+        # one process per GPU; launched BEFORE anything in this process touches the GPU (importing the package / torch does not);
+        # refused under a profiler, where the preloaded tool already has (rdm_amd.parallel.safe_self_launch)
+        sys.path.insert(0, ROOT)
+        import rdm_amd  # noqa: F401
+        from rdm_amd import parallel
+        sys.exit(parallel.safe_self_launch(__file__, opt.gpus, sys.argv[1:] if argv is None else list(argv)))
     sys.path.insert(0, ROOT)
     opt.savepath.mkdir(parents=True, exist_ok=True)
     is_writer = True

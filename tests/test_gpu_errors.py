@@ -125,3 +125,17 @@ def test_no_device_memory_growth_across_calls_and_contexts():
         ctx.close(); del ctx, x, c, uc
         torch.cuda.empty_cache()
     assert abs(levels[0] - levels[2]) < (4 << 20), f"a closed context leaves device memory behind: {levels}"
+
+
+def test_token_and_code_ids_out_of_range_are_refused(fresh):
+    """nn.Embedding (RetrievalPatchTransformer.proj_in) and taming's get_codebook_entry raise on an id outside the table; the
+    kernels would read row 0 instead: the binding checks the range (advisor finding, round 2)."""
+    from rdm_amd import _lib, packing
+    d = fresh.device
+    rs = orarm.RarmSpec(vocab_in=514, vocab_out=512, n_heads=2, d_head=64, depth=2, context_dim=512, sequence_length=64)
+    rcfg = _lib.make_rarm_cfg(in_channels=514, out_channels=512, n_heads=2, d_head=64, depth=2, context_dim=512, sequence_length=64)
+    fresh.load_rarm(rcfg, packing.pack("rarm", rcfg, ounet.synth_state_dict(orarm.rarm_param_shapes(rs), seed=7)))
+    ctx2 = torch.zeros(2, 2, 512, device=d)
+    assert "[0, 514)" in _err(lambda: fresh.rarm_forward(torch.full((2, 3), 514, dtype=torch.long, device=d), ctx2))
+    assert "[0, 514)" in _err(lambda: fresh.rarm_sample(torch.full((2, 1), -1, dtype=torch.long, device=d), ctx2, 4, torch.rand(4, 2, device=d), top_k=8))
+    fresh.rarm_forward(torch.full((2, 3), 513, dtype=torch.long, device=d), ctx2)          # the last valid id passes

@@ -28,7 +28,7 @@ pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
 # per-step growth bound of the free-running DDIM trajectory: the state error after loop iteration i (0-based) must stay
-# below DDIM_E0 * (1 + DDIM_G)^i.  Measured (profiles/r02_parity.md): 2.1e-3 after the first step, 3.8e-3 from iteration 10 to
+# below DDIM_E0 * (1 + DDIM_G)^i.  Measured: 2.1e-3 after the first step, 3.8e-3 from iteration 10 to
 # the final latent -- the error of 100 chained bf16 forwards does not accumulate (each step's eps error enters x scaled by
 # its DDIM coefficient, and later steps at low t contribute ~1e-5) -- so the bound is flat at ~2.5x the measured value.
 DDIM_E0, DDIM_G = 1.0e-2, 0.0

@@ -638,3 +638,24 @@ def test_sample_with_query_image_and_caption_queries(model, ctx):
     # omit_query / n_reps / normalize switches (ddpm.py:762-777)
     e = model.sample_with_query(query=torch.from_numpy(emb), query_embedded=True, omit_query=True, normalize=True, n_reps=2, **kw)["query_samples"]
     assert e.shape == (2, 3, 64, 64) and bool(torch.isfinite(e).all())
+
+
+def test_c_abi_rccl_wrappers_single_rank():
+    """include/rdm_hip.h rdm_comm_*: the RCCL all-gather behind the C ABI.  A one-GPU box can only form a world of
+    one (RCCL refuses two ranks on one device): the wrappers load RCCL, create the communicator on the context's device and
+    stream, and the gather of a single rank is the identity.  N > 1 over xGMI is UNMEASURED here (the driver's multi-GPU run)."""
+    from rdm_amd import _lib
+    ctx = _lib.Context(0); d = ctx.device
+    uid = ctx.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    ctx.comm_init(uid, 0, 1)
+    x = torch.randn(3, 5, 7, device=d)
+    y = ctx.comm_all_gather(x, 1)
+    torch.cuda.synchronize()
+    assert y.shape == (1, 3, 5, 7) and torch.equal(y[0], x)
+    with pytest.raises(_lib.RdmError):
+        ctx.comm_init(uid, 0, 1)                           # already initialised
+    ctx.comm_destroy()
+    with pytest.raises(_lib.RdmError):
+        ctx.comm_all_gather(x, 1)                          # no communicator
+    ctx.close()

@@ -277,6 +277,39 @@ def test_batch_sharding_world2_gloo(n_total):
         assert np.array_equal(a, b)                               # sharding is bit-invariant
 
 
+def _worker_unseeded(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from rdm_amd import parallel
+    parallel.init_distributed("gloo")
+    m = _dist_model()
+    np.random.seed(100 + rank); torch.manual_seed(7 + rank)          # what an un-seeded run looks like: every process has its own streams
+    qids = m.get_qids(50, 6)
+    out = m.sample_from_rdata(6, k_nn=4, memsize=50, unconditional_guidance_scale=2.0, unconditional_retro_guidance_label=0.,
+                              ddim=True, ddim_steps=10)["samples_with_sampled_nns"].numpy()
+    q.put((rank, np.asarray(qids), out))
+    parallel.shutdown()
+
+
+def test_unseeded_ranks_share_rank0_pseudo_queries():
+    """Advisor finding (round 2): pseudo-query ids come from numpy's process-local generator; without a seed every rank drew its own,
+    and a row-sharded search merged the top-k lists of DIFFERENT queries.  get_qids now broadcasts rank 0's draw: both ranks hold the
+    same ids and the sharded result equals the 1-rank run that uses rank 0's streams."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_unseeded, args=(r, 2, 29677, q)) for r in range(2)]
+    for p in procs: p.start()
+    got = dict((r, (a, b)) for r, a, b in (q.get(timeout=180), q.get(timeout=180)))
+    for p in procs: p.join(timeout=60)
+    assert np.array_equal(got[0][0], got[1][0])
+    assert np.array_equal(got[0][1], got[1][1])
+    m = _dist_model()
+    np.random.seed(100); torch.manual_seed(7)
+    qids = m.get_qids(50, 6)
+    ref = m.sample_from_rdata(6, k_nn=4, memsize=50, unconditional_guidance_scale=2.0, unconditional_retro_guidance_label=0.,
+                              ddim=True, ddim_steps=10)["samples_with_sampled_nns"].numpy()
+    assert np.array_equal(np.asarray(qids), got[0][0]) and np.array_equal(ref, got[0][1])
+
+
 def test_set_distributed_rejects_tiny_batches():
     m = _dist_model()
     m._shard(1)                                                   # world 1: fine
