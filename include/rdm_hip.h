@@ -227,6 +227,11 @@ int rdm_op_linear(rdm_ctx* ctx, const void* a_bf16, const void* w_bf16, const fl
 int rdm_op_conv3x3(rdm_ctx* ctx, const void* x0_bf16, const void* x1_bf16, int C0, int C1, const void* w_bf16,
                    const float* bias, const float* rowvec, int rowvec_ld, const void* residual_bf16, void* out_bf16,
                    int B, int Hin, int Win, int N, int stride, int ups);
+/* the RARM sampler kernel alone (taming top_k_logits + softmax + multinomial as an inverse CDF in vocabulary order, after the
+ * classifier-free combine lu + scale (lc - lu) and the temperature; transformer.py:237-263): logits [dev] f32 [(cfg ? 2 : 1) * b, vocab]
+ * (conditional rows first), uniforms [dev] f32 [b], tokens_out [dev] int64 [b].  top_k <= 0: no filter. */
+int rdm_op_rarm_sampler(rdm_ctx* ctx, const float* logits, int b, int vocab, int cfg, float guidance_scale, float temperature,
+                        int top_k, const float* uniforms, int64_t* tokens_out);
 int rdm_op_groupnorm(rdm_ctx* ctx, const void* x0_bf16, const void* x1_bf16, int C0, int C1, int B, int HW,
                      const float* gamma, const float* beta, float eps, int silu, void* out_bf16);
 int rdm_op_layernorm(rdm_ctx* ctx, const void* x, int in_is_f32, const float* gamma, const float* beta, int M, int C,

@@ -108,6 +108,7 @@ SIGNATURES = {
     "rdm_op_linear": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "rdm_op_conv3x3": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int]),
+    "rdm_op_rarm_sampler": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P]),
     "rdm_op_groupnorm": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_float, C.c_int, _P]),
     "rdm_op_layernorm": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "rdm_op_self_attention": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
@@ -563,6 +564,18 @@ class Context:
         self._check(lib.rdm_op_conv3x3(self._h, _ptr(x0), _ptr(x1), C0, C1, _ptr(w), _ptr(bias), _ptr(rowvec),
                                        0 if rowvec is None else rowvec.shape[1], _ptr(residual), _ptr(out), B, Hin, Win, N,
                                        stride, ups))
+        return out
+
+    def op_rarm_sampler(self, logits, uniforms, guidance_scale=1.0, temperature=1.0, top_k=None):
+        """The sampler kernel alone: logits f32 [(2 if guided else 1) * b, vocab] (conditional rows first), uniforms f32 [b] -> int64 [b]."""
+        logits = self._dev(logits, torch.float32); uniforms = self._dev(uniforms, torch.float32)
+        b = uniforms.shape[0]
+        cfg = guidance_scale > 1.0
+        if logits.ndim != 2 or logits.shape[0] != (2 * b if cfg else b):
+            raise RdmError(f"op_rarm_sampler: logits must be [{2 * b if cfg else b}, vocab], got {tuple(logits.shape)}")
+        out = torch.empty((b,), device=self.device, dtype=torch.int64)
+        self._check(lib.rdm_op_rarm_sampler(self._h, _ptr(logits), b, logits.shape[1], int(cfg), float(guidance_scale), float(temperature),
+                                            int(top_k) if top_k is not None else 0, _ptr(uniforms), _ptr(out)))
         return out
 
     def op_groupnorm(self, x0, gamma, beta, eps, silu, x1=None):

@@ -1555,6 +1555,21 @@ int rdm_op_conv3x3(rdm_ctx* c, const void* x0, const void* x1, int C0, int C1, c
     RDM_CHECK_HIP(c, launch_conv3x3(p, c->stream));
     return 0;
 }
+int rdm_op_rarm_sampler(rdm_ctx* c, const float* logits, int b, int vocab, int cfg, float guidance_scale, float temperature, int top_k,
+                        const float* uniforms, int64_t* tokens_out) {
+    RDM_ENTER(c);
+    if (!logits || !uniforms || !tokens_out || b < 1 || vocab < 1) return c->fail(-1, "rdm_op_rarm_sampler: bad arguments");
+    if (!(temperature > 0.f)) return c->fail(-1, "rdm_op_rarm_sampler: temperature must be positive");
+    RDM_TRY(ensure_bytes(c, &c->samp, &c->samp_bytes, (size_t)b * 8 + 64));
+    int* pos = (int*)c->samp; int* done = pos + 1; long long* next = (long long*)(c->samp + 64);
+    RDM_CHECK_HIP(c, launch_set_int(pos, 0, c->stream));
+    RDM_CHECK_HIP(c, launch_set_int(done, 0, c->stream));
+    RarmSampleParams sp{}; sp.logits = logits; sp.vocab = vocab; sp.B = b; sp.cfg = cfg ? 1 : 0; sp.scale = guidance_scale; sp.temperature = temperature;
+    sp.top_k = top_k > 0 ? top_k : vocab; sp.uniforms = uniforms; sp.pos = pos; sp.pos0 = 0; sp.steps = 1; sp.tokens_out = (long long*)tokens_out;
+    sp.next_tokens = next; sp.done = done;
+    RDM_CHECK_HIP(c, launch_rarm_sample(sp, c->stream));
+    return 0;
+}
 int rdm_op_groupnorm(rdm_ctx* c, const void* x0, const void* x1, int C0, int C1, int B, int HW, const float* gamma,
                      const float* beta, float eps, int silu, void* out) {
     RDM_ENTER(c);

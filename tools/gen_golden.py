@@ -182,6 +182,57 @@ def gen_rarm():
                             logits_last=y_ref[:, -2:].numpy().astype(np.float32), seed=np.int64(777))
 
 
+def gen_rarm_deep():
+    """RARM at the size that is benchmarked (BASELINE config #5: 18 x 768, vocab 16386 -> 16384, k = 8), at DEPTH: the 8-token prefix
+    of rarm_shipped.npz exercises neither the K/V cache beyond position 8 nor the sampler at vocab 16384 / top-k 256.  Stored from
+    the reference's in-tree RetrievalPatchTransformer (rdm/modules/attention.py:199-272), same weights (seed 777):
+      * a full 256-token prefix, one row with random neighbours and one with ZERO neighbours (the unconditional half of a guided
+        batch): logits at positions 0, 31, 127, 255;
+      * a 32-step guided (scale 2.0), temperature 1.0, top-k 256 sampled continuation from <sos> for two rows through the oracle's
+        sampling loop with the REFERENCE class as the transformer (LatentImageRETRO.sample, transformer.py:224-271): all tokens, the
+        guided logits at steps 0, 7, 31, and the RAW conditional / unconditional logits at steps 0 and 31 (what the sampler kernel
+        combines itself)."""
+    from rdm.modules.attention import RetrievalPatchTransformer
+    from oracle import rarm as orarm
+    spec = orarm.shipped_rarm_spec()
+    m = RetrievalPatchTransformer(in_channels=spec.vocab_in, n_heads=spec.n_heads, d_head=spec.d_head, depth=spec.depth,
+                                  context_dim=spec.context_dim, positional_encodings=True, sequence_length=spec.sequence_length,
+                                  out_channels=spec.vocab_out, cross_attend=True, causal=True, continuous=False).eval()
+    shapes = {n: tuple(v.shape) for n, v in m.state_dict().items()}
+    assert shapes == orarm.rarm_param_shapes(spec)
+    sd = ounet.synth_state_dict(shapes, seed=777)
+    m.load_state_dict(sd)
+    rng = np.random.default_rng(4242)
+    L = spec.sequence_length
+    tokens = torch.from_numpy(rng.integers(0, spec.vocab_out, size=(2, L)).astype(np.int64))
+    tokens[:, 0] = spec.vocab_in - 1
+    ctx = torch.from_numpy((rng.standard_normal((2, 8, 512)) * 0.45).astype(np.float32))
+    ctx[1] = 0.0
+    y_ref = m(tokens, context=ctx)
+    check("rarm/deep forward", orarm.rarm_forward(sd, spec, tokens, ctx), y_ref, atol=2e-4, rtol=2e-4)
+    pos = np.array([0, 31, 127, 255])
+    steps = 32
+    sctx = torch.from_numpy((rng.standard_normal((2, 8, 512)) * 0.45).astype(np.float32))
+    u = torch.from_numpy(rng.random((steps, 2)).astype(np.float32))
+    cond = torch.full((2, 1), spec.vocab_in - 1, dtype=torch.long)
+    raw = {}
+
+    def fwd(t_, c_):
+        out = m(t_, context=c_)
+        raw[t_.shape[1] - 1] = out[:, -1].clone()          # [2B, vocab]: conditional rows first, then the zero-neighbour rows
+        return out
+    toks, lg = orarm.rarm_sample(sd, spec, cond, sctx, steps, u, temperature=1.0, top_k=256, guidance_scale=2.0, forward=fwd)
+    toks_o, lg_o = orarm.rarm_sample(sd, spec, cond, sctx, steps, u, temperature=1.0, top_k=256, guidance_scale=2.0)
+    assert torch.equal(toks, toks_o)
+    check("rarm/deep sampled logits", lg_o, lg, atol=3e-4, rtol=3e-4)
+    keep = [0, 7, 31]
+    np.savez_compressed(os.path.join(OUT, "rarm_shipped_deep.npz"), tokens=tokens.numpy(), ctx=ctx.numpy(), positions=pos,
+                        logits_at=y_ref[:, pos].numpy().astype(np.float32), sample_ctx=sctx.numpy(), uniforms=u.numpy(),
+                        sampled=toks.numpy(), guided_steps=np.array(keep), guided_logits=lg[:, keep].numpy().astype(np.float32),
+                        raw_steps=np.array([0, 31]), raw_logits=torch.stack([raw[0], raw[31]]).numpy().astype(np.float32),
+                        seed=np.int64(777), temperature=np.float32(1.0), top_k=np.int64(256), guidance_scale=np.float32(2.0))
+
+
 def gen_script_flags():
     """Flag table of the reference CLI (scripts/rdm_sample.py:22-143), read from its argparse calls with `ast` (the script
     itself cannot be imported: torchvision / clip / omegaconf are absent).  Stored as data: option strings, type name,
@@ -206,6 +257,8 @@ def gen_script_flags():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--rarm-deep" in sys.argv:                  # only the deep RARM fixture (~2 min of CPU)
+        gen_rarm_deep(); sys.exit(0)
     gen_script_flags()
     gen_rarm()
     gen_attention()
@@ -214,4 +267,5 @@ if __name__ == "__main__":
     gen_tokenizer()
     if "--full" in sys.argv:
         gen_unet("shipped", ounet.shipped_spec(), B=1, k=4, hw=64, seed=1234)
+        gen_rarm_deep()
     print("golden fixtures written to", OUT)
