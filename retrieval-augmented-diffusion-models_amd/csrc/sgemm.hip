@@ -7,6 +7,8 @@
 // (32x32x16 bf16, fp32), every lane issues all of its 16-byte operand loads for a K quarter up front, and the four partial tiles
 // meet in LDS for a fused bias / activation / residual epilogue.  GEGLU: the packed weight rows interleave 32 x-rows with their
 // 32 gate rows (packing._geglu_perm), so a block owns a 64-row strip and emits x * gelu(gate) for 32 outputs.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 template <int MF, int NF, int U>   // MF: 32-row blocks of M (1..4); NF: 1 plain, 2 GEGLU (x strip + gate strip); U: k-steps of 32 per batch of loads
@@ -19,6 +21,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q4 = lane >> 4;
     const int n0 = blockIdx.x * 32 * NF;                  // first weight row of this block's strip
+    const int mb0 = blockIdx.y * 32 * MF;                 // first of this block's rows (grid.y row blocks: more, lighter blocks -- a launch is
+                                                          // as long as ONE block's dependent operand fetch, and 24 blocks left 232 CUs idle)
     const int kq = p.K >> 2, k0 = wave * kq;              // this wave's K quarter
     constexpr int MA = 2 * MF, NB = 2 * NF;               // 16-row fragments of M, 16-column fragments of the strip(s)
     const bf16_t* wp[NB];
@@ -26,7 +30,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
     for (int j = 0; j < NB; j++) wp[j] = p.W + (long long)(n0 + j * 16 + r16) * p.K + k0 + q4 * 8;
     const bf16_t* ap[MA];
 #pragma unroll
-    for (int i = 0; i < MA; i++) { int m = i * 16 + r16; if (m >= p.M) m = p.M - 1; ap[i] = p.A + (long long)m * p.lda + k0 + q4 * 8; }
+    for (int i = 0; i < MA; i++) { int m = mb0 + i * 16 + r16; if (m >= p.M) m = p.M - 1; ap[i] = p.A + (long long)m * p.lda + k0 + q4 * 8; }
     f32x4 acc[MA][NB];
 #pragma unroll
     for (int i = 0; i < MA; i++)
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
 #pragma unroll
     for (int it = 0; it < IT; it++) {
         const int e = tid + it * 256;
-        const int i = e >> 10, row = (e >> 5) & 31, col = e & 31, m = i * 32 + row;
+        const int i = e >> 10, row = (e >> 5) & 31, col = e & 31, m = mb0 + i * 32 + row;
         ok_[it] = m < p.M;
         oi_[it] = (long long)m * p.ldo + ncol0 + col;
         float r = 0.f;
@@ -125,12 +129,14 @@ static hipError_t launch_one(const SgemmParams& p, int grid, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr = true;
     }
-    sgemm_kernel<MF, NF, U><<<grid, 256, sm, st>>>(p);
+    sgemm_kernel<MF, NF, U><<<dim3(grid, (p.M + 32 * MF - 1) / (32 * MF)), 256, sm, st>>>(p);
     return hipGetLastError();
 }
 template <int NF>
 static hipError_t launch_nf(const SgemmParams& p, int grid, hipStream_t st) {
-    const int mf = (p.M + 31) / 32;
+    // rows per block: all of them (<= 128) when the column strips alone fill the chip, else 32-row blocks (grid.y = ceil(M / 32))
+    static const int rowsplit = getenv("RDM_SGEMM_ROWSPLIT") ? atoi(getenv("RDM_SGEMM_ROWSPLIT")) : 1;
+    const int mf = (rowsplit && grid < 256) ? 1 : (p.M + 31) / 32;
     const bool deep = ((p.K >> 2) % 192) == 0;            // K quarter is a multiple of 6 k-steps of 32 (K = 768, 1536, 3072 ...)
     switch (mf) {
         case 1: return deep ? launch_one<1, NF, 6>(p, grid, st) : launch_one<1, NF, 2>(p, grid, st);

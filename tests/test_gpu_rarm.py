@@ -201,13 +201,13 @@ def test_latent_image_retro_surface(ctx):
     retrieval, 64 sampled tokens (8x8 code grid of the tiny first stage), decode; seeded runs repeat."""
     from rdm_amd.data.retrieval_dataset.dsetbuilder import DatasetBuilder
     from rdm_amd.models.autoregression.transformer import LatentImageRETRO
-    spec = orarm.RarmSpec(vocab_in=1002, vocab_out=1000, n_heads=2, d_head=64, depth=2, context_dim=512, sequence_length=64)
+    spec = orarm.RarmSpec(vocab_in=514, vocab_out=512, n_heads=2, d_head=64, depth=2, context_dim=512, sequence_length=64)
     vspec = ovq.tiny_vqgan_spec()                      # 32x32 image, 8x8 code grid, attention at the 8x8 level
     tcfg = {"params": dict(in_channels=spec.vocab_in, out_channels=spec.vocab_out, n_heads=spec.n_heads, d_head=64, depth=spec.depth,
                            context_dim=512, sequence_length=spec.sequence_length, continuous=False, causal=True)}
     fcfg = {"params": {"embed_dim": 64, "n_embed": 512, "ddconfig": {"z_channels": 64, "ch": 64, "ch_mult": vspec.ch_mult, "num_res_blocks": 1,
                                                                    "resolution": 32, "attn_resolutions": vspec.attn_resolutions}}}
-    m = LatentImageRETRO(tcfg, fcfg, mask_token=1000, sos_token=1001, nn_memory=np.arange(500), k_nn=4, ctx=ctx)
+    m = LatentImageRETRO(tcfg, fcfg, mask_token=512, sos_token=513, nn_memory=np.arange(500), k_nn=4, ctx=ctx)
     m.load_transformer_state_dict(ounet.synth_state_dict(orarm.rarm_param_shapes(spec), seed=777))
     m.load_first_stage_state_dict(ounet.synth_state_dict(ovq.vq_param_shapes(vspec), seed=888))
     rng = np.random.default_rng(21)
