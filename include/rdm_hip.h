@@ -99,6 +99,13 @@ void rdm_ctx_destroy(rdm_ctx* ctx);
 const char* rdm_last_error(rdm_ctx* ctx);
 int rdm_set_stream(rdm_ctx* ctx, void* hip_stream);
 const char* rdm_version(void);
+/* Batch-invariant ("deterministic") execution: every kernel-selection decision of the library (skinny vs tiled GEMM, halo vs generic
+ * 3x3 conv, conv split-K, the zero-context shortcut) becomes a function of the per-sample layer shape only, so a sample's result is
+ * bitwise independent of the batch it is computed in and of the number of ranks the batch is sharded over (the reference gives no such
+ * guarantee either way: cuDNN picks algorithms per shape).  Default off (env RDM_DETERMINISTIC=1 turns it on for new contexts); the
+ * speed cost is stated in DESIGN.md. */
+int rdm_set_deterministic(rdm_ctx* ctx, int on);
+int rdm_get_deterministic(rdm_ctx* ctx);
 
 /* ---- weights --------------------------------------------------------------------------------
  * The library defines the packed-blob layout; rdm_*_manifest writes it as text, one line per entry:

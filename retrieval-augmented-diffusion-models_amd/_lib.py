@@ -98,6 +98,8 @@ SIGNATURES = {
     "rdm_knn_f64": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "rdm_knn_last_fallback": (C.c_int, [_P]),
     "rdm_db_gather": (C.c_int, [_P, _P, C.c_longlong, _P]),
+    "rdm_set_deterministic": (C.c_int, [_P, C.c_int]),
+    "rdm_get_deterministic": (C.c_int, [_P]),
     "rdm_prof_enable": (C.c_int, [_P, C.c_int]),
     "rdm_prof_collect": (C.c_int, [_P, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rdm_prof_reset": (C.c_int, [_P]),
@@ -515,6 +517,14 @@ class Context:
         for k in (kinds or ()):
             mask |= 1 << int(k)
         self._check(lib.rdm_prof_enable(self._h, mask))
+
+    def set_deterministic(self, on: bool = True):
+        """Batch-invariant execution (include/rdm_hip.h rdm_set_deterministic): bitwise the same row whatever batch / rank count."""
+        self._check(lib.rdm_set_deterministic(self._h, int(bool(on))))
+
+    @property
+    def deterministic(self) -> bool:
+        return lib.rdm_get_deterministic(self._h) == 1
 
     # ---- RCCL through the C ABI (include/rdm_hip.h "multi-GPU"); the package's own multi-GPU path uses torch.distributed
     def comm_unique_id(self) -> bytes:

@@ -433,6 +433,10 @@ struct rdm_ctx {
         wfrag[key] = d;
         return d;
     }
+    // batch-invariant execution (rdm_set_deterministic / env RDM_DETERMINISTIC): every kernel-selection decision (skinny vs tiled GEMM,
+    // halo vs generic conv, conv split-K, the zero-context shortcut) is a function of the PER-SAMPLE layer shape only, so a row's
+    // result is bitwise independent of the batch it sits in and of the number of ranks the batch is sharded over
+    bool deterministic = getenv("RDM_DETERMINISTIC") ? atoi(getenv("RDM_DETERMINISTIC")) != 0 : false;
     // RCCL communicator (rdm_comm_*): library handle from dlopen, function table, communicator
     void* rccl_lib = nullptr; void* comm = nullptr; int comm_world = 0;
     // optional per-launch HIP-event profiler for the GEMM-class kernels (bench.py roofline)
@@ -472,7 +476,10 @@ struct Ops {
     void linear(const bf16_t* A0, const bf16_t* A1, int C0, int C1, size_t woff, size_t boff, bool has_bias, int M, int N,
                 int act, const bf16_t* res, bf16_t* out, float* out_f32 = nullptr, const float* res_f32 = nullptr) {
         if (plan) return;
-        if (M <= 128 && !A1 && C1 == 0) {       // decode-sized batch: weight-streaming kernel with N/32 blocks (sgemm.hip)
+        // skinny (weight-streaming) kernel for decode-sized operands.  Fast mode: whenever M <= 128.  Deterministic mode: exactly for
+        // the ops with ONE row per sample (`single_row`: time embedding, RARM decode step, CLIP projection), at any batch
+        const bool skinny = c->deterministic ? single_row : (M <= 128);
+        if (skinny && !A1 && C1 == 0) {         // N/32 x ceil(M/32) blocks (sgemm.hip)
             SgemmParams q{}; q.A = A0; q.lda = C0; q.W = w<bf16_t>(woff); q.M = M; q.N = N; q.K = C0; q.bias = has_bias ? w<float>(boff) : nullptr;
             q.act = act; q.res_f32 = res_f32; q.res_bf16 = res; q.out_f32 = out_f32; q.out_bf16 = out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
             if (sgemm_supported(q)) {
@@ -498,13 +505,18 @@ struct Ops {
         p.A0 = A0; p.A1 = A1; p.C0 = C0; p.C1 = C1; p.W = w<bf16_t>(woff); p.bias = w<float>(boff);
         p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.stride = stride; p.ups = ups;
         p.rowvec = rowvec; p.rowvec_ld = rowvec_ld; p.rows_per_sample = Hout * Wout; p.res_bf16 = res; p.out_bf16 = out;
-        const int ks = conv_halo_ksplit(p);
+        // deterministic mode: the halo kernels need whole 256-pixel tiles, which at < 256 pixels per sample exist only for batches
+        // that are multiples of 256 / HW -- there the generic implicit GEMM (another summation order) runs for EVERY batch; and no
+        // split-K (its factor follows the tile count, i.e. the batch)
+        const bool det_generic = c->deterministic && ((Hout * Wout) % 256 != 0);
+        const int ks = c->deterministic ? 1 : conv_halo_ksplit(p);
         if (ks > 1 && ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)ks * p.M * N * 4) == 0) { p.ksplit = ks; p.ws = (float*)c->splitk_ws; }
-        if (conv_halo_supported(p)) p.Wfrag = c->frag_for(p.W, N, C0 + C1);
+        if (!det_generic && conv_halo_supported(p)) p.Wfrag = c->frag_for(p.W, N, C0 + C1);
         prof_begin(RDM_PROF_CONV3X3, 2.0 * p.M * N * (double)p.K);
-        check(launch_conv3x3(p, c->stream), "conv3x3");
+        check(det_generic ? launch_igemm(p, true, 1, c->stream) : launch_conv3x3(p, c->stream), "conv3x3");
         prof_end();
     }
+    bool single_row = false;     // set by callers around ops whose operand has one row per sample (see linear)
     bool prof_open = false;
     void prof_begin(int kind, double work) {       // work: FLOPs (GEMM-class kinds) or bytes (bandwidth-class kinds)
         prof_open = (c->prof >> kind) & 1u;
@@ -596,11 +608,13 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
     bf16_t* temb = o.abf((size_t)B * mc);
     if (!o.plan) o.check(launch_timestep_embedding(t, temb, B, mcl, mc, o.c->stream), "timestep_embedding");
     bf16_t* e1 = o.abf((size_t)B * ted);
+    o.single_row = true;                                  // one row per sample (see Ops::linear)
     o.linear(temb, nullptr, mc, 0, u.te0w, u.te0b, true, B, ted, ACT_SILU, nullptr, e1);
     bf16_t* semb = o.abf((size_t)B * ted);
     o.linear(e1, nullptr, ted, 0, u.te2w, u.te2b, true, B, ted, ACT_SILU, nullptr, semb);
     float* emb_all = o.af32((size_t)B * u.emb_total);     // all 22 emb_layers in one GEMM
     o.linear(semb, nullptr, ted, 0, u.embw, u.embb, true, B, u.emb_total, ACT_NONE, nullptr, nullptr, emb_all);
+    o.single_row = false;
 
     struct Act { bf16_t* p; int C, H, W, L; };          // C: padded channels (row stride), L: logical channels
     std::vector<Act> hs;
@@ -933,7 +947,9 @@ static void clip_text_body(Ops& o, ClipModel& m, const long long* tokens, int B,
     float* eot = o.af32((size_t)B * Wd); bf16_t* ln = o.abf((size_t)B * Wd);
     if (!o.plan) o.check(launch_clip_gather_eot(tokens, x, eot, B, L, Wd, o.c->stream), "gather eot");
     o.layernorm(eot, 1, m.lnfg, m.lnfb, ln, 0, B, Wd);
+    o.single_row = true;                                  // the pooled token: one row per sample
     o.linear(ln, nullptr, Wd, 0, m.tproj, 0, false, B, c.embed_dim, ACT_NONE, nullptr, nullptr, out);
+    o.single_row = false;
 }
 // raw_h > 0: `img` is the un-preprocessed [B,3,raw_h,raw_w] image in [-1,1]; the bicubic resize + normalisation of
 // ClipImageRetriever.preprocess (rdm/modules/retrievers.py:83-91) is fused into the patch gather
@@ -953,7 +969,9 @@ static void clip_image_body(Ops& o, ClipModel& m, const float* img, int B, float
     float* cls = o.af32((size_t)B * Wd); bf16_t* ln = o.abf((size_t)B * Wd);
     if (!o.plan) o.check(launch_gather_rows_f32(x, cls, B, L, Wd, o.c->stream), "gather cls");
     o.layernorm(cls, 1, m.lnpostg, m.lnpostb, ln, 0, B, Wd);
+    o.single_row = true;                                  // the pooled token: one row per sample
     o.linear(ln, nullptr, Wd, 0, m.vproj, 0, false, B, c.embed_dim, ACT_NONE, nullptr, nullptr, out);
+    o.single_row = false;
 }
 
 // ==================================================================================== C ABI
@@ -995,6 +1013,8 @@ void rdm_ctx_destroy(rdm_ctx* c) {
 }
 
 const char* rdm_last_error(rdm_ctx* c) { return c ? c->err : "null context"; }
+int rdm_set_deterministic(rdm_ctx* c, int on) { if (!c) return -1; c->deterministic = on != 0; return 0; }
+int rdm_get_deterministic(rdm_ctx* c) { return c ? (c->deterministic ? 1 : 0) : -1; }
 int rdm_set_stream(rdm_ctx* c, void* s) { if (!c) return -1; c->stream = (hipStream_t)s; return 0; }
 
 long long rdm_unet_manifest(const rdm_unet_cfg* cfg, char* buf, size_t buflen, size_t* blob_bytes) {
@@ -1103,7 +1123,7 @@ static int prepare_kv(rdm_ctx* c, const float* cond, const float* uncond, int B,
         RDM_CHECK_HIP(c, hipStreamSynchronize(c->stream));
         int rows = nb;
         while (rows > 0 && flags[rows - 1] == 0) rows--;
-        if (!off) u.ctx_rows = rows;
+        if (!off && !c->deterministic) u.ctx_rows = rows;     // (which rows are "trailing" depends on the batch)
     }
     return run_with_arena(c, u.arena, u.blob, [&](Ops& o) {
         unet_compute_kv(o, u, cat, nb, k, u.kv_cache);
@@ -1294,6 +1314,7 @@ static int rarm_step(rdm_ctx* c, int B2, int k) {
     RarmModel& m = c->rarm; const rdm_rarm_cfg& g = m.cfg; const int C = m.C, L = g.sequence_length;
     RarmState st = rarm_state(m, B2);
     return run_with_arena(c, m.arena, m.blob, [&](Ops& o) {
+        o.single_row = true;                              // a decode step is one row per sequence throughout
         float* x = o.af32((size_t)B2 * C);
         bf16_t* ln = o.abf((size_t)B2 * C); bf16_t* qkv = o.abf((size_t)B2 * 3 * C); bf16_t* ao = o.abf((size_t)B2 * C);
         bf16_t* q2 = o.abf((size_t)B2 * C); bf16_t* ff = o.abf((size_t)B2 * 4 * C);
@@ -1543,7 +1564,9 @@ int rdm_op_conv3x3(rdm_ctx* c, const void* x0, const void* x1, int C0, int C1, c
     p.A0 = (const bf16_t*)x0; p.A1 = (const bf16_t*)x1; p.C0 = C0; p.C1 = C1; p.W = (const bf16_t*)w; p.bias = bias;
     p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.stride = stride; p.ups = ups;
     p.rowvec = rowvec; p.rowvec_ld = rowvec_ld; p.rows_per_sample = Hout * Wout; p.res_bf16 = (const bf16_t*)res; p.out_bf16 = (bf16_t*)out;
-    const int ks = conv_halo_ksplit(p);
+    const bool det_generic = c->deterministic && ((Hout * Wout) % 256 != 0);
+    if (det_generic) { RDM_CHECK_HIP(c, launch_igemm(p, true, 1, c->stream)); return 0; }
+    const int ks = c->deterministic ? 1 : conv_halo_ksplit(p);
     if (ks > 1) { RDM_TRY(ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)ks * p.M * N * 4)); p.ksplit = ks; p.ws = (float*)c->splitk_ws; }
     static const int op_cache = getenv("RDM_OP_FRAG_CACHE") ? atoi(getenv("RDM_OP_FRAG_CACHE")) : 0;     // dev-only (tools/conv_bench.py): the caller promises constant weights
     if (conv_halo_supported(p) && op_cache) p.Wfrag = c->frag_for(p.W, N, C0 + C1);

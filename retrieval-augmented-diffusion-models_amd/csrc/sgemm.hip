@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
 
 bool sgemm_supported(const SgemmParams& p) {
     static const int off = getenv("RDM_NO_SGEMM") ? atoi(getenv("RDM_NO_SGEMM")) : 0;
-    if (off || p.M < 1 || p.M > 128 || p.K % 256 != 0 || p.lda % 8 != 0) return false;
+    if (off || p.M < 1 || p.K % 256 != 0 || p.lda % 8 != 0) return false;      // any M: rows beyond 128 run as 32-row blocks (grid.y)
     if (p.act == ACT_GEGLU) return p.N % 64 == 0;
     return p.N % 32 == 0 && (p.act == ACT_NONE || p.act == ACT_SILU || p.act == ACT_QUICKGELU);
 }
@@ -136,7 +136,7 @@ template <int NF>
 static hipError_t launch_nf(const SgemmParams& p, int grid, hipStream_t st) {
     // rows per block: all of them (<= 128) when the column strips alone fill the chip, else 32-row blocks (grid.y = ceil(M / 32))
     static const int rowsplit = getenv("RDM_SGEMM_ROWSPLIT") ? atoi(getenv("RDM_SGEMM_ROWSPLIT")) : 1;
-    const int mf = (rowsplit && grid < 256) ? 1 : (p.M + 31) / 32;
+    const int mf = ((rowsplit && grid < 256) || p.M > 128) ? 1 : (p.M + 31) / 32;
     const bool deep = ((p.K >> 2) % 192) == 0;            // K quarter is a multiple of 6 k-steps of 32 (K = 768, 1536, 3072 ...)
     switch (mf) {
         case 1: return deep ? launch_one<1, NF, 6>(p, grid, st) : launch_one<1, NF, 2>(p, grid, st);
