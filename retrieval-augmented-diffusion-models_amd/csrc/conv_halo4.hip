@@ -68,6 +68,10 @@ hipError_t launch_conv_w_fragpack(const bf16_t* W, bf16_t* dst, int N, int Cin, 
 // (the loop-carried fragment variables are plain "=v" outputs re-defined in straight-line code -- no branch merges between their
 //  definitions and uses: a register copy of a fragment whose load is still in flight would read stale data; the loop is checked
 //  for v_mov of fragment registers in the assembly)
+// epilogue stores as asm: invisible to hipcc's wait-count model (it guarded the registers of its own stores with vmcnt waits inside
+// the hand-counted stream), counted by the first step of the next work item instead of drained
+typedef __attribute__((ext_vector_type(4))) unsigned h4_u32x4;
+#define H4_GSTORE(vaddr, data) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(vaddr), "v"(data) : "memory")
 #define H4_PIN1(a) asm volatile("" : "+v"(a))
 #define H4_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 #define H4_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
@@ -304,6 +308,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     if (p.dbg & 16) tp0 = __builtin_readcyclecounter();
     // descriptors of the NEXT tap-step (uniform), refreshed before every step
     bool slice_last_tap = false;
+    int epi_stores = 0;                                     // stores of the epilogue just finished that may still be in flight
     const char* sbn = Wf; unsigned noff = 0; int q0 = 0;
     auto describe = [&]() {
         slice_last_tap = tap == 8;
@@ -321,7 +326,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
             H4_MFMA(i * FN + j, fa[ks & 1][i], fb[P][ks][j]);
         };
         // ---- k-step 0: this step's weights (requested during the previous step's first k-step; its 3 halo requests are younger)
-        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        // (right after an epilogue its stores are younger still: FM * NIT of them, or 4 FM FN split-K plane stores)
+        if (epi_stores == 0) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else if (epi_stores == FM * ((32 * (WN / 8)) / 64)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(3 + FM * ((32 * (WN / 8)) / 64)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(3 + 4 * FM * FN) : "memory");
+        epi_stores = 0;
         H4_LDSW(hdst[P][0], hreg[P][0]);
 #pragma unroll
         for (int m = 0; m < FM * FN; m++) {
@@ -420,7 +429,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
                     for (int it = 0; it < 4; it++) {
                         const int idx = it * 64 + lane_e, row = idx >> 3, ch = idx & 7;
                         const float4 u = *(const float4*)(stg + row * 32 + ch * 4);
-                        *(float4*)(wsp + (long long)(em0 + wm * 128 + i * 32 + row) * p.N + en0 + wn * WN + j * 32 + ch * 4) = u;
+                        float* const dst = wsp + (long long)(em0 + wm * 128 + i * 32 + row) * p.N + en0 + wn * WN + j * 32 + ch * 4;
+                        const h4_u32x4 dv = {__float_as_uint(u.x), __float_as_uint(u.y), __float_as_uint(u.z), __float_as_uint(u.w)};
+                        H4_GSTORE(dst, dv);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
@@ -444,18 +455,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
                     pbias[i][j] = bv;
                 }
             }
+            // the residual rows of a fragment row are requested one fragment row AHEAD (those of row 0 before anything else): their
+            // HBM latency then hides behind a whole transpose instead of standing in front of every row's stores (measured: a tile with
+            // residual cost 8 k cycles more than one without, 2 k per fragment row)
+            uint4 rr4[2][NIT];
+            auto res_request = [&](int i, uint4 (&dst)[NIT]) {
+                const int mf = em0 + wm * 128 + i * 32;
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const int idx = it * 64 + lane_e, row = idx / CPR, ch = idx - row * CPR;
+                    dst[it] = *(const uint4*)(rb + (long long)(mf + row) * p.ldo + eno + ch * 8);
+                }
+            };
+            if (rb) res_request(0, rr4[0]);
 #pragma unroll
             for (int i = 0; i < FM; i++) {
                 const int mf = em0 + wm * 128 + i * 32;
-                // the residual rows of this fragment row: requested before the transpose so their latency hides behind it
-                uint4 rr4[NIT];
-                if (rb) {
-#pragma unroll
-                    for (int it = 0; it < NIT; it++) {
-                        const int idx = it * 64 + lane_e, row = idx / CPR, ch = idx - row * CPR;
-                        rr4[it] = *(const uint4*)(rb + (long long)(mf + row) * p.ldo + eno + ch * 8);
-                    }
-                }
+                if (rb && i + 1 < FM) res_request(i + 1, rr4[(i + 1) & 1]);
 #pragma unroll
                 for (int j = 0; j < FN; j++) {
                     __builtin_amdgcn_sched_barrier(0);         // one fragment's 16 accumulators at a time (no wholesale AGPR -> VGPR hoist)
@@ -479,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
                     uint4 u = *(const uint4*)(stg + row * ROWB + ch * 16);
                     const long long o = (long long)(mf + row) * p.ldo + eno + ch * 8;
                     if (rb) {
-                        const uint4 r4 = rr4[it];
+                        const uint4 r4 = rr4[i & 1][it];
                         const uint32_t uu[4] = {u.x, u.y, u.z, u.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
                         uint32_t oo[4];
 #pragma unroll
@@ -488,14 +504,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
                                                 __uint_as_float(uu[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u));
                         u = make_uint4(oo[0], oo[1], oo[2], oo[3]);
                     }
-                    *(uint4*)(ob + o) = u;
+                    bf16_t* const dst = ob + o;
+                    const h4_u32x4 dv = {u.x, u.y, u.z, u.w};
+                    H4_GSTORE(dst, dv);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
-        // hipcc's own wait-count model must see the epilogue's loads and stores retired (a builtin wait, which it parses): it would
-        // otherwise guard the registers they touched with vmcnt(6..9) waits of its own inside the hand-counted stream
-        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+        // (the epilogue's own loads -- bias, residual -- were consumed above, i.e. waited for; its stores are asm)
+        epi_stores = (S > 1) ? 4 * FM * FN : FM * ((32 * (WN / 8)) / 64);
         if (p.dbg & 16) tprof[1] += __builtin_readcyclecounter() - tp1;
         if (!has_next) return true;
         // the staging area is the buffer the next tile's SECOND slice is staged into during its first steps: every wave must have
