@@ -239,6 +239,20 @@ int rdm_op_conv3x3(rdm_ctx* ctx, const void* x0_bf16, const void* x1_bf16, int C
  * (conditional rows first), uniforms [dev] f32 [b], tokens_out [dev] int64 [b].  top_k <= 0: no filter. */
 int rdm_op_rarm_sampler(rdm_ctx* ctx, const float* logits, int b, int vocab, int cfg, float guidance_scale, float temperature,
                         int top_k, const float* uniforms, int64_t* tokens_out);
+/* ---- backward building blocks of the training step (reference rdm/models/diffusion/ddpm.py:390-443 shared_step -> ldm
+ * p_losses -> autograd through UNetModel): gradients of the ResBlock's ops.  bf16 activations / activation gradients, fp32 weight
+ * gradients.  conv3x3: stride 1, pad 1, weights [N][3][3][C].  Tested against torch autograd (tests/test_gpu_backward.py). */
+int rdm_op_conv3x3_dgrad(rdm_ctx* ctx, const void* dy_bf16 /*[B,H,W,N]*/, const void* w_bf16, void* dx_bf16 /*[B,H,W,C]*/, int B, int H, int W,
+                         int C, int N);
+int rdm_op_conv3x3_wgrad(rdm_ctx* ctx, const void* x_bf16 /*[B,H,W,C]*/, const void* dy_bf16 /*[B,H,W,N]*/, float* dw /*[N,3,3,C]*/, int B, int H,
+                         int W, int C, int N);
+int rdm_op_groupnorm_bwd(rdm_ctx* ctx, const void* x_bf16, const void* dy_bf16, const float* gamma, const float* beta, int B, int HW, int C,
+                         float eps, int silu, void* dx_bf16, float* dgamma, float* dbeta);
+int rdm_op_layernorm_bwd(rdm_ctx* ctx, const void* x_bf16, const void* dy_bf16, const float* gamma, int M, int C, float eps, void* dx_bf16,
+                         float* dgamma, float* dbeta);
+int rdm_op_colsum(rdm_ctx* ctx, const void* x_bf16 /*[M,N]*/, float* out /*[N]*/, long long M, int N);
+int rdm_op_transpose(rdm_ctx* ctx, const void* x_bf16 /*[rows,cols]*/, void* y_bf16 /*[cols,rows]*/, int rows, int cols);
+int rdm_op_add(rdm_ctx* ctx, const void* a_bf16, const void* b_bf16, void* out_bf16, long long n);
 int rdm_op_groupnorm(rdm_ctx* ctx, const void* x0_bf16, const void* x1_bf16, int C0, int C1, int B, int HW,
                      const float* gamma, const float* beta, float eps, int silu, void* out_bf16);
 int rdm_op_layernorm(rdm_ctx* ctx, const void* x, int in_is_f32, const float* gamma, const float* beta, int M, int C,

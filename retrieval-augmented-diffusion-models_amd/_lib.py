@@ -111,6 +111,13 @@ SIGNATURES = {
     "rdm_op_conv3x3": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int]),
     "rdm_op_rarm_sampler": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P]),
+    "rdm_op_conv3x3_dgrad": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rdm_op_conv3x3_wgrad": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rdm_op_groupnorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P, _P, _P]),
+    "rdm_op_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P]),
+    "rdm_op_colsum": (C.c_int, [_P, _P, _P, C.c_longlong, C.c_int]),
+    "rdm_op_transpose": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
+    "rdm_op_add": (C.c_int, [_P, _P, _P, _P, C.c_longlong]),
     "rdm_op_groupnorm": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_float, C.c_int, _P]),
     "rdm_op_layernorm": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "rdm_op_self_attention": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
@@ -586,6 +593,50 @@ class Context:
         out = torch.empty((b,), device=self.device, dtype=torch.int64)
         self._check(lib.rdm_op_rarm_sampler(self._h, _ptr(logits), b, logits.shape[1], int(cfg), float(guidance_scale), float(temperature),
                                             int(top_k) if top_k is not None else 0, _ptr(uniforms), _ptr(out)))
+        return out
+
+    # ---- backward building blocks (include/rdm_hip.h "backward"; composed in rdm_amd/training.py)
+    def op_conv3x3_dgrad(self, dy, w):
+        B, H, W, N = dy.shape
+        Cc = w.shape[3]
+        dx = torch.empty((B, H, W, Cc), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_conv3x3_dgrad(self._h, _ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cc, N))
+        return dx
+
+    def op_conv3x3_wgrad(self, x, dy):
+        B, H, W, Cc = x.shape
+        N = dy.shape[3]
+        dw = torch.empty((N, 3, 3, Cc), device=self.device, dtype=torch.float32)
+        self._check(lib.rdm_op_conv3x3_wgrad(self._h, _ptr(x), _ptr(dy), _ptr(dw), B, H, W, Cc, N))
+        return dw
+
+    def op_groupnorm_bwd(self, x, dy, gamma, beta, eps, silu):
+        B, HW, Cc = x.shape
+        dx = torch.empty_like(x); dg = torch.empty((Cc,), device=self.device, dtype=torch.float32); db = torch.empty_like(dg)
+        self._check(lib.rdm_op_groupnorm_bwd(self._h, _ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), B, HW, Cc, float(eps), int(silu), _ptr(dx), _ptr(dg), _ptr(db)))
+        return dx, dg, db
+
+    def op_layernorm_bwd(self, x, dy, gamma, eps=1e-5):
+        M, Cc = x.shape
+        dx = torch.empty_like(x); dg = torch.empty((Cc,), device=self.device, dtype=torch.float32); db = torch.empty_like(dg)
+        self._check(lib.rdm_op_layernorm_bwd(self._h, _ptr(x), _ptr(dy), _ptr(gamma), M, Cc, float(eps), _ptr(dx), _ptr(dg), _ptr(db)))
+        return dx, dg, db
+
+    def op_colsum(self, x):
+        M, N = x.shape
+        out = torch.empty((N,), device=self.device, dtype=torch.float32)
+        self._check(lib.rdm_op_colsum(self._h, _ptr(x), _ptr(out), M, N))
+        return out
+
+    def op_transpose(self, x):
+        r, c_ = x.shape
+        y = torch.empty((c_, r), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_transpose(self._h, _ptr(x), _ptr(y), r, c_))
+        return y
+
+    def op_add(self, a, b):
+        out = torch.empty_like(a)
+        self._check(lib.rdm_op_add(self._h, _ptr(a), _ptr(b), _ptr(out), a.numel()))
         return out
 
     def op_groupnorm(self, x0, gamma, beta, eps, silu, x1=None):

@@ -1,0 +1,284 @@
+// Backward pieces of the training step (MinimalRETRODiffusion.shared_step / ldm p_losses, reference
+// rdm/models/diffusion/ddpm.py:390-443), round 3: the two FLOP carriers of the UNet's ResBlocks and the normalisations around them.
+//
+//   * 3x3 conv dgrad  dX = conv3x3(dY, W~),  W~[c][ky][kx][n] = W[n][2-ky][2-kx][c]: one weight permutation (conv_w_dgrad_kernel) and
+//     the FORWARD kernel (conv_halo4.hip / igemm.hip) -- the gradient w.r.t. the input of a stride-1, pad-1 correlation is the
+//     correlation of the output gradient with the flipped, transposed filter.
+//   * 3x3 conv wgrad  dW[n][tap][c] = sum_pixels dY[p][n] X[p + tap][c]: a pixel-reduction GEMM (M' = N_out, N' = C_in, K' = pixels).
+//     Both operands are copied once into K-major, spatially ZERO-PADDED form (pad_transpose_kernel: [C][B (H+2) WP] with the row
+//     pitch WP a multiple of 8 and the column shift kx baked into three copies of X), so that a tap is a pure, 16-byte-aligned
+//     offset along K and the padding of dY zeroes every product that would wrap around an image edge; the reduction runs on the
+//     MFMA implicit-GEMM kernel (igemm.hip) as 9 taps x Z K-chunks (blockIdx.z) of fp32 partials, summed in a fixed order.
+//   * GroupNorm(+SiLU) and LayerNorm backward (two passes: group / row sums, then the elementwise gradient), bias / affine gradients
+//     as deterministic column sums.
+// Everything is fp32-accumulated from bf16 operands like the forward path; gradients w.r.t. weights are fp32.
+#include <stdio.h>
+
+#include "kernels.h"
+
+// ---- dgrad weight permutation: w [N][9][C] -> wd [C][9][N] with the taps reversed
+__global__ __launch_bounds__(256) void conv_w_dgrad_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wd, int N, int C) {
+    const long long total = (long long)N * 9 * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int n = (int)(i % N); const long long r = i / N; const int tap = (int)(r % 9); const int c = (int)(r / 9);
+        wd[i] = w[((long long)n * 9 + (8 - tap)) * C + c];
+    }
+}
+hipError_t launch_conv_w_dgrad(const bf16_t* w, bf16_t* wd, int N, int C, hipStream_t st) {
+    const long long total = (long long)N * 9 * C;
+    long long g = (total + 255) / 256; if (g > 8192) g = 8192;
+    conv_w_dgrad_kernel<<<dim3((unsigned)g), 256, 0, st>>>(w, wd, N, C);
+    return hipGetLastError();
+}
+
+// ---- K-major zero-padded copy: x [B, H, W, C] bf16 -> out [C][PR], PR = margin + B (H+2) WP + margin + tail, element (c, b, y, x)
+// at  margin + ((b (H+2) + y + 1) WP + x + 1 + shift);  everything else zero.  32 x 32 tiles through LDS (coalesced both ways).
+__global__ __launch_bounds__(256) void pad_transpose_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int H, int W, int C,
+                                                            int WP, int PR, int margin, int shift) {
+    __shared__ bf16_t tile[32][33];
+    const int HW = H * W;
+    const long long M = (long long)B * HW;
+    const long long m0 = (long long)blockIdx.x * 32; const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;             // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const long long m = m0 + r; const int c = c0 + tx;
+        tile[r][tx] = (m < M && c < C) ? x[m * C + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r; const long long m = m0 + tx;
+        if (c < C && m < M) {
+            const int b = (int)(m / HW); const int rem = (int)(m - (long long)b * HW); const int y = rem / W, xx = rem - y * W;
+            out[(long long)c * PR + margin + ((long long)(b * (H + 2) + y + 1) * WP + xx + 1 + shift)] = tile[tx][r];
+        }
+    }
+}
+
+// ---- fixed-order sum of Z fp32 partial planes
+__global__ __launch_bounds__(256) void reduce_planes_kernel(const float* __restrict__ parts, float* __restrict__ out, long long n, int Z) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int z = 0; z < Z; z++) s += parts[(long long)z * n + i];
+        out[i] = s;
+    }
+}
+hipError_t launch_reduce_planes(const float* parts, float* out, long long n, int Z, hipStream_t st) {
+    long long g = (n + 255) / 256; if (g > 8192) g = 8192;
+    reduce_planes_kernel<<<dim3((unsigned)g), 256, 0, st>>>(parts, out, n, Z);
+    return hipGetLastError();
+}
+
+// ---- column sums of a bf16 [M, N] matrix (bias gradient), deterministic: one block per 64 columns, tree over rows
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, long long M, int N) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float s = 0.f;
+    if (col < N) for (long long m = part; m < M; m += 4) s += bf2f(x[m * N + col]);
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && col < N) out[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+hipError_t launch_colsum(const bf16_t* x, float* out, long long M, int N, hipStream_t st) {
+    colsum_kernel<<<dim3((N + 63) / 64), 256, 0, st>>>(x, out, M, N);
+    return hipGetLastError();
+}
+
+// ---- wgrad driver
+// scratch layout (bf16 elements): dyT [N][PR], xT0 / xT1 / xT2 [C][PR] (column shifts -1, 0, +1); then fp32 partials [Z][N][9][C]
+size_t conv_wgrad_scratch_bytes(int B, int H, int W, int C, int N, int* pWP, int* pPR, int* pK, int* pZ, int* pmargin) {
+    const int WP = (W + 2 + 7) & ~7;
+    const int margin = WP + 8;
+    const long long P = (long long)B * (H + 2) * WP;
+    // K' = P rounded up so that Z chunks of a multiple of 64 cover it
+    int Z = (int)((P + 8191) / 8192); if (Z < 1) Z = 1; if (Z > 64) Z = 64;
+    long long Kc = (P + Z - 1) / Z; Kc = (Kc + 63) & ~63LL;
+    const long long K = Kc * Z;
+    const long long PR = margin + K + margin;
+    if (pWP) *pWP = WP; if (pPR) *pPR = (int)PR; if (pK) *pK = (int)Kc; if (pZ) *pZ = Z; if (pmargin) *pmargin = margin;
+    return (size_t)(N + 3LL * C) * PR * 2 + (size_t)Z * N * 9 * C * 4 + 256;
+}
+
+hipError_t launch_conv_wgrad(const bf16_t* x, const bf16_t* dy, float* dw, int B, int H, int W, int C, int N, char* scratch, const void* zero_page,
+                             hipStream_t st) {
+    int WP, PR, Kc, Z, margin;
+    conv_wgrad_scratch_bytes(B, H, W, C, N, &WP, &PR, &Kc, &Z, &margin);
+    bf16_t* dyT = (bf16_t*)scratch;
+    bf16_t* xT[3] = {dyT + (size_t)N * PR, dyT + (size_t)(N + C) * PR, dyT + (size_t)(N + 2 * C) * PR};
+    float* parts = (float*)(scratch + (((size_t)(N + 3LL * C) * PR * 2 + 255) & ~(size_t)255));
+    hipError_t e = hipMemsetAsync(scratch, 0, (size_t)(N + 3LL * C) * PR * 2, st);
+    if (e != hipSuccess) return e;
+    const long long M = (long long)B * H * W;
+    pad_transpose_kernel<<<dim3((unsigned)((M + 31) / 32), (N + 31) / 32), 256, 0, st>>>(dy, dyT, B, H, W, N, WP, PR, margin, 0);
+    for (int s = 0; s < 3; s++)            // X shifted so that tap column kx = s reads element p of the dY image: X(p + kx - 1) sits at p
+        pad_transpose_kernel<<<dim3((unsigned)((M + 31) / 32), (C + 31) / 32), 256, 0, st>>>(x, xT[s], B, H, W, C, WP, PR, margin, 1 - s);
+    e = hipGetLastError(); if (e != hipSuccess) return e;
+    for (int tap = 0; tap < 9; tap++) {
+        const int ky = tap / 3, kx = tap % 3;
+        IgemmParams p{}; p.M = N; p.N = C; p.K = Kc; p.alpha = 1.f; p.zero_page = zero_page;
+        p.Hin = p.Win = p.Hout = p.Wout = 1; p.stride = 1; p.rows_per_sample = 1;
+        p.A0 = dyT + margin; p.C0 = Kc; p.lda = PR; p.sA = Kc;
+        p.W = xT[kx] + margin + (ky - 1) * WP; p.ldw = PR; p.sW = Kc;       // row offset: a multiple of 8 elements (16-byte aligned)
+        p.out_f32 = parts + (size_t)tap * C; p.ldo = 9 * C; p.sO = (long long)N * 9 * C;
+        e = launch_igemm(p, false, Z, st);
+        if (e != hipSuccess) return e;
+    }
+    return launch_reduce_planes(parts, dw, (long long)N * 9 * C, Z, st);
+}
+
+// ---- GroupNorm (+SiLU) backward.  x [B, HW, C] bf16 (the forward INPUT), dy [B, HW, C] bf16 (gradient w.r.t. the OUTPUT).
+// pass 1 (one block per (sample, group)): mean / rstd from x (recomputed: two reads instead of keeping forward state), then
+//   S1 = sum dxh, S2 = sum dxh * xh over the group, with dz = dy * silu'(z) (z = xh * gamma + beta) and dxh = dz * gamma;
+// pass 2 (elementwise): dx = rstd * (dxh - S1 / n - xh * S2 / n), and per-(sample, channel) partials of dgamma = sum dz * xh and
+//   dbeta = sum dz, summed over samples by gn_bwd_affine_kernel in a fixed order.
+struct GnBwdParams {
+    const bf16_t* x; const bf16_t* dy; const float* gamma; const float* beta;
+    int B, HW, C, groups, silu; float eps;
+    float* stats;                   // [B, groups, 4]: mean, rstd, S1 / n, S2 / n
+    bf16_t* dx; float* part_g; float* part_b;       // partials [B, C]
+    float* dgamma; float* dbeta;
+};
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(GnBwdParams p) {
+    __shared__ float red[4];
+    const int b = blockIdx.x / p.groups, g = blockIdx.x % p.groups;
+    const int cg = p.C / p.groups; const long long n = (long long)p.HW * cg;
+    const bf16_t* xb = p.x + (long long)b * p.HW * p.C + g * cg;
+    const bf16_t* db = p.dy + (long long)b * p.HW * p.C + g * cg;
+    float s = 0.f, ss = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) { const float v = bf2f(xb[(i / cg) * p.C + (i % cg)]); s += v; ss += v * v; }
+    s = block_sum_256(s, red); ss = block_sum_256(ss, red);
+    const float mean = s / (float)n, var = fmaxf(ss / (float)n - mean * mean, 0.f), rstd = rsqrtf(var + p.eps);
+    float s1 = 0.f, s2 = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) {
+        const int c = (int)(i % cg); const long long o = (i / cg) * p.C + c;
+        const float xh = (bf2f(xb[o]) - mean) * rstd;
+        const float ga = p.gamma[g * cg + c];
+        float dz = bf2f(db[o]);
+        if (p.silu) { const float z = xh * ga + p.beta[g * cg + c]; const float sg = 1.f / (1.f + __expf(-z)); dz *= sg * (1.f + z * (1.f - sg)); }
+        const float dxh = dz * ga;
+        s1 += dxh; s2 += dxh * xh;
+    }
+    s1 = block_sum_256(s1, red); s2 = block_sum_256(s2, red);
+    if (threadIdx.x == 0) { float* st = p.stats + (long long)blockIdx.x * 4; st[0] = mean; st[1] = rstd; st[2] = s1 / (float)n; st[3] = s2 / (float)n; }
+}
+// one block per (sample, 64-channel chunk): walks the pixels, writes dx, accumulates the channel's dgamma / dbeta partials
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdParams p) {
+    __shared__ float rg[4][64], rb_[4][64];
+    const int nch = (p.C + 63) / 64;
+    const int b = blockIdx.x / nch, c = (blockIdx.x % nch) * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int cg = p.C / p.groups;
+    float ag = 0.f, ab = 0.f;
+    if (c < p.C) {
+        const int g = c / cg;
+        const float* st = p.stats + ((long long)b * p.groups + g) * 4;
+        const float mean = st[0], rstd = st[1], m1 = st[2], m2 = st[3];
+        const float ga = p.gamma[c], be = p.beta[c];
+        for (int i = part; i < p.HW; i += 4) {
+            const long long o = ((long long)b * p.HW + i) * p.C + c;
+            const float xh = (bf2f(p.x[o]) - mean) * rstd;
+            float dz = bf2f(p.dy[o]);
+            if (p.silu) { const float z = xh * ga + be; const float sg = 1.f / (1.f + __expf(-z)); dz *= sg * (1.f + z * (1.f - sg)); }
+            ag += dz * xh; ab += dz;
+            p.dx[o] = f2bf(rstd * (dz * ga - m1 - xh * m2));
+        }
+    }
+    rg[part][threadIdx.x & 63] = ag; rb_[part][threadIdx.x & 63] = ab;
+    __syncthreads();
+    if (part == 0 && c < p.C) {
+        const int l = threadIdx.x;
+        p.part_g[(long long)b * p.C + c] = (rg[0][l] + rg[1][l]) + (rg[2][l] + rg[3][l]);
+        p.part_b[(long long)b * p.C + c] = (rb_[0][l] + rb_[1][l]) + (rb_[2][l] + rb_[3][l]);
+    }
+}
+__global__ __launch_bounds__(256) void gn_bwd_affine_kernel(GnBwdParams p) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.C) return;
+    float g = 0.f, bb = 0.f;
+    for (int b = 0; b < p.B; b++) { g += p.part_g[(long long)b * p.C + c]; bb += p.part_b[(long long)b * p.C + c]; }
+    p.dgamma[c] = g; p.dbeta[c] = bb;
+}
+hipError_t launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* beta, int B, int HW, int C, int groups,
+                                float eps, int silu, float* scratch /* B*groups*4 + 2*B*C floats */, bf16_t* dx, float* dgamma, float* dbeta,
+                                hipStream_t st) {
+    GnBwdParams p{}; p.x = x; p.dy = dy; p.gamma = gamma; p.beta = beta; p.B = B; p.HW = HW; p.C = C; p.groups = groups; p.silu = silu; p.eps = eps;
+    p.stats = scratch; p.part_g = scratch + (size_t)B * groups * 4; p.part_b = p.part_g + (size_t)B * C; p.dx = dx; p.dgamma = dgamma; p.dbeta = dbeta;
+    gn_bwd_stats_kernel<<<B * groups, 256, 0, st>>>(p);
+    gn_bwd_apply_kernel<<<B * ((C + 63) / 64), 256, 0, st>>>(p);
+    gn_bwd_affine_kernel<<<(C + 255) / 256, 256, 0, st>>>(p);
+    return hipGetLastError();
+}
+
+// ---- LayerNorm backward: x, dy [M, C] bf16; dx = rstd (dxh - mean(dxh) - xh mean(dxh xh)), dxh = dy * gamma.  One wave per row;
+// dgamma / dbeta through per-block partials [nblocks, C] summed in a fixed order.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const float* __restrict__ gamma,
+                                                     int M, int C, float eps, bf16_t* __restrict__ dx, float* __restrict__ part_g,
+                                                     float* __restrict__ part_b, int rows_per_block) {
+    extern __shared__ float acc[];                      // [4 waves][2][C]: a wave owns its slice -- no atomics, fixed summation order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* mine = acc + (size_t)wave * 2 * C;
+    for (int c = lane; c < 2 * C; c += 64) mine[c] = 0.f;
+    const int r0 = blockIdx.x * rows_per_block;
+    for (int r = r0 + wave; r < r0 + rows_per_block && r < M; r += 4) {
+        const bf16_t* xr = x + (long long)r * C; const bf16_t* dr = dy + (long long)r * C;
+        float s = 0.f, ss = 0.f;
+        for (int c = lane; c < C; c += 64) { const float v = bf2f(xr[c]); s += v; ss += v * v; }
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+        const float mean = s / C, rstd = rsqrtf(fmaxf(ss / C - mean * mean, 0.f) + eps);
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < C; c += 64) { const float xh = (bf2f(xr[c]) - mean) * rstd, dxh = bf2f(dr[c]) * gamma[c]; s1 += dxh; s2 += dxh * xh; }
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        s1 /= C; s2 /= C;
+        for (int c = lane; c < C; c += 64) {
+            const float xh = (bf2f(xr[c]) - mean) * rstd, d = bf2f(dr[c]);
+            dx[(long long)r * C + c] = f2bf(rstd * (d * gamma[c] - s1 - xh * s2));
+            mine[c] += d * xh; mine[C + c] += d;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        part_g[(long long)blockIdx.x * C + c] = (acc[c] + acc[2 * C + c]) + (acc[4 * C + c] + acc[6 * C + c]);
+        part_b[(long long)blockIdx.x * C + c] = (acc[C + c] + acc[3 * C + c]) + (acc[5 * C + c] + acc[7 * C + c]);
+    }
+}
+__global__ __launch_bounds__(256) void ln_bwd_affine_kernel(const float* part_g, const float* part_b, int nb, int C, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float g = 0.f, b = 0.f;
+    for (int i = 0; i < nb; i++) { g += part_g[(long long)i * C + c]; b += part_b[(long long)i * C + c]; }
+    dgamma[c] = g; dbeta[c] = b;
+}
+hipError_t launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, int M, int C, float eps, float* scratch /* 2*nb*C */,
+                                int* nb_out, bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st) {
+    const int rows_per_block = 16;
+    const int nb = (M + rows_per_block - 1) / rows_per_block;
+    if (nb_out) *nb_out = nb;
+    float* pg = scratch; float* pb = scratch + (size_t)nb * C;
+    ln_bwd_kernel<<<nb, 256, (size_t)8 * C * sizeof(float), st>>>(x, dy, gamma, M, C, eps, dx, pg, pb, rows_per_block);
+    ln_bwd_affine_kernel<<<(C + 255) / 256, 256, 0, st>>>(pg, pb, nb, C, dgamma, dbeta);
+    return hipGetLastError();
+}
+
+// ---- out = a + b (bf16, 8 elements per thread): gradient accumulation where two paths meet (residual / skip connections)
+__global__ __launch_bounds__(256) void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out, long long n) {
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long long)gridDim.x * 256 * 8) {
+        if (i + 8 <= n) {
+            const uint4 x = *(const uint4*)(a + i), y = *(const uint4*)(b + i);
+            const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w}; uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                o[e] = cvt_pk_bf16(__uint_as_float(xs[e] << 16) + __uint_as_float(ys[e] << 16), __uint_as_float(xs[e] & 0xffff0000u) + __uint_as_float(ys[e] & 0xffff0000u));
+            *(uint4*)(out + i) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else for (long long j = i; j < n; j++) out[j] = f2bf(bf2f(a[j]) + bf2f(b[j]));
+    }
+}
+hipError_t launch_add_bf16(const bf16_t* a, const bf16_t* b, bf16_t* out, long long n, hipStream_t st) {
+    long long g = (n / 8 + 255) / 256; if (g < 1) g = 1; if (g > 8192) g = 8192;
+    add_bf16_kernel<<<dim3((unsigned)g), 256, 0, st>>>(a, b, out, n);
+    return hipGetLastError();
+}

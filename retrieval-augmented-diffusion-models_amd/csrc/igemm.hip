@@ -155,6 +155,7 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
         const bool second = k_ci >= p.C0;
         const bf16_t* src = second ? A1 : A0;
         int ld = second ? p.C1 : p.C0;
+        if (CONV == 0 && p.lda) ld = p.lda;
         const bf16_t* lane_src = src + ((second ? k_ci - p.C0 : k_ci) + sc8);
         if (CONV == 0 && !GEGLU && a_kt >= nkw) {       // residual slice: columns of this tile's own output block
             ld = p.ldo;
@@ -207,9 +208,10 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
             for (int i = 0; i < BP; i++) glds16(lane_e + (i * RPP + lrow) * RDM_EYE_N, Bs + (i * RPP + wave * 8) * 128);
         } else {
             const bf16_t* lane_w = W + ((long long)b_kt * BK + sc8);
+            const long long ldw = (CONV == 0 && p.ldw) ? p.ldw : p.K;
 #pragma unroll
             for (int i = 0; i < BP; i++) {
-                const void* g = (b_n[i] >= 0) ? (const void*)(lane_w + (long long)b_n[i] * p.K) : (const void*)zero;
+                const void* g = (b_n[i] >= 0) ? (const void*)(lane_w + (long long)b_n[i] * ldw) : (const void*)zero;
                 glds16(g, Bs + (i * RPP + wave * 8) * 128);
             }
         }

@@ -86,6 +86,18 @@ hipError_t launch_conv_w_fragpack(const bf16_t* W, bf16_t* dst, int N, int Cin, 
 inline hipError_t launch_conv3x3(const IgemmParams& p, hipStream_t st) {
     return conv_halo_supported(p) ? launch_conv_halo(p, st) : launch_igemm(p, true, 1, st);
 }
+// ---- backward pieces (backward.hip)
+hipError_t launch_conv_w_dgrad(const bf16_t* w, bf16_t* wd, int N, int C, hipStream_t st);             // [N][9][C] -> flipped [C][9][N]
+size_t conv_wgrad_scratch_bytes(int B, int H, int W, int C, int N, int* WP, int* PR, int* Kc, int* Z, int* margin);
+hipError_t launch_conv_wgrad(const bf16_t* x, const bf16_t* dy, float* dw, int B, int H, int W, int C, int N, char* scratch, const void* zero_page,
+                             hipStream_t st);
+hipError_t launch_reduce_planes(const float* parts, float* out, long long n, int Z, hipStream_t st);
+hipError_t launch_add_bf16(const bf16_t* a, const bf16_t* b, bf16_t* out, long long n, hipStream_t st);
+hipError_t launch_colsum(const bf16_t* x, float* out, long long M, int N, hipStream_t st);
+hipError_t launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* beta, int B, int HW, int C, int groups,
+                                float eps, int silu, float* scratch, bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st);
+hipError_t launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, int M, int C, float eps, float* scratch, int* nb_out,
+                                bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st);
 hipError_t launch_groupnorm(GnParams p, hipStream_t st);
 hipError_t launch_layernorm(const void* x, int in_is_f32, const float* gamma, const float* beta, void* out, int out_is_f32,
                             int M, int C, float eps, hipStream_t st, int Clog = -1);   // Clog: logical width of zero-padded rows (statistics over Clog)

@@ -421,6 +421,7 @@ struct rdm_ctx {
     char* samp = nullptr; size_t samp_bytes = 0;     // sampler scratch
     // fragment-ordered copies of the 3x3 conv weights (conv_halo4.hip), built on first use per weight, dropped when a model is reloaded
     std::unordered_map<unsigned long long, bf16_t*> wfrag;      // key: weight address mixed with (N, Cin)
+    char* bwd_tmp = nullptr; size_t bwd_tmp_bytes = 0;          // scratch of the backward ops (backward.hip)
     char* wfrag_tmp = nullptr; size_t wfrag_tmp_bytes = 0;      // rdm_op_conv3x3: caller-owned weights are re-packed per call
     void drop_frags() { for (auto& kv : wfrag) (void)hipFree(kv.second); wfrag.clear(); }
     const bf16_t* frag_for(const bf16_t* W, int N, int Cin) {
@@ -1005,7 +1006,7 @@ void rdm_ctx_destroy(rdm_ctx* c) {
     hipDeviceSynchronize();
     void* ptrs[] = {c->zero_page, c->unet.blob, c->unet.arena.base, c->unet.kv_cache, c->vq.blob, c->vq.arena.base,
                     c->clip.blob, c->clip.arena.base, c->gn_partial, c->samp, c->splitk_ws, c->unet.xa_cache,
-                    c->rarm.blob, c->rarm.arena.base, c->rarm.cache, c->rarm.ctxkv, c->rarm.state, c->wfrag_tmp};
+                    c->rarm.blob, c->rarm.arena.base, c->rarm.cache, c->rarm.ctxkv, c->rarm.state, c->wfrag_tmp, c->bwd_tmp};
     for (void* p : ptrs) if (p) hipFree(p);
     c->drop_frags();
     knn_free(c->db);
@@ -1591,6 +1592,58 @@ int rdm_op_rarm_sampler(rdm_ctx* c, const float* logits, int b, int vocab, int c
     sp.top_k = top_k > 0 ? top_k : vocab; sp.uniforms = uniforms; sp.pos = pos; sp.pos0 = 0; sp.steps = 1; sp.tokens_out = (long long*)tokens_out;
     sp.next_tokens = next; sp.done = done;
     RDM_CHECK_HIP(c, launch_rarm_sample(sp, c->stream));
+    return 0;
+}
+// ---- backward ops (kernels in backward.hip)
+int rdm_op_conv3x3_dgrad(rdm_ctx* c, const void* dy, const void* w, void* dx, int B, int H, int W, int C, int N) {
+    RDM_ENTER(c);
+    if (!dy || !w || !dx || C % 64 || N % 64) return c->fail(-1, "rdm_op_conv3x3_dgrad: null argument or channel counts not multiples of 64");
+    // dX = conv3x3(dY, W~): the flipped, transposed filter through the FORWARD kernel (input channels N, output channels C)
+    RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, (size_t)N * 9 * C * 2));
+    RDM_CHECK_HIP(c, launch_conv_w_dgrad((const bf16_t*)w, (bf16_t*)c->bwd_tmp, N, C, c->stream));
+    return rdm_op_conv3x3(c, dy, nullptr, N, 0, c->bwd_tmp, nullptr, nullptr, 0, nullptr, dx, B, H, W, C, 1, 0);
+}
+int rdm_op_conv3x3_wgrad(rdm_ctx* c, const void* x, const void* dy, float* dw, int B, int H, int W, int C, int N) {
+    RDM_ENTER(c);
+    if (!x || !dy || !dw || C % 2 || N < 1) return c->fail(-1, "rdm_op_conv3x3_wgrad: bad arguments");
+    const size_t need = conv_wgrad_scratch_bytes(B, H, W, C, N, nullptr, nullptr, nullptr, nullptr, nullptr);
+    RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, need));
+    RDM_CHECK_HIP(c, launch_conv_wgrad((const bf16_t*)x, (const bf16_t*)dy, dw, B, H, W, C, N, c->bwd_tmp, c->zero_page, c->stream));
+    return 0;
+}
+int rdm_op_groupnorm_bwd(rdm_ctx* c, const void* x, const void* dy, const float* gamma, const float* beta, int B, int HW, int C, float eps, int silu,
+                         void* dx, float* dgamma, float* dbeta) {
+    RDM_ENTER(c);
+    if (!x || !dy || !gamma || !beta || !dx || !dgamma || !dbeta || C % 32) return c->fail(-1, "rdm_op_groupnorm_bwd: bad arguments");
+    RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, ((size_t)B * 32 * 4 + 2 * (size_t)B * C) * 4));
+    RDM_CHECK_HIP(c, launch_groupnorm_bwd((const bf16_t*)x, (const bf16_t*)dy, gamma, beta, B, HW, C, 32, eps, silu, (float*)c->bwd_tmp, (bf16_t*)dx,
+                                          dgamma, dbeta, c->stream));
+    return 0;
+}
+int rdm_op_layernorm_bwd(rdm_ctx* c, const void* x, const void* dy, const float* gamma, int M, int C, float eps, void* dx, float* dgamma, float* dbeta) {
+    RDM_ENTER(c);
+    if (!x || !dy || !gamma || !dx || !dgamma || !dbeta) return c->fail(-1, "rdm_op_layernorm_bwd: null argument");
+    RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, (size_t)2 * ((M + 15) / 16) * C * 4));
+    RDM_CHECK_HIP(c, launch_layernorm_bwd((const bf16_t*)x, (const bf16_t*)dy, gamma, M, C, eps, (float*)c->bwd_tmp, nullptr, (bf16_t*)dx, dgamma, dbeta,
+                                          c->stream));
+    return 0;
+}
+int rdm_op_colsum(rdm_ctx* c, const void* x, float* out, long long M, int N) {
+    RDM_ENTER(c);
+    if (!x || !out) return c->fail(-1, "rdm_op_colsum: null argument");
+    RDM_CHECK_HIP(c, launch_colsum((const bf16_t*)x, out, M, N, c->stream));
+    return 0;
+}
+int rdm_op_transpose(rdm_ctx* c, const void* x, void* y, int rows, int cols) {
+    RDM_ENTER(c);
+    if (!x || !y) return c->fail(-1, "rdm_op_transpose: null argument");
+    RDM_CHECK_HIP(c, launch_transpose_bf16((const bf16_t*)x, (bf16_t*)y, rows, cols, c->stream));
+    return 0;
+}
+int rdm_op_add(rdm_ctx* c, const void* a, const void* b, void* out, long long n) {
+    RDM_ENTER(c);
+    if (!a || !b || !out) return c->fail(-1, "rdm_op_add: null argument");
+    RDM_CHECK_HIP(c, launch_add_bf16((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n, c->stream));
     return 0;
 }
 int rdm_op_groupnorm(rdm_ctx* c, const void* x0, const void* x1, int C0, int C1, int B, int HW, const float* gamma,

@@ -1,0 +1,78 @@
+"""Backward of the UNet's ResBlock on the native path (the first backward pieces of the training
+step; reference: rdm/models/diffusion/ddpm.py:390-443 shared_step -> ldm p_losses -> autograd through UNetModel, whose ResBlock is
+ldm's `h = conv(silu(gn(x))); h += linear(silu(emb)); h = conv(silu(gn(h))); return skip(x) + h`).
+
+Every arithmetic step is a C-ABI call into librdm_hip (include/rdm_hip.h "backward"): conv dgrad through the forward conv kernel with
+the flipped / transposed filter, conv wgrad as a pixel-reduction GEMM on the MFMA kernel, GroupNorm+SiLU backward, deterministic column
+sums, GEMMs for the time-embedding projection.  torch is used for device memory only (allocation, reshapes / views, zero padding).
+What is NOT here yet: attention / GEGLU / LayerNorm-in-block backward, the optimiser, EMA, the first-stage encoder, the RCCL gradient
+all-reduce."""
+import torch
+
+from . import _lib
+
+
+def _pad_rows(t, mult=64):
+    """[M, K] -> [ceil(M / mult) * mult, K] with zero rows (the GEMM's contraction length must be a multiple of 64)."""
+    m = t.shape[0]
+    mp = (m + mult - 1) // mult * mult
+    if mp == m:
+        return t
+    out = torch.zeros((mp, t.shape[1]), device=t.device, dtype=t.dtype)
+    out[:m] = t
+    return out
+
+
+def linear_backward(ctx, a, w, dy):
+    """y = a w^T + b  (a [M,K], w [N,K], dy [M,N], all bf16)  ->  da bf16 [M,K], dw f32 [N,K], db f32 [N]."""
+    da = ctx.op_linear(dy, ctx.op_transpose(w))                                        # dy [M,N] . (w^T)^T
+    dw = ctx.op_linear(ctx.op_transpose(_pad_rows(dy)), ctx.op_transpose(_pad_rows(a)), out_f32=True)   # dy^T [N,M] . (a^T)^T
+    return da, dw, ctx.op_colsum(dy)
+
+
+def resblock_forward(ctx, p, x, semb):
+    """x bf16 [B,H,W,Cin], semb = silu(time embedding) bf16 [B,E].  p: gn1_g/gn1_b/gn2_g/gn2_b f32, w1 [Cout,3,3,Cin] / w2 bf16, b1 / b2 f32,
+    emb_w bf16 [Cout,E], emb_b f32, optional skip_w bf16 [Cout,Cin] / skip_b.  -> (out, saved activations)"""
+    B, H, W, Cin = x.shape
+    n1 = ctx.op_groupnorm(x.reshape(B, H * W, Cin), p["gn1_g"], p["gn1_b"], 1e-5, 1).reshape(B, H, W, Cin)
+    emb_out = ctx.op_linear(semb, p["emb_w"], p["emb_b"], out_f32=True)                # [B, Cout] f32 (the conv adds it per sample)
+    h1 = ctx.op_conv3x3(n1, p["w1"], p["b1"], rowvec=emb_out)
+    Cout = h1.shape[3]
+    n2 = ctx.op_groupnorm(h1.reshape(B, H * W, Cout), p["gn2_g"], p["gn2_b"], 1e-5, 1).reshape(B, H, W, Cout)
+    if "skip_w" in p:
+        res = ctx.op_linear(x.reshape(B * H * W, Cin), p["skip_w"], p["skip_b"]).reshape(B, H, W, Cout)
+    else:
+        res = x
+    out = ctx.op_conv3x3(n2, p["w2"], p["b2"], residual=res)
+    return out, {"n1": n1, "h1": h1, "n2": n2}
+
+
+def resblock_backward(ctx, p, x, semb, saved, dout):
+    """Gradients of `resblock_forward` given dout (bf16 [B,H,W,Cout]): -> dict with dx, dsemb (bf16) and fp32 parameter gradients."""
+    B, H, W, Cin = x.shape
+    Cout = dout.shape[3]
+    HW, M = H * W, B * H * W
+    g = {}
+    dflat = dout.reshape(M, Cout)
+    # out = conv2(n2) + b2 + res
+    g["w2"] = ctx.op_conv3x3_wgrad(saved["n2"], dout)
+    g["b2"] = ctx.op_colsum(dflat)
+    dn2 = ctx.op_conv3x3_dgrad(dout, p["w2"])
+    # n2 = silu(gn2(h1))
+    dh1, g["gn2_g"], g["gn2_b"] = ctx.op_groupnorm_bwd(saved["h1"].reshape(B, HW, Cout), dn2.reshape(B, HW, Cout), p["gn2_g"], p["gn2_b"], 1e-5, 1)
+    dh1 = dh1.reshape(B, H, W, Cout)
+    # h1 = conv1(n1) + b1 + emb_out[b]
+    g["w1"] = ctx.op_conv3x3_wgrad(saved["n1"], dh1)
+    g["b1"] = ctx.op_colsum(dh1.reshape(M, Cout))
+    demb = torch.stack([ctx.op_colsum(dh1[b].reshape(HW, Cout)) for b in range(B)]).to(torch.bfloat16)      # [B, Cout]: sum over a sample's pixels
+    g["dsemb"], g["emb_w"], g["emb_b"] = linear_backward(ctx, semb, p["emb_w"], demb)
+    dn1 = ctx.op_conv3x3_dgrad(dh1, p["w1"])
+    # n1 = silu(gn1(x))
+    dx, g["gn1_g"], g["gn1_b"] = ctx.op_groupnorm_bwd(x.reshape(B, HW, Cin), dn1.reshape(B, HW, Cin), p["gn1_g"], p["gn1_b"], 1e-5, 1)
+    # skip path
+    if "skip_w" in p:
+        dxs, g["skip_w"], g["skip_b"] = linear_backward(ctx, x.reshape(M, Cin), p["skip_w"], dflat)
+    else:
+        dxs = dflat
+    g["dx"] = ctx.op_add(dx.reshape(M, Cin), dxs.reshape(M, Cin)).reshape(B, H, W, Cin)
+    return g

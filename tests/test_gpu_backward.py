@@ -1,0 +1,101 @@
+"""GPU parity of the backward building blocks against torch autograd on the fp32 restatement of the same
+ops (bf16-rounded operands): 3x3 conv dgrad / wgrad, GroupNorm(+SiLU) and LayerNorm backward, and a whole ResBlock
+(rdm_amd/training.py) -- with and without the 1x1 skip projection -- through the C ABI.  Stated tolerance: 3e-2 relative L2 per
+gradient (bf16 activation gradients between the stages, fp32 accumulation)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import bf16_round, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 3e-2
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("B,H,C,N", [(2, 16, 64, 128), (3, 8, 128, 64), (1, 32, 64, 64), (4, 16, 192, 192)])
+def test_conv3x3_dgrad_wgrad(ctx, B, H, C, N):
+    d = ctx.device
+    x = bf16_round(_rand((B, H, H, C), 1)).requires_grad_(True)
+    w = bf16_round(_rand((N, C, 3, 3), 2, (9 * C) ** -0.5)).requires_grad_(True)
+    dy = bf16_round(_rand((B, H, H, N), 3))
+    y = F.conv2d(x.permute(0, 3, 1, 2), w, None, padding=1).permute(0, 2, 3, 1)
+    y.backward(dy)
+    wp = w.detach().permute(0, 2, 3, 1).contiguous().to(d, torch.bfloat16)
+    dx = ctx.op_conv3x3_dgrad(dy.to(d, torch.bfloat16), wp)
+    dw = ctx.op_conv3x3_wgrad(x.detach().to(d, torch.bfloat16), dy.to(d, torch.bfloat16))
+    e_dx, e_dw = rel_l2(dx.float(), x.grad), rel_l2(dw, w.grad.permute(0, 2, 3, 1))
+    print(f"conv B={B} {H}x{H} {C}->{N}: dgrad rel L2 {e_dx:.2e}, wgrad {e_dw:.2e}")
+    assert e_dx <= TOL and e_dw <= 5e-3            # wgrad: fp32 output of exact bf16 products
+
+
+@pytest.mark.parametrize("B,HW,C,silu", [(2, 64, 64, 1), (3, 256, 192, 1), (2, 1024, 96, 0)])
+def test_groupnorm_backward(ctx, B, HW, C, silu):
+    d = ctx.device
+    x = bf16_round(_rand((B, HW, C), 4) * 1.5 + 0.3).requires_grad_(True)
+    g = (1 + 0.1 * _rand((C,), 5)).requires_grad_(True); b = (0.1 * _rand((C,), 6)).requires_grad_(True)
+    dy = bf16_round(_rand((B, HW, C), 7))
+    y = F.group_norm(x.permute(0, 2, 1), 32, g, b, 1e-5).permute(0, 2, 1)
+    if silu:
+        y = F.silu(y)
+    y.backward(dy)
+    dx, dg, db = ctx.op_groupnorm_bwd(x.detach().to(d, torch.bfloat16), dy.to(d, torch.bfloat16), g.detach().to(d), b.detach().to(d), 1e-5, silu)
+    e = (rel_l2(dx.float(), x.grad), rel_l2(dg, g.grad), rel_l2(db, b.grad))
+    print(f"groupnorm bwd B={B} HW={HW} C={C} silu={silu}: dx {e[0]:.2e} dgamma {e[1]:.2e} dbeta {e[2]:.2e}")
+    assert max(e) <= TOL
+
+
+@pytest.mark.parametrize("M,C", [(100, 384), (513, 960), (7, 128)])
+def test_layernorm_backward(ctx, M, C):
+    d = ctx.device
+    x = bf16_round(_rand((M, C), 8) * 1.5 + 0.3).requires_grad_(True)
+    g = (1 + 0.1 * _rand((C,), 9)).requires_grad_(True); b = (0.1 * _rand((C,), 10)).requires_grad_(True)
+    dy = bf16_round(_rand((M, C), 11))
+    F.layer_norm(x, (C,), g, b, 1e-5).backward(dy)
+    dx, dg, db = ctx.op_layernorm_bwd(x.detach().to(d, torch.bfloat16), dy.to(d, torch.bfloat16), g.detach().to(d))
+    e = (rel_l2(dx.float(), x.grad), rel_l2(dg, g.grad), rel_l2(db, b.grad))
+    print(f"layernorm bwd M={M} C={C}: dx {e[0]:.2e} dgamma {e[1]:.2e} dbeta {e[2]:.2e}")
+    assert max(e) <= TOL
+
+
+@pytest.mark.parametrize("Cin,Cout", [(64, 64), (128, 64)])
+def test_resblock_backward_matches_autograd(ctx, Cin, Cout):
+    """ldm ResBlock forward + backward on the native path vs torch autograd: gradients w.r.t. every parameter,
+    the input and the (SiLU'd) time embedding."""
+    from rdm_amd import training
+    d = ctx.device
+    B, H, E = 2, 16, 256
+    f = {"gn1_g": 1 + 0.1 * _rand((Cin,), 20), "gn1_b": 0.1 * _rand((Cin,), 21), "gn2_g": 1 + 0.1 * _rand((Cout,), 22), "gn2_b": 0.1 * _rand((Cout,), 23),
+         "w1": bf16_round(_rand((Cout, Cin, 3, 3), 24, (9 * Cin) ** -0.5)), "b1": 0.1 * _rand((Cout,), 25),
+         "w2": bf16_round(_rand((Cout, Cout, 3, 3), 26, (9 * Cout) ** -0.5)), "b2": 0.1 * _rand((Cout,), 27),
+         "emb_w": bf16_round(_rand((Cout, E), 28, E ** -0.5)), "emb_b": 0.1 * _rand((Cout,), 29)}
+    if Cin != Cout:
+        f["skip_w"] = bf16_round(_rand((Cout, Cin), 30, Cin ** -0.5)); f["skip_b"] = 0.1 * _rand((Cout,), 31)
+    x = bf16_round(_rand((B, H, H, Cin), 32)); semb = bf16_round(F.silu(_rand((B, E), 33))); dout = bf16_round(_rand((B, H, H, Cout), 34))
+    # fp32 autograd reference
+    r = {k: v.clone().requires_grad_(True) for k, v in f.items()}
+    xr, sr = x.clone().requires_grad_(True), semb.clone().requires_grad_(True)
+    xc = xr.permute(0, 3, 1, 2)
+    h = F.conv2d(F.silu(F.group_norm(xc, 32, r["gn1_g"], r["gn1_b"], 1e-5)), r["w1"], r["b1"], padding=1)
+    h = h + F.linear(sr, r["emb_w"], r["emb_b"])[:, :, None, None]
+    h = F.conv2d(F.silu(F.group_norm(h, 32, r["gn2_g"], r["gn2_b"], 1e-5)), r["w2"], r["b2"], padding=1)
+    skip = F.conv2d(xc, r["skip_w"][:, :, None, None], r["skip_b"]) if Cin != Cout else xc
+    out_ref = (skip + h).permute(0, 2, 3, 1)
+    out_ref.backward(dout)
+    # native
+    p = {k: (v.permute(0, 2, 3, 1).contiguous().to(d, torch.bfloat16) if k in ("w1", "w2") else v.to(d, torch.bfloat16) if k in ("emb_w", "skip_w") else v.to(d))
+         for k, v in f.items()}
+    xd, sd, dd = x.to(d, torch.bfloat16), semb.to(d, torch.bfloat16), dout.to(d, torch.bfloat16)
+    out, saved = training.resblock_forward(ctx, p, xd, sd)
+    assert rel_l2(out.float(), out_ref.detach()) <= 1.5e-2
+    g = training.resblock_backward(ctx, p, xd, sd, saved, dd)
+    torch.cuda.synchronize()
+    errs = {"dx": rel_l2(g["dx"].float(), xr.grad), "dsemb": rel_l2(g["dsemb"].float(), sr.grad)}
+    for k in f:
+        ref = r[k].grad.permute(0, 2, 3, 1) if k in ("w1", "w2") else r[k].grad
+        errs[k] = rel_l2(g[k].float(), ref)
+    print("resblock backward rel L2:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) <= TOL, errs
