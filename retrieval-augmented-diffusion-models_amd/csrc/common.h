@@ -44,6 +44,19 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     const float erf_abs = 1.0f - poly * __expf(-z * z);
     return 0.5f * x + 0.5f * fabsf(x) * erf_abs;      // 0.5 x (1 + sign(x) erf|.|)
 }
+// two at a time on the packed-fp32 VALU forms (v_pk_mul_f32 / v_pk_fma_f32: one issue slot per pair): same formula, same error
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_erf_f2(f32x2_t x) {
+    f32x2_t ax; ax.x = fabsf(x.x); ax.y = fabsf(x.y);
+    const f32x2_t z = ax * 0.70710678118654752f;
+    const f32x2_t d = z * 0.3275911f + 1.0f;
+    f32x2_t t; t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
+    const f32x2_t poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const f32x2_t a = (z * z) * -1.4426950408889634f;
+    f32x2_t e; e.x = __builtin_amdgcn_exp2f(a.x); e.y = __builtin_amdgcn_exp2f(a.y);
+    const f32x2_t erf_abs = 1.0f - poly * e;
+    return (x + ax * erf_abs) * 0.5f;
+}
 __device__ __forceinline__ float quickgelu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 
 // 16-byte async global->LDS copy: LDS address = wave-uniform `lds_wave_base` + lane*16.

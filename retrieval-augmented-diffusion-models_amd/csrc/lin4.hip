@@ -1,0 +1,477 @@
+// Linear / 1x1-conv GEMM  out[M, N] = A[M, K] W[N, K]^T + bias (+ residual)  for bf16 activations on gfx950, ONE WAVE PER SIMD:
+// the short-K projections of the UNet's SpatialTransformer (proj_in / to_q / to_k / to_out / proj_out, ldm attention.py:52-72,
+// 147-183 as reached from rdm/modules/diffusionmodules/openaimodel.py) and the ResBlock skip_connection 1x1 convs.
+//
+// Why a second GEMM kernel beside igemm.hip: at K = 384..576 the 8-wave persistent kernel runs its K loop at 35-40 % of the
+// matrix pipe (two waves interleave MFMAs on every SIMD, LDS-DMA issue parks them) and at 3 TB/s of the 5+ the same bytes can
+// move at.  Here the loop is conv_halo4.hip's, with one tap instead of nine:
+//   * 4 waves, one per SIMD, each owning a 128 x 96 tile of the block's 256 rows x 192 columns in 192 literal AGPRs;
+//   * weights in MFMA fragment order (lin_w_fragpack_kernel), loaded L2 -> VGPR one whole K-slice (12 fragments) ahead;
+//   * activations staged THROUGH REGISTERS: global_load (8 rows x 128 B per instruction, fully coalesced) three slices ahead,
+//     ds_write_b128 two steps later into a padded (144-byte rows: conflict-free fragment reads) double-buffered LDS slice;
+//     vmcnt retires in order, so the single counted wait of a step -- "my weights have landed" -- also retires the
+//     activation pieces of the step before the previous one, and nothing else;
+//   * SWAPPED OPERANDS: the MFMA computes D^T (rows = output channels, columns = rows of A), so a lane ends up with 4
+//     consecutive channels of ONE row of the output; a v_permlane32_swap per register pair makes that 8 consecutive channels =
+//     one 16-byte store, with no LDS transpose, no DPP and no LDS wait in the epilogue; the bias is the accumulators' initial
+//     value (written when the previous tile's results are read out), so the epilogue adds nothing but the residual.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "kernels.h"
+#include "h4_asm.h"
+
+__device__ unsigned long long g_lin4_prof[4];
+
+// fragment-ordered weight copy: dst[(nb * KQ + kq) * 512 + lane * 8 + e] = W[nb * 32 + (lane & 31)][kq * 16 + (lane >> 5) * 8 + e]
+// GEGLU (W rows stored as [32 x | 32 gates] blocks, packing.py _geglu_perm): fragment nb = rows {16 x, then their 16 gates} of block
+// nb / 2, half nb % 2 -- after the read-out's lane swap a lane holds 8 x values and the 8 gates of the SAME channels
+__host__ __device__ inline int l4_geglu_row(int n) {              // fragment-ordered row -> stored row
+    const int nb = n >> 5, fr = n & 31;
+    return 64 * (nb >> 1) + 16 * (nb & 1) + (fr < 16 ? fr : 32 + (fr - 16));
+}
+__global__ __launch_bounds__(256) void lin_w_fragpack_kernel(const bf16_t* __restrict__ W, bf16_t* __restrict__ dst, int N, int K, int ldw, int geglu) {
+    const int KQ = K >> 4;
+    const long long nvec = (long long)N * K / 8;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
+        const int lane = (int)(v & 63);
+        const long long f = v >> 6;
+        const int kq = (int)(f % KQ), nb = (int)(f / KQ);
+        int n = nb * 32 + (lane & 31);
+        const int c = kq * 16 + (lane >> 5) * 8;
+        if (geglu) n = l4_geglu_row(n);
+        *(uint4*)(dst + v * 8) = *(const uint4*)(W + (long long)n * ldw + c);
+    }
+}
+hipError_t launch_lin_w_fragpack(const bf16_t* W, bf16_t* dst, int N, int K, int ldw, int geglu, hipStream_t st) {
+    const long long nvec = (long long)N * K / 8;
+    long long g = (nvec + 255) / 256; if (g > 8192) g = 8192;
+    lin_w_fragpack_kernel<<<dim3((unsigned)g), 256, 0, st>>>(W, dst, N, K, ldw > 0 ? ldw : K, geglu);
+    return hipGetLastError();
+}
+
+
+struct ASrc { const char* base; unsigned pstride; unsigned voff; };      // activation pieces of one K-slice: SGPR base, piece stride, lane offset
+__device__ __forceinline__ unsigned long long l4_uni64(unsigned long long v) {    // uniform value -> SGPR pair (hipcc does 64-bit multiplies on the VALU)
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ ASrc l4_asrc(bool dead, int row0, int kc, int C0, const char* A0p, const char* A1p, unsigned ld0, unsigned ld1,
+                                        const char* zero, unsigned voffA0, unsigned voffA1, unsigned lane16) {
+    ASrc s;
+    const bool second = kc >= C0;
+    const unsigned ld = second ? ld1 : ld0;
+    const char* b = (second ? A1p : A0p) + (unsigned long long)row0 * ld + (unsigned)((second ? kc - C0 : kc) * 2);
+    s.base = (const char*)l4_uni64((unsigned long long)(dead ? zero : b));
+    s.pstride = (unsigned)__builtin_amdgcn_readfirstlane((int)(dead ? 0u : 32u * ld));
+    s.voff = dead ? lane16 : (second ? voffA1 : voffA0);
+    return s;
+}
+
+// WM: wave arrangement.  2 = 2 x 2 waves, block tile 256 x 192; 1 = 1 x 4 waves, block tile 128 x 384 (N % 384 == 0): every wave
+// reads the same 128 rows of A from LDS and no weight fragment is loaded by two waves -- 64 instead of 80 KiB per K-slice through the
+// CU's vector-memory return path (which, not the matrix pipe, paces the loop), and A is read from HBM by ONE block when N = 384
+template <int VAR, bool GEGLU, int WM>       // VAR: dev-only ablations (RDM_L4_VAR): 1 = activation pieces from the zero page, 2 = no stores
+__global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
+    constexpr int BM = 128 * WM, BK = 64, FM = 4, FN = 3, WN = FN * 32, BN = (4 / WM) * WN;
+    constexpr int L4_ABUF = BM * 144;          // one staged K-slice: BM rows x (128 bytes of channels + 16 of padding)
+    constexpr int NPC = 4 * WM;                // activation pieces (8 rows x 128 B) per wave per slice
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [A slice buffer 0][A slice buffer 1]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = WM == 2 ? wave >> 1 : 0, wn = WM == 2 ? wave & 1 : wave;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int lp = lane >> 3, lc = lane & 7;
+
+    const int K = p.K, nslice = K / BK, KQ = K >> 4;
+    const int nbn = p.N / BN, nbm = p.M / BM;
+    const int ntiles = nbm * nbn;
+    const int G = gridDim.x, xcd = blockIdx.x & 7;
+    const int gx = (G - xcd + 7) >> 3;
+    const int tq = ntiles >> 3, tr = ntiles & 7;
+    const int t_begin = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int t_end = t_begin + tq + (xcd < tr ? 1 : 0);
+    const int tile0 = t_begin + (blockIdx.x >> 3);
+    if (tile0 >= t_end) return;
+    const int gxq = gx / nbn, gxr = gx - gxq * nbn;
+
+    const char* const A0p = (const char*)p.A0; const char* const A1p = (const char*)p.A1;
+    const int C0 = p.C0;
+    const float* const biasp = p.bias;
+    const int ldo = p.ldo;
+    const char* const zero = (const char*)p.zero_page;
+    const char* const Wf = (const char*)p.Wfrag;
+    const unsigned ld0 = (unsigned)(p.lda > 0 ? p.lda : p.C0) * 2u, ld1 = (unsigned)p.C1 * 2u;     // row strides in bytes
+
+    // ---- per-lane constants
+    unsigned vbase[FM];                                         // LDS offset of row `frow` of A fragment i, k-step 0, buffer 0
+#pragma unroll
+    for (int i = 0; i < FM; i++) vbase[i] = (unsigned)((wm * 128 + i * 32 + frow) * 144 + fhalf * 16);
+    unsigned voffj[FN];
+#pragma unroll
+    for (int j = 0; j < FN; j++) voffj[j] = (unsigned)(lane * 16) + (unsigned)j * (unsigned)(KQ * 1024);
+    // activation pieces: piece q of wave w = rows (q * 4 + w) * 8 + lp of the tile, 16-byte chunk lc of the slice
+    const unsigned voffA0 = (unsigned)(wave * 8 + lp) * ld0 + (unsigned)(lc * 16);
+    const unsigned voffA1 = (unsigned)(wave * 8 + lp) * ld1 + (unsigned)(lc * 16);
+    const unsigned lane16 = (unsigned)(lane * 16);
+    const unsigned ldsw0 = (unsigned)((wave * 8 + lp) * 144 + lc * 16);           // + q * 4608 (+ L4_ABUF for buffer 1)
+    const unsigned ldsw1 = ldsw0 + (unsigned)L4_ABUF;
+
+    bf16_t* const ob = p.out_bf16;
+    const bf16_t* const rb = p.res_bf16;
+
+    // ---- cursors over the block's stream of K-slices (tile after tile): compute (C), weights (B: one step ahead), activations
+    // (A: three steps ahead).  All uniform.
+    struct Cur { int tile, bm, bn, sl; };
+    auto cur_adv = [&](Cur& c) __attribute__((always_inline)) {
+        c.sl++;
+        if (c.sl == nslice) { c.sl = 0; c.tile += gx; c.bn += gxr; c.bm += gxq; if (c.bn >= nbn) { c.bn -= nbn; c.bm++; } }
+    };
+    auto w_base = [&](const Cur& c) __attribute__((always_inline)) -> const char* {             // fragments of this wave's FN column blocks, slice c.sl, k-step 0
+        const int nb0 = c.bn * (BN / 32) + wn * FN;
+        const long long off = ((long long)nb0 * KQ + c.sl * 4) * 1024;
+        return (const char*)l4_uni64((unsigned long long)(Wf + off));
+    };
+    auto a_src = [&](const Cur& c) __attribute__((always_inline)) {
+        return l4_asrc(VAR == 1 || c.tile >= t_end, c.bm * BM, c.sl * BK, C0, A0p, A1p, ld0, ld1, zero, voffA0, voffA1, lane16);
+    };
+
+    asm volatile("" ::: H4_ACC_CLOBBERS);                    // the kernel descriptor must allocate the accumulator AGPRs
+    bf16x8 fa[2][FM];                                       // activation fragments: k-step parity
+    bf16x8 fb[2][4][FN];                                    // weight fragments: [step parity][k-step][column fragment]
+    bf16x8 hreg[2][NPC];                                      // activation pieces in flight: [step parity][piece]
+
+    Cur cc{tile0, tile0 / nbn, tile0 % nbn, 0};
+    Cur cb = cc, ca = cc;
+
+    // accumulators start at the bias of their output channel: fragment (i, j) register r = channel 8 (r >> 2) + 4 fhalf + (r & 3)
+    // the bias vector lives in LDS (staged once per block): the epilogue must not issue global loads of its own -- vmcnt retires in
+    // order, so waiting for one would drain the activation pieces and weight fragments already in flight for the next steps
+    constexpr int L4_STG = 2 * L4_ABUF;                        // per-wave output staging: 32 rows x 208 bytes
+    constexpr int L4_BIAS = L4_STG + 4 * 32 * 208;
+    for (int n = tid; n < p.N; n += 256) *(float*)(smem + L4_BIAS + n * 4) = biasp ? biasp[GEGLU ? l4_geglu_row(n) : n] : 0.f;
+    __syncthreads();
+    const unsigned vbias = (unsigned)(L4_BIAS + (wn * WN + 4 * fhalf) * 4);       // + (bn * BN + j * 32 + g * 8) * 4
+    auto acc_init = [&](int bn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < FN; j++) {
+            float4 b4[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) b4[g] = *(const float4*)(smem + vbias + (bn * BN + j * 32 + g * 8) * 4);
+#pragma unroll
+            for (int i = 0; i < FM; i++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    H4_ACCWRITE(i * FN + j, g * 4 + 0, b4[g].x); H4_ACCWRITE(i * FN + j, g * 4 + 1, b4[g].y);
+                    H4_ACCWRITE(i * FN + j, g * 4 + 2, b4[g].z); H4_ACCWRITE(i * FN + j, g * 4 + 3, b4[g].w);
+                }
+        }
+    };
+
+    // ---- block prologue: slice 0 into LDS buffer 0; slices 1 and 2 in flight in the two piece sets; weights of slice 0
+    {
+        ASrc s0 = a_src(ca); cur_adv(ca);
+#pragma unroll
+        for (int q = 0; q < NPC; q++) H4_GLOADB(hreg[0][q], s0.voff, s0.base + (unsigned)q * s0.pstride, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < NPC; q++) H4_LDSWO(ldsw0, hreg[0][q], q * 4608);
+        ASrc s1 = a_src(ca); cur_adv(ca);
+#pragma unroll
+        for (int q = 0; q < NPC; q++) H4_GLOADB(hreg[0][q], s1.voff, s1.base + (unsigned)q * s1.pstride, 0);
+        const char* sb = w_base(cb); cur_adv(cb);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+            for (int j = 0; j < FN; j++) { H4_GLOADB(fb[0][ks][j], voffj[j], sb, ks * 1024); fb[1][ks][j] = fb[0][ks][j]; }
+        ASrc s2 = a_src(ca); cur_adv(ca);
+#pragma unroll
+        for (int q = 0; q < NPC; q++) H4_GLOADB(hreg[1][q], s2.voff, s2.base + (unsigned)q * s2.pstride, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < FM; i++) { H4_LDSR(fa[0][i], vbase[i], 0); fa[1][i] = fa[0][i]; }
+    }
+    acc_init(cc.bn);
+
+    unsigned long long tprof[2] = {0, 0};
+    unsigned long long tp0 = 0, tp1 = 0;
+    if (p.dbg & 16) tp0 = __builtin_readcyclecounter();
+
+    // ---- main stream: one step = one 64-deep K-slice = 4 k-steps x 12 MFMAs.  Outstanding vector-memory requests at a step's
+    // start, oldest first: [NPC pieces of step X-2][12 weight fragments requested in step X-1][NPC pieces of step X-1]: vmcnt(NPC).
+    int epi_stores = 0;
+    const char* sbn = Wf; ASrc an{zero, 0u, lane16};
+    auto describe = [&]() __attribute__((always_inline)) {
+        sbn = (const char*)l4_uni64((unsigned long long)((cb.tile < t_end) ? w_base(cb) : Wf));
+        cur_adv(cb);
+        an = a_src(ca);
+        cur_adv(ca);
+    };
+    auto step = [&](auto ptag) __attribute__((always_inline)) {
+        constexpr int P = decltype(ptag)::value;
+        constexpr int RB = P * L4_ABUF;                      // buffer read by this step; the other one is being written
+        auto mfma = [&](int ks, int m) {
+            const int j = m / FM, i = m % FM;
+            H4_MFMA(i * FN + j, fb[P][ks][j], fa[ks & 1][i]);                 // D^T: rows = channels, columns = rows of A
+        };
+        if (epi_stores == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(NPC) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(NPC + (GEGLU ? FM * FN : 2 * FM * FN)) : "memory");
+        epi_stores = 0;
+#pragma unroll
+        for (int m = 0; m < FM * FN; m++) {
+            mfma(0, m);
+            H4_GLOADB(fb[P ^ 1][m / FN][m % FN], voffj[m % FN], sbn, (m / FN) * 1024);
+            if (m == 3) {
+#pragma unroll
+                for (int i = 0; i < FM; i++) H4_LDSR(fa[1][i], vbase[i], RB + 32);
+            }
+        }
+#pragma unroll
+        for (int ks = 1; ks < 4; ks++) {
+            const int q0 = NPC == 8 ? (ks - 1) * 3 : (ks == 1 ? 0 : ks), nq = NPC == 8 ? (ks < 3 ? 3 : 2) : (ks == 1 ? 2 : 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // pieces requested two steps ago (slice X + 1) -> the buffer this step does not read
+#pragma unroll
+            for (int q = q0; q < q0 + nq; q++) {
+                if (P == 0) H4_LDSWO(ldsw1, hreg[P][q], q * 4608); else H4_LDSWO(ldsw0, hreg[P][q], q * 4608);
+            }
+            mfma(ks, 0); mfma(ks, 1); mfma(ks, 2); mfma(ks, 3);
+            if (ks < 3) {
+#pragma unroll
+                for (int i = 0; i < FM; i++) H4_LDSR(fa[(ks + 1) & 1][i], vbase[i], RB + (ks + 1) * 32);
+            } else {
+                // every wave has retired its reads of this step's buffer and its writes of the next one
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int i = 0; i < FM; i++) H4_LDSR(fa[0][i], vbase[i], (P ^ 1) * L4_ABUF);
+            }
+            mfma(ks, 4); mfma(ks, 5);
+            // ... and the pieces of slice X + 3 into the registers just written out
+#pragma unroll
+            for (int q = q0; q < q0 + nq; q++) {
+                H4_GLOADB(hreg[P][q], an.voff, an.base + (unsigned)q * an.pstride, 0);
+                mfma(ks, 6 + 2 * (q - q0)); mfma(ks, 7 + 2 * (q - q0));
+            }
+            if (nq <= 2) { mfma(ks, 10); mfma(ks, 11); }
+            if (nq == 1) { mfma(ks, 8); mfma(ks, 9); }
+        }
+    };
+
+    // after a step: the next slice, or the tile's epilogue.  Returns true when the block has no work left.
+    auto advance = [&]() __attribute__((always_inline)) -> bool {
+        const int sl_done = cc.sl;
+        if (sl_done + 1 < nslice) { cc.sl++; return false; }
+        const int em0 = cc.bm * BM, en0 = cc.bn * BN;
+        Cur nx = cc; cur_adv(nx);
+        const bool has_next = nx.tile < t_end;
+        // the requests made for the (non-existent) steps after the last one are still in flight towards registers hipcc now
+        // considers dead: drain them before anything else may be allocated there
+        if (!has_next) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // last MFMA -> v_accvgpr_read: 18 wait states (hipcc does not pad around asm)
+        if (p.dbg & 16) { tp1 = __builtin_readcyclecounter(); tprof[0] += tp1 - tp0; }
+
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int erow = lane_e & 31, ehalf = lane_e >> 5;
+        // Read-out: fragment (i, j) register r = channel 8 (r >> 2) + 4 ehalf + (r & 3) of row erow; a v_permlane32_swap per register
+        // pair leaves every lane with 8 consecutive channels (16 bytes packed) x 2.  Rows leave as 16-byte stores with 12 lanes per
+        // 192-byte row segment (a 32-bytes-per-row store pattern straight from the fragments cost 20 % of the whole GEMM): the
+        // chunks of a fragment row cross the wave through a wave-private LDS tile (ds_write_b128 / ds_read_b128 only).
+        char* const stg = smem + L4_STG + wave * (32 * 208);
+        const unsigned swr = (unsigned)(erow * 208 + ehalf * 16);
+        const unsigned vb = (unsigned)(L4_BIAS + (wn * WN + 4 * ehalf) * 4) + (unsigned)((has_next ? nx.bn : cc.bn) * BN * 4);
+        const int eno = en0 + wn * WN;
+        if constexpr (GEGLU) {
+            // fragment rows 0..15 = x, 16..31 = the gates of the same 16 channels: after the lane swap v[0..7] = x, v[8..15] = gates of
+            // this lane's 8 channels; 16 outputs per fragment, 48 per wave: output channel 96 bn + 48 wn + 16 j + 8 ehalf + k
+            const int eno_o = (en0 >> 1) + wn * (WN / 2);
+            const unsigned swr_g = (unsigned)(erow * 112 + ehalf * 16);
+#pragma unroll
+            for (int i = 0; i < FM; i++) {
+#pragma unroll
+                for (int j = 0; j < FN; j++) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    float4 b4[4];
+#pragma unroll
+                    for (int g = 0; g < 4; g++) b4[g] = *(const float4*)(smem + vb + (j * 32 + g * 8) * 4);
+                    float v[16];
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        H4_ACCREAD(v[g * 4 + 0], i * FN + j, g * 4 + 0); H4_ACCREAD(v[g * 4 + 1], i * FN + j, g * 4 + 1);
+                        H4_ACCREAD(v[g * 4 + 2], i * FN + j, g * 4 + 2); H4_ACCREAD(v[g * 4 + 3], i * FN + j, g * 4 + 3);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        H4_ACCWRITE(i * FN + j, g * 4 + 0, b4[g].x); H4_ACCWRITE(i * FN + j, g * 4 + 1, b4[g].y);
+                        H4_ACCWRITE(i * FN + j, g * 4 + 2, b4[g].z); H4_ACCWRITE(i * FN + j, g * 4 + 3, b4[g].w);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 2; c++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) H4_PERMSWAP(v[8 * c + q], v[8 * c + 4 + q]);
+                    float o[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        f32x2_t gt; gt.x = v[8 + k]; gt.y = v[9 + k];
+                        f32x2_t xv; xv.x = v[k]; xv.y = v[k + 1];
+                        const f32x2_t r2 = xv * gelu_erf_f2(gt);
+                        o[k] = r2.x; o[k + 1] = r2.y;
+                    }
+                    *(uint4*)(stg + swr_g + j * 32) = make_uint4(cvt_pk_bf16(o[0], o[1]), cvt_pk_bf16(o[2], o[3]), cvt_pk_bf16(o[4], o[5]), cvt_pk_bf16(o[6], o[7]));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int mf = em0 + wm * 128 + i * 32;
+#pragma unroll
+                for (int it = 0; it < 3; it++) {
+                    const int idx = it * 64 + lane_e, row = idx / 6, ch = idx - row * 6;
+                    const uint4 u = *(const uint4*)(stg + row * 112 + ch * 16);
+                    bf16_t* const dst = ob + (long long)(mf + row) * ldo + eno_o + ch * 8;
+                    const h4_u32x4 dv = {u.x, u.y, u.z, u.w};
+                    if constexpr (VAR == 2) { asm volatile("" :: "v"(dv), "v"(dst)); } else H4_GSTORE(dst, dv);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        } else {
+        uint4 rr4[2][6];
+        auto res_request = [&](int i, uint4 (&dst)[6]) __attribute__((always_inline)) {
+            const int mf = em0 + wm * 128 + i * 32;
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int idx = it * 64 + lane_e, row = idx / 12, ch = idx - row * 12;
+                dst[it] = *(const uint4*)(rb + (long long)(mf + row) * ldo + eno + ch * 8);
+            }
+        };
+        if (rb) res_request(0, rr4[0]);
+#pragma unroll
+        for (int i = 0; i < FM; i++) {
+            if (rb && i + 1 < FM) res_request(i + 1, rr4[(i + 1) & 1]);
+#pragma unroll
+            for (int j = 0; j < FN; j++) {
+                __builtin_amdgcn_sched_barrier(0);             // one fragment's 16 accumulators at a time
+                float4 b4[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) b4[g] = *(const float4*)(smem + vb + (j * 32 + g * 8) * 4);
+                float v[16];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    H4_ACCREAD(v[g * 4 + 0], i * FN + j, g * 4 + 0); H4_ACCREAD(v[g * 4 + 1], i * FN + j, g * 4 + 1);
+                    H4_ACCREAD(v[g * 4 + 2], i * FN + j, g * 4 + 2); H4_ACCREAD(v[g * 4 + 3], i * FN + j, g * 4 + 3);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++) {                  // the next tile starts from its bias
+                    H4_ACCWRITE(i * FN + j, g * 4 + 0, b4[g].x); H4_ACCWRITE(i * FN + j, g * 4 + 1, b4[g].y);
+                    H4_ACCWRITE(i * FN + j, g * 4 + 2, b4[g].z); H4_ACCWRITE(i * FN + j, g * 4 + 3, b4[g].w);
+                }
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) H4_PERMSWAP(v[8 * c + q], v[8 * c + 4 + q]);
+                    const uint4 dv = make_uint4(cvt_pk_bf16(v[8 * c], v[8 * c + 1]), cvt_pk_bf16(v[8 * c + 2], v[8 * c + 3]),
+                                                cvt_pk_bf16(v[8 * c + 4], v[8 * c + 5]), cvt_pk_bf16(v[8 * c + 6], v[8 * c + 7]));
+                    *(uint4*)(stg + swr + (j * 4 + c * 2) * 16) = dv;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int mf = em0 + wm * 128 + i * 32;
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int idx = it * 64 + lane_e, row = idx / 12, ch = idx - row * 12;
+                uint4 u = *(const uint4*)(stg + row * 208 + ch * 16);
+                if (rb) {
+                    const uint4 r4 = rr4[i & 1][it];
+                    const uint32_t uu[4] = {u.x, u.y, u.z, u.w}, rw[4] = {r4.x, r4.y, r4.z, r4.w};
+                    uint32_t oo[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        oo[e] = cvt_pk_bf16(__uint_as_float(uu[e] << 16) + __uint_as_float(rw[e] << 16),
+                                            __uint_as_float(uu[e] & 0xffff0000u) + __uint_as_float(rw[e] & 0xffff0000u));
+                    u = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+                }
+                bf16_t* const dst = ob + (long long)(mf + row) * ldo + eno + ch * 8;
+                const h4_u32x4 dv = {u.x, u.y, u.z, u.w};
+                if constexpr (VAR == 2) { asm volatile("" :: "v"(dv), "v"(dst)); } else H4_GSTORE(dst, dv);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        }
+        epi_stores = (VAR == 2) ? 0 : (GEGLU ? FM * FN : 2 * FM * FN);
+        if (p.dbg & 16) tprof[1] += __builtin_readcyclecounter() - tp1;
+        if (!has_next) return true;
+        cc = nx;
+        if (p.dbg & 16) tp0 = __builtin_readcyclecounter();
+        return false;
+    };
+    while (true) {
+        describe(); step(std::integral_constant<int, 0>{}); if (advance()) break;
+        describe(); step(std::integral_constant<int, 1>{}); if (advance()) break;
+    }
+    if ((p.dbg & 16) && tid == 0) {
+        atomicAdd(&g_lin4_prof[0], tprof[0]); atomicAdd(&g_lin4_prof[1], tprof[1]); atomicAdd(&g_lin4_prof[3], 1ull);
+    }
+}
+
+static int lin4_wm(const IgemmParams& p) {        // wave arrangement: 1 x 4 waves (128 x 384 tiles) whenever N allows, else 2 x 2 (256 x 192)
+    static const int force = getenv("RDM_L4_WM") ? atoi(getenv("RDM_L4_WM")) : 0;
+    if (p.N % 384 == 0 && p.M % 128 == 0 && force != 2) return 1;
+    if (p.N % 192 == 0 && p.M % 256 == 0) return 2;
+    return 0;
+}
+bool lin4_supported(const IgemmParams& p, int batch) {
+    static const int off = getenv("RDM_NO_LIN4") ? atoi(getenv("RDM_NO_LIN4")) : 0;
+    if ((off & 1) || !p.Wfrag || batch != 1) return false;
+    const int wm = lin4_wm(p);
+    if (!wm || p.K % 64 || p.C0 % 64 || p.C1 % 64 || p.K != p.C0 + p.C1) return false;
+    if (p.alpha != 1.0f || p.rowvec || p.res_f32 || p.out_f32 || !p.out_bf16) return false;
+    const bool geglu = p.act == ACT_GEGLU;
+    if (p.act != ACT_NONE && !geglu) return false;
+    if (geglu && (p.res_bf16 || (off & 2))) return false;
+    const int No = geglu ? p.N / 2 : p.N;
+    if (p.N > 8192 || p.ldo % 8 || p.ldo < No || (p.ldw > 0 && p.ldw != p.K)) return false;
+    if (p.C1 > 0 && p.lda > 0) return false;
+    if ((long long)(p.M / (128 * wm)) * (p.N / (wm == 1 ? 384 : 192)) < 192) return false;     // fewer tiles than CUs: the 128-row tiles of igemm.hip
+    return true;
+}
+
+template <int VAR, bool GEGLU, int WM>
+static hipError_t launch_lin4_cfg(const IgemmParams& p, hipStream_t st) {
+    const int smem = 2 * (128 * WM * 144) + 4 * 32 * 208 + p.N * 4;
+    static int ncu_dev[RDM_MAX_DEVICES] = {0};
+    const int dev = rdm_cur_device();
+    if (!ncu_dev[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)lin4_kernel<VAR, GEGLU, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        hipDeviceGetAttribute(&ncu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    const long long ntiles = (long long)(p.M / (128 * WM)) * (p.N / (WM == 1 ? 384 : 192));
+    long long g = (ncu_dev[dev] + 7) & ~7;
+    if (g > ntiles) g = ntiles;
+    static const int prof = getenv("RDM_LIN4_PROF") ? atoi(getenv("RDM_LIN4_PROF")) : 0;
+    if (prof) {
+        IgemmParams q = p; q.dbg |= 16;
+        unsigned long long z[4] = {0, 0, 0, 0}, r[4];
+        hipMemcpyToSymbol(HIP_SYMBOL(g_lin4_prof), z, sizeof(z));
+        lin4_kernel<VAR, GEGLU, WM><<<dim3((unsigned)g), 256, smem, st>>>(q);
+        hipStreamSynchronize(st);
+        hipMemcpyFromSymbol(r, HIP_SYMBOL(g_lin4_prof), sizeof(r));
+        fprintf(stderr, "[lin4<%d,%d> M=%d N=%d K=%d] blocks=%llu per-block cycles: main %.0f epilogue %.0f (tiles/block %.2f)\n", (int)GEGLU, WM, p.M, p.N, p.K,
+                r[3], (double)r[0] / r[3], (double)r[1] / r[3], (double)ntiles / g);
+        return hipGetLastError();
+    }
+    lin4_kernel<VAR, GEGLU, WM><<<dim3((unsigned)g), 256, smem, st>>>(p);
+    return hipGetLastError();
+}
+template <int VAR>
+static hipError_t launch_lin4_var(const IgemmParams& p, hipStream_t st) {
+    const int wm = lin4_wm(p);
+    if (p.act == ACT_GEGLU) return wm == 1 ? launch_lin4_cfg<VAR, true, 1>(p, st) : launch_lin4_cfg<VAR, true, 2>(p, st);
+    return wm == 1 ? launch_lin4_cfg<VAR, false, 1>(p, st) : launch_lin4_cfg<VAR, false, 2>(p, st);
+}
+hipError_t launch_lin4(const IgemmParams& p, hipStream_t st) {
+    static const int var = getenv("RDM_L4_VAR") ? atoi(getenv("RDM_L4_VAR")) : 0;
+    return var == 2 ? launch_lin4_var<2>(p, st) : var == 1 ? launch_lin4_var<1>(p, st) : launch_lin4_var<0>(p, st);
+}

@@ -434,6 +434,16 @@ struct rdm_ctx {
         wfrag[key] = d;
         return d;
     }
+    const bf16_t* frag_for_lin(const bf16_t* W, int N, int K, int geglu) {       // fragment-ordered copy of a Linear / 1x1 weight (lin4.hip)
+        const unsigned long long key = ~((unsigned long long)(uintptr_t)W ^ ((unsigned long long)N << 48) ^ ((unsigned long long)K << 32)) ^ (geglu ? 1ull << 63 : 0ull);
+        auto it = wfrag.find(key);
+        if (it != wfrag.end()) return it->second;
+        bf16_t* d = nullptr;
+        if (hipMalloc((void**)&d, (size_t)N * K * 2) != hipSuccess) return nullptr;
+        if (launch_lin_w_fragpack(W, d, N, K, K, geglu, stream) != hipSuccess) { (void)hipFree(d); return nullptr; }
+        wfrag[key] = d;
+        return d;
+    }
     // batch-invariant execution (rdm_set_deterministic / env RDM_DETERMINISTIC): every kernel-selection decision (skinny vs tiled GEMM,
     // halo vs generic conv, conv split-K, the zero-context shortcut) is a function of the PER-SAMPLE layer shape only, so a row's
     // result is bitwise independent of the batch it sits in and of the number of ranks the batch is sharded over
@@ -494,6 +504,8 @@ struct Ops {
         p.A0 = A0; p.A1 = A1; p.C0 = C0; p.C1 = C1; p.W = w<bf16_t>(woff); p.bias = has_bias ? w<float>(boff) : nullptr;
         p.act = act; p.res_bf16 = res; p.res_f32 = res_f32; p.out_bf16 = out; p.out_f32 = out_f32;
         if (act == ACT_GEGLU) p.ldo = N / 2;
+        // one-wave-per-SIMD kernel for the big-M projections (its tile choice follows M, so not in deterministic mode)
+        if (!c->deterministic) { IgemmParams t = p; t.Wfrag = p.W; if (lin4_supported(t, 1)) p.Wfrag = c->frag_for_lin(p.W, N, C0 + C1, act == ACT_GEGLU); }
         prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)(C0 + C1));
         check(launch_igemm(p, false, 1, c->stream), "linear");
         prof_end();
@@ -1552,6 +1564,18 @@ int rdm_op_linear(rdm_ctx* c, const void* a, const void* w, const float* bias, c
     p.Hin = p.Win = p.Hout = p.Wout = 1; p.stride = 1; p.rows_per_sample = 1;
     p.A0 = (const bf16_t*)a; p.C0 = K; p.W = (const bf16_t*)w; p.bias = bias; p.res_bf16 = (const bf16_t*)res;
     p.out_bf16 = (bf16_t*)out; p.out_f32 = out_f32; p.act = act;
+    {
+        IgemmParams t = p; t.Wfrag = p.W;
+        if (!c->deterministic && lin4_supported(t, 1)) {
+            static const int op_cache = getenv("RDM_OP_FRAG_CACHE") ? atoi(getenv("RDM_OP_FRAG_CACHE")) : 0;   // dev-only: the caller promises constant weights
+            if (op_cache) p.Wfrag = c->frag_for_lin(p.W, N, K, act == ACT_GEGLU);
+            else {
+                RDM_TRY(ensure_bytes(c, &c->wfrag_tmp, &c->wfrag_tmp_bytes, (size_t)N * K * 2));
+                RDM_CHECK_HIP(c, launch_lin_w_fragpack(p.W, (bf16_t*)c->wfrag_tmp, N, K, K, act == ACT_GEGLU, c->stream));
+                p.Wfrag = (const bf16_t*)c->wfrag_tmp;
+            }
+        }
+    }
     RDM_CHECK_HIP(c, launch_igemm(p, false, 1, c->stream));
     return 0;
 }

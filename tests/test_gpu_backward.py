@@ -12,6 +12,13 @@ pytestmark = pytest.mark.gpu
 TOL = 3e-2
 
 
+@pytest.fixture(autouse=True)
+def _autograd_on():
+    # other test modules switch autograd off process-wide at import (collection imports them all): the references here need it
+    with torch.enable_grad():
+        yield
+
+
 def _rand(shape, seed, scale=1.0):
     return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
 
