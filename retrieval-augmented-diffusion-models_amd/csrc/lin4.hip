@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
     // the bias vector lives in LDS (staged once per block): the epilogue must not issue global loads of its own -- vmcnt retires in
     // order, so waiting for one would drain the activation pieces and weight fragments already in flight for the next steps
     constexpr int L4_STG = 2 * L4_ABUF;                        // per-wave output staging: 32 rows x 208 bytes
-    constexpr int L4_BIAS = L4_STG + 4 * 32 * 208;
+    constexpr int L4_BIAS = L4_STG + 2 * 4 * 32 * 208;       // two staging buffers per wave (buffer b of wave w at (b * 4 + w) * 6656)
     for (int n = tid; n < p.N; n += 256) *(float*)(smem + L4_BIAS + n * 4) = biasp ? biasp[GEGLU ? l4_geglu_row(n) : n] : 0.f;
     __syncthreads();
     const unsigned vbias = (unsigned)(L4_BIAS + (wn * WN + 4 * fhalf) * 4);       // + (bn * BN + j * 32 + g * 8) * 4
@@ -337,25 +337,46 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         } else {
+        // row-contiguous side: chunk idx = it * 64 + lane of a 32-row x 12-chunk fragment row -> (row, 16-byte chunk); byte offset from
+        // the fragment row's first element, for saddr-form stores / residual loads (one uniform base per fragment row)
+        unsigned voffs[6], lrd[6];
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const int idx = it * 64 + lane_e, row = idx / 12, ch = idx - row * 12;
+            voffs[it] = (unsigned)(row * ldo + ch * 8) * 2u;
+            lrd[it] = (unsigned)(row * 208 + ch * 16);
+        }
+        // next tile's bias for the wave's three column fragments: 12 LDS reads per tile, kept across the four fragment rows
+        // (2 x 2 arrangement: 32 more registers hold activation pieces, so the bias is fetched per fragment there)
+        constexpr bool B4PRE = WM == 1;
+        float4 b4[B4PRE ? FN : 1][4];
+        if constexpr (B4PRE) {
+#pragma unroll
+            for (int j = 0; j < FN; j++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) b4[j][g] = *(const float4*)(smem + vb + (j * 32 + g * 8) * 4);
+        }
+        const char* const obase = (const char*)(ob + (long long)(em0 + wm * 128) * ldo + eno);
+        const char* const rbase = (const char*)(rb + (long long)(em0 + wm * 128) * ldo + eno);
+        const unsigned long long rowstep = (unsigned long long)(32 * ldo) * 2ull;
         uint4 rr4[2][6];
         auto res_request = [&](int i, uint4 (&dst)[6]) __attribute__((always_inline)) {
-            const int mf = em0 + wm * 128 + i * 32;
+            const char* const rp = (const char*)l4_uni64((unsigned long long)(rbase + i * rowstep));
 #pragma unroll
-            for (int it = 0; it < 6; it++) {
-                const int idx = it * 64 + lane_e, row = idx / 12, ch = idx - row * 12;
-                dst[it] = *(const uint4*)(rb + (long long)(mf + row) * ldo + eno + ch * 8);
-            }
+            for (int it = 0; it < 6; it++) dst[it] = *(const uint4*)(rp + voffs[it]);
         };
-        if (rb) res_request(0, rr4[0]);
-#pragma unroll
-        for (int i = 0; i < FM; i++) {
-            if (rb && i + 1 < FM) res_request(i + 1, rr4[(i + 1) & 1]);
+        // fragment row i: accumulators -> 16-byte chunks in staging buffer i & 1 (no wait inside); the chunks of row i - 1 are read
+        // back and stored while row i's LDS writes are in flight
+        auto stage_row = [&](int i) __attribute__((always_inline)) {
+            char* const sw = stg + (i & 1) * (32 * 208) * 4 + swr;
 #pragma unroll
             for (int j = 0; j < FN; j++) {
-                __builtin_amdgcn_sched_barrier(0);             // one fragment's 16 accumulators at a time
-                float4 b4[4];
+                constexpr int JB = 0;
+                const int jb = B4PRE ? j : JB;
+                if constexpr (!B4PRE) {
 #pragma unroll
-                for (int g = 0; g < 4; g++) b4[g] = *(const float4*)(smem + vb + (j * 32 + g * 8) * 4);
+                    for (int g = 0; g < 4; g++) b4[0][g] = *(const float4*)(smem + vb + (j * 32 + g * 8) * 4);
+                }
                 float v[16];
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
@@ -364,8 +385,8 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
                 }
 #pragma unroll
                 for (int g = 0; g < 4; g++) {                  // the next tile starts from its bias
-                    H4_ACCWRITE(i * FN + j, g * 4 + 0, b4[g].x); H4_ACCWRITE(i * FN + j, g * 4 + 1, b4[g].y);
-                    H4_ACCWRITE(i * FN + j, g * 4 + 2, b4[g].z); H4_ACCWRITE(i * FN + j, g * 4 + 3, b4[g].w);
+                    H4_ACCWRITE(i * FN + j, g * 4 + 0, b4[jb][g].x); H4_ACCWRITE(i * FN + j, g * 4 + 1, b4[jb][g].y);
+                    H4_ACCWRITE(i * FN + j, g * 4 + 2, b4[jb][g].z); H4_ACCWRITE(i * FN + j, g * 4 + 3, b4[jb][g].w);
                 }
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
@@ -373,30 +394,39 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
                     for (int q = 0; q < 4; q++) H4_PERMSWAP(v[8 * c + q], v[8 * c + 4 + q]);
                     const uint4 dv = make_uint4(cvt_pk_bf16(v[8 * c], v[8 * c + 1]), cvt_pk_bf16(v[8 * c + 2], v[8 * c + 3]),
                                                 cvt_pk_bf16(v[8 * c + 4], v[8 * c + 5]), cvt_pk_bf16(v[8 * c + 6], v[8 * c + 7]));
-                    *(uint4*)(stg + swr + (j * 4 + c * 2) * 16) = dv;
+                    *(uint4*)(sw + (j * 4 + c * 2) * 16) = dv;
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int mf = em0 + wm * 128 + i * 32;
+        };
+        auto store_row = [&](int i) __attribute__((always_inline)) {
+            const char* const sr = stg + (i & 1) * (32 * 208) * 4;
+            const char* const op = (const char*)l4_uni64((unsigned long long)(obase + i * rowstep));
+            uint4 u[6];
+#pragma unroll
+            for (int it = 0; it < 6; it++) u[it] = *(const uint4*)(sr + lrd[it]);
 #pragma unroll
             for (int it = 0; it < 6; it++) {
-                const int idx = it * 64 + lane_e, row = idx / 12, ch = idx - row * 12;
-                uint4 u = *(const uint4*)(stg + row * 208 + ch * 16);
                 if (rb) {
                     const uint4 r4 = rr4[i & 1][it];
-                    const uint32_t uu[4] = {u.x, u.y, u.z, u.w}, rw[4] = {r4.x, r4.y, r4.z, r4.w};
+                    const uint32_t uu[4] = {u[it].x, u[it].y, u[it].z, u[it].w}, rw[4] = {r4.x, r4.y, r4.z, r4.w};
                     uint32_t oo[4];
 #pragma unroll
                     for (int e = 0; e < 4; e++)
                         oo[e] = cvt_pk_bf16(__uint_as_float(uu[e] << 16) + __uint_as_float(rw[e] << 16),
                                             __uint_as_float(uu[e] & 0xffff0000u) + __uint_as_float(rw[e] & 0xffff0000u));
-                    u = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+                    u[it] = make_uint4(oo[0], oo[1], oo[2], oo[3]);
                 }
-                bf16_t* const dst = ob + (long long)(mf + row) * ldo + eno + ch * 8;
-                const h4_u32x4 dv = {u.x, u.y, u.z, u.w};
-                if constexpr (VAR == 2) { asm volatile("" :: "v"(dv), "v"(dst)); } else H4_GSTORE(dst, dv);
+                const h4_u32x4 dv = {u[it].x, u[it].y, u[it].z, u[it].w};
+                if constexpr (VAR == 2) { asm volatile("" :: "v"(dv), "v"(voffs[it])); } else H4_GSTORES(voffs[it], dv, op);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        if (rb) res_request(0, rr4[0]);
+        stage_row(0);
+#pragma unroll
+        for (int i = 0; i < FM; i++) {
+            if (rb && i + 1 < FM) res_request(i + 1, rr4[(i + 1) & 1]);
+            if (i + 1 < FM) stage_row(i + 1);
+            store_row(i);                                      // (its LDS reads wait for row i's writes: compiler-counted lgkmcnt)
         }
         }
         epi_stores = (VAR == 2) ? 0 : (GEGLU ? FM * FN : 2 * FM * FN);
@@ -439,7 +469,7 @@ bool lin4_supported(const IgemmParams& p, int batch) {
 
 template <int VAR, bool GEGLU, int WM>
 static hipError_t launch_lin4_cfg(const IgemmParams& p, hipStream_t st) {
-    const int smem = 2 * (128 * WM * 144) + 4 * 32 * 208 + p.N * 4;
+    const int smem = 2 * (128 * WM * 144) + 2 * 4 * 32 * 208 + p.N * 4;
     static int ncu_dev[RDM_MAX_DEVICES] = {0};
     const int dev = rdm_cur_device();
     if (!ncu_dev[dev]) {
