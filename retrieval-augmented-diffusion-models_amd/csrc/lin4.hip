@@ -147,28 +147,39 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
     Cur cc{tile0, tile0 / nbn, tile0 % nbn, 0};
     Cur cb = cc, ca = cc;
 
-    // accumulators start at the bias of their output channel: fragment (i, j) register r = channel 8 (r >> 2) + 4 fhalf + (r & 3)
-    // the bias vector lives in LDS (staged once per block): the epilogue must not issue global loads of its own -- vmcnt retires in
-    // order, so waiting for one would drain the activation pieces and weight fragments already in flight for the next steps
-    constexpr int L4_STG = 2 * L4_ABUF;                        // per-wave output staging: 32 rows x 208 bytes
-    constexpr int L4_BIAS = L4_STG + 2 * 4 * 32 * 208;       // two staging buffers per wave (buffer b of wave w at (b * 4 + w) * 6656)
-    for (int n = tid; n < p.N; n += 256) *(float*)(smem + L4_BIAS + n * 4) = biasp ? biasp[GEGLU ? l4_geglu_row(n) : n] : 0.f;
+    // Accumulators start at the bias of their output channel -- written by the MATRIX PIPE: one MFMA with C = 0 per fragment,
+    // A = the fragment's 32 channels as (hi, lo) bf16 pairs in k = 0, 1 (hi + lo = the fp32 bias to 2^-17), B = ones in k = 0, 1:
+    // 12 issue slots per tile where v_accvgpr_write needed 192.  The packed (hi | lo << 16) words live in LDS (staged once per
+    // block): the epilogue must not issue global loads of its own -- vmcnt retires in order, so waiting for one would drain the
+    // activation pieces and weight fragments already in flight for the next steps.
+    constexpr int L4_STG = 2 * L4_ABUF;                        // per-wave fp32 staging of one fragment row: 32 rows x 400 bytes
+    constexpr int L4_BIAS = L4_STG + 4 * 32 * 400;
+    for (int n = tid; n < p.N; n += 256) {
+        const float bv = biasp ? biasp[GEGLU ? l4_geglu_row(n) : n] : 0.f;
+        const uint32_t hi = cvt_pk_bf16(bv, 0.f) & 0xffffu;
+        const uint32_t lo = cvt_pk_bf16(bv - __uint_as_float(hi << 16), 0.f) & 0xffffu;
+        *(uint32_t*)(smem + L4_BIAS + n * 4) = hi | (lo << 16);
+    }
     __syncthreads();
-    const unsigned vbias = (unsigned)(L4_BIAS + (wn * WN + 4 * fhalf) * 4);       // + (bn * BN + j * 32 + g * 8) * 4
-    auto acc_init = [&](int bn) __attribute__((always_inline)) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    union FragU { u32x4_t u; bf16x8 f; };
+    auto bias_frags = [&](int bn, int row, int half, bf16x8 (&bf)[FN], bf16x8& ones) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < FN; j++) {
-            float4 b4[4];
-#pragma unroll
-            for (int g = 0; g < 4; g++) b4[g] = *(const float4*)(smem + vbias + (bn * BN + j * 32 + g * 8) * 4);
-#pragma unroll
-            for (int i = 0; i < FM; i++)
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    H4_ACCWRITE(i * FN + j, g * 4 + 0, b4[g].x); H4_ACCWRITE(i * FN + j, g * 4 + 1, b4[g].y);
-                    H4_ACCWRITE(i * FN + j, g * 4 + 2, b4[g].z); H4_ACCWRITE(i * FN + j, g * 4 + 3, b4[g].w);
-                }
+            const uint32_t w = *(const uint32_t*)(smem + L4_BIAS + (bn * BN + wn * WN + j * 32 + row) * 4);
+            FragU t; t.u = (u32x4_t){half ? 0u : w, 0u, 0u, 0u};
+            bf[j] = t.f;
         }
+        FragU o; o.u = (u32x4_t){half ? 0u : 0x3f803f80u, 0u, 0u, 0u};
+        ones = o.f;
+    };
+    auto acc_init = [&](int bn) __attribute__((always_inline)) {
+        bf16x8 bf[FN], ones;
+        bias_frags(bn, frow, fhalf, bf, ones);
+#pragma unroll
+        for (int i = 0; i < FM; i++)
+#pragma unroll
+            for (int j = 0; j < FN; j++) H4_MFMA0(i * FN + j, bf[j], ones);
     };
 
     // ---- block prologue: slice 0 into LDS buffer 0; slices 1 and 2 in flight in the two piece sets; weights of slice 0
@@ -278,156 +289,98 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int erow = lane_e & 31, ehalf = lane_e >> 5;
-        // Read-out: fragment (i, j) register r = channel 8 (r >> 2) + 4 ehalf + (r & 3) of row erow; a v_permlane32_swap per register
-        // pair leaves every lane with 8 consecutive channels (16 bytes packed) x 2.  Rows leave as 16-byte stores with 12 lanes per
-        // 192-byte row segment (a 32-bytes-per-row store pattern straight from the fragments cost 20 % of the whole GEMM): the
-        // chunks of a fragment row cross the wave through a wave-private LDS tile (ds_write_b128 / ds_read_b128 only).
-        char* const stg = smem + L4_STG + wave * (32 * 208);
-        const unsigned swr = (unsigned)(erow * 208 + ehalf * 16);
-        const unsigned vb = (unsigned)(L4_BIAS + (wn * WN + 4 * ehalf) * 4) + (unsigned)((has_next ? nx.bn : cc.bn) * BN * 4);
-        const int eno = en0 + wn * WN;
-        if constexpr (GEGLU) {
-            // fragment rows 0..15 = x, 16..31 = the gates of the same 16 channels: after the lane swap v[0..7] = x, v[8..15] = gates of
-            // this lane's 8 channels; 16 outputs per fragment, 48 per wave: output channel 96 bn + 48 wn + 16 j + 8 ehalf + k
-            const int eno_o = (en0 >> 1) + wn * (WN / 2);
-            const unsigned swr_g = (unsigned)(erow * 112 + ehalf * 16);
-#pragma unroll
-            for (int i = 0; i < FM; i++) {
-#pragma unroll
-                for (int j = 0; j < FN; j++) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    float4 b4[4];
-#pragma unroll
-                    for (int g = 0; g < 4; g++) b4[g] = *(const float4*)(smem + vb + (j * 32 + g * 8) * 4);
-                    float v[16];
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        H4_ACCREAD(v[g * 4 + 0], i * FN + j, g * 4 + 0); H4_ACCREAD(v[g * 4 + 1], i * FN + j, g * 4 + 1);
-                        H4_ACCREAD(v[g * 4 + 2], i * FN + j, g * 4 + 2); H4_ACCREAD(v[g * 4 + 3], i * FN + j, g * 4 + 3);
-                    }
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        H4_ACCWRITE(i * FN + j, g * 4 + 0, b4[g].x); H4_ACCWRITE(i * FN + j, g * 4 + 1, b4[g].y);
-                        H4_ACCWRITE(i * FN + j, g * 4 + 2, b4[g].z); H4_ACCWRITE(i * FN + j, g * 4 + 3, b4[g].w);
-                    }
-#pragma unroll
-                    for (int c = 0; c < 2; c++)
-#pragma unroll
-                        for (int q = 0; q < 4; q++) H4_PERMSWAP(v[8 * c + q], v[8 * c + 4 + q]);
-                    float o[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k += 2) {
-                        f32x2_t gt; gt.x = v[8 + k]; gt.y = v[9 + k];
-                        f32x2_t xv; xv.x = v[k]; xv.y = v[k + 1];
-                        const f32x2_t r2 = xv * gelu_erf_f2(gt);
-                        o[k] = r2.x; o[k + 1] = r2.y;
-                    }
-                    *(uint4*)(stg + swr_g + j * 32) = make_uint4(cvt_pk_bf16(o[0], o[1]), cvt_pk_bf16(o[2], o[3]), cvt_pk_bf16(o[4], o[5]), cvt_pk_bf16(o[6], o[7]));
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const int mf = em0 + wm * 128 + i * 32;
-#pragma unroll
-                for (int it = 0; it < 3; it++) {
-                    const int idx = it * 64 + lane_e, row = idx / 6, ch = idx - row * 6;
-                    const uint4 u = *(const uint4*)(stg + row * 112 + ch * 16);
-                    bf16_t* const dst = ob + (long long)(mf + row) * ldo + eno_o + ch * 8;
-                    const h4_u32x4 dv = {u.x, u.y, u.z, u.w};
-                    if constexpr (VAR == 2) { asm volatile("" :: "v"(dv), "v"(dst)); } else H4_GSTORE(dst, dv);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-        } else {
-        // row-contiguous side: chunk idx = it * 64 + lane of a 32-row x 12-chunk fragment row -> (row, 16-byte chunk); byte offset from
-        // the fragment row's first element, for saddr-form stores / residual loads (one uniform base per fragment row)
-        unsigned voffs[6], lrd[6];
-#pragma unroll
-        for (int it = 0; it < 6; it++) {
-            const int idx = it * 64 + lane_e, row = idx / 12, ch = idx - row * 12;
-            voffs[it] = (unsigned)(row * ldo + ch * 8) * 2u;
-            lrd[it] = (unsigned)(row * 208 + ch * 16);
-        }
-        // next tile's bias for the wave's three column fragments: 12 LDS reads per tile, kept across the four fragment rows
-        // (2 x 2 arrangement: 32 more registers hold activation pieces, so the bias is fetched per fragment there)
-        constexpr bool B4PRE = WM == 1;
-        float4 b4[B4PRE ? FN : 1][4];
-        if constexpr (B4PRE) {
-#pragma unroll
-            for (int j = 0; j < FN; j++)
-#pragma unroll
-                for (int g = 0; g < 4; g++) b4[j][g] = *(const float4*)(smem + vb + (j * 32 + g * 8) * 4);
-        }
-        const char* const obase = (const char*)(ob + (long long)(em0 + wm * 128) * ldo + eno);
-        const char* const rbase = (const char*)(rb + (long long)(em0 + wm * 128) * ldo + eno);
-        const unsigned long long rowstep = (unsigned long long)(32 * ldo) * 2ull;
-        uint4 rr4[2][6];
-        auto res_request = [&](int i, uint4 (&dst)[6]) __attribute__((always_inline)) {
-            const char* const rp = (const char*)l4_uni64((unsigned long long)(rbase + i * rowstep));
-#pragma unroll
-            for (int it = 0; it < 6; it++) dst[it] = *(const uint4*)(rp + voffs[it]);
-        };
-        // fragment row i: accumulators -> 16-byte chunks in staging buffer i & 1 (no wait inside); the chunks of row i - 1 are read
-        // back and stored while row i's LDS writes are in flight
+        // Read-out.  Fragment (i, j) register group g (4 registers) = channels j 32 + 8 g + 4 ehalf .. + 3 of row erow, fp32: the
+        // groups go from the AGPRs STRAIGHT to a wave-private LDS tile (ds_write_b128 takes accumulator registers: no
+        // v_accvgpr_read, no lane exchange), one fragment row (32 rows x 96 channels) at a time, and come back row-contiguous --
+        // 8 consecutive channels per lane, 12 lanes per 192-byte row segment -- to be rounded, (+ residual,) packed and stored.
+        // (A 32-bytes-per-row store pattern straight from the fragments cost 20 % of the whole GEMM.)
+        const unsigned stgw = (unsigned)(L4_STG + wave * (32 * 400) + erow * 400 + ehalf * 16);
+        const char* const stgr = smem + L4_STG + wave * (32 * 400);
+        bf16x8 nbf[FN], nones;                                 // the next tile's bias fragments
+        bias_frags(has_next ? nx.bn : cc.bn, erow, ehalf, nbf, nones);
         auto stage_row = [&](int i) __attribute__((always_inline)) {
-            char* const sw = stg + (i & 1) * (32 * 208) * 4 + swr;
 #pragma unroll
             for (int j = 0; j < FN; j++) {
-                constexpr int JB = 0;
-                const int jb = B4PRE ? j : JB;
-                if constexpr (!B4PRE) {
-#pragma unroll
-                    for (int g = 0; g < 4; g++) b4[0][g] = *(const float4*)(smem + vb + (j * 32 + g * 8) * 4);
-                }
-                float v[16];
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    H4_ACCREAD(v[g * 4 + 0], i * FN + j, g * 4 + 0); H4_ACCREAD(v[g * 4 + 1], i * FN + j, g * 4 + 1);
-                    H4_ACCREAD(v[g * 4 + 2], i * FN + j, g * 4 + 2); H4_ACCREAD(v[g * 4 + 3], i * FN + j, g * 4 + 3);
-                }
-#pragma unroll
-                for (int g = 0; g < 4; g++) {                  // the next tile starts from its bias
-                    H4_ACCWRITE(i * FN + j, g * 4 + 0, b4[jb][g].x); H4_ACCWRITE(i * FN + j, g * 4 + 1, b4[jb][g].y);
-                    H4_ACCWRITE(i * FN + j, g * 4 + 2, b4[jb][g].z); H4_ACCWRITE(i * FN + j, g * 4 + 3, b4[jb][g].w);
-                }
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) H4_PERMSWAP(v[8 * c + q], v[8 * c + 4 + q]);
-                    const uint4 dv = make_uint4(cvt_pk_bf16(v[8 * c], v[8 * c + 1]), cvt_pk_bf16(v[8 * c + 2], v[8 * c + 3]),
-                                                cvt_pk_bf16(v[8 * c + 4], v[8 * c + 5]), cvt_pk_bf16(v[8 * c + 6], v[8 * c + 7]));
-                    *(uint4*)(sw + (j * 4 + c * 2) * 16) = dv;
-                }
+                H4_LDSW_ACC(stgw, i * FN + j, 0, (j * 8 + 0) * 16); H4_LDSW_ACC(stgw, i * FN + j, 1, (j * 8 + 2) * 16);
+                H4_LDSW_ACC(stgw, i * FN + j, 2, (j * 8 + 4) * 16); H4_LDSW_ACC(stgw, i * FN + j, 3, (j * 8 + 6) * 16);
             }
-        };
-        auto store_row = [&](int i) __attribute__((always_inline)) {
-            const char* const sr = stg + (i & 1) * (32 * 208) * 4;
-            const char* const op = (const char*)l4_uni64((unsigned long long)(obase + i * rowstep));
-            uint4 u[6];
+            // (the writes above read their accumulators when they issue; the matrix pipe overwrites them 16 passes later)
 #pragma unroll
-            for (int it = 0; it < 6; it++) u[it] = *(const uint4*)(sr + lrd[it]);
+            for (int j = 0; j < FN; j++) H4_MFMA0(i * FN + j, nbf[j], nones);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        if constexpr (GEGLU) {
+            // fragment channels 0..15 = x, 16..31 = the gates of the same 16 channels; 16 outputs per fragment, 48 per wave:
+            // output channel 96 bn + 48 wn + 16 j + k.  Task idx = it 64 + lane: (row, j, half h) -> 8 outputs = one 16-byte store
+            const int eno_o = (en0 >> 1) + wn * (WN / 2);
+            unsigned voffs[3], lrd[3];
+#pragma unroll
+            for (int it = 0; it < 3; it++) {
+                const int idx = it * 64 + lane_e, row = idx / 6, c6 = idx - row * 6;
+                voffs[it] = (unsigned)(row * ldo + c6 * 8) * 2u;
+                lrd[it] = (unsigned)(row * 400 + ((c6 >> 1) * 32 + (c6 & 1) * 8) * 4);
+            }
+            const char* const obase = (const char*)(ob + (long long)(em0 + wm * 128) * ldo + eno_o);
+            const unsigned long long rowstep = (unsigned long long)(32 * ldo) * 2ull;
+            auto store_row = [&](int i) __attribute__((always_inline)) {
+                const char* const op = (const char*)l4_uni64((unsigned long long)(obase + i * rowstep));
+#pragma unroll
+                for (int it = 0; it < 3; it++) {
+                    const float4 x0 = *(const float4*)(stgr + lrd[it]), x1 = *(const float4*)(stgr + lrd[it] + 16);
+                    const float4 g0 = *(const float4*)(stgr + lrd[it] + 64), g1 = *(const float4*)(stgr + lrd[it] + 80);
+                    const f32x2_t r0 = (f32x2_t){x0.x, x0.y} * gelu_erf_f2((f32x2_t){g0.x, g0.y});
+                    const f32x2_t r1 = (f32x2_t){x0.z, x0.w} * gelu_erf_f2((f32x2_t){g0.z, g0.w});
+                    const f32x2_t r2 = (f32x2_t){x1.x, x1.y} * gelu_erf_f2((f32x2_t){g1.x, g1.y});
+                    const f32x2_t r3 = (f32x2_t){x1.z, x1.w} * gelu_erf_f2((f32x2_t){g1.z, g1.w});
+                    const h4_u32x4 dv = {cvt_pk_bf16(r0.x, r0.y), cvt_pk_bf16(r1.x, r1.y), cvt_pk_bf16(r2.x, r2.y), cvt_pk_bf16(r3.x, r3.y)};
+                    if constexpr (VAR == 2) { asm volatile("" :: "v"(dv), "v"(voffs[it])); } else H4_GSTORES(voffs[it], dv, op);
+                }
+            };
+            stage_row(0); store_row(0);
+            stage_row(1); store_row(1);
+            stage_row(2); store_row(2);
+            stage_row(3); store_row(3);
+        } else {
+            const int eno = en0 + wn * WN;
+            unsigned voffs[6], lrd[6];
 #pragma unroll
             for (int it = 0; it < 6; it++) {
-                if (rb) {
-                    const uint4 r4 = rr4[i & 1][it];
-                    const uint32_t uu[4] = {u[it].x, u[it].y, u[it].z, u[it].w}, rw[4] = {r4.x, r4.y, r4.z, r4.w};
-                    uint32_t oo[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        oo[e] = cvt_pk_bf16(__uint_as_float(uu[e] << 16) + __uint_as_float(rw[e] << 16),
-                                            __uint_as_float(uu[e] & 0xffff0000u) + __uint_as_float(rw[e] & 0xffff0000u));
-                    u[it] = make_uint4(oo[0], oo[1], oo[2], oo[3]);
-                }
-                const h4_u32x4 dv = {u[it].x, u[it].y, u[it].z, u[it].w};
-                if constexpr (VAR == 2) { asm volatile("" :: "v"(dv), "v"(voffs[it])); } else H4_GSTORES(voffs[it], dv, op);
+                const int idx = it * 64 + lane_e, row = idx / 12, ch = idx - row * 12;
+                voffs[it] = (unsigned)(row * ldo + ch * 8) * 2u;
+                lrd[it] = (unsigned)(row * 400 + ch * 32);
             }
-        };
-        if (rb) res_request(0, rr4[0]);
-        stage_row(0);
+            const char* const obase = (const char*)(ob + (long long)(em0 + wm * 128) * ldo + eno);
+            const char* const rbase = (const char*)(rb + (long long)(em0 + wm * 128) * ldo + eno);
+            const unsigned long long rowstep = (unsigned long long)(32 * ldo) * 2ull;
+            uint4 rr4[2][6];
+            auto res_request = [&](int i, uint4 (&dst)[6]) __attribute__((always_inline)) {
+                const char* const rp = (const char*)l4_uni64((unsigned long long)(rbase + i * rowstep));
 #pragma unroll
-        for (int i = 0; i < FM; i++) {
-            if (rb && i + 1 < FM) res_request(i + 1, rr4[(i + 1) & 1]);
-            if (i + 1 < FM) stage_row(i + 1);
-            store_row(i);                                      // (its LDS reads wait for row i's writes: compiler-counted lgkmcnt)
-        }
+                for (int it = 0; it < 6; it++) dst[it] = *(const uint4*)(rp + voffs[it]);
+            };
+            auto store_row = [&](int i) __attribute__((always_inline)) {
+                const char* const op = (const char*)l4_uni64((unsigned long long)(obase + i * rowstep));
+#pragma unroll
+                for (int it = 0; it < 6; it++) {
+                    float4 a0 = *(const float4*)(stgr + lrd[it]), a1 = *(const float4*)(stgr + lrd[it] + 16);
+                    if (rb) {                                  // added in fp32: one rounding
+                        const uint4 r4 = rr4[i & 1][it];
+                        a0.x += __uint_as_float(r4.x << 16); a0.y += __uint_as_float(r4.x & 0xffff0000u);
+                        a0.z += __uint_as_float(r4.y << 16); a0.w += __uint_as_float(r4.y & 0xffff0000u);
+                        a1.x += __uint_as_float(r4.z << 16); a1.y += __uint_as_float(r4.z & 0xffff0000u);
+                        a1.z += __uint_as_float(r4.w << 16); a1.w += __uint_as_float(r4.w & 0xffff0000u);
+                    }
+                    const h4_u32x4 dv = {cvt_pk_bf16(a0.x, a0.y), cvt_pk_bf16(a0.z, a0.w), cvt_pk_bf16(a1.x, a1.y), cvt_pk_bf16(a1.z, a1.w)};
+                    if constexpr (VAR == 2) { asm volatile("" :: "v"(dv), "v"(voffs[it])); } else H4_GSTORES(voffs[it], dv, op);
+                }
+            };
+            if (rb) { res_request(0, rr4[0]); res_request(1, rr4[1]); }
+            stage_row(0); store_row(0);
+            if (rb) res_request(2, rr4[0]);
+            stage_row(1); store_row(1);
+            if (rb) res_request(3, rr4[1]);
+            stage_row(2); store_row(2);
+            stage_row(3); store_row(3);
         }
         epi_stores = (VAR == 2) ? 0 : (GEGLU ? FM * FN : 2 * FM * FN);
         if (p.dbg & 16) tprof[1] += __builtin_readcyclecounter() - tp1;
@@ -469,7 +422,7 @@ bool lin4_supported(const IgemmParams& p, int batch) {
 
 template <int VAR, bool GEGLU, int WM>
 static hipError_t launch_lin4_cfg(const IgemmParams& p, hipStream_t st) {
-    const int smem = 2 * (128 * WM * 144) + 2 * 4 * 32 * 208 + p.N * 4;
+    const int smem = 2 * (128 * WM * 144) + 4 * 32 * 400 + p.N * 4;
     static int ncu_dev[RDM_MAX_DEVICES] = {0};
     const int dev = rdm_cur_device();
     if (!ncu_dev[dev]) {
