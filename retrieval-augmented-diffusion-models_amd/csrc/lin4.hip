@@ -176,6 +176,8 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
     auto acc_init = [&](int bn) __attribute__((always_inline)) {
         bf16x8 bf[FN], ones;
         bias_frags(bn, frow, fhalf, bf, ones);
+        // the fragments were just written by the VALU: hipcc pads VALU -> MFMA operand hazards for its own MFMAs, not around asm
+        asm volatile("s_nop 7" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(ones));
 #pragma unroll
         for (int i = 0; i < FM; i++)
 #pragma unroll
@@ -304,10 +306,11 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
                 H4_LDSW_ACC(stgw, i * FN + j, 0, (j * 8 + 0) * 16); H4_LDSW_ACC(stgw, i * FN + j, 1, (j * 8 + 2) * 16);
                 H4_LDSW_ACC(stgw, i * FN + j, 2, (j * 8 + 4) * 16); H4_LDSW_ACC(stgw, i * FN + j, 3, (j * 8 + 6) * 16);
             }
-            // (the writes above read their accumulators when they issue; the matrix pipe overwrites them 16 passes later)
+            // the LDS writes read their accumulator registers when they are EXECUTED, not when they issue (measured: re-initialising
+            // the fragments right behind them gave intermittently corrupted tiles): retire them first
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int j = 0; j < FN; j++) H4_MFMA0(i * FN + j, nbf[j], nones);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         if constexpr (GEGLU) {
             // fragment channels 0..15 = x, 16..31 = the gates of the same 16 channels; 16 outputs per fragment, 48 per wave:

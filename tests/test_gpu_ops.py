@@ -68,6 +68,42 @@ def test_linear_geglu(ctx):
     _close(out, ref, what="geglu")
 
 
+# Big-M projections: the one-wave-per-SIMD kernel (lin4.hip) takes them when M is a multiple of 128 / 256 and there are >= 192 tiles --
+# both wave arrangements (N % 384 == 0: 1 x 4, else 2 x 2), one or two tiles per block (dead look-ahead cursors), a one-slice K,
+# residual, no bias, and the GEGLU read-out.  Each case runs twice: the first version of the kernel failed intermittently.
+@pytest.mark.parametrize("M,N,K,bias,res", [(49152, 192, 64, 1, 0), (49152, 384, 384, 1, 0), (65536, 384, 384, 1, 1), (32768, 768, 128, 0, 1),
+                                            (49408, 192, 192, 1, 1), (49152, 576, 192, 1, 0)])
+def test_linear_big_m(ctx, M, N, K, bias, res):
+    d = ctx.device
+    a, w = bf16_round(_rand((M, K), 21)), bf16_round(_rand((N, K), 22, K ** -0.5))
+    b = _rand((N,), 23, 0.5) if bias else None
+    r = bf16_round(_rand((M, N), 24)) if res else None
+    ref = a @ w.t()
+    if bias: ref = ref + b
+    if res: ref = ref + r
+    ab, wb = a.to(d, torch.bfloat16), w.to(d, torch.bfloat16)
+    for rep in range(2):
+        out = ctx.op_linear(ab, wb, None if b is None else b.to(d), residual=None if r is None else r.to(d, torch.bfloat16))
+        assert torch.isfinite(out).all()
+        _close(out, ref, what=f"big-M linear (run {rep})")
+
+
+@pytest.mark.parametrize("M,C", [(49152, 192), (32768, 384)])
+def test_linear_geglu_big_m(ctx, M, C):
+    from rdm_amd import _lib
+    from rdm_amd.packing import _geglu_perm
+    d = ctx.device
+    a, w, b = bf16_round(_rand((M, C), 25)), bf16_round(_rand((8 * C, C), 26, C ** -0.5)), _rand((8 * C,), 27, 0.3)
+    x, g = (a @ w.t() + b).chunk(2, dim=-1)
+    ref = x * F.gelu(g)
+    perm = _geglu_perm(8 * C)
+    ab, wp, bp = a.to(d, torch.bfloat16), w[perm].contiguous().to(d, torch.bfloat16), b[perm].contiguous().to(d)
+    for rep in range(2):
+        out = ctx.op_linear(ab, wp, bp, act=_lib.ACT_GEGLU)
+        assert out.shape == (M, 4 * C) and torch.isfinite(out).all()
+        _close(out, ref, what=f"big-M geglu (run {rep})")
+
+
 @pytest.mark.parametrize("M,N,K,act", [(1, 768, 768, 0), (2, 2304, 768, 0), (33, 768, 3072, 0), (64, 16384, 768, 0), (128, 2304, 768, 0),
                                        (128, 768, 768, 3), (96, 512, 256, 2), (64, 6144, 768, 1), (128, 6144, 768, 1), (3, 1024, 256, 1)])
 def test_skinny_linear(ctx, M, N, K, act):

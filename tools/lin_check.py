@@ -29,6 +29,9 @@ for (M, N, K, bias, res) in [(49152, 192, 64, 1, 0), (49152, 384, 384, 1, 0), (6
         e = (out - ref).abs()
         rows = (e.amax(dim=1) > 0.1).nonzero().flatten(); cols = (e.amax(dim=0) > 0.1).nonzero().flatten()
         print("  bad rows", len(rows), rows[:16].tolist(), "bad cols", len(cols), cols[:32].tolist())
+        nn = torch.isnan(out)
+        nr = nn.any(dim=1).nonzero().flatten(); nc = nn.any(dim=0).nonzero().flatten()
+        print("  nan entries", int(nn.sum()), "rows", len(nr), nr[:8].tolist(), (nr // 128).unique()[:24].tolist(), "cols", len(nc), nc[:24].tolist())
 # GEGLU: W rows stored as [32 x | 32 gates] blocks (packing.py _geglu_perm)
 for (M, N, K) in [(49152, 768, 192), (65536, 3072, 384)]:
     g = torch.Generator().manual_seed(M + N + K)
