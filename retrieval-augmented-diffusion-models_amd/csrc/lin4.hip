@@ -355,11 +355,14 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
             const char* const obase = (const char*)(ob + (long long)(em0 + wm * 128) * ldo + eno);
             const char* const rbase = (const char*)(rb + (long long)(em0 + wm * 128) * ldo + eno);
             const unsigned long long rowstep = (unsigned long long)(32 * ldo) * 2ull;
-            uint4 rr4[2][6];
-            auto res_request = [&](int i, uint4 (&dst)[6]) __attribute__((always_inline)) {
+            // residual rows: asm loads (saddr form) with counted waits -- as compiler-visible loads they became flat_load + vmcnt(0).
+            // Program order of the vector-memory requests: R0 R1 | S0 (6 stores) R2 | S1 R3 | S2 | S3; the wait in front of row i's
+            // adds leaves exactly the younger requests in flight
+            h4_u32x4 rr4[2][6];
+            auto res_request = [&](int i, h4_u32x4 (&dst)[6]) __attribute__((always_inline)) {
                 const char* const rp = (const char*)l4_uni64((unsigned long long)(rbase + i * rowstep));
 #pragma unroll
-                for (int it = 0; it < 6; it++) dst[it] = *(const uint4*)(rp + voffs[it]);
+                for (int it = 0; it < 6; it++) H4_GLOADB(dst[it], voffs[it], rp, 0);
             };
             auto store_row = [&](int i) __attribute__((always_inline)) {
                 const char* const op = (const char*)l4_uni64((unsigned long long)(obase + i * rowstep));
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
                 for (int it = 0; it < 6; it++) {
                     float4 a0 = *(const float4*)(stgr + lrd[it]), a1 = *(const float4*)(stgr + lrd[it] + 16);
                     if (rb) {                                  // added in fp32: one rounding
-                        const uint4 r4 = rr4[i & 1][it];
+                        const h4_u32x4 r4 = rr4[i & 1][it];
                         a0.x += __uint_as_float(r4.x << 16); a0.y += __uint_as_float(r4.x & 0xffff0000u);
                         a0.z += __uint_as_float(r4.y << 16); a0.w += __uint_as_float(r4.y & 0xffff0000u);
                         a1.x += __uint_as_float(r4.z << 16); a1.y += __uint_as_float(r4.z & 0xffff0000u);
@@ -377,13 +380,29 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
                     if constexpr (VAR == 2) { asm volatile("" :: "v"(dv), "v"(voffs[it])); } else H4_GSTORES(voffs[it], dv, op);
                 }
             };
-            if (rb) { res_request(0, rr4[0]); res_request(1, rr4[1]); }
-            stage_row(0); store_row(0);
-            if (rb) res_request(2, rr4[0]);
-            stage_row(1); store_row(1);
-            if (rb) res_request(3, rr4[1]);
-            stage_row(2); store_row(2);
-            stage_row(3); store_row(3);
+            constexpr int NST = VAR == 2 ? 0 : 6;              // stores per fragment row
+            if (rb) {
+                res_request(0, rr4[0]); res_request(1, rr4[1]);
+                stage_row(0);
+                asm volatile("s_waitcnt vmcnt(6)" : "+v"(rr4[0][0]), "+v"(rr4[0][1]), "+v"(rr4[0][2]), "+v"(rr4[0][3]), "+v"(rr4[0][4]), "+v"(rr4[0][5]) :: "memory");
+                store_row(0);
+                res_request(2, rr4[0]);
+                stage_row(1);
+                asm volatile("s_waitcnt vmcnt(%6)" : "+v"(rr4[1][0]), "+v"(rr4[1][1]), "+v"(rr4[1][2]), "+v"(rr4[1][3]), "+v"(rr4[1][4]), "+v"(rr4[1][5]) : "i"(6 + NST) : "memory");
+                store_row(1);
+                res_request(3, rr4[1]);
+                stage_row(2);
+                asm volatile("s_waitcnt vmcnt(%6)" : "+v"(rr4[0][0]), "+v"(rr4[0][1]), "+v"(rr4[0][2]), "+v"(rr4[0][3]), "+v"(rr4[0][4]), "+v"(rr4[0][5]) : "i"(6 + NST) : "memory");
+                store_row(2);
+                stage_row(3);
+                asm volatile("s_waitcnt vmcnt(%6)" : "+v"(rr4[1][0]), "+v"(rr4[1][1]), "+v"(rr4[1][2]), "+v"(rr4[1][3]), "+v"(rr4[1][4]), "+v"(rr4[1][5]) : "i"(NST) : "memory");
+                store_row(3);
+            } else {
+                stage_row(0); store_row(0);
+                stage_row(1); store_row(1);
+                stage_row(2); store_row(2);
+                stage_row(3); store_row(3);
+            }
         }
         epi_stores = (VAR == 2) ? 0 : (GEGLU ? FM * FN : 2 * FM * FN);
         if (p.dbg & 16) tprof[1] += __builtin_readcyclecounter() - tp1;
