@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     unsigned hdst[2][3] = {{dump, dump, dump}, {dump, dump, dump}};
     unsigned va[FM];                                        // A fragment rows of the current tap (k-step 0)
     int hb = 0;                                             // halo buffer of the slice being computed
-    int em0 = 0, en0 = 0, part = 0, next = 0, s_begin = 0, s_end = 0, ns_begin = 0;
+    int em0 = 0, en0 = 0, nem0 = 0, nen0 = 0, part = 0, next = 0, s_begin = 0, s_end = 0, ns_begin = 0;
     bool has_next = false;
     const char* wb_tile = Wf; const char* wb_next = Wf;
     HaloTile ht_tile{0, 0}, ht_next{0, 0};
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
         wb_tile = w_base(tile);
         wb_next = has_next ? w_base(next) + (long long)ns_begin * 4096 : wb_tile;       // first step of the next work item
         ht_next = has_next ? halo_tile(next) : HaloTile{0, 0};
+        { const int nmn = (has_next ? next : tile) % ntiles_mn; nem0 = (nmn / nbn) * BM; nen0 = (nmn % nbn) * BN; }
         ht_tile = halo_tile(tile);
     };
     int sl = 0, tap = 0;
@@ -265,11 +266,48 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
         for (int k = 0; k < 3; k++) { hreg[0][k] = hreg[0][0]; hreg[1][k] = hreg[0][0]; }
     }
     slice_setup();
-    // the accumulators start at zero; later tiles find them zeroed by the epilogue that read them out
+    // The accumulators of a work item start at bias (+ the sample's time-embedding row), written by the MATRIX PIPE: one MFMA with
+    // C = 0 per fragment, A = the fragment's 32 output channels as (hi, lo) bf16 pairs in k = 0, 1 (hi + lo = the fp32 value to
+    // 2^-17), B = ones in k = 0, 1 -- 4 FN issue slots where v_accvgpr_write needed 64 FN.  K-split parts start at zero (their
+    // finisher adds the bias).  The epilogue of a tile writes the next tile's start values as it empties the accumulators.
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    union FragU { u32x4_t u; bf16x8 f; };
+    auto start_values = [&](int tm0, int tn0, int row, float (&pb)[FM][FN]) {      // fp32 start value of channel `row` of fragment (i, j), tile at (tm0, tn0)
 #pragma unroll
-    for (int f = 0; f < FM * FN; f++) {
+        for (int i = 0; i < FM; i++) {
+            const int mf = tm0 + wm * 128 + i * 32;
+            const float* rv = p.rowvec ? p.rowvec + (long long)(mf / p.rows_per_sample) * p.rowvec_ld : nullptr;
 #pragma unroll
-        for (int r = 0; r < 16; r++) H4_ACCZERO(f, r);
+            for (int j = 0; j < FN; j++) {
+                const int ncol = tn0 + wn * WN + j * 32 + row;
+                float bv = (S == 1 && p.bias) ? p.bias[ncol] : 0.f;
+                if (S == 1 && rv) bv += rv[ncol];
+                pb[i][j] = bv;
+            }
+        }
+    };
+    auto start_frag = [&](float bv, int half) -> bf16x8 {
+        const uint32_t hi = cvt_pk_bf16(bv, 0.f) & 0xffffu;
+        const uint32_t lo = cvt_pk_bf16(bv - __uint_as_float(hi << 16), 0.f) & 0xffffu;
+        FragU t; t.u = (u32x4_t){half ? 0u : (hi | (lo << 16)), 0u, 0u, 0u};
+        return t.f;
+    };
+    {
+        float pb[FM][FN];
+        start_values(em0, en0, frow, pb);
+        FragU o; o.u = (u32x4_t){fhalf ? 0u : 0x3f803f80u, 0u, 0u, 0u};
+        bf16x8 ones = o.f;
+#pragma unroll
+        for (int i = 0; i < FM; i++) {
+            bf16x8 sf[FN];
+#pragma unroll
+            for (int j = 0; j < FN; j++) sf[j] = start_frag(pb[i][j], fhalf);
+            // (VALU-written MFMA operands: hipcc pads that hazard for its own MFMAs, not around asm)
+            if constexpr (FN == 3) asm volatile("s_nop 7" : "+v"(sf[0]), "+v"(sf[1]), "+v"(sf[2]), "+v"(ones));
+            else asm volatile("s_nop 7" : "+v"(sf[0]), "+v"(sf[1]), "+v"(ones));
+#pragma unroll
+            for (int j = 0; j < FN; j++) H4_MFMA0(i * FN + j, sf[j], ones);
+        }
     }
 
     // ---- main stream: one iteration = one tap-step (a tap of a 64-channel slice: 4 k-steps of 16 channels, 16 FN MFMAs).
@@ -299,7 +337,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
         constexpr int P = decltype(ptag)::value;
         auto mfma = [&](int ks, int m) {
             const int j = m / FM, i = m % FM;
-            H4_MFMA(i * FN + j, fa[ks & 1][i], fb[P][ks][j]);
+            H4_MFMA(i * FN + j, fb[P][ks][j], fa[ks & 1][i]);          // D^T: rows = output channels, columns = pixels
         };
         // ---- k-step 0: this step's weights (requested during the previous step's first k-step; its 3 halo requests are younger)
         // (right after an epilogue its stores are younger still: FM * NIT of them, or 4 FM FN split-K plane stores)
@@ -389,106 +427,130 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
         // it would sit in registers across the main loop, which has none to spare
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        const int frow = lane_e & 31, fhalf = lane_e >> 5, odd = lane_e & 1;
+        const int erow = lane_e & 31, ehalf = lane_e >> 5;
+        // Read-out.  Fragment (i, j) register group g (4 registers) = channels j 32 + 8 g + 4 ehalf .. + 3 of pixel erow, fp32: the
+        // groups go from the AGPRs STRAIGHT to a wave-private LDS tile (ds_write_b128 takes accumulator registers: no
+        // v_accvgpr_read, no lane exchange, no conversion), one fragment row (32 pixels x WN channels) at a time, and come back
+        // pixel-contiguous -- 8 consecutive channels per lane -- to be (+ residual) rounded once, packed and stored 16 bytes a lane.
+        constexpr int CPR = WN / 8, NIT = (32 * CPR) / 64;
+        static_assert((32 * CPR) % 64 == 0, "epilogue staging geometry");
+        // LDS tile rows: WN fp32 + 16 bytes of padding where the free halo buffer has room (conflict-free as is); else unpadded with
+        // the 16-byte unit index XOR-ed by (row >> 1) & 7 inside its group of 8 (an unpadded 384-byte row stride alone puts the 16
+        // lanes of a ds_write_b128 phase on 8 banks)
+        const bool swz = HBYTES < 4 * 32 * (WN * 4 + 16);                     // uniform
+        const int SROW = swz ? WN * 4 : WN * 4 + 16;
+        const unsigned stg0 = (unsigned)((hb ^ 1) * HBYTES + wave * 32 * SROW);
+        const unsigned fw = swz ? (unsigned)((erow >> 1) & 7) : 0u;
+        unsigned stgw[4];                                      // this lane's unit (2 g + ehalf) of a fragment's 8: + j * 128
+#pragma unroll
+        for (int g = 0; g < 4; g++) stgw[g] = stg0 + (unsigned)(erow * SROW) + ((((unsigned)(2 * g + ehalf)) ^ fw) << 4);
+        const int eno = en0 + wn * WN;
+        // the next work item's start values (bias + time-embedding row; zero for K-split parts): requested before the read-out
+        float pb[FM][FN];
+        start_values(nem0, nen0, erow, pb);
+        FragU o1; o1.u = (u32x4_t){ehalf ? 0u : 0x3f803f80u, 0u, 0u, 0u};
+        bf16x8 ones = o1.f;
+        auto stage_row = [&](int i) {
+#pragma unroll
+            for (int j = 0; j < FN; j++) {
+                H4_LDSW_ACC(stgw[0], i * FN + j, 0, j * 128); H4_LDSW_ACC(stgw[1], i * FN + j, 1, j * 128);
+                H4_LDSW_ACC(stgw[2], i * FN + j, 2, j * 128); H4_LDSW_ACC(stgw[3], i * FN + j, 3, j * 128);
+            }
+            bf16x8 sf[FN];
+#pragma unroll
+            for (int j = 0; j < FN; j++) sf[j] = start_frag(pb[i][j], ehalf);
+            // the LDS writes read their accumulator registers when they execute: retire them before the matrix pipe overwrites those
+            if constexpr (FN == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" : "+v"(sf[0]), "+v"(sf[1]), "+v"(sf[2]), "+v"(ones) :: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" : "+v"(sf[0]), "+v"(sf[1]), "+v"(ones) :: "memory");
+#pragma unroll
+            for (int j = 0; j < FN; j++) H4_MFMA0(i * FN + j, sf[j], ones);
+        };
         if (S > 1) {
-            float* stg = (float*)(stg_base + wave * 4096);
-            float* wsp = p.ws + (long long)part * p.M * p.N;
+            // K-split part: fp32 planes [part][M][N]; 16-byte units (4 channels), WN / 4 lanes per row segment
+            constexpr int CPR4 = WN / 4, NIT4 = (32 * CPR4) / 64;
+            unsigned voffs[NIT4], lrd4[NIT4];
 #pragma unroll
-            for (int i = 0; i < FM; i++)
-#pragma unroll
-                for (int j = 0; j < FN; j++) {
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int r = 0; r < 16; r++) { float a; H4_ACCREAD(a, i * FN + j, r); H4_ACCZERO(i * FN + j, r); stg[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * 32 + frow] = a; }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int it = 0; it < 4; it++) {
-                        const int idx = it * 64 + lane_e, row = idx >> 3, ch = idx & 7;
-                        const float4 u = *(const float4*)(stg + row * 32 + ch * 4);
-                        float* const dst = wsp + (long long)(em0 + wm * 128 + i * 32 + row) * p.N + en0 + wn * WN + j * 32 + ch * 4;
-                        const h4_u32x4 dv = {__float_as_uint(u.x), __float_as_uint(u.y), __float_as_uint(u.z), __float_as_uint(u.w)};
-                        H4_GSTORE(dst, dv);
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-        } else {
-            constexpr int ROWB = WN * 2, CPR = WN / 8, NIT = (32 * CPR) / 64;
-            static_assert((32 * CPR) % 64 == 0, "epilogue staging geometry");    // 4 waves x 6 KB <= any halo buffer (>= 48 KB)
-            char* stg = stg_base + wave * (32 * ROWB);
-            const int eno = en0 + wn * WN;
-            // per-column bias (+ this sample's time-embedding row): requested here, not at the tile start -- twelve registers the
-            // main loop needs; the vectors are tiny and L2-resident
-            float pbias[FM][FN];
+            for (int it = 0; it < NIT4; it++) {
+                const int idx = it * 64 + lane_e, row = idx / CPR4, c4 = idx - row * CPR4;
+                voffs[it] = (unsigned)(row * p.N + c4 * 4) * 4u;
+                const unsigned fr = swz ? (unsigned)((row >> 1) & 7) : 0u;
+                lrd4[it] = stg0 + (unsigned)(row * SROW) + ((((unsigned)c4 & ~7u) | (((unsigned)c4 ^ fr) & 7u)) << 4);
+            }
+            const char* const wbase = (const char*)(p.ws + (long long)part * p.M * p.N + (long long)(em0 + wm * 128) * p.N + eno);
+            const unsigned long long rowstep = (unsigned long long)(32 * p.N) * 4ull;
 #pragma unroll
             for (int i = 0; i < FM; i++) {
-                const int mf = em0 + wm * 128 + i * 32;
-                const float* rv = p.rowvec ? p.rowvec + (long long)(mf / p.rows_per_sample) * p.rowvec_ld : nullptr;
+                stage_row(i);
+                const char* const op = (const char*)h4_uni64((unsigned long long)(wbase + i * rowstep));
 #pragma unroll
-                for (int j = 0; j < FN; j++) {
-                    const int ncol = eno + j * 32 + frow;
-                    float bv = p.bias ? p.bias[ncol] : 0.f;
-                    if (rv) bv += rv[ncol];
-                    pbias[i][j] = bv;
+                for (int it = 0; it < NIT4; it++) {
+                    const float4 a0 = *(const float4*)(smem + lrd4[it]);
+                    const h4_u32x4 d0 = {__float_as_uint(a0.x), __float_as_uint(a0.y), __float_as_uint(a0.z), __float_as_uint(a0.w)};
+                    H4_GSTORES(voffs[it], d0, op);
                 }
             }
-            // the residual rows of a fragment row are requested one fragment row AHEAD (those of row 0 before anything else): their
-            // HBM latency then hides behind a whole transpose instead of standing in front of every row's stores (measured: a tile with
-            // residual cost 8 k cycles more than one without, 2 k per fragment row)
-            uint4 rr4[2][NIT];
-            auto res_request = [&](int i, uint4 (&dst)[NIT]) {
-                const int mf = em0 + wm * 128 + i * 32;
+        } else {
+            unsigned voffs[NIT], lrd[NIT];                         // chunk = 8 channels = two 16-byte LDS units (2 ch, 2 ch + 1)
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int idx = it * 64 + lane_e, row = idx / CPR, ch = idx - row * CPR;
+                voffs[it] = (unsigned)(row * p.ldo + ch * 8) * 2u;
+                const unsigned fr = swz ? (unsigned)((row >> 1) & 7) : 0u, c4 = (unsigned)(2 * ch);
+                lrd[it] = stg0 + (unsigned)(row * SROW) + (((c4 & ~7u) | ((c4 ^ fr) & 7u)) << 4);
+            }
+            const unsigned lx = swz ? 16u : 0u, la = swz ? 0u : 16u;   // second unit: XOR 16 (swizzled) / + 16 (padded)
+            const char* const obase = (const char*)(ob + (long long)(em0 + wm * 128) * p.ldo + eno);
+            const char* const rbase = (const char*)(rb + (long long)(em0 + wm * 128) * p.ldo + eno);
+            const unsigned long long rowstep = (unsigned long long)(32 * p.ldo) * 2ull;
+            // residual rows: asm loads (saddr form) with counted waits.  Program order of the vector-memory requests:
+            // R0 R1 | S0 (NIT stores) R2 | S1 R3 | S2 | S3 -- the wait in front of row i's adds leaves exactly the younger ones in flight
+            h4_u32x4 rr4[2][NIT];
+            auto res_request = [&](int i, h4_u32x4 (&dst)[NIT]) {
+                const char* const rp = (const char*)h4_uni64((unsigned long long)(rbase + i * rowstep));
+#pragma unroll
+                for (int it = 0; it < NIT; it++) H4_GLOADB(dst[it], voffs[it], rp, 0);
+            };
+            auto res_wait = [&](h4_u32x4 (&r)[NIT], auto ntag) {
+                constexpr int N = decltype(ntag)::value;
+#pragma unroll
+                for (int it = 0; it < NIT; it++) asm volatile("" : "+v"(r[it]));
+                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory");
+#pragma unroll
+                for (int it = 0; it < NIT; it++) asm volatile("" : "+v"(r[it]));
+            };
+            auto store_row = [&](int i) {
+                const char* const op = (const char*)h4_uni64((unsigned long long)(obase + i * rowstep));
 #pragma unroll
                 for (int it = 0; it < NIT; it++) {
-                    const int idx = it * 64 + lane_e, row = idx / CPR, ch = idx - row * CPR;
-                    dst[it] = *(const uint4*)(rb + (long long)(mf + row) * p.ldo + eno + ch * 8);
+                    float4 a0 = *(const float4*)(smem + lrd[it]), a1 = *(const float4*)(smem + ((lrd[it] ^ lx) + la));
+                    if (rb) {                                  // added in fp32: one rounding
+                        const h4_u32x4 r4 = rr4[i & 1][it];
+                        a0.x += __uint_as_float(r4.x << 16); a0.y += __uint_as_float(r4.x & 0xffff0000u);
+                        a0.z += __uint_as_float(r4.y << 16); a0.w += __uint_as_float(r4.y & 0xffff0000u);
+                        a1.x += __uint_as_float(r4.z << 16); a1.y += __uint_as_float(r4.z & 0xffff0000u);
+                        a1.z += __uint_as_float(r4.w << 16); a1.w += __uint_as_float(r4.w & 0xffff0000u);
+                    }
+                    const h4_u32x4 dv = {cvt_pk_bf16(a0.x, a0.y), cvt_pk_bf16(a0.z, a0.w), cvt_pk_bf16(a1.x, a1.y), cvt_pk_bf16(a1.z, a1.w)};
+                    H4_GSTORES(voffs[it], dv, op);
                 }
             };
-            if (rb) res_request(0, rr4[0]);
-#pragma unroll
-            for (int i = 0; i < FM; i++) {
-                const int mf = em0 + wm * 128 + i * 32;
-                if (rb && i + 1 < FM) res_request(i + 1, rr4[(i + 1) & 1]);
-#pragma unroll
-                for (int j = 0; j < FN; j++) {
-                    __builtin_amdgcn_sched_barrier(0);         // one fragment's 16 accumulators at a time (no wholesale AGPR -> VGPR hoist)
-                    float v[16];
-#pragma unroll
-                    for (int r = 0; r < 16; r++) { float a; H4_ACCREAD(a, i * FN + j, r); H4_ACCZERO(i * FN + j, r); v[r] = a + pbias[i][j]; }
-                    char* wp = stg + (4 * fhalf + odd) * ROWB + (j * 32 + frow - odd) * 2;
-#pragma unroll
-                    for (int t = 0; t < 8; t++) {
-                        const int roff = ((2 * t) & 3) + 8 * ((2 * t) >> 2);
-                        const float give = odd ? v[2 * t] : v[2 * t + 1];
-                        const float got = swap_adjacent_lane(give);
-                        const float lo = odd ? got : v[2 * t], hi = odd ? v[2 * t + 1] : got;
-                        *(uint32_t*)(wp + roff * ROWB) = cvt_pk_bf16(lo, hi);
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int it = 0; it < NIT; it++) {
-                    const int idx = it * 64 + lane_e, row = idx / CPR, ch = idx - row * CPR;
-                    uint4 u = *(const uint4*)(stg + row * ROWB + ch * 16);
-                    const long long o = (long long)(mf + row) * p.ldo + eno + ch * 8;
-                    if (rb) {
-                        const uint4 r4 = rr4[i & 1][it];
-                        const uint32_t uu[4] = {u.x, u.y, u.z, u.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
-                        uint32_t oo[4];
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            oo[e] = cvt_pk_bf16(__uint_as_float(uu[e] << 16) + __uint_as_float(rr[e] << 16),
-                                                __uint_as_float(uu[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u));
-                        u = make_uint4(oo[0], oo[1], oo[2], oo[3]);
-                    }
-                    bf16_t* const dst = ob + o;
-                    const h4_u32x4 dv = {u.x, u.y, u.z, u.w};
-                    H4_GSTORE(dst, dv);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (rb) {
+                res_request(0, rr4[0]); res_request(1, rr4[1]);
+                stage_row(0); res_wait(rr4[0], std::integral_constant<int, NIT>{}); store_row(0);
+                res_request(2, rr4[0]);
+                stage_row(1); res_wait(rr4[1], std::integral_constant<int, 2 * NIT>{}); store_row(1);
+                res_request(3, rr4[1]);
+                stage_row(2); res_wait(rr4[0], std::integral_constant<int, 2 * NIT>{}); store_row(2);
+                stage_row(3); res_wait(rr4[1], std::integral_constant<int, NIT>{}); store_row(3);
+            } else {
+                stage_row(0); store_row(0);
+                stage_row(1); store_row(1);
+                stage_row(2); store_row(2);
+                stage_row(3); store_row(3);
             }
         }
         // (the epilogue's own loads -- bias, residual -- were consumed above, i.e. waited for; its stores are asm)
-        epi_stores = (S > 1) ? 4 * FM * FN : FM * ((32 * (WN / 8)) / 64);
+        epi_stores = (S > 1) ? 2 * FM * ((32 * (WN / 8)) / 64) : FM * ((32 * (WN / 8)) / 64);
         if (p.dbg & 16) tprof[1] += __builtin_readcyclecounter() - tp1;
         if (!has_next) return true;
         // the staging area is the buffer the next tile's SECOND slice is staged into during its first steps: every wave must have

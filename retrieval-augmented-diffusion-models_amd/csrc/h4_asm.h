@@ -30,6 +30,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned h4_u32x4;
 #define H4_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
 #define H4_GSTOREO(vaddr, data, off) asm volatile("global_store_dwordx4 %0, %1, off offset:%2\n\ts_nop 1" :: "v"(vaddr), "v"(data), "i"(off) : "memory")
 #define H4_GSTORES(voff, data, sbase) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(voff), "v"(data), "s"(sbase) : "memory")
+#define H4_GSTORESO(voff, data, sbase, off) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" :: "v"(voff), "v"(data), "s"(sbase), "i"(off) : "memory")
+__device__ __forceinline__ unsigned long long h4_uni64(unsigned long long v) {    // uniform value -> SGPR pair
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 // accumulator group G (4 registers) of fragment IDX straight from the AGPRs to LDS
 #define H4_LDSW_ACC(addr, IDX, G, off) asm volatile("ds_write_b128 %0, a[%c1:%c2] offset:%3" :: "v"(addr), "i"(H4_ACC0 + (IDX) * 16 + (G) * 4), "i"(H4_ACC0 + (IDX) * 16 + (G) * 4 + 3), "i"(off) : "memory")
 #define H4_ACCWRITE(IDX, R, src) asm volatile("v_accvgpr_write_b32 a%c0, %1" :: "i"(H4_ACC0 + (IDX) * 16 + (R)), "v"(src))
