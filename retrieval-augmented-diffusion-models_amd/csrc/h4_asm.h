@@ -35,6 +35,9 @@ __device__ __forceinline__ unsigned long long h4_uni64(unsigned long long v) {  
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
+// the low AGPRs (below H4_ACC0) as landing registers for loads the VGPR file has no room for: 16 bytes into a[AIDX : AIDX + 3]
+#define H4_GLOADB_A(AIDX, voff, sbase) asm volatile("global_load_dwordx4 a[%c0:%c1], %2, %3" :: "i"(AIDX), "i"((AIDX) + 3), "v"(voff), "s"(sbase) : "memory")
+#define H4_AREAD(dst, AIDX) asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(dst) : "i"(AIDX))
 // accumulator group G (4 registers) of fragment IDX straight from the AGPRs to LDS
 #define H4_LDSW_ACC(addr, IDX, G, off) asm volatile("ds_write_b128 %0, a[%c1:%c2] offset:%3" :: "v"(addr), "i"(H4_ACC0 + (IDX) * 16 + (G) * 4), "i"(H4_ACC0 + (IDX) * 16 + (G) * 4 + 3), "i"(off) : "memory")
 #define H4_ACCWRITE(IDX, R, src) asm volatile("v_accvgpr_write_b32 a%c0, %1" :: "i"(H4_ACC0 + (IDX) * 16 + (R)), "v"(src))
