@@ -72,7 +72,7 @@ def test_linear_geglu(ctx):
 # both wave arrangements (N % 384 == 0: 1 x 4, else 2 x 2), one or two tiles per block (dead look-ahead cursors), a one-slice K,
 # residual, no bias, and the GEGLU read-out.  Each case runs twice: the first version of the kernel failed intermittently.
 @pytest.mark.parametrize("M,N,K,bias,res", [(49152, 192, 64, 1, 0), (49152, 384, 384, 1, 0), (65536, 384, 384, 1, 1), (32768, 768, 128, 0, 1),
-                                            (49408, 192, 192, 1, 1), (49152, 576, 192, 1, 0)])
+                                            (49408, 192, 192, 1, 1), (49152, 576, 192, 1, 0), (8192, 960, 960, 1, 1)])
 def test_linear_big_m(ctx, M, N, K, bias, res):
     d = ctx.device
     a, w = bf16_round(_rand((M, K), 21)), bf16_round(_rand((N, K), 22, K ** -0.5))
