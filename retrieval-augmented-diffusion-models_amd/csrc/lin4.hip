@@ -439,7 +439,7 @@ bool lin4_supported(const IgemmParams& p, int batch) {
     if (p.N > 8192 || p.ldo % 8 || p.ldo < No || (p.ldw > 0 && p.ldw != p.K)) return false;
     if (p.C1 > 0 && p.lda > 0) return false;
     static const int min_tiles = getenv("RDM_L4_MIN_TILES") ? atoi(getenv("RDM_L4_MIN_TILES")) : 128;
-    if ((long long)(p.M / (128 * wm)) * (p.N / (wm == 1 ? 384 : 192)) < min_tiles) return false;     // far fewer tiles than CUs: the 128-row tiles of igemm.hip (160 tiles -- the 8x8-level projections -- still win here: 28 vs 32 us)
+    if (!p.l4_any_tiles && (long long)(p.M / (128 * wm)) * (p.N / (wm == 1 ? 384 : 192)) < min_tiles) return false;     // far fewer tiles than CUs: the 128-row tiles of igemm.hip (160 tiles -- the 8x8-level projections -- still win here: 28 vs 32 us)
     return true;
 }
 

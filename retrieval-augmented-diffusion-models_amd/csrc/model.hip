@@ -505,7 +505,15 @@ struct Ops {
         p.act = act; p.res_bf16 = res; p.res_f32 = res_f32; p.out_bf16 = out; p.out_f32 = out_f32;
         if (act == ACT_GEGLU) p.ldo = N / 2;
         // one-wave-per-SIMD kernel for the big-M projections (its tile choice follows M, so not in deterministic mode)
-        if (!c->deterministic) { IgemmParams t = p; t.Wfrag = p.W; if (lin4_supported(t, 1)) p.Wfrag = c->frag_for_lin(p.W, N, C0 + C1, act == ACT_GEGLU); }
+        // (deterministic mode: its use must not follow the batch -- exactly when the rows of ONE sample fill whole 128 / 256-row tiles,
+        //  at any tile count; a row's sum order is the same in every tile position)
+        {
+            IgemmParams t = p; t.Wfrag = p.W;
+            const int tile_rows = (N % 384 == 0) ? 128 : 256;
+            const bool det_ok = rows_hint > 0 && rows_hint % tile_rows == 0;
+            if (c->deterministic) t.l4_any_tiles = p.l4_any_tiles = 1;
+            if ((!c->deterministic || det_ok) && lin4_supported(t, 1)) p.Wfrag = c->frag_for_lin(p.W, N, C0 + C1, act == ACT_GEGLU);
+        }
         prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)(C0 + C1));
         check(launch_igemm(p, false, 1, c->stream), "linear");
         prof_end();
@@ -530,6 +538,7 @@ struct Ops {
         prof_end();
     }
     bool single_row = false;     // set by callers around ops whose operand has one row per sample (see linear)
+    int rows_hint = 0;           // rows per sample of the operand of the linear ops that follow (0 = unknown); set by the UNet block executors
     bool prof_open = false;
     void prof_begin(int kind, double work) {       // work: FLOPs (GEMM-class kinds) or bytes (bandwidth-class kinds)
         prof_open = (c->prof >> kind) & 1u;
@@ -647,6 +656,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
 
     auto resblock = [&](const ResW& r, const Act& a, const Act* skip) -> Act {
         const int C0 = a.C, C1 = skip ? skip->C : 0, HW = a.H * a.W, M = B * HW;
+        o.rows_hint = HW;
         const bf16_t* x1 = skip ? skip->p : nullptr;
         bf16_t* n1 = o.abf((size_t)M * r.cin);
         o.groupnorm(a.p, x1, C0, C1, B, HW, r.gn1g, r.gn1b, 1e-5f, 1, n1, a.L, skip ? skip->L : 0);
@@ -666,6 +676,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
     };
     auto transformer = [&](const StW& s, const Act& a) -> Act {
         const int C = s.c, n = a.H * a.W, M = B * n;
+        o.rows_hint = n;
         bf16_t* xn = o.abf((size_t)M * C);
         o.groupnorm(a.p, nullptr, C, 0, B, n, s.gng, s.gnb, 1e-6f, 0, xn, s.lc, 0);
         bf16_t* t0 = o.abf((size_t)M * C);
