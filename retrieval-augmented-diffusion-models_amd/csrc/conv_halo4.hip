@@ -349,7 +349,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
 #pragma unroll
         for (int m = 0; m < FM * FN; m++) {
             mfma(0, m);
-            H4_GLOADB(fb[P ^ 1][m / FN][m % FN], voffj[m % FN], sbn, (m / FN) * 1024);
+            if constexpr (VAR == 3) H4_GLOADB(fb[P ^ 1][m / FN][m % FN], voffj[0], Wf, 0);      // ablation: every weight request hits the same KiB (wrong results)
+            else H4_GLOADB(fb[P ^ 1][m / FN][m % FN], voffj[m % FN], sbn, (m / FN) * 1024);
             if (m == 3) {
 #pragma unroll
                 for (int i = 0; i < FM; i++) H4_LDSR(fa[1][i], va[i], 32);
@@ -624,6 +625,7 @@ hipError_t launch_conv_halo4(const IgemmParams& p, hipStream_t st) {
     static const int var = getenv("RDM_H4_VAR") ? atoi(getenv("RDM_H4_VAR")) : 0;
     if (p.N % 192 == 0) {
         if (var == 1) return launch_halo4_cfg<3, 1>(p, st);
+        if (var == 3) return launch_halo4_cfg<3, 3>(p, st);
         if (var == 2) return launch_halo4_cfg<3, 2>(p, st);
         return launch_halo4_cfg<3, 0>(p, st);
     }
