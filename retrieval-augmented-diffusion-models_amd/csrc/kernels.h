@@ -71,6 +71,7 @@ hipError_t launch_set_int(int* p, int v, hipStream_t st);
 struct SgemmParams {
     const bf16_t* A; int lda; const bf16_t* W; int M, N, K;     // W [N][K]; GEGLU: N = 2 x outputs, rows interleaved in blocks of 32
     const float* bias; int act; const float* res_f32; const bf16_t* res_bf16; float* out_f32; bf16_t* out_bf16; int ldo;
+    const float* ln_x; const float* ln_g; const float* ln_b; float ln_eps;      // A = LayerNorm(ln_x [M][K] fp32) formed in the kernel (A ignored)
 };
 bool sgemm_supported(const SgemmParams& p);
 hipError_t launch_sgemm(const SgemmParams& p, hipStream_t st);

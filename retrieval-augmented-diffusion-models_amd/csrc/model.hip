@@ -518,6 +518,20 @@ struct Ops {
         check(launch_igemm(p, false, 1, c->stream), "linear");
         prof_end();
     }
+    // out = act(LayerNorm(x) W^T + bias) with the LayerNorm formed inside the skinny GEMM (sgemm.hip): decode-sized operands only.
+    // false = not available for this shape (the caller runs layernorm + linear)
+    bool linear_ln(const float* x, size_t g, size_t b, int C, size_t woff, size_t boff, bool has_bias, int M, int N, int act, bf16_t* out) {
+        static const int off = getenv("RDM_NO_LNFUSE") ? atoi(getenv("RDM_NO_LNFUSE")) : 0;
+        const bool skinny = c->deterministic ? single_row : (M <= 128);
+        SgemmParams q{}; q.ln_x = x; q.ln_g = w<float>(g); q.ln_b = w<float>(b); q.ln_eps = 1e-5f; q.W = w<bf16_t>(woff); q.M = M; q.N = N; q.K = C;
+        q.bias = has_bias ? w<float>(boff) : nullptr; q.act = act; q.out_bf16 = out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
+        if (off || !skinny || !sgemm_supported(q)) return false;
+        if (plan) return true;
+        prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)C);
+        check(launch_sgemm(q, c->stream), "skinny linear on a LayerNorm");
+        prof_end();
+        return true;
+    }
     void conv3(const bf16_t* A0, const bf16_t* A1, int C0, int C1, size_t woff, size_t boff, int B, int Hin, int Win, int N,
                int stride, int ups, const float* rowvec, int rowvec_ld, const bf16_t* res, bf16_t* out) {
         if (plan) return;
@@ -1346,8 +1360,10 @@ static int rarm_step(rdm_ctx* c, int B2, int k) {
         const float scale = 1.0f / sqrtf((float)g.d_head);
         for (int l = 0; l < g.depth; l++) {
             const RarmBlk& b = m.blk[l];
-            o.layernorm(x, 1, b.ln1g, b.ln1b, ln, 0, B2, C);
-            o.linear(ln, nullptr, C, 0, b.wqkv, 0, false, B2, 3 * C, ACT_NONE, nullptr, qkv);
+            if (!o.linear_ln(x, b.ln1g, b.ln1b, C, b.wqkv, 0, false, B2, 3 * C, ACT_NONE, qkv)) {
+                o.layernorm(x, 1, b.ln1g, b.ln1b, ln, 0, B2, C);
+                o.linear(ln, nullptr, C, 0, b.wqkv, 0, false, B2, 3 * C, ACT_NONE, nullptr, qkv);
+            }
             if (!o.plan) {
                 RarmAttnParams p{}; p.q = qkv; p.ldq = 3 * C; p.k_new = qkv + C; p.v_new = qkv + 2 * C;
                 p.Kc = (bf16_t*)m.cache + ((size_t)l * 2) * B2 * L * C; p.Vc = (bf16_t*)m.cache + ((size_t)l * 2 + 1) * B2 * L * C;
@@ -1355,16 +1371,20 @@ static int rarm_step(rdm_ctx* c, int B2, int k) {
                 o.check(launch_rarm_decode_attention(p, g.n_heads, B2, c->stream), "rarm self attention");
             }
             o.linear(ao, nullptr, C, 0, b.wo1, b.bo1, true, B2, C, ACT_NONE, nullptr, nullptr, x, x);
-            o.layernorm(x, 1, b.ln2g, b.ln2b, ln, 0, B2, C);
-            o.linear(ln, nullptr, C, 0, b.wq2, 0, false, B2, C, ACT_NONE, nullptr, q2);
+            if (!o.linear_ln(x, b.ln2g, b.ln2b, C, b.wq2, 0, false, B2, C, ACT_NONE, q2)) {
+                o.layernorm(x, 1, b.ln2g, b.ln2b, ln, 0, B2, C);
+                o.linear(ln, nullptr, C, 0, b.wq2, 0, false, B2, C, ACT_NONE, nullptr, q2);
+            }
             if (!o.plan) {
                 RarmAttnParams p{}; p.q = q2; p.ldq = C; p.Kc = (bf16_t*)m.ctxkv + (size_t)l * 2 * C; p.Vc = (bf16_t*)m.ctxkv + (size_t)l * 2 * C + C;
                 p.batch_stride = (long long)k * m.kv_total; p.row_stride = m.kv_total; p.nkv = k; p.scale = scale; p.out = ao; p.ldo = C;
                 o.check(launch_rarm_decode_attention(p, g.n_heads, B2, c->stream), "rarm cross attention");
             }
             o.linear(ao, nullptr, C, 0, b.wo2, b.bo2, true, B2, C, ACT_NONE, nullptr, nullptr, x, x);
-            o.layernorm(x, 1, b.ln3g, b.ln3b, ln, 0, B2, C);
-            o.linear(ln, nullptr, C, 0, b.wff1, b.bff1, true, B2, 8 * C, ACT_GEGLU, nullptr, ff);
+            if (!o.linear_ln(x, b.ln3g, b.ln3b, C, b.wff1, b.bff1, true, B2, 8 * C, ACT_GEGLU, ff)) {
+                o.layernorm(x, 1, b.ln3g, b.ln3b, ln, 0, B2, C);
+                o.linear(ln, nullptr, C, 0, b.wff1, b.bff1, true, B2, 8 * C, ACT_GEGLU, nullptr, ff);
+            }
             o.linear(ff, nullptr, 4 * C, 0, b.wff2, b.bff2, true, B2, C, ACT_NONE, nullptr, nullptr, x, x);
         }
         if (!o.plan) o.check(launch_cast_f32_bf16(x, ln, (long long)B2 * C, c->stream), "cast x");
