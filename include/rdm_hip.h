@@ -253,6 +253,10 @@ int rdm_op_layernorm_bwd(rdm_ctx* ctx, const void* x_bf16, const void* dy_bf16, 
 int rdm_op_colsum(rdm_ctx* ctx, const void* x_bf16 /*[M,N]*/, float* out /*[N]*/, long long M, int N);
 int rdm_op_transpose(rdm_ctx* ctx, const void* x_bf16 /*[rows,cols]*/, void* y_bf16 /*[cols,rows]*/, int rows, int cols);
 int rdm_op_add(rdm_ctx* ctx, const void* a_bf16, const void* b_bf16, void* out_bf16, long long n);
+/* GEGLU (ldm attention.py GEGLU.forward: `x, gate = proj(x).chunk(2, dim=-1); return x * F.gelu(gate)`) on an UNPERMUTED
+ * pre-activation pre [M, 2F] = [x | gate], bf16.  dh null: forward, out [M, F].  dh [M, F] given: backward, out [M, 2F] = [dx | dgate]
+ * (what autograd computes for that line in the training step). */
+int rdm_op_geglu(rdm_ctx* ctx, const void* pre_bf16, const void* dh_bf16_or_null, void* out_bf16, long long M, int F);
 int rdm_op_groupnorm(rdm_ctx* ctx, const void* x0_bf16, const void* x1_bf16, int C0, int C1, int B, int HW,
                      const float* gamma, const float* beta, float eps, int silu, void* out_bf16);
 int rdm_op_layernorm(rdm_ctx* ctx, const void* x, int in_is_f32, const float* gamma, const float* beta, int M, int C,

@@ -118,6 +118,7 @@ SIGNATURES = {
     "rdm_op_colsum": (C.c_int, [_P, _P, _P, C.c_longlong, C.c_int]),
     "rdm_op_transpose": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "rdm_op_add": (C.c_int, [_P, _P, _P, _P, C.c_longlong]),
+    "rdm_op_geglu": (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_int]),
     "rdm_op_groupnorm": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_float, C.c_int, _P]),
     "rdm_op_layernorm": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "rdm_op_self_attention": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
@@ -637,6 +638,13 @@ class Context:
     def op_add(self, a, b):
         out = torch.empty_like(a)
         self._check(lib.rdm_op_add(self._h, _ptr(a), _ptr(b), _ptr(out), a.numel()))
+        return out
+
+    def op_geglu(self, pre, dh=None):
+        """pre bf16 [M, 2F] = [x | gate] (unpermuted).  dh None -> x * gelu(gate) [M, F]; else the gradient [dx | dgate] [M, 2F]."""
+        M, F2 = pre.shape
+        out = torch.empty((M, F2 // 2) if dh is None else (M, F2), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_geglu(self._h, _ptr(pre), _ptr(dh) if dh is not None else None, _ptr(out), M, F2 // 2))
         return out
 
     def op_groupnorm(self, x0, gamma, beta, eps, silu, x1=None):

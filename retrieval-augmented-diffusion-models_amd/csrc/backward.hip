@@ -282,3 +282,51 @@ hipError_t launch_add_bf16(const bf16_t* a, const bf16_t* b, bf16_t* out, long l
     add_bf16_kernel<<<dim3((unsigned)g), 256, 0, st>>>(a, b, out, n);
     return hipGetLastError();
 }
+
+// ---- GEGLU (ldm attention.py GEGLU: x, gate = proj(x).chunk(2, -1); return x * gelu(gate)) on a pre-activation matrix [M, 2F] bf16:
+// forward h = a * gelu(g); backward da = dh * gelu(g), dg = dh * a * (Phi(g) + g phi(g)).  One thread = 8 outputs (16-byte accesses).
+__device__ __forceinline__ float gelu_grad_f(float g) {       // d/dg [g Phi(g)] = Phi(g) + g phi(g)
+    const float phi = 0.3989422804014327f * __expf(-0.5f * g * g);
+    const float Phi = (g == 0.f) ? 0.5f : gelu_erf_f(g) / g;
+    return Phi + g * phi;
+}
+template <bool BWD>
+__global__ __launch_bounds__(256) void geglu_kernel(const bf16_t* __restrict__ pre, const bf16_t* __restrict__ dh, bf16_t* __restrict__ out, long long M, int F) {
+    const long long nvec = M * (F / 8);
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
+        const long long m = v / (F / 8); const int f0 = (int)(v - m * (F / 8)) * 8;
+        const uint4 av = *(const uint4*)(pre + m * 2 * F + f0), gv = *(const uint4*)(pre + m * 2 * F + F + f0);
+        const uint32_t as[4] = {av.x, av.y, av.z, av.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+        float a[8], g[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            a[2 * e] = __uint_as_float(as[e] << 16); a[2 * e + 1] = __uint_as_float(as[e] & 0xffff0000u);
+            g[2 * e] = __uint_as_float(gs[e] << 16); g[2 * e + 1] = __uint_as_float(gs[e] & 0xffff0000u);
+        }
+        if (!BWD) {
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = cvt_pk_bf16(a[2 * e] * gelu_erf_f(g[2 * e]), a[2 * e + 1] * gelu_erf_f(g[2 * e + 1]));
+            *(uint4*)(out + m * F + f0) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            const uint4 dv = *(const uint4*)(dh + m * F + f0);
+            const uint32_t ds[4] = {dv.x, dv.y, dv.z, dv.w};
+            uint32_t oa[4], og[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float d0 = __uint_as_float(ds[e] << 16), d1 = __uint_as_float(ds[e] & 0xffff0000u);
+                oa[e] = cvt_pk_bf16(d0 * gelu_erf_f(g[2 * e]), d1 * gelu_erf_f(g[2 * e + 1]));
+                og[e] = cvt_pk_bf16(d0 * a[2 * e] * gelu_grad_f(g[2 * e]), d1 * a[2 * e + 1] * gelu_grad_f(g[2 * e + 1]));
+            }
+            *(uint4*)(out + m * 2 * F + f0) = make_uint4(oa[0], oa[1], oa[2], oa[3]);
+            *(uint4*)(out + m * 2 * F + F + f0) = make_uint4(og[0], og[1], og[2], og[3]);
+        }
+    }
+}
+hipError_t launch_geglu(const bf16_t* pre, const bf16_t* dh, bf16_t* out, long long M, int F, hipStream_t st) {
+    if (F % 8 != 0) return hipErrorInvalidValue;
+    long long g = (M * (F / 8) + 255) / 256; if (g < 1) g = 1; if (g > 16384) g = 16384;
+    if (dh) geglu_kernel<true><<<dim3((unsigned)g), 256, 0, st>>>(pre, dh, out, M, F);
+    else geglu_kernel<false><<<dim3((unsigned)g), 256, 0, st>>>(pre, nullptr, out, M, F);
+    return hipGetLastError();
+}

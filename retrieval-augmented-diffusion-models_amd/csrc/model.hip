@@ -1701,6 +1701,12 @@ int rdm_op_add(rdm_ctx* c, const void* a, const void* b, void* out, long long n)
     RDM_CHECK_HIP(c, launch_add_bf16((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n, c->stream));
     return 0;
 }
+int rdm_op_geglu(rdm_ctx* c, const void* pre, const void* dh, void* out, long long M, int F) {
+    RDM_ENTER(c);
+    if (!pre || !out || M < 1 || F < 8 || F % 8) return c->fail(-1, "rdm_op_geglu: bad argument (F must be a positive multiple of 8)");
+    RDM_CHECK_HIP(c, launch_geglu((const bf16_t*)pre, (const bf16_t*)dh, (bf16_t*)out, M, F, c->stream));
+    return 0;
+}
 int rdm_op_groupnorm(rdm_ctx* c, const void* x0, const void* x1, int C0, int C1, int B, int HW, const float* gamma,
                      const float* beta, float eps, int silu, void* out) {
     RDM_ENTER(c);

@@ -5,8 +5,9 @@ ldm's `h = conv(silu(gn(x))); h += linear(silu(emb)); h = conv(silu(gn(h))); ret
 Every arithmetic step is a C-ABI call into librdm_hip (include/rdm_hip.h "backward"): conv dgrad through the forward conv kernel with
 the flipped / transposed filter, conv wgrad as a pixel-reduction GEMM on the MFMA kernel, GroupNorm+SiLU backward, deterministic column
 sums, GEMMs for the time-embedding projection.  torch is used for device memory only (allocation, reshapes / views, zero padding).
-What is NOT here yet: attention / GEGLU / LayerNorm-in-block backward, the optimiser, EMA, the first-stage encoder, the RCCL gradient
-all-reduce."""
+The feed-forward sub-block of BasicTransformerBlock (`x + ff(norm3(x))`, ldm attention.py FeedForward / GEGLU) has its forward and
+backward here too (ff_forward / ff_backward).  What is NOT here yet: attention backward, the optimiser, EMA, the first-stage encoder,
+the RCCL gradient all-reduce."""
 import torch
 
 from . import _lib
@@ -75,4 +76,27 @@ def resblock_backward(ctx, p, x, semb, saved, dout):
     else:
         dxs = dflat
     g["dx"] = ctx.op_add(dx.reshape(M, Cin), dxs.reshape(M, Cin)).reshape(B, H, W, Cin)
+    return g
+
+
+def ff_forward(ctx, p, x):
+    """BasicTransformerBlock's feed-forward residual branch: out = x + W2 (a * gelu(g)) + b2 with [a | g] = W1 LayerNorm(x) + b1
+    (ldm attention.py: `x = self.ff(self.norm3(x)) + x`, FeedForward(glu=True) = GEGLU -> Dropout(0) -> Linear).
+    x bf16 [M, C]; p: ln_g / ln_b f32 [C], w1 bf16 [2F, C] (rows [x | gate], UNPERMUTED), b1 f32 [2F], w2 bf16 [C, F], b2 f32 [C].
+    -> (out bf16 [M, C], saved activations)"""
+    ln = ctx.op_layernorm(x, p["ln_g"], p["ln_b"])
+    pre = ctx.op_linear(ln, p["w1"], p["b1"])                                         # [M, 2F]
+    h = ctx.op_geglu(pre)                                                               # [M, F]
+    out = ctx.op_linear(h, p["w2"], p["b2"], residual=x)
+    return out, {"ln": ln, "pre": pre, "h": h}
+
+
+def ff_backward(ctx, p, x, saved, dout):
+    """Gradients of `ff_forward` given dout (bf16 [M, C]) -> dx bf16 and fp32 parameter gradients (w1, b1, w2, b2, ln_g, ln_b)."""
+    g = {}
+    dh, g["w2"], g["b2"] = linear_backward(ctx, saved["h"], p["w2"], dout)              # out = h w2^T + b2 (+ x)
+    dpre = ctx.op_geglu(saved["pre"], dh)                                               # [da | dg]
+    dln, g["w1"], g["b1"] = linear_backward(ctx, saved["ln"], p["w1"], dpre)
+    dx_ln, g["ln_g"], g["ln_b"] = ctx.op_layernorm_bwd(x, dln, p["ln_g"])
+    g["x"] = ctx.op_add(dx_ln, dout)                                                    # + the residual path
     return g

@@ -5,6 +5,7 @@ gradient (bf16 activation gradients between the stages, fp32 accumulation)."""
 import pytest
 import torch
 import torch.nn.functional as F
+import torch.nn.functional as F_
 
 from _util import bf16_round, rel_l2
 
@@ -106,3 +107,44 @@ def test_resblock_backward_matches_autograd(ctx, Cin, Cout):
         errs[k] = rel_l2(g[k].float(), ref)
     print("resblock backward rel L2:", {k: f"{v:.2e}" for k, v in errs.items()})
     assert max(errs.values()) <= TOL, errs
+
+
+@pytest.mark.parametrize("M,F", [(300, 256), (64, 1536)])
+def test_geglu_forward_backward(ctx, M, F):
+    d = ctx.device
+    pre = bf16_round(_rand((M, 2 * F), 40) * 1.5).requires_grad_(True)
+    dh = bf16_round(_rand((M, F), 41))
+    a, g = pre.chunk(2, dim=-1)
+    h = a * F_.gelu(g)
+    h.backward(dh)
+    out = ctx.op_geglu(pre.detach().to(d, torch.bfloat16))
+    dpre = ctx.op_geglu(pre.detach().to(d, torch.bfloat16), dh.to(d, torch.bfloat16))
+    e = (rel_l2(out.float(), h.detach()), rel_l2(dpre.float(), pre.grad))
+    print(f"geglu M={M} F={F}: forward {e[0]:.2e} backward {e[1]:.2e}")
+    assert max(e) <= 1e-2
+
+
+@pytest.mark.parametrize("M,C", [(512, 128), (192, 384)])
+def test_feed_forward_block_backward(ctx, M, C):
+    """x + ff(norm3(x)) of BasicTransformerBlock (GEGLU feed-forward, inner width 4 C): forward and every gradient vs autograd."""
+    from rdm_amd import training
+    d = ctx.device
+    Fh = 4 * C
+    x = bf16_round(_rand((M, C), 50)).requires_grad_(True)
+    prm = {"ln_g": 1 + 0.1 * _rand((C,), 51), "ln_b": 0.1 * _rand((C,), 52), "w1": bf16_round(_rand((2 * Fh, C), 53, C ** -0.5)), "b1": 0.1 * _rand((2 * Fh,), 54),
+           "w2": bf16_round(_rand((C, Fh), 55, Fh ** -0.5)), "b2": 0.1 * _rand((C,), 56)}
+    ref_p = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+    dout = bf16_round(_rand((M, C), 57))
+    ln = F_.layer_norm(x, (C,), ref_p["ln_g"], ref_p["ln_b"], 1e-5)
+    a, g = (ln @ ref_p["w1"].t() + ref_p["b1"]).chunk(2, dim=-1)
+    out_ref = x + (a * F_.gelu(g)) @ ref_p["w2"].t() + ref_p["b2"]
+    out_ref.backward(dout)
+    dev = {k: (v.to(d, torch.bfloat16) if k in ("w1", "w2") else v.to(d)) for k, v in prm.items()}
+    xd = x.detach().to(d, torch.bfloat16)
+    out, saved = training.ff_forward(ctx, dev, xd)
+    grads = training.ff_backward(ctx, dev, xd, saved, dout.to(d, torch.bfloat16))
+    errs = {"out": rel_l2(out.float(), out_ref.detach()), "x": rel_l2(grads["x"].float(), x.grad)}
+    for k in ("w1", "b1", "w2", "b2", "ln_g", "ln_b"):
+        errs[k] = rel_l2(grads[k].float(), ref_p[k].grad)
+    print(f"feed-forward block M={M} C={C}: " + " ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert max(errs.values()) <= TOL
