@@ -253,6 +253,19 @@ int rdm_op_layernorm_bwd(rdm_ctx* ctx, const void* x_bf16, const void* dy_bf16, 
 int rdm_op_colsum(rdm_ctx* ctx, const void* x_bf16 /*[M,N]*/, float* out /*[N]*/, long long M, int N);
 int rdm_op_transpose(rdm_ctx* ctx, const void* x_bf16 /*[rows,cols]*/, void* y_bf16 /*[cols,rows]*/, int rows, int cols);
 int rdm_op_add(rdm_ctx* ctx, const void* a_bf16, const void* b_bf16, void* out_bf16, long long n);
+/* Attention backward, unfused first version (autograd through ldm CrossAttention.forward, attention.py:52-72:
+ * sim = einsum(q, k) * scale; attn = sim.softmax(-1); out = einsum(attn, v)).  The scores are materialised per (sample, head):
+ *   rdm_op_heads   x [B, n, ldx] (head h = columns [h D, (h+1) D)) <-> per-head matrices zero-padded to 64 columns:
+ *                  mode 0 -> [B H][n][64], mode 1 -> transposed [B H][64][n], mode 2: [B H][n][64] -> [B, n, H D];
+ *   rdm_op_bmm     out[z] = alpha * A[z] W[z]^T for batch contiguous bf16 matrices A [M, K], W [N, K] (K % 64 == 0), bf16 and / or fp32 out;
+ *   rdm_op_transpose_batched, rdm_op_softmax (fp32 scores -> bf16 probabilities, row-wise), rdm_op_softmax_bwd
+ *   (dS = P * (dP - rowsum(P * dP))).  rdm_amd/training.py attention_forward / attention_backward assemble them. */
+int rdm_op_bmm(rdm_ctx* ctx, const void* a_bf16, const void* w_bf16, void* out_bf16_or_null, float* out_f32_or_null, int batch, int M, int N, int K,
+               float alpha);
+int rdm_op_heads(rdm_ctx* ctx, const void* x_bf16, void* out_bf16, int B, int n, int H, int D, int ldx, int mode);
+int rdm_op_transpose_batched(rdm_ctx* ctx, const void* x_bf16, void* y_bf16, int batch, int rows, int cols);
+int rdm_op_softmax(rdm_ctx* ctx, const float* scores, void* p_bf16, long long rows, int n, int n_valid /* columns >= n_valid are padding: probability 0 (0 = all valid) */);
+int rdm_op_softmax_bwd(rdm_ctx* ctx, const void* p_bf16, const float* dp, void* ds_bf16, long long rows, int n);
 /* GEGLU (ldm attention.py GEGLU.forward: `x, gate = proj(x).chunk(2, dim=-1); return x * F.gelu(gate)`) on an UNPERMUTED
  * pre-activation pre [M, 2F] = [x | gate], bf16.  dh null: forward, out [M, F].  dh [M, F] given: backward, out [M, 2F] = [dx | dgate]
  * (what autograd computes for that line in the training step). */

@@ -119,6 +119,11 @@ SIGNATURES = {
     "rdm_op_transpose": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "rdm_op_add": (C.c_int, [_P, _P, _P, _P, C.c_longlong]),
     "rdm_op_geglu": (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_int]),
+    "rdm_op_bmm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "rdm_op_heads": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rdm_op_transpose_batched": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "rdm_op_softmax": (C.c_int, [_P, _P, _P, C.c_longlong, C.c_int, C.c_int]),
+    "rdm_op_softmax_bwd": (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_int]),
     "rdm_op_groupnorm": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_float, C.c_int, _P]),
     "rdm_op_layernorm": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "rdm_op_self_attention": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
@@ -639,6 +644,41 @@ class Context:
         out = torch.empty_like(a)
         self._check(lib.rdm_op_add(self._h, _ptr(a), _ptr(b), _ptr(out), a.numel()))
         return out
+
+    def op_bmm(self, a, w, alpha=1.0, out_f32=False):
+        """a bf16 [Z, M, K], w bf16 [Z, N, K] -> alpha * a w^T [Z, M, N] (bf16, or fp32 with out_f32)."""
+        Z, M, K = a.shape; N = w.shape[1]
+        out = torch.empty((Z, M, N), device=self.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        self._check(lib.rdm_op_bmm(self._h, _ptr(a), _ptr(w), None if out_f32 else _ptr(out), _ptr(out) if out_f32 else None, Z, M, N, K, float(alpha)))
+        return out
+
+    def op_heads(self, x, H, D, mode, n=None):
+        """mode 0 / 1: x bf16 [B, n, >= H D] -> per-head [B H, n, 64] / transposed [B H, 64, n]; mode 2: [B H, n, 64] -> [B, n, H D]."""
+        if mode == 2:
+            BH, n_, _ = x.shape; B = BH // H
+            out = torch.empty((B, n_, H * D), device=self.device, dtype=torch.bfloat16)
+            self._check(lib.rdm_op_heads(self._h, _ptr(x), _ptr(out), B, n_, H, D, H * D, 2))
+            return out
+        B, n_, ldx = x.shape
+        out = torch.empty((B * H, n_, 64) if mode == 0 else (B * H, 64, n_), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_heads(self._h, _ptr(x), _ptr(out), B, n_, H, D, ldx, mode))
+        return out
+
+    def op_transpose_batched(self, x):
+        Z, r, c_ = x.shape
+        y = torch.empty((Z, c_, r), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_transpose_batched(self._h, _ptr(x), _ptr(y), Z, r, c_))
+        return y
+
+    def op_softmax(self, s, n_valid=0):
+        p = torch.empty(s.shape, device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_softmax(self._h, _ptr(s), _ptr(p), s.numel() // s.shape[-1], s.shape[-1], int(n_valid)))
+        return p
+
+    def op_softmax_bwd(self, p, dp):
+        ds = torch.empty_like(p)
+        self._check(lib.rdm_op_softmax_bwd(self._h, _ptr(p), _ptr(dp), _ptr(ds), p.numel() // p.shape[-1], p.shape[-1]))
+        return ds
 
     def op_geglu(self, pre, dh=None):
         """pre bf16 [M, 2F] = [x | gate] (unpermuted).  dh None -> x * gelu(gate) [M, F]; else the gradient [dx | dgate] [M, 2F]."""

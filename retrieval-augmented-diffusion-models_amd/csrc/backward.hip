@@ -330,3 +330,57 @@ hipError_t launch_geglu(const bf16_t* pre, const bf16_t* dh, bf16_t* out, long l
     else geglu_kernel<false><<<dim3((unsigned)g), 256, 0, st>>>(pre, nullptr, out, M, F);
     return hipGetLastError();
 }
+
+// ---- attention backward helpers (unfused first version of the training step's attention gradient, SURVEY 8 f-4: the scores are
+// materialised per (sample, head); the GEMMs run on the MFMA implicit-GEMM kernel as batches).
+// heads: x [B, n, ldx] with head h in columns [h D, (h + 1) D)  <->  per-head matrices zero-padded to 64 columns (the GEMM's K unit):
+//   mode 0: out [B H][n][64] = head slices;  mode 1: out [B H][64][n] = their transposes;  mode 2: x-layout [B, n, H D] <- in [B H][n][64]
+__global__ __launch_bounds__(256) void heads_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int n, int H, int D, int ldx, int mode) {
+    const long long total = (long long)B * H * n * 64;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        if (mode == 1) {        // i over [bh][d][row]
+            const int row = (int)(i % n); const long long r = i / n; const int d = (int)(r % 64); const long long bh = r / 64;
+            const int b = (int)(bh / H), h = (int)(bh % H);
+            out[i] = d < D ? x[((long long)b * n + row) * ldx + h * D + d] : (bf16_t)0;
+        } else {                // i over [bh][row][d]
+            const int d = (int)(i % 64); const long long r = i / 64; const int row = (int)(r % n); const long long bh = r / n;
+            const int b = (int)(bh / H), h = (int)(bh % H);
+            if (mode == 0) out[i] = d < D ? x[((long long)b * n + row) * ldx + h * D + d] : (bf16_t)0;
+            else if (d < D) out[((long long)b * n + row) * (H * D) + h * D + d] = x[i];
+        }
+    }
+}
+hipError_t launch_heads(const bf16_t* x, bf16_t* out, int B, int n, int H, int D, int ldx, int mode, hipStream_t st) {
+    if (D < 1 || D > 64 || mode < 0 || mode > 2) return hipErrorInvalidValue;
+    const long long total = (long long)B * H * n * 64;
+    long long g = (total + 255) / 256; if (g > 16384) g = 16384;
+    heads_kernel<<<dim3((unsigned)g), 256, 0, st>>>(x, out, B, n, H, D, ldx, mode);
+    return hipGetLastError();
+}
+// softmax backward per row: dS = P (dP - sum_j P_j dP_j).  One wave per row (n a multiple of 4), the row's P and dP read twice.
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ P, const float* __restrict__ dP, bf16_t* __restrict__ dS, long long rows, int n) {
+    const int lane = threadIdx.x & 63;
+    for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+        const bf16_t* pr = P + row * n; const float* dr = dP + row * n;
+        float s = 0.f;
+        for (int i = lane * 4; i < n; i += 256) {
+            const float4 d = *(const float4*)(dr + i); const uint2 pv = *(const uint2*)(pr + i);
+            s += __uint_as_float(pv.x << 16) * d.x + __uint_as_float(pv.x & 0xffff0000u) * d.y + __uint_as_float(pv.y << 16) * d.z + __uint_as_float(pv.y & 0xffff0000u) * d.w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        for (int i = lane * 4; i < n; i += 256) {
+            const float4 d = *(const float4*)(dr + i); const uint2 pv = *(const uint2*)(pr + i);
+            uint2 w;
+            w.x = cvt_pk_bf16(__uint_as_float(pv.x << 16) * (d.x - s), __uint_as_float(pv.x & 0xffff0000u) * (d.y - s));
+            w.y = cvt_pk_bf16(__uint_as_float(pv.y << 16) * (d.z - s), __uint_as_float(pv.y & 0xffff0000u) * (d.w - s));
+            *(uint2*)(dS + row * n + i) = w;
+        }
+    }
+}
+hipError_t launch_softmax_bwd(const bf16_t* P, const float* dP, bf16_t* dS, long long rows, int n, hipStream_t st) {
+    if (n % 4) return hipErrorInvalidValue;
+    long long g = (rows + 3) / 4; if (g > 8192) g = 8192; if (g < 1) g = 1;
+    softmax_bwd_kernel<<<dim3((unsigned)g), 256, 0, st>>>(P, dP, dS, rows, n);
+    return hipGetLastError();
+}

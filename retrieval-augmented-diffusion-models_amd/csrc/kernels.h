@@ -116,7 +116,10 @@ hipError_t launch_conv_out(const bf16_t* x, const float* w, const float* bias, f
                            int Cout, hipStream_t st);
 hipError_t launch_timestep_embedding(const long long* t, bf16_t* out, int B, int dim, int ld, hipStream_t st);   // rows of ld >= dim, tail zeroed
 hipError_t launch_cast_f32_bf16(const float* x, bf16_t* y, long long n, hipStream_t st);
-hipError_t launch_transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st);       // y[c][r] = x[r][c]
+hipError_t launch_transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st, int batch = 1);       // y[c][r] = x[r][c] (batch contiguous matrices)
+// attention backward helpers (backward.hip)
+hipError_t launch_heads(const bf16_t* x, bf16_t* out, int B, int n, int H, int D, int ldx, int mode, hipStream_t st);
+hipError_t launch_softmax_bwd(const bf16_t* P, const float* dP, bf16_t* dS, long long rows, int n, hipStream_t st);
 hipError_t launch_expand_heads(const bf16_t* kv, int ld, int B, int k, int heads, int hd, int NP, float scale, bf16_t* out, hipStream_t st);
 hipError_t launch_add_bias_rows(const bf16_t* x, const float* bias, bf16_t* out, long long rows, int C, hipStream_t st);
 hipError_t launch_row_nonzero(const float* x, int rows, long long n, int* flag, hipStream_t st);   // flag[r] = row r has a non-zero element
@@ -124,7 +127,7 @@ hipError_t launch_ddim_step(const DdimStepParams& p, hipStream_t st);
 hipError_t launch_ddpm_step(const DdpmStepParams& p, hipStream_t st);
 hipError_t launch_vq_quantize(const float* z, const float* codebook, int n_embed, const float* pq_w, const float* pq_b,
                               float* out, int* idx_out, int B, int HW, int quantize, hipStream_t st);
-hipError_t launch_softmax_rows(const float* s, bf16_t* p, long long rows, int n, hipStream_t st);
+hipError_t launch_softmax_rows(const float* s, bf16_t* p, long long rows, int n, hipStream_t st, int n_valid = 0);   // columns >= n_valid: probability 0
 hipError_t launch_clip_embed(const long long* tokens, const float* tok_emb, const float* pos_emb, float* out, int B, int L,
                              int Wd, hipStream_t st);
 hipError_t launch_clip_gather_eot(const long long* tokens, const float* x, float* out, int B, int L, int Wd, hipStream_t st);

@@ -186,6 +186,7 @@ hipError_t launch_cast_f32_bf16(const float* x, bf16_t* y, long long n, hipStrea
 __global__ void transpose_bf16_kernel(const bf16_t* x, bf16_t* y, int rows, int cols) {
     __shared__ bf16_t tile[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    x += (long long)blockIdx.z * rows * cols; y += (long long)blockIdx.z * rows * cols;       // batch of matrices
     for (int i = threadIdx.y; i < 32; i += 8) {
         const int r = r0 + i, c = c0 + threadIdx.x;
         tile[i][threadIdx.x] = (r < rows && c < cols) ? x[(long long)r * cols + c] : (bf16_t)0;
@@ -196,8 +197,8 @@ __global__ void transpose_bf16_kernel(const bf16_t* x, bf16_t* y, int rows, int 
         if (r < rows && c < cols) y[(long long)c * rows + r] = tile[threadIdx.x][i];
     }
 }
-hipError_t launch_transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st) {
-    transpose_bf16_kernel<<<dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st>>>(x, y, rows, cols);
+hipError_t launch_transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st, int batch) {
+    transpose_bf16_kernel<<<dim3((cols + 31) / 32, (rows + 31) / 32, batch < 1 ? 1 : batch), dim3(32, 8), 0, st>>>(x, y, rows, cols);
     return hipGetLastError();
 }
 
@@ -369,21 +370,21 @@ hipError_t launch_vq_quantize(const float* z, const float* codebook, int n_embed
 
 // ------------------------------------------------------------------ row softmax f32 -> bf16
 // VQ decoder AttnBlock (single head, 4096 tokens): softmax over the key axis of the f32 score matrix.
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, bf16_t* p, long long rows, int n) {
-    const int lane = threadIdx.x & 63;
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, bf16_t* p, long long rows, int n, int nv) {
+    const int lane = threadIdx.x & 63;                    // nv: valid columns (the rest are padding: probability 0)
     for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
         const float* sr = s + row * n;
         float mx = -INFINITY;
         for (int i = lane * 4; i < n; i += 256) {
             const float4 v = *(const float4*)(sr + i);
-            mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+            mx = fmaxf(fmaxf(mx, fmaxf(i < nv ? v.x : -INFINITY, i + 1 < nv ? v.y : -INFINITY)), fmaxf(i + 2 < nv ? v.z : -INFINITY, i + 3 < nv ? v.w : -INFINITY));
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         float sum = 0.f;
         for (int i = lane * 4; i < n; i += 256) {
             const float4 v = *(const float4*)(sr + i);
-            sum += (__expf(v.x - mx) + __expf(v.y - mx)) + (__expf(v.z - mx) + __expf(v.w - mx));
+            sum += ((i < nv ? __expf(v.x - mx) : 0.f) + (i + 1 < nv ? __expf(v.y - mx) : 0.f)) + ((i + 2 < nv ? __expf(v.z - mx) : 0.f) + (i + 3 < nv ? __expf(v.w - mx) : 0.f));
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -391,16 +392,16 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, bf16_
         for (int i = lane * 4; i < n; i += 256) {
             const float4 v = *(const float4*)(sr + i);
             uint2 w;
-            w.x = pack2bf(__expf(v.x - mx) * inv, __expf(v.y - mx) * inv);
-            w.y = pack2bf(__expf(v.z - mx) * inv, __expf(v.w - mx) * inv);
+            w.x = pack2bf(i < nv ? __expf(v.x - mx) * inv : 0.f, i + 1 < nv ? __expf(v.y - mx) * inv : 0.f);
+            w.y = pack2bf(i + 2 < nv ? __expf(v.z - mx) * inv : 0.f, i + 3 < nv ? __expf(v.w - mx) * inv : 0.f);
             *(uint2*)(p + row * n + i) = w;
         }
     }
 }
-hipError_t launch_softmax_rows(const float* s, bf16_t* p, long long rows, int n, hipStream_t st) {
+hipError_t launch_softmax_rows(const float* s, bf16_t* p, long long rows, int n, hipStream_t st, int n_valid) {
     if (n % 4) return hipErrorInvalidValue;
     int grid = (int)((rows + 3) / 4); if (grid > 8192) grid = 8192;
-    softmax_rows_kernel<<<grid, 256, 0, st>>>(s, p, rows, n);
+    softmax_rows_kernel<<<grid, 256, 0, st>>>(s, p, rows, n, (n_valid > 0 && n_valid < n) ? n_valid : n);
     return hipGetLastError();
 }
 

@@ -1701,6 +1701,41 @@ int rdm_op_add(rdm_ctx* c, const void* a, const void* b, void* out, long long n)
     RDM_CHECK_HIP(c, launch_add_bf16((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n, c->stream));
     return 0;
 }
+int rdm_op_bmm(rdm_ctx* c, const void* a, const void* w, void* out_bf16, float* out_f32, int batch, int M, int N, int K, float alpha) {
+    RDM_ENTER(c);
+    if (!a || !w || (!out_bf16 && !out_f32) || batch < 1 || M < 1 || N < 2 || K < 64 || K % 64 || N % 2)
+        return c->fail(-1, "rdm_op_bmm: bad argument (K must be a multiple of 64, N even)");
+    IgemmParams p{}; p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.ldo = N; p.zero_page = c->zero_page;
+    p.Hin = p.Win = p.Hout = p.Wout = 1; p.stride = 1; p.rows_per_sample = 1;
+    p.A0 = (const bf16_t*)a; p.C0 = K; p.W = (const bf16_t*)w; p.out_bf16 = (bf16_t*)out_bf16; p.out_f32 = out_f32;
+    p.sA = (long long)M * K; p.sW = (long long)N * K; p.sO = (long long)M * N;
+    RDM_CHECK_HIP(c, launch_igemm(p, false, batch, c->stream));
+    return 0;
+}
+int rdm_op_heads(rdm_ctx* c, const void* x, void* out, int B, int n, int H, int D, int ldx, int mode) {
+    RDM_ENTER(c);
+    if (!x || !out || B < 1 || n < 1 || H < 1) return c->fail(-1, "rdm_op_heads: bad argument");
+    RDM_CHECK_HIP(c, launch_heads((const bf16_t*)x, (bf16_t*)out, B, n, H, D, ldx, mode, c->stream));
+    return 0;
+}
+int rdm_op_transpose_batched(rdm_ctx* c, const void* x, void* y, int batch, int rows, int cols) {
+    RDM_ENTER(c);
+    if (!x || !y || batch < 1 || batch > 65535) return c->fail(-1, "rdm_op_transpose_batched: bad argument");
+    RDM_CHECK_HIP(c, launch_transpose_bf16((const bf16_t*)x, (bf16_t*)y, rows, cols, c->stream, batch));
+    return 0;
+}
+int rdm_op_softmax(rdm_ctx* c, const float* s, void* p_bf16, long long rows, int n, int n_valid) {
+    RDM_ENTER(c);
+    if (!s || !p_bf16 || n % 4) return c->fail(-1, "rdm_op_softmax: bad argument (n must be a multiple of 4)");
+    RDM_CHECK_HIP(c, launch_softmax_rows(s, (bf16_t*)p_bf16, rows, n, c->stream, n_valid));
+    return 0;
+}
+int rdm_op_softmax_bwd(rdm_ctx* c, const void* p_bf16, const float* dp, void* ds_bf16, long long rows, int n) {
+    RDM_ENTER(c);
+    if (!p_bf16 || !dp || !ds_bf16 || n % 4) return c->fail(-1, "rdm_op_softmax_bwd: bad argument (n must be a multiple of 4)");
+    RDM_CHECK_HIP(c, launch_softmax_bwd((const bf16_t*)p_bf16, dp, (bf16_t*)ds_bf16, rows, n, c->stream));
+    return 0;
+}
 int rdm_op_geglu(rdm_ctx* c, const void* pre, const void* dh, void* out, long long M, int F) {
     RDM_ENTER(c);
     if (!pre || !out || M < 1 || F < 8 || F % 8) return c->fail(-1, "rdm_op_geglu: bad argument (F must be a positive multiple of 8)");

@@ -6,7 +6,8 @@ Every arithmetic step is a C-ABI call into librdm_hip (include/rdm_hip.h "backwa
 the flipped / transposed filter, conv wgrad as a pixel-reduction GEMM on the MFMA kernel, GroupNorm+SiLU backward, deterministic column
 sums, GEMMs for the time-embedding projection.  torch is used for device memory only (allocation, reshapes / views, zero padding).
 The feed-forward sub-block of BasicTransformerBlock (`x + ff(norm3(x))`, ldm attention.py FeedForward / GEGLU) has its forward and
-backward here too (ff_forward / ff_backward).  What is NOT here yet: attention backward, the optimiser, EMA, the first-stage encoder,
+backward here too (ff_forward / ff_backward).  Attention (ldm CrossAttention: softmax(q k^T scale) v per head) has an unfused forward / backward here as well (attention_forward /
+attention_backward: scores materialised per (sample, head), batched GEMMs on the MFMA kernel).  What is NOT here yet: the optimiser, EMA, the first-stage encoder,
 the RCCL gradient all-reduce."""
 import torch
 
@@ -21,6 +22,17 @@ def _pad_rows(t, mult=64):
         return t
     out = torch.zeros((mp, t.shape[1]), device=t.device, dtype=t.dtype)
     out[:m] = t
+    return out
+
+
+def _pad_keys(t, mult=64):
+    """[B, m, C] -> [B, ceil(m / mult) * mult, C] with zero rows."""
+    m = t.shape[1]
+    mp = (m + mult - 1) // mult * mult
+    if mp == m:
+        return t
+    out = torch.zeros((t.shape[0], mp, t.shape[2]), device=t.device, dtype=t.dtype)
+    out[:, :m] = t
     return out
 
 
@@ -100,3 +112,93 @@ def ff_backward(ctx, p, x, saved, dout):
     dx_ln, g["ln_g"], g["ln_b"] = ctx.op_layernorm_bwd(x, dln, p["ln_g"])
     g["x"] = ctx.op_add(dx_ln, dout)                                                    # + the residual path
     return g
+
+
+def attention_forward(ctx, q, k, v, heads):
+    """ldm CrossAttention core (attention.py:52-72): per head softmax(q k^T / sqrt(d)) v.  q [B, n, C], k / v [B, m, C] bf16 (already
+    projected), C = heads * d, d <= 64, n and m multiples of 4 -> (out [B, n, C] bf16, saved)."""
+    B, n, C = q.shape
+    d = C // heads
+    scale = d ** -0.5
+    m = k.shape[1]
+    k, v = _pad_keys(k), _pad_keys(v)                                                   # key count -> multiple of 64 (a GEMM K unit); padding gets probability 0
+    qp, kp = ctx.op_heads(q, heads, d, 0), ctx.op_heads(k, heads, d, 0)                # [BH, n|mp, 64]
+    vt = ctx.op_heads(v, heads, d, 1)                                                   # [BH, 64, mp]
+    s = ctx.op_bmm(qp, kp, alpha=scale, out_f32=True)                                   # [BH, n, mp] fp32
+    p = ctx.op_softmax(s, n_valid=m)
+    o = ctx.op_bmm(p, vt)                                                               # [BH, n, 64]
+    return ctx.op_heads(o, heads, d, 2), {"p": p, "kpad": k, "vpad": v, "m": m}
+
+
+def attention_backward(ctx, q, k, v, heads, saved, dout):
+    """Gradients of `attention_forward`: dV = P^T dO, dP = dO V^T, dS = P (dP - rowsum(P dP)), dQ = dS K scale, dK = dS^T Q scale."""
+    B, n, C = q.shape
+    d = C // heads
+    scale = d ** -0.5
+    p, k, v, m = saved["p"], saved["kpad"], saved["vpad"], saved["m"]
+    dop, dot_ = ctx.op_heads(dout, heads, d, 0), ctx.op_heads(dout, heads, d, 1)        # [BH, n, 64], [BH, 64, n]
+    vp = ctx.op_heads(v, heads, d, 0)                                                   # [BH, m, 64]
+    dv = ctx.op_bmm(ctx.op_transpose_batched(p), dot_)                                  # [BH, m, 64]
+    dp = ctx.op_bmm(dop, vp, out_f32=True)                                              # [BH, n, m]
+    ds = ctx.op_softmax_bwd(p, dp)
+    kt, qt = ctx.op_heads(k, heads, d, 1), ctx.op_heads(q, heads, d, 1)                 # [BH, 64, m], [BH, 64, n]
+    dq = ctx.op_bmm(ds, kt, alpha=scale)                                                # [BH, n, 64]
+    dk = ctx.op_bmm(ctx.op_transpose_batched(ds), qt, alpha=scale)                      # [BH, m, 64]
+    return {"q": ctx.op_heads(dq, heads, d, 2), "k": ctx.op_heads(dk, heads, d, 2)[:, :m].contiguous(), "v": ctx.op_heads(dv, heads, d, 2)[:, :m].contiguous()}
+
+
+def attn_block_forward(ctx, p, x, context=None):
+    """One attention residual branch of BasicTransformerBlock: out = x + to_out(attention(to_q(norm(x)), to_k(c), to_v(c))) with
+    c = norm(x) (self-attention, attn1) or the conditioning `context` [B, m, Cc] (cross-attention, attn2); attention.py:84-96, 52-72.
+    x bf16 [B, n, C]; p: ln_g / ln_b f32, wq [C, C], wk / wv [C, Cc] bf16 (no bias), wo [C, C] bf16, bo f32, heads."""
+    B, n, C = x.shape
+    ln = ctx.op_layernorm(x.reshape(B * n, C), p["ln_g"], p["ln_b"])
+    c = ln if context is None else context.reshape(-1, context.shape[-1])
+    m = n if context is None else context.shape[1]
+    q = ctx.op_linear(ln, p["wq"]).reshape(B, n, C)
+    k = ctx.op_linear(c, p["wk"]).reshape(B, m, C)
+    v = ctx.op_linear(c, p["wv"]).reshape(B, m, C)
+    att, saved = attention_forward(ctx, q, k, v, p["heads"])
+    out = ctx.op_linear(att.reshape(B * n, C), p["wo"], p["bo"], residual=x.reshape(B * n, C)).reshape(B, n, C)
+    saved.update({"ln": ln, "q": q, "k": k, "v": v, "att": att})
+    return out, saved
+
+
+def attn_block_backward(ctx, p, x, saved, dout, context=None):
+    """-> dict: x (bf16), context (bf16, cross-attention only), fp32 wq / wk / wv / wo / bo / ln_g / ln_b."""
+    B, n, C = x.shape
+    g = {}
+    dflat = dout.reshape(B * n, C)
+    datt, g["wo"], g["bo"] = linear_backward(ctx, saved["att"].reshape(B * n, C), p["wo"], dflat)
+    d = attention_backward(ctx, saved["q"], saved["k"], saved["v"], p["heads"], saved, datt.reshape(B, n, C))
+    c = saved["ln"] if context is None else context.reshape(-1, context.shape[-1])
+    m = saved["k"].shape[1]
+    dln, g["wq"], _ = linear_backward(ctx, saved["ln"], p["wq"], d["q"].reshape(B * n, C))
+    dck, g["wk"], _ = linear_backward(ctx, c, p["wk"], d["k"].reshape(B * m, C))
+    dcv, g["wv"], _ = linear_backward(ctx, c, p["wv"], d["v"].reshape(B * m, C))
+    dc = ctx.op_add(dck, dcv)
+    if context is None:
+        dln = ctx.op_add(dln, dc)
+    else:
+        g["context"] = dc.reshape(context.shape)
+    dx_ln, g["ln_g"], g["ln_b"] = ctx.op_layernorm_bwd(x.reshape(B * n, C), dln, p["ln_g"])
+    g["x"] = ctx.op_add(dx_ln, dflat).reshape(B, n, C)
+    return g
+
+
+def transformer_block_forward(ctx, p, x, context):
+    """BasicTransformerBlock.forward (attention.py:88-96): x = attn1(norm1(x)) + x; x = attn2(norm2(x), context) + x; x = ff(norm3(x)) + x.
+    p = {"attn1": ..., "attn2": ..., "ff": ...} (see attn_block_forward / ff_forward)."""
+    B, n, C = x.shape
+    x1, s1 = attn_block_forward(ctx, p["attn1"], x)
+    x2, s2 = attn_block_forward(ctx, p["attn2"], x1, context)
+    x3, s3 = ff_forward(ctx, p["ff"], x2.reshape(B * n, C))
+    return x3.reshape(B, n, C), {"x1": x1, "x2": x2, "attn1": s1, "attn2": s2, "ff": s3}
+
+
+def transformer_block_backward(ctx, p, x, context, saved, dout):
+    B, n, C = x.shape
+    gff = ff_backward(ctx, p["ff"], saved["x2"].reshape(B * n, C), saved["ff"], dout.reshape(B * n, C))
+    g2 = attn_block_backward(ctx, p["attn2"], saved["x1"], saved["attn2"], gff["x"].reshape(B, n, C), context)
+    g1 = attn_block_backward(ctx, p["attn1"], x, saved["attn1"], g2["x"])
+    return {"x": g1["x"], "context": g2["context"], "attn1": g1, "attn2": g2, "ff": gff}

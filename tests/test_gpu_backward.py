@@ -148,3 +148,70 @@ def test_feed_forward_block_backward(ctx, M, C):
         errs[k] = rel_l2(grads[k].float(), ref_p[k].grad)
     print(f"feed-forward block M={M} C={C}: " + " ".join(f"{k} {v:.2e}" for k, v in errs.items()))
     assert max(errs.values()) <= TOL
+
+
+@pytest.mark.parametrize("B,n,m,heads,d", [(2, 256, 256, 6, 32), (3, 64, 64, 4, 32), (2, 128, 64, 2, 64)])
+def test_attention_forward_backward(ctx, B, n, m, heads, d):
+    """softmax(q k^T / sqrt(d)) v per head (ldm CrossAttention core, self- and cross-shaped): output and dq / dk / dv vs autograd."""
+    from rdm_amd import training
+    dev = ctx.device
+    C = heads * d
+    q = bf16_round(_rand((B, n, C), 60)).requires_grad_(True)
+    k = bf16_round(_rand((B, m, C), 61)).requires_grad_(True)
+    v = bf16_round(_rand((B, m, C), 62)).requires_grad_(True)
+    dout = bf16_round(_rand((B, n, C), 63))
+    sp = lambda t, L: t.reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    att = (sp(q, n) @ sp(k, m).transpose(-1, -2) * d ** -0.5).softmax(-1)
+    ref = (att @ sp(v, m)).permute(0, 2, 1, 3).reshape(B, n, C)
+    ref.backward(dout)
+    qd, kd, vd = (t.detach().to(dev, torch.bfloat16) for t in (q, k, v))
+    out, saved = training.attention_forward(ctx, qd, kd, vd, heads)
+    g = training.attention_backward(ctx, qd, kd, vd, heads, saved, dout.to(dev, torch.bfloat16))
+    errs = {"out": rel_l2(out.float(), ref.detach()), "q": rel_l2(g["q"].float(), q.grad), "k": rel_l2(g["k"].float(), k.grad), "v": rel_l2(g["v"].float(), v.grad)}
+    print(f"attention B={B} n={n} m={m} heads={heads} d={d}: " + " ".join(f"{kk} {vv:.2e}" for kk, vv in errs.items()))
+    assert max(errs.values()) <= TOL
+
+
+def test_basic_transformer_block_backward(ctx):
+    """A whole BasicTransformerBlock (self-attention, cross-attention over k = 4 conditioning rows of width 512, GEGLU feed-forward; each
+    with its LayerNorm and residual) forward + backward against torch autograd: output, dx, dcontext and every parameter gradient."""
+    from rdm_amd import training
+    dev = ctx.device
+    B, n, C, heads, m, Cc = 2, 256, 192, 6, 4, 512
+    Fh = 4 * C
+    x = bf16_round(_rand((B, n, C), 70)).requires_grad_(True)
+    cx = bf16_round(_rand((B, m, Cc), 71)).requires_grad_(True)
+    def attn_params(seed, kc):
+        return {"ln_g": 1 + 0.1 * _rand((C,), seed), "ln_b": 0.1 * _rand((C,), seed + 1), "wq": bf16_round(_rand((C, C), seed + 2, C ** -0.5)),
+                "wk": bf16_round(_rand((C, kc), seed + 3, kc ** -0.5)), "wv": bf16_round(_rand((C, kc), seed + 4, kc ** -0.5)),
+                "wo": bf16_round(_rand((C, C), seed + 5, C ** -0.5)), "bo": 0.1 * _rand((C,), seed + 6)}
+    prm = {"attn1": attn_params(80, C), "attn2": attn_params(90, Cc),
+           "ff": {"ln_g": 1 + 0.1 * _rand((C,), 100), "ln_b": 0.1 * _rand((C,), 101), "w1": bf16_round(_rand((2 * Fh, C), 102, C ** -0.5)), "b1": 0.1 * _rand((2 * Fh,), 103),
+                  "w2": bf16_round(_rand((C, Fh), 104, Fh ** -0.5)), "b2": 0.1 * _rand((C,), 105)}}
+    ref = {blk: {k: v.clone().requires_grad_(True) for k, v in d_.items()} for blk, d_ in prm.items()}
+    dout = bf16_round(_rand((B, n, C), 110))
+    def attn_ref(pp, xx, c):
+        ln = F_.layer_norm(xx, (C,), pp["ln_g"], pp["ln_b"], 1e-5)
+        c = ln if c is None else c
+        sp = lambda t: t.reshape(t.shape[0], t.shape[1], heads, C // heads).permute(0, 2, 1, 3)
+        q, k, v = sp(ln @ pp["wq"].t()), sp(c @ pp["wk"].t()), sp(c @ pp["wv"].t())
+        a = (q @ k.transpose(-1, -2) * (C // heads) ** -0.5).softmax(-1) @ v
+        return xx + a.permute(0, 2, 1, 3).reshape(xx.shape) @ pp["wo"].t() + pp["bo"]
+    x1 = attn_ref(ref["attn1"], x, None)
+    x2 = attn_ref(ref["attn2"], x1, cx)
+    a, g = (F_.layer_norm(x2, (C,), ref["ff"]["ln_g"], ref["ff"]["ln_b"], 1e-5) @ ref["ff"]["w1"].t() + ref["ff"]["b1"]).chunk(2, dim=-1)
+    out_ref = x2 + (a * F_.gelu(g)) @ ref["ff"]["w2"].t() + ref["ff"]["b2"]
+    out_ref.backward(dout)
+    to_dev = lambda d_: {k: (v.to(dev, torch.bfloat16) if k.startswith("w") else v.to(dev)) for k, v in d_.items()}
+    dp = {blk: to_dev(d_) for blk, d_ in prm.items()}
+    dp["attn1"]["heads"] = dp["attn2"]["heads"] = heads
+    xd, cd = x.detach().to(dev, torch.bfloat16), cx.detach().to(dev, torch.bfloat16)
+    out, saved = training.transformer_block_forward(ctx, dp, xd, cd)
+    grads = training.transformer_block_backward(ctx, dp, xd, cd, saved, dout.to(dev, torch.bfloat16))
+    errs = {"out": rel_l2(out.float(), out_ref.detach()), "x": rel_l2(grads["x"].float(), x.grad), "context": rel_l2(grads["context"].float(), cx.grad)}
+    for blk in ("attn1", "attn2", "ff"):
+        for k in prm[blk]:
+            errs[f"{blk}.{k}"] = rel_l2(grads[blk][k].float(), ref[blk][k].grad)
+    worst = max(errs, key=errs.get)
+    print("transformer block: " + " ".join(f"{k} {v:.1e}" for k, v in errs.items()))
+    assert errs[worst] <= TOL, (worst, errs[worst])
