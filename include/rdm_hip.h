@@ -253,6 +253,11 @@ int rdm_op_layernorm_bwd(rdm_ctx* ctx, const void* x_bf16, const void* dy_bf16, 
 int rdm_op_colsum(rdm_ctx* ctx, const void* x_bf16 /*[M,N]*/, float* out /*[N]*/, long long M, int N);
 int rdm_op_transpose(rdm_ctx* ctx, const void* x_bf16 /*[rows,cols]*/, void* y_bf16 /*[cols,rows]*/, int rows, int cols);
 int rdm_op_add(rdm_ctx* ctx, const void* a_bf16, const void* b_bf16, void* out_bf16, long long n);
+/* One AdamW step (torch.optim.AdamW: decoupled weight decay, bias-corrected moments; the reference's configure_optimizers,
+ * rdm/models/diffusion/ddpm.py, hands the UNet parameters to it) on fp32 master parameters / moments in place; p_bf16 (optional) receives
+ * the bf16 working copy the kernels read.  step counts from 1. */
+int rdm_op_adamw(rdm_ctx* ctx, float* p, const float* grad, float* exp_avg, float* exp_avg_sq, void* p_bf16_or_null, long long n, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, int step);
 /* Attention backward, unfused first version (autograd through ldm CrossAttention.forward, attention.py:52-72:
  * sim = einsum(q, k) * scale; attn = sim.softmax(-1); out = einsum(attn, v)).  The scores are materialised per (sample, head):
  *   rdm_op_heads   x [B, n, ldx] (head h = columns [h D, (h+1) D)) <-> per-head matrices zero-padded to 64 columns:

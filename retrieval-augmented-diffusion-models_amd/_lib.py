@@ -119,6 +119,7 @@ SIGNATURES = {
     "rdm_op_transpose": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "rdm_op_add": (C.c_int, [_P, _P, _P, _P, C.c_longlong]),
     "rdm_op_geglu": (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_int]),
+    "rdm_op_adamw": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]),
     "rdm_op_bmm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "rdm_op_heads": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rdm_op_transpose_batched": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int]),
@@ -644,6 +645,11 @@ class Context:
         out = torch.empty_like(a)
         self._check(lib.rdm_op_add(self._h, _ptr(a), _ptr(b), _ptr(out), a.numel()))
         return out
+
+    def op_adamw(self, p, g, m, v, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, p_bf16=None):
+        """In-place AdamW step on fp32 tensors p / m / v with gradient g; p_bf16 (same shape, bf16) receives the rounded new parameters."""
+        self._check(lib.rdm_op_adamw(self._h, _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(p_bf16) if p_bf16 is not None else None, p.numel(),
+                                     float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step)))
 
     def op_bmm(self, a, w, alpha=1.0, out_f32=False):
         """a bf16 [Z, M, K], w bf16 [Z, N, K] -> alpha * a w^T [Z, M, N] (bf16, or fp32 with out_f32)."""

@@ -384,3 +384,28 @@ hipError_t launch_softmax_bwd(const bf16_t* P, const float* dP, bf16_t* dS, long
     softmax_bwd_kernel<<<dim3((unsigned)g), 256, 0, st>>>(P, dP, dS, rows, n);
     return hipGetLastError();
 }
+
+// ---- AdamW step (torch.optim.AdamW semantics, decoupled weight decay, bias correction; ldm configure_optimizers in
+// rdm/models/diffusion/ddpm.py uses torch.optim.AdamW(params, lr)): fp32 master parameters and moments updated in place, optional
+// bf16 working copy of the new parameters for the next forward.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_t* __restrict__ pb, long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i];
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        pi -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+        p[i] = pi;
+        if (pb) pb[i] = f2bf(pi);
+    }
+}
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* pb, long long n, float lr, float b1, float b2, float eps, float wd, int step,
+                        hipStream_t st) {
+    if (step < 1) return hipErrorInvalidValue;
+    long long grid = (n + 255) / 256; if (grid > 16384) grid = 16384; if (grid < 1) grid = 1;
+    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+    adamw_kernel<<<dim3((unsigned)grid), 256, 0, st>>>(p, g, m, v, pb, n, lr, b1, b2, eps, wd, bc1, bc2);
+    return hipGetLastError();
+}

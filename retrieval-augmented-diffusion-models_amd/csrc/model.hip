@@ -1701,6 +1701,13 @@ int rdm_op_add(rdm_ctx* c, const void* a, const void* b, void* out, long long n)
     RDM_CHECK_HIP(c, launch_add_bf16((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n, c->stream));
     return 0;
 }
+int rdm_op_adamw(rdm_ctx* c, float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step) {
+    RDM_ENTER(c);
+    if (!p || !g || !m || !v || n < 1 || step < 1) return c->fail(-1, "rdm_op_adamw: bad argument");
+    RDM_CHECK_HIP(c, launch_adamw(p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay, step, c->stream));
+    return 0;
+}
 int rdm_op_bmm(rdm_ctx* c, const void* a, const void* w, void* out_bf16, float* out_f32, int batch, int M, int N, int K, float alpha) {
     RDM_ENTER(c);
     if (!a || !w || (!out_bf16 && !out_f32) || batch < 1 || M < 1 || N < 2 || K < 64 || K % 64 || N % 2)

@@ -7,7 +7,9 @@ the flipped / transposed filter, conv wgrad as a pixel-reduction GEMM on the MFM
 sums, GEMMs for the time-embedding projection.  torch is used for device memory only (allocation, reshapes / views, zero padding).
 The feed-forward sub-block of BasicTransformerBlock (`x + ff(norm3(x))`, ldm attention.py FeedForward / GEGLU) has its forward and
 backward here too (ff_forward / ff_backward).  Attention (ldm CrossAttention: softmax(q k^T scale) v per head) has an unfused forward / backward here as well (attention_forward /
-attention_backward: scores materialised per (sample, head), batched GEMMs on the MFMA kernel).  What is NOT here yet: the optimiser, EMA, the first-stage encoder,
+attention_backward: scores materialised per (sample, head), batched GEMMs on the MFMA kernel).  SpatialTransformer (GroupNorm -> proj_in -> block -> proj_out + x) and an AdamW step (rdm_op_adamw) close the loop for a small
+ResBlock + SpatialTransformer stack (training_step_demo).  What is NOT here yet: the whole-UNet graph in training form (down / up
+sampling, stem / head convs, time-embedding MLP backward), EMA, the first-stage encoder,
 the RCCL gradient all-reduce."""
 import torch
 
@@ -202,3 +204,66 @@ def transformer_block_backward(ctx, p, x, context, saved, dout):
     g2 = attn_block_backward(ctx, p["attn2"], saved["x1"], saved["attn2"], gff["x"].reshape(B, n, C), context)
     g1 = attn_block_backward(ctx, p["attn1"], x, saved["attn1"], g2["x"])
     return {"x": g1["x"], "context": g2["context"], "attn1": g1, "attn2": g2, "ff": gff}
+
+
+def spatial_transformer_forward(ctx, p, x, context):
+    """SpatialTransformer.forward (attention.py:147-183, depth 1): h = proj_in(norm(x)) -> BasicTransformerBlock(h, context) -> proj_out(h) + x.
+    x bf16 [B, H, W, C] (NHWC); p: gn_g / gn_b f32, win / wout bf16 [C, C] (the 1x1 convs), bin / bout f32, block = transformer-block params."""
+    B, H, W, C = x.shape
+    n = H * W
+    xn = ctx.op_groupnorm(x.reshape(B, n, C), p["gn_g"], p["gn_b"], 1e-6, 0)                       # Normalize: GroupNorm(32, eps 1e-6), no SiLU
+    h = ctx.op_linear(xn.reshape(B * n, C), p["win"], p["bin"]).reshape(B, n, C)
+    hb, sb = transformer_block_forward(ctx, p["block"], h, context)
+    out = ctx.op_linear(hb.reshape(B * n, C), p["wout"], p["bout"], residual=x.reshape(B * n, C)).reshape(B, H, W, C)
+    return out, {"xn": xn, "h": h, "hb": hb, "block": sb}
+
+
+def spatial_transformer_backward(ctx, p, x, context, saved, dout):
+    B, H, W, C = x.shape
+    n = H * W
+    g = {}
+    dflat = dout.reshape(B * n, C)
+    dhb, g["wout"], g["bout"] = linear_backward(ctx, saved["hb"].reshape(B * n, C), p["wout"], dflat)
+    gb = transformer_block_backward(ctx, p["block"], saved["h"], context, saved["block"], dhb.reshape(B, n, C))
+    dxn, g["win"], g["bin"] = linear_backward(ctx, saved["xn"].reshape(B * n, C), p["win"], gb["x"].reshape(B * n, C))
+    dx_gn, g["gn_g"], g["gn_b"] = ctx.op_groupnorm_bwd(x.reshape(B, n, C), dxn.reshape(B, n, C), p["gn_g"], p["gn_b"], 1e-6, 0)
+    g["x"] = ctx.op_add(dx_gn.reshape(B * n, C), dflat).reshape(B, H, W, C)
+    g["context"] = gb["context"]
+    g["block"] = gb
+    return g
+
+
+def flatten_params(p, prefix=""):
+    """nested dict of tensors -> {dotted name: tensor} (ints such as `heads` skipped)."""
+    out = {}
+    for k, v in p.items():
+        if isinstance(v, dict):
+            out.update(flatten_params(v, prefix + k + "."))
+        elif torch.is_tensor(v):
+            out[prefix + k] = v
+    return out
+
+
+def training_step_demo(ctx, master, state, x, semb, context, target, step, lr=1e-3, weight_decay=1e-2):
+    """One optimisation step of `ResBlock -> SpatialTransformer` under an MSE loss against `target` (the shape of ldm p_losses'
+    `loss_simple` for a two-block network): forward, loss gradient, backward through both blocks, AdamW on the fp32 master weights.
+    master: {"res": ..., "st": ...} fp32 tensors; state: {"m": {...}, "v": {...}} flat fp32 moments (zeros at step 1).  Weights the
+    kernels read in bf16 are re-cast from the masters.  -> (loss value, flat fp32 gradients)"""
+    def working(p):
+        return {k: (working(v) if isinstance(v, dict) else (v.to(torch.bfloat16) if torch.is_tensor(v) and v.dim() >= 2 else v)) for k, v in p.items()}
+    w = working(master)
+    h, s_res = resblock_forward(ctx, w["res"], x, semb)
+    y, s_st = spatial_transformer_forward(ctx, w["st"], h, context)
+    diff = y.float() - target.float()
+    loss = float((diff * diff).mean())
+    dy = (diff * (2.0 / diff.numel())).to(torch.bfloat16)
+    g_st = spatial_transformer_backward(ctx, w["st"], h, context, s_st, dy)
+    g_res = resblock_backward(ctx, w["res"], x, semb, s_res, g_st["x"])
+    grads = {**{"res." + k: v for k, v in flatten_params(g_res).items()}, **{"st." + k: v for k, v in flatten_params(g_st).items()}}
+    flat = flatten_params(master)
+    for name, pm in flat.items():
+        if name not in grads:
+            continue
+        gfl = grads[name].float().reshape(pm.shape).contiguous()
+        ctx.op_adamw(pm, gfl, state["m"][name], state["v"][name], step, lr=lr, weight_decay=weight_decay)
+    return loss, grads
