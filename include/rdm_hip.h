@@ -253,6 +253,11 @@ int rdm_op_layernorm_bwd(rdm_ctx* ctx, const void* x_bf16, const void* dy_bf16, 
 int rdm_op_colsum(rdm_ctx* ctx, const void* x_bf16 /*[M,N]*/, float* out /*[N]*/, long long M, int N);
 int rdm_op_transpose(rdm_ctx* ctx, const void* x_bf16 /*[rows,cols]*/, void* y_bf16 /*[cols,rows]*/, int rows, int cols);
 int rdm_op_add(rdm_ctx* ctx, const void* a_bf16, const void* b_bf16, void* out_bf16, long long n);
+/* Elementwise pieces of the UNet's training graph: SiLU of the time-embedding MLP (`nn.SiLU()` in
+ * openaimodel.py time_embed / emb_layers) -- dy null: out bf16 = silu(x), else out fp32 = dy * silu'(x) -- and the 2 x 2 sum pooling
+ * that is the gradient of Upsample's nearest-neighbour F.interpolate: x bf16 [B, 2H, 2W, C] -> out bf16 [B, H, W, C]. */
+int rdm_op_silu(rdm_ctx* ctx, const float* x, const float* dy_or_null, void* out_bf16_or_f32, long long n);
+int rdm_op_sumpool2(rdm_ctx* ctx, const void* x_bf16, void* out_bf16, int B, int H, int W, int C);
 /* One AdamW step (torch.optim.AdamW: decoupled weight decay, bias-corrected moments; the reference's configure_optimizers,
  * rdm/models/diffusion/ddpm.py, hands the UNet parameters to it) on fp32 master parameters / moments in place; p_bf16 (optional) receives
  * the bf16 working copy the kernels read.  step counts from 1. */

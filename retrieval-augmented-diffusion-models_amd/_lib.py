@@ -119,6 +119,8 @@ SIGNATURES = {
     "rdm_op_transpose": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "rdm_op_add": (C.c_int, [_P, _P, _P, _P, C.c_longlong]),
     "rdm_op_geglu": (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_int]),
+    "rdm_op_silu": (C.c_int, [_P, _P, _P, _P, C.c_longlong]),
+    "rdm_op_sumpool2": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rdm_op_adamw": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]),
     "rdm_op_bmm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "rdm_op_heads": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -644,6 +646,18 @@ class Context:
     def op_add(self, a, b):
         out = torch.empty_like(a)
         self._check(lib.rdm_op_add(self._h, _ptr(a), _ptr(b), _ptr(out), a.numel()))
+        return out
+
+    def op_silu(self, x, dy=None):
+        """x fp32: -> silu(x) bf16, or with dy (fp32) the gradient dy * silu'(x) fp32."""
+        out = torch.empty(x.shape, device=self.device, dtype=torch.bfloat16 if dy is None else torch.float32)
+        self._check(lib.rdm_op_silu(self._h, _ptr(x), _ptr(dy) if dy is not None else None, _ptr(out), x.numel()))
+        return out
+
+    def op_sumpool2(self, x):
+        B, H2, W2, Cc = x.shape
+        out = torch.empty((B, H2 // 2, W2 // 2, Cc), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_sumpool2(self._h, _ptr(x), _ptr(out), B, H2 // 2, W2 // 2, Cc))
         return out
 
     def op_adamw(self, p, g, m, v, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, p_bf16=None):

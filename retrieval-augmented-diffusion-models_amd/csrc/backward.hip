@@ -409,3 +409,45 @@ hipError_t launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* pb
     adamw_kernel<<<dim3((unsigned)grid), 256, 0, st>>>(p, g, m, v, pb, n, lr, b1, b2, eps, wd, bc1, bc2);
     return hipGetLastError();
 }
+
+// ---- SiLU on an fp32 vector (the time-embedding MLP: ldm TimestepEmbedSequential `nn.SiLU()` between / after the two Linear layers):
+// dy null: out_bf16 = silu(x) (the next Linear's operand); else out_f32 = dy * silu'(x)
+__global__ __launch_bounds__(256) void silu_kernel(const float* __restrict__ x, const float* __restrict__ dy, bf16_t* __restrict__ ob, float* __restrict__ of, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = x[i], s = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        if (dy) of[i] = dy[i] * (s * (1.0f + v * (1.0f - s)));
+        else ob[i] = f2bf(v * s);
+    }
+}
+hipError_t launch_silu(const float* x, const float* dy, bf16_t* ob, float* of, long long n, hipStream_t st) {
+    long long g = (n + 255) / 256; if (g > 8192) g = 8192; if (g < 1) g = 1;
+    silu_kernel<<<dim3((unsigned)g), 256, 0, st>>>(x, dy, ob, of, n);
+    return hipGetLastError();
+}
+// ---- 2 x 2 sum pooling of an NHWC bf16 tensor [B, 2H, 2W, C] -> [B, H, W, C]: the gradient of the nearest-neighbour 2x upsample in front
+// of Upsample's conv (ldm openaimodel.py Upsample.forward: F.interpolate(scale_factor=2, mode="nearest") then conv).  8 channels per thread.
+__global__ __launch_bounds__(256) void sumpool2_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int H, int W, int C) {
+    const int CV = C / 8;
+    const long long total = (long long)B * H * W * CV;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % CV); long long r = i / CV; const int xw = (int)(r % W); r /= W; const int y = (int)(r % H); const int b = (int)(r / H);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 2; dx++) {
+                const uint4 v = *(const uint4*)(x + (((long long)b * 2 * H + 2 * y + dy) * 2 * W + 2 * xw + dx) * C + cv * 8);
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) { acc[2 * e] += __uint_as_float(w4[e] << 16); acc[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u); }
+            }
+        *(uint4*)(out + (((long long)b * H + y) * W + xw) * C + cv * 8) =
+            make_uint4(cvt_pk_bf16(acc[0], acc[1]), cvt_pk_bf16(acc[2], acc[3]), cvt_pk_bf16(acc[4], acc[5]), cvt_pk_bf16(acc[6], acc[7]));
+    }
+}
+hipError_t launch_sumpool2(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t st) {
+    if (C % 8) return hipErrorInvalidValue;
+    long long g = ((long long)B * H * W * (C / 8) + 255) / 256; if (g > 16384) g = 16384; if (g < 1) g = 1;
+    sumpool2_kernel<<<dim3((unsigned)g), 256, 0, st>>>(x, out, B, H, W, C);
+    return hipGetLastError();
+}

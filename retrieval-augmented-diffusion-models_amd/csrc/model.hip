@@ -1701,6 +1701,18 @@ int rdm_op_add(rdm_ctx* c, const void* a, const void* b, void* out, long long n)
     RDM_CHECK_HIP(c, launch_add_bf16((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n, c->stream));
     return 0;
 }
+int rdm_op_silu(rdm_ctx* c, const float* x, const float* dy, void* out, long long n) {
+    RDM_ENTER(c);
+    if (!x || !out || n < 1) return c->fail(-1, "rdm_op_silu: bad argument");
+    RDM_CHECK_HIP(c, launch_silu(x, dy, dy ? nullptr : (bf16_t*)out, dy ? (float*)out : nullptr, n, c->stream));
+    return 0;
+}
+int rdm_op_sumpool2(rdm_ctx* c, const void* x, void* out, int B, int H, int W, int C) {
+    RDM_ENTER(c);
+    if (!x || !out || B < 1 || H < 1 || W < 1 || C < 8 || C % 8) return c->fail(-1, "rdm_op_sumpool2: bad argument (C must be a multiple of 8)");
+    RDM_CHECK_HIP(c, launch_sumpool2((const bf16_t*)x, (bf16_t*)out, B, H, W, C, c->stream));
+    return 0;
+}
 int rdm_op_adamw(rdm_ctx* c, float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step) {
     RDM_ENTER(c);

@@ -162,3 +162,31 @@ def merge_sharded_topk(idx_global: torch.Tensor, score: torch.Tensor, k: int, gr
     idx, sc = torch.gather(idx, 1, o1), torch.gather(sc, 1, o1)
     o2 = torch.argsort(sc, dim=1, descending=True, stable=True)                             # ... then the stable primary sort
     return torch.gather(idx, 1, o2)[:, :k].contiguous(), torch.gather(sc, 1, o2)[:, :k].contiguous()
+
+
+def average_gradients(grads, bucket_bytes: int = 64 << 20, group=None):
+    """Data-parallel gradient averaging for the training step (what DistributedDataParallel does under the reference's
+    Lightning trainer): the fp32 gradients of `grads` (dict name -> tensor, identical keys / shapes on every rank) are flattened in
+    sorted-name order into buckets of <= bucket_bytes, each bucket ONE all-reduce (RCCL over xGMI on the GPU box: few, large,
+    per-link-bound ring collectives instead of one per tensor), then divided by the world size and scattered back in place.
+    Deterministic: the bucket layout depends on names and shapes only.  No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return grads
+    world = dist.get_world_size(group)
+    names = sorted(grads)
+    i = 0
+    while i < len(names):
+        j, size = i, 0
+        while j < len(names) and (j == i or size + grads[names[j]].numel() * 4 <= bucket_bytes):
+            size += grads[names[j]].numel() * 4
+            j += 1
+        flat = torch.cat([grads[n].reshape(-1).float() for n in names[i:j]])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat /= world
+        off = 0
+        for n in names[i:j]:
+            k = grads[n].numel()
+            grads[n] = flat[off:off + k].reshape(grads[n].shape).to(grads[n].dtype)
+            off += k
+        i = j
+    return grads

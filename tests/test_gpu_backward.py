@@ -313,3 +313,61 @@ def test_training_step_resblock_plus_spatial_transformer(ctx):
     worst = max(drift, key=drift.get)
     print(f"training step: losses {losses}; worst update mismatch {worst} {drift[worst]:.2e}")
     assert drift[worst] <= 0.2           # sign flips of near-zero gradient elements under bf16 activations; the bulk moves identically
+
+
+def test_whole_unet_loss_gradients(ctx):
+    """The whole UNet (tiny topology twin of the shipped one: conv stem, ResBlocks, SpatialTransformers at two resolutions, Downsample,
+    Upsample, skip concatenations, time-embedding MLP, GroupNorm + SiLU + conv head) in training form on the native ops: the MSE loss of
+    ldm p_losses and its gradient w.r.t. EVERY parameter against torch autograd through the oracle's restatement of the same network."""
+    from oracle import unet as ounet
+    from rdm_amd import training_unet as TU
+    dev = ctx.device
+    spec = ounet.tiny_spec()
+    sd = {k: bf16_round(v) if v.dim() >= 2 else v for k, v in ounet.synth_state_dict(ounet.param_shapes(spec), seed=7).items()}
+    B, H = 2, 32
+    x = bf16_round(_rand((B, 3, H, H), 300))
+    cx = bf16_round(_rand((B, 4, 512), 301, 0.5))
+    noise = bf16_round(_rand((B, 3, H, H), 302))
+    tsteps = torch.tensor([37, 911])
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss_ref = ((ounet.unet_forward(ref_sd, spec, x, tsteps, cx) - noise) ** 2).mean()
+    loss_ref.backward()
+    P = TU.params_from_state_dict(sd, dev)
+    to_nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev, torch.bfloat16)
+    loss, grads = TU.unet_loss_and_grads(ctx, P, spec, to_nhwc(x), tsteps.to(dev), cx.to(dev, torch.bfloat16), to_nhwc(noise))
+    g = TU.grads_to_state_dict_layout({k: v.cpu() for k, v in grads.items()}, sd)
+    missing = sorted(set(sd) - set(g))
+    assert not missing, missing
+    errs = {k: rel_l2(g[k], ref_sd[k].grad) for k in sd}
+    worst = sorted(errs, key=errs.get)[-3:]
+    print(f"whole UNet: loss {loss:.5f} vs {loss_ref.item():.5f}; {len(errs)} parameter gradients, worst " + ", ".join(f"{k} {errs[k]:.2e}" for k in worst))
+    assert abs(loss - loss_ref.item()) <= 2e-2 * loss_ref.item()
+    assert errs[worst[-1]] <= 5e-2       # ~60 bf16 layers deep on both passes
+
+
+def test_whole_unet_training_steps_track_torch(ctx):
+    """Three AdamW steps of the whole (tiny-topology) UNet on the native ops beside torch.optim.AdamW on the oracle network: same loss
+    curve (the ldm p_losses MSE on a fixed batch)."""
+    from oracle import unet as ounet
+    from rdm_amd import training_unet as TU
+    dev = ctx.device
+    spec = ounet.tiny_spec()
+    sd = {k: bf16_round(v) if v.dim() >= 2 else v for k, v in ounet.synth_state_dict(ounet.param_shapes(spec), seed=11).items()}
+    B, H = 2, 32
+    x, cx, noise = bf16_round(_rand((B, 3, H, H), 310)), bf16_round(_rand((B, 4, 512), 311, 0.5)), bf16_round(_rand((B, 3, H, H), 312))
+    tsteps = torch.tensor([120, 640])
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.AdamW(list(ref_sd.values()), lr=2e-4, weight_decay=1e-2)
+    P = TU.params_from_state_dict(sd, dev)
+    state = {"m": {k: torch.zeros_like(v) for k, v in P.items()}, "v": {k: torch.zeros_like(v) for k, v in P.items()}}
+    to_nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev, torch.bfloat16)
+    xd, nd, cd, td = to_nhwc(x), to_nhwc(noise), cx.to(dev, torch.bfloat16), tsteps.to(dev)
+    curve = []
+    for step in (1, 2, 3):
+        opt.zero_grad()
+        loss_ref = ((ounet.unet_forward(ref_sd, spec, x, tsteps, cx) - noise) ** 2).mean()
+        loss_ref.backward(); opt.step()
+        curve.append((TU.unet_training_step(ctx, P, state, spec, xd, td, cd, nd, step, lr=2e-4, weight_decay=1e-2), loss_ref.item()))
+    print(f"whole UNet training: loss curve native vs torch {[(round(a, 4), round(b, 4)) for a, b in curve]}")
+    assert all(abs(a - b) <= 3e-2 * b for a, b in curve), curve
+    assert curve[2][1] < curve[0][1] and curve[2][0] < curve[0][0], curve

@@ -552,3 +552,29 @@ def test_instantiate_from_config_with_the_shipped_config_structure(tmp_path):
             instantiate_from_config(c2)
     with pytest.raises(TypeError):
         instantiate_from_config({"target": cfg["target"], "params": dict(cfg["params"], unet_config={"params": dict(unet["params"], no_such_option=1)})})
+
+
+def _worker_avg(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from rdm_amd import parallel
+    parallel.init_distributed("gloo")
+    g = torch.Generator().manual_seed(50 + rank)
+    grads = {f"p{i}": torch.randn(sh, generator=g) for i, sh in enumerate([(7,), (33, 5), (1000,), (3, 3, 3, 4), (2049,)])}
+    out = parallel.average_gradients({k: v.clone() for k, v in grads.items()}, bucket_bytes=4096)      # several buckets, one tensor > bucket
+    q.put((rank, {k: v.numpy() for k, v in grads.items()}, {k: v.numpy() for k, v in out.items()}))
+    parallel.shutdown()
+
+
+def test_gradient_averaging_world2_gloo():
+    """The training step's data-parallel exchange: bucketed all-reduce of the gradient dict == the plain per-tensor mean, same on both ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_avg, args=(r, 2, 29691, q)) for r in range(2)]
+    for p in procs: p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs: p.join(timeout=60)
+    (_, g0, o0), (_, g1, o1) = got
+    for k in g0:
+        assert o0[k].shape == g0[k].shape
+        assert np.array_equal(o0[k], o1[k])
+        assert np.allclose(o0[k], (g0[k] + g1[k]) / 2, rtol=0, atol=1e-7)
