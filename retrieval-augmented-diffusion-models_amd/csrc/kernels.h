@@ -100,7 +100,8 @@ hipError_t launch_reduce_planes(const float* parts, float* out, long long n, int
 hipError_t launch_add_bf16(const bf16_t* a, const bf16_t* b, bf16_t* out, long long n, hipStream_t st);
 // GEGLU on an unpermuted pre-activation [M, 2F] ([x | gate]): dh null -> out [M, F] = x gelu(gate); else out [M, 2F] = [dx | dgate]
 hipError_t launch_geglu(const bf16_t* pre, const bf16_t* dh, bf16_t* out, long long M, int F, hipStream_t st);
-hipError_t launch_colsum(const bf16_t* x, float* out, long long M, int N, hipStream_t st);
+hipError_t launch_colsum(const bf16_t* x, float* out, long long M, int N, hipStream_t st, float* scratch = nullptr);     // scratch: colsum_scratch_bytes(M, N)
+size_t colsum_scratch_bytes(long long M, int N);
 hipError_t launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* beta, int B, int HW, int C, int groups,
                                 float eps, int silu, float* scratch, bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st);
 hipError_t launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, int M, int C, float eps, float* scratch, int* nb_out,

@@ -1686,7 +1686,8 @@ int rdm_op_layernorm_bwd(rdm_ctx* c, const void* x, const void* dy, const float*
 int rdm_op_colsum(rdm_ctx* c, const void* x, float* out, long long M, int N) {
     RDM_ENTER(c);
     if (!x || !out) return c->fail(-1, "rdm_op_colsum: null argument");
-    RDM_CHECK_HIP(c, launch_colsum((const bf16_t*)x, out, M, N, c->stream));
+    RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, colsum_scratch_bytes(M, N) + 256));
+    RDM_CHECK_HIP(c, launch_colsum((const bf16_t*)x, out, M, N, c->stream, (float*)c->bwd_tmp));
     return 0;
 }
 int rdm_op_transpose(rdm_ctx* c, const void* x, void* y, int rows, int cols) {
