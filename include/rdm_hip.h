@@ -250,6 +250,9 @@ int rdm_op_groupnorm_bwd(rdm_ctx* ctx, const void* x_bf16, const void* dy_bf16, 
                          float eps, int silu, void* dx_bf16, float* dgamma, float* dbeta);
 int rdm_op_layernorm_bwd(rdm_ctx* ctx, const void* x_bf16, const void* dy_bf16, const float* gamma, int M, int C, float eps, void* dx_bf16,
                          float* dgamma, float* dbeta);
+/* nn.Linear weight gradient dW [N, K] fp32 = dy^T a for dy [M, N], a [M, K] bf16 (autograd of F.linear in the training step): K-split
+ * over the M rows, deterministic fixed-order sum of the fp32 partial planes. */
+int rdm_op_linear_wgrad(rdm_ctx* ctx, const void* dy_bf16, const void* a_bf16, float* dw, long long M, int N, int K);
 int rdm_op_colsum(rdm_ctx* ctx, const void* x_bf16 /*[M,N]*/, float* out /*[N]*/, long long M, int N);
 int rdm_op_transpose(rdm_ctx* ctx, const void* x_bf16 /*[rows,cols]*/, void* y_bf16 /*[cols,rows]*/, int rows, int cols);
 int rdm_op_add(rdm_ctx* ctx, const void* a_bf16, const void* b_bf16, void* out_bf16, long long n);

@@ -119,6 +119,7 @@ SIGNATURES = {
     "rdm_op_transpose": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "rdm_op_add": (C.c_int, [_P, _P, _P, _P, C.c_longlong]),
     "rdm_op_geglu": (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_int]),
+    "rdm_op_linear_wgrad": (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_int, C.c_int]),
     "rdm_op_silu": (C.c_int, [_P, _P, _P, _P, C.c_longlong]),
     "rdm_op_sumpool2": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rdm_op_adamw": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]),
@@ -647,6 +648,13 @@ class Context:
         out = torch.empty_like(a)
         self._check(lib.rdm_op_add(self._h, _ptr(a), _ptr(b), _ptr(out), a.numel()))
         return out
+
+    def op_linear_wgrad(self, dy, a):
+        """dy bf16 [M, N], a bf16 [M, K] -> dy^T a fp32 [N, K] (the weight gradient of y = a w^T)."""
+        M, N = dy.shape; K = a.shape[1]
+        dw = torch.empty((N, K), device=self.device, dtype=torch.float32)
+        self._check(lib.rdm_op_linear_wgrad(self._h, _ptr(dy), _ptr(a), _ptr(dw), M, N, K))
+        return dw
 
     def op_silu(self, x, dy=None):
         """x fp32: -> silu(x) bf16, or with dy (fp32) the gradient dy * silu'(x) fp32."""

@@ -168,6 +168,36 @@ hipError_t launch_conv_wgrad(const bf16_t* x, const bf16_t* dy, float* dw, int B
     return launch_reduce_planes(parts, dw, (long long)N * 9 * C, Z, st);
 }
 
+// ---- Linear weight gradient dW [N][K] = dy^T a: the reduction runs over the M rows, the output is tiny -- as ONE GEMM it is 6 tiles on
+// 256 CUs walking K' = M serially (0.2 ms each, a third of the training step).  Like the conv wgrad: row-major transposes dy^T [N][Mp],
+// a^T [K][Mp] (zero padded), Z K-chunks as a batched launch of fp32 planes, fixed-order sum.
+static void linear_wgrad_geom(long long M, int* pZ, long long* pKc) {
+    int Z = (int)((M + 2047) / 2048); if (Z < 1) Z = 1; if (Z > 64) Z = 64;
+    long long Kc = (M + Z - 1) / Z; Kc = (Kc + 63) & ~63LL;
+    *pZ = Z; *pKc = Kc;
+}
+size_t linear_wgrad_scratch_bytes(long long M, int N, int K) {
+    int Z; long long Kc; linear_wgrad_geom(M, &Z, &Kc);
+    return (size_t)(N + K) * Kc * Z * 2 + 256 + (size_t)Z * N * K * 4;
+}
+hipError_t launch_linear_wgrad(const bf16_t* dy, const bf16_t* a, float* dw, long long M, int N, int K, char* scratch, const void* zero_page, hipStream_t st) {
+    int Z; long long Kc; linear_wgrad_geom(M, &Z, &Kc);
+    const long long Mp = Kc * Z;
+    bf16_t* dyT = (bf16_t*)scratch; bf16_t* aT = dyT + (size_t)N * Mp;
+    float* parts = (float*)(scratch + (((size_t)(N + K) * Mp * 2 + 255) & ~(size_t)255));
+    hipError_t e = hipSuccess;
+    if (Mp != M) { e = hipMemsetAsync(scratch, 0, (size_t)(N + K) * Mp * 2, st); if (e != hipSuccess) return e; }
+    e = launch_transpose_bf16(dy, dyT, (int)M, N, st, 1, (int)Mp); if (e != hipSuccess) return e;
+    e = launch_transpose_bf16(a, aT, (int)M, K, st, 1, (int)Mp); if (e != hipSuccess) return e;
+    IgemmParams p{}; p.M = N; p.N = K; p.K = (int)Kc; p.alpha = 1.f; p.zero_page = zero_page;
+    p.Hin = p.Win = p.Hout = p.Wout = 1; p.stride = 1; p.rows_per_sample = 1;
+    p.A0 = dyT; p.C0 = (int)Kc; p.lda = (int)Mp; p.sA = Kc;
+    p.W = aT; p.ldw = (int)Mp; p.sW = Kc;
+    p.out_f32 = parts; p.ldo = K; p.sO = (long long)N * K;
+    e = launch_igemm(p, false, Z, st); if (e != hipSuccess) return e;
+    return launch_reduce_planes(parts, dw, (long long)N * K, Z, st);
+}
+
 // ---- GroupNorm (+SiLU) backward.  x [B, HW, C] bf16 (the forward INPUT), dy [B, HW, C] bf16 (gradient w.r.t. the OUTPUT).
 // pass 1 (one block per (sample, group)): mean / rstd from x (recomputed: two reads instead of keeping forward state), then
 //   S1 = sum dxh, S2 = sum dxh * xh over the group, with dz = dy * silu'(z) (z = xh * gamma + beta) and dxh = dz * gamma;
@@ -298,7 +328,7 @@ __global__ __launch_bounds__(256) void ln_bwd_affine_kernel(const float* part_g,
 }
 hipError_t launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, int M, int C, float eps, float* scratch /* 2*nb*C */,
                                 int* nb_out, bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st) {
-    const int rows_per_block = 16;
+    const int rows_per_block = M >= 16384 ? 64 : 16;      // (the fixed-order sum over the block partials is serial per channel: keep nb in the hundreds)
     const int nb = (M + rows_per_block - 1) / rows_per_block;
     if (nb_out) *nb_out = nb;
     float* pg = scratch; float* pb = scratch + (size_t)nb * C;

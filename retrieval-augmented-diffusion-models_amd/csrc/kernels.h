@@ -102,6 +102,9 @@ hipError_t launch_add_bf16(const bf16_t* a, const bf16_t* b, bf16_t* out, long l
 hipError_t launch_geglu(const bf16_t* pre, const bf16_t* dh, bf16_t* out, long long M, int F, hipStream_t st);
 hipError_t launch_colsum(const bf16_t* x, float* out, long long M, int N, hipStream_t st, float* scratch = nullptr);     // scratch: colsum_scratch_bytes(M, N)
 size_t colsum_scratch_bytes(long long M, int N);
+// dW [N][K] fp32 = dy^T a for dy [M, N], a [M, K] bf16 (Linear weight gradient): K-split over the M rows, fp32 planes summed in fixed order
+size_t linear_wgrad_scratch_bytes(long long M, int N, int K);
+hipError_t launch_linear_wgrad(const bf16_t* dy, const bf16_t* a, float* dw, long long M, int N, int K, char* scratch, const void* zero_page, hipStream_t st);
 hipError_t launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* beta, int B, int HW, int C, int groups,
                                 float eps, int silu, float* scratch, bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st);
 hipError_t launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, int M, int C, float eps, float* scratch, int* nb_out,
@@ -117,7 +120,7 @@ hipError_t launch_conv_out(const bf16_t* x, const float* w, const float* bias, f
                            int Cout, hipStream_t st);
 hipError_t launch_timestep_embedding(const long long* t, bf16_t* out, int B, int dim, int ld, hipStream_t st);   // rows of ld >= dim, tail zeroed
 hipError_t launch_cast_f32_bf16(const float* x, bf16_t* y, long long n, hipStream_t st);
-hipError_t launch_transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st, int batch = 1);       // y[c][r] = x[r][c] (batch contiguous matrices)
+hipError_t launch_transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st, int batch = 1, int ldy = 0);       // y[c][r] = x[r][c] (batch contiguous matrices)
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* pb, long long n, float lr, float b1, float b2, float eps, float wd, int step,
                         hipStream_t st);
 hipError_t launch_silu(const float* x, const float* dy, bf16_t* ob, float* of, long long n, hipStream_t st);

@@ -183,10 +183,10 @@ hipError_t launch_cast_f32_bf16(const float* x, bf16_t* y, long long n, hipStrea
 }
 
 // y[c][r] = x[r][c] (small weight matrices, once per sampling call)
-__global__ void transpose_bf16_kernel(const bf16_t* x, bf16_t* y, int rows, int cols) {
+__global__ void transpose_bf16_kernel(const bf16_t* x, bf16_t* y, int rows, int cols, int ldy) {
     __shared__ bf16_t tile[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    x += (long long)blockIdx.z * rows * cols; y += (long long)blockIdx.z * rows * cols;       // batch of matrices
+    x += (long long)blockIdx.z * rows * cols; y += (long long)blockIdx.z * cols * ldy;        // batch of matrices; ldy: output row pitch (>= rows)
     for (int i = threadIdx.y; i < 32; i += 8) {
         const int r = r0 + i, c = c0 + threadIdx.x;
         tile[i][threadIdx.x] = (r < rows && c < cols) ? x[(long long)r * cols + c] : (bf16_t)0;
@@ -194,11 +194,11 @@ __global__ void transpose_bf16_kernel(const bf16_t* x, bf16_t* y, int rows, int 
     __syncthreads();
     for (int i = threadIdx.y; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + threadIdx.x;
-        if (r < rows && c < cols) y[(long long)c * rows + r] = tile[threadIdx.x][i];
+        if (r < rows && c < cols) y[(long long)c * ldy + r] = tile[threadIdx.x][i];
     }
 }
-hipError_t launch_transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st, int batch) {
-    transpose_bf16_kernel<<<dim3((cols + 31) / 32, (rows + 31) / 32, batch < 1 ? 1 : batch), dim3(32, 8), 0, st>>>(x, y, rows, cols);
+hipError_t launch_transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st, int batch, int ldy) {
+    transpose_bf16_kernel<<<dim3((cols + 31) / 32, (rows + 31) / 32, batch < 1 ? 1 : batch), dim3(32, 8), 0, st>>>(x, y, rows, cols, ldy > 0 ? ldy : rows);
     return hipGetLastError();
 }
 

@@ -1683,6 +1683,13 @@ int rdm_op_layernorm_bwd(rdm_ctx* c, const void* x, const void* dy, const float*
                                           c->stream));
     return 0;
 }
+int rdm_op_linear_wgrad(rdm_ctx* c, const void* dy, const void* a, float* dw, long long M, int N, int K) {
+    RDM_ENTER(c);
+    if (!dy || !a || !dw || M < 1 || M > 0x7fffffffLL || N < 2 || K < 2 || N % 2 || K % 2) return c->fail(-1, "rdm_op_linear_wgrad: bad argument (N, K even)");
+    RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, linear_wgrad_scratch_bytes(M, N, K)));
+    RDM_CHECK_HIP(c, launch_linear_wgrad((const bf16_t*)dy, (const bf16_t*)a, dw, M, N, K, c->bwd_tmp, c->zero_page, c->stream));
+    return 0;
+}
 int rdm_op_colsum(rdm_ctx* c, const void* x, float* out, long long M, int N) {
     RDM_ENTER(c);
     if (!x || !out) return c->fail(-1, "rdm_op_colsum: null argument");

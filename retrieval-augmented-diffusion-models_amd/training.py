@@ -41,7 +41,7 @@ def _pad_keys(t, mult=64):
 def linear_backward(ctx, a, w, dy):
     """y = a w^T + b  (a [M,K], w [N,K], dy [M,N], all bf16)  ->  da bf16 [M,K], dw f32 [N,K], db f32 [N]."""
     da = ctx.op_linear(dy, ctx.op_transpose(w))                                        # dy [M,N] . (w^T)^T
-    dw = ctx.op_linear(ctx.op_transpose(_pad_rows(dy)), ctx.op_transpose(_pad_rows(a)), out_f32=True)   # dy^T [N,M] . (a^T)^T
+    dw = ctx.op_linear_wgrad(dy, a)                                                    # dy^T a, K-split over the M rows
     return da, dw, ctx.op_colsum(dy)
 
 
