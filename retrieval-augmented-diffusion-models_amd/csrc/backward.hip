@@ -82,12 +82,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 // 2-byte loads took 0.46 ms per call -- two thirds of a whole-UNet training step): (1) row chunks of 2048 x column blocks of 256, a
 // thread sums 8 columns (16-byte loads) of every 8th row of its chunk, the block's 8 row lanes meet in LDS; (2) the chunk partials are
 // added in chunk order.
-constexpr int CS_ROWS = 2048;
-__global__ __launch_bounds__(256) void colsum_part_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, long long M, int N) {
+constexpr int CS_ROWS = 2048;                 // rows per chunk for tall matrices; 128 below 16 k rows (more blocks than columns allow alone)
+__global__ __launch_bounds__(256) void colsum_part_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, long long M, int N, int CS) {
     __shared__ float red[8][256];
     const int cv = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int col0 = blockIdx.y * 256 + cv * 8;
-    const long long r0 = (long long)blockIdx.x * CS_ROWS, r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
+    const long long r0 = (long long)blockIdx.x * CS, r1 = r0 + CS < M ? r0 + CS : M;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (col0 < N)
         for (long long m = r0 + rl; m < r1; m += 8) {
@@ -114,14 +114,15 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
     for (int c = 0; c < nchunk; c++) t += part[(long long)c * N + col];
     out[col] = t;
 }
-size_t colsum_scratch_bytes(long long M, int N) { return (size_t)((M + CS_ROWS - 1) / CS_ROWS) * N * sizeof(float); }
+size_t colsum_scratch_bytes(long long M, int N) { return (size_t)((M + 127) / 128) * N * sizeof(float); }
 hipError_t launch_colsum(const bf16_t* x, float* out, long long M, int N, hipStream_t st, float* scratch) {
-    if (!scratch || N % 8 != 0 || M < 2 * CS_ROWS) {
+    if (!scratch || N % 8 != 0 || M < 256) {
         colsum_kernel<<<dim3((N + 63) / 64), 256, 0, st>>>(x, out, M, N);
         return hipGetLastError();
     }
-    const int nchunk = (int)((M + CS_ROWS - 1) / CS_ROWS);
-    colsum_part_kernel<<<dim3(nchunk, (N + 255) / 256), 256, 0, st>>>(x, scratch, M, N);
+    const int CS = M >= 16384 ? CS_ROWS : 128;
+    const int nchunk = (int)((M + CS - 1) / CS);
+    colsum_part_kernel<<<dim3(nchunk, (N + 255) / 256), 256, 0, st>>>(x, scratch, M, N, CS);
     colsum_finish_kernel<<<dim3((N + 255) / 256), 256, 0, st>>>(scratch, out, nchunk, N);
     return hipGetLastError();
 }

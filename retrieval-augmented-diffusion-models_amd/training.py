@@ -38,11 +38,11 @@ def _pad_keys(t, mult=64):
     return out
 
 
-def linear_backward(ctx, a, w, dy):
-    """y = a w^T + b  (a [M,K], w [N,K], dy [M,N], all bf16)  ->  da bf16 [M,K], dw f32 [N,K], db f32 [N]."""
+def linear_backward(ctx, a, w, dy, bias=True):
+    """y = a w^T + b  (a [M,K], w [N,K], dy [M,N], all bf16)  ->  da bf16 [M,K], dw f32 [N,K], db f32 [N] (None for bias=False)."""
     da = ctx.op_linear(dy, ctx.op_transpose(w))                                        # dy [M,N] . (w^T)^T
     dw = ctx.op_linear_wgrad(dy, a)                                                    # dy^T a, K-split over the M rows
-    return da, dw, ctx.op_colsum(dy)
+    return da, dw, (ctx.op_colsum(dy) if bias else None)
 
 
 def resblock_forward(ctx, p, x, semb):
@@ -175,9 +175,9 @@ def attn_block_backward(ctx, p, x, saved, dout, context=None):
     d = attention_backward(ctx, saved["q"], saved["k"], saved["v"], p["heads"], saved, datt.reshape(B, n, C))
     c = saved["ln"] if context is None else context.reshape(-1, context.shape[-1])
     m = saved["k"].shape[1]
-    dln, g["wq"], _ = linear_backward(ctx, saved["ln"], p["wq"], d["q"].reshape(B * n, C))
-    dck, g["wk"], _ = linear_backward(ctx, c, p["wk"], d["k"].reshape(B * m, C))
-    dcv, g["wv"], _ = linear_backward(ctx, c, p["wv"], d["v"].reshape(B * m, C))
+    dln, g["wq"], _ = linear_backward(ctx, saved["ln"], p["wq"], d["q"].reshape(B * n, C), bias=False)
+    dck, g["wk"], _ = linear_backward(ctx, c, p["wk"], d["k"].reshape(B * m, C), bias=False)
+    dcv, g["wv"], _ = linear_backward(ctx, c, p["wv"], d["v"].reshape(B * m, C), bias=False)
     dc = ctx.op_add(dck, dcv)
     if context is None:
         dln = ctx.op_add(dln, dc)
