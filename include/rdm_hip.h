@@ -261,6 +261,9 @@ int rdm_op_add(rdm_ctx* ctx, const void* a_bf16, const void* b_bf16, void* out_b
  * that is the gradient of Upsample's nearest-neighbour F.interpolate: x bf16 [B, 2H, 2W, C] -> out bf16 [B, H, W, C]. */
 int rdm_op_silu(rdm_ctx* ctx, const float* x, const float* dy_or_null, void* out_bf16_or_f32, long long n);
 int rdm_op_sumpool2(rdm_ctx* ctx, const void* x_bf16, void* out_bf16, int B, int H, int W, int C);
+/* LitEma.forward (ldm/modules/ema.py: `shadow.sub_(one_minus_decay * (shadow - param))`; the caller computes
+ * decay = min(decay, (1 + num_updates) / (10 + num_updates)) like the reference) on fp32 tensors in place. */
+int rdm_op_ema(rdm_ctx* ctx, float* shadow, const float* param, long long n, float one_minus_decay);
 /* One AdamW step (torch.optim.AdamW: decoupled weight decay, bias-corrected moments; the reference's configure_optimizers,
  * rdm/models/diffusion/ddpm.py, hands the UNet parameters to it) on fp32 master parameters / moments in place; p_bf16 (optional) receives
  * the bf16 working copy the kernels read.  step counts from 1. */

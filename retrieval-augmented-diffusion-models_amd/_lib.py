@@ -120,6 +120,7 @@ SIGNATURES = {
     "rdm_op_add": (C.c_int, [_P, _P, _P, _P, C.c_longlong]),
     "rdm_op_geglu": (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_int]),
     "rdm_op_linear_wgrad": (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_int, C.c_int]),
+    "rdm_op_ema": (C.c_int, [_P, _P, _P, C.c_longlong, C.c_float]),
     "rdm_op_silu": (C.c_int, [_P, _P, _P, _P, C.c_longlong]),
     "rdm_op_sumpool2": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rdm_op_adamw": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]),
@@ -655,6 +656,9 @@ class Context:
         dw = torch.empty((N, K), device=self.device, dtype=torch.float32)
         self._check(lib.rdm_op_linear_wgrad(self._h, _ptr(dy), _ptr(a), _ptr(dw), M, N, K))
         return dw
+
+    def op_ema(self, shadow, p, one_minus_decay):
+        self._check(lib.rdm_op_ema(self._h, _ptr(shadow), _ptr(p), p.numel(), float(one_minus_decay)))
 
     def op_silu(self, x, dy=None):
         """x fp32: -> silu(x) bf16, or with dy (fp32) the gradient dy * silu'(x) fp32."""

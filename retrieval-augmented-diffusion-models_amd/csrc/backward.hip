@@ -525,3 +525,13 @@ hipError_t launch_sumpool2(const bf16_t* x, bf16_t* out, int B, int H, int W, in
     sumpool2_kernel<<<dim3((unsigned)g), 256, 0, st>>>(x, out, B, H, W, C);
     return hipGetLastError();
 }
+
+// ---- LitEma update (ldm/modules/ema.py forward(): shadow.sub_(one_minus_decay * (shadow - param))) on fp32 tensors
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ shadow, const float* __restrict__ p, long long n, float omd) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) { const float s = shadow[i]; shadow[i] = s - omd * (s - p[i]); }
+}
+hipError_t launch_ema(float* shadow, const float* p, long long n, float one_minus_decay, hipStream_t st) {
+    long long g = (n + 255) / 256; if (g > 16384) g = 16384; if (g < 1) g = 1;
+    ema_kernel<<<dim3((unsigned)g), 256, 0, st>>>(shadow, p, n, one_minus_decay);
+    return hipGetLastError();
+}

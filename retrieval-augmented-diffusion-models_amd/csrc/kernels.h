@@ -123,6 +123,7 @@ hipError_t launch_cast_f32_bf16(const float* x, bf16_t* y, long long n, hipStrea
 hipError_t launch_transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st, int batch = 1, int ldy = 0);       // y[c][r] = x[r][c] (batch contiguous matrices)
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* pb, long long n, float lr, float b1, float b2, float eps, float wd, int step,
                         hipStream_t st);
+hipError_t launch_ema(float* shadow, const float* p, long long n, float one_minus_decay, hipStream_t st);
 hipError_t launch_silu(const float* x, const float* dy, bf16_t* ob, float* of, long long n, hipStream_t st);
 hipError_t launch_sumpool2(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t st);
 // attention backward helpers (backward.hip)

@@ -1709,6 +1709,12 @@ int rdm_op_add(rdm_ctx* c, const void* a, const void* b, void* out, long long n)
     RDM_CHECK_HIP(c, launch_add_bf16((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n, c->stream));
     return 0;
 }
+int rdm_op_ema(rdm_ctx* c, float* shadow, const float* p, long long n, float one_minus_decay) {
+    RDM_ENTER(c);
+    if (!shadow || !p || n < 1) return c->fail(-1, "rdm_op_ema: bad argument");
+    RDM_CHECK_HIP(c, launch_ema(shadow, p, n, one_minus_decay, c->stream));
+    return 0;
+}
 int rdm_op_silu(rdm_ctx* c, const float* x, const float* dy, void* out, long long n) {
     RDM_ENTER(c);
     if (!x || !out || n < 1) return c->fail(-1, "rdm_op_silu: bad argument");

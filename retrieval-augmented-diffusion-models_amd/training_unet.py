@@ -267,3 +267,18 @@ def unet_training_step(ctx, P, state, spec, x, timesteps, context, target, step,
         ctx.op_adamw(p, grads[k].float().reshape(p.shape).contiguous(), state["m"][k], state["v"][k], step, lr=lr, betas=betas, eps=eps,
                      weight_decay=weight_decay)
     return loss
+
+
+class Ema:
+    """ldm LitEma (ldm/modules/ema.py): exponential moving average of the parameters with the warm-up decay
+    min(decay, (1 + n) / (10 + n)); `MinimalRETRODiffusion` (like LatentDiffusion) samples from these weights (`use_ema`)."""
+
+    def __init__(self, P, decay=0.9999):
+        self.decay, self.num_updates = decay, 0
+        self.shadow = {k: v.clone() for k, v in P.items()}
+
+    def update(self, ctx, P):
+        self.num_updates += 1
+        decay = min(self.decay, (1 + self.num_updates) / (10 + self.num_updates))
+        for k, v in P.items():
+            ctx.op_ema(self.shadow[k], v, 1.0 - decay)

@@ -371,3 +371,18 @@ def test_whole_unet_training_steps_track_torch(ctx):
     print(f"whole UNet training: loss curve native vs torch {[(round(a, 4), round(b, 4)) for a, b in curve]}")
     assert all(abs(a - b) <= 3e-2 * b for a, b in curve), curve
     assert curve[2][1] < curve[0][1] and curve[2][0] < curve[0][0], curve
+
+
+def test_ema_matches_litema_formula(ctx):
+    from rdm_amd import training_unet as TU
+    d = ctx.device
+    P = {"a": _rand((1000,), 400).to(d), "b": _rand((33, 7), 401).to(d)}
+    ema = TU.Ema(P, decay=0.9999)
+    ref = {k: v.clone().cpu() for k, v in P.items()}
+    for n in range(1, 4):
+        for k in P: P[k] += 0.1 * n
+        ema.update(ctx, P)
+        decay = min(0.9999, (1 + n) / (10 + n))
+        for k in ref: ref[k] -= (1 - decay) * (ref[k] - P[k].cpu())
+    for k in ref:
+        assert (ema.shadow[k].cpu() - ref[k]).abs().max().item() <= 1e-6
