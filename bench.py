@@ -300,7 +300,7 @@ def main():
                 roof[name] = {"bound": "mfma", "achieved": w_ / (ms_ * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                               "frac": w_ / (ms_ * 1e-3) / 1e12 / 2500.0, "launches": n_, "time_ms_per_step": ms_}
                 if name == "linear_gemm":
-                    roof[name]["kernel"] = "lin4_kernel<GEGLU, WM> (big-M projections) + igemm_kernel / sgemm_kernel (the rest)
+                    roof[name]["kernel"] = "lin4_kernel<GEGLU, WM> (big-M projections) + igemm_kernel / sgemm_kernel (the rest)"
             else:
                 roof[name] = {"bound": "hbm", "achieved": w_ / (ms_ * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                               "frac": w_ / (ms_ * 1e-3) / 1e9 / 8000.0, "launches": n_, "time_ms_per_step": ms_,
