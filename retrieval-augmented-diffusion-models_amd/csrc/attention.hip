@@ -103,9 +103,22 @@ __global__ __launch_bounds__(256, 2) void flash_d32_lds_kernel(FlashParams p) {
     __shared__ __attribute__((aligned(16))) char lds[DEPTH * CH];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    // XCD-aware work mapping: workgroups go round-robin over the 8 XCDs in linear id order (x fastest), so the query blocks of one
+    // (sample, head) -- which all stream the same K / V -- would land on 8 different L2s and fetch K / V from HBM 8 times (measured
+    // 708 MB per launch against 400 MB of tensors: the kernel is HBM bound).  Remapped: the blocks with linear id = 8 s + x form XCD
+    // x's queue; consecutive queue slots are the query blocks of ONE (sample, head) group, groups dealt to the XCDs round-robin.
+    int xb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    {
+        const int gx = gridDim.x, G = gridDim.y * gridDim.z;
+        if ((G & 7) == 0 && p.xcd_remap) {
+            const int lin = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+            const int xcd = lin & 7, slot = lin >> 3;
+            const int grp = (slot / gx) * 8 + xcd;
+            xb = slot - (slot / gx) * gx; h = grp % gridDim.y; b = grp / gridDim.y;
+        }
+    }
+    const int q0 = (xb * 4 + wave) * 32;
     const bool active = q0 < p.n;
-    const int h = blockIdx.y, b = blockIdx.z;
     const int l31 = lane & 31, hf = lane >> 5;
     const long long tok0 = (long long)b * p.n;
 
@@ -205,7 +218,9 @@ hipError_t launch_flash_d32(const FlashParams& p, int heads, int batch, hipStrea
     if (p.n % 32 != 0 || p.C != heads * 32) return hipErrorInvalidValue;
     if (p.n % 64 == 0) {
         dim3 grid((p.n / 32 + 3) / 4, heads, batch);
-        flash_d32_lds_kernel<<<grid, 256, 0, st>>>(p);
+        static const int old = getenv("RDM_FLASH_OLD") ? atoi(getenv("RDM_FLASH_OLD")) : 0;
+        FlashParams q = p; q.xcd_remap = old ? 0 : 1;          // RDM_FLASH_OLD=1: plain blockIdx mapping (A/B)
+        flash_d32_lds_kernel<<<grid, 256, 0, st>>>(q);
         return hipGetLastError();
     }
     int nw = p.n / 32; if (nw > 4) nw = 4;

@@ -19,7 +19,8 @@ struct FlashParams {
     const bf16_t* vt;                // vt[((b*C) + h*32 + d)*n + j]
     bf16_t* out; int ldo;            // out[(b*n + i)*ldo + h*32 + d]
     int n, C;                        // tokens, channels (= heads*32)
-    float scale_log2e;               // d^-0.5 * log2(e)
+    float scale_log2e;
+    int xcd_remap;                   // set by the launcher: XCD-aware (sample, head) grouping of the query blocks               // d^-0.5 * log2(e)
 };
 
 struct SmallAttnParams {
