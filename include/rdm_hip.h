@@ -276,6 +276,10 @@ int rdm_op_adamw(rdm_ctx* ctx, float* p, const float* grad, float* exp_avg, floa
  *   rdm_op_bmm     out[z] = alpha * A[z] W[z]^T for batch contiguous bf16 matrices A [M, K], W [N, K] (K % 64 == 0), bf16 and / or fp32 out;
  *   rdm_op_transpose_batched, rdm_op_softmax (fp32 scores -> bf16 probabilities, row-wise), rdm_op_softmax_bwd
  *   (dS = P * (dP - rowsum(P * dP))).  rdm_amd/training.py attention_forward / attention_backward assemble them. */
+/* Fused attention backward for d_head = 32 (no n x m score matrix): q, o, dout [B, n, heads * 32], k, v [B, m, heads * 32] bf16 (o = the forward
+ * output) -> dq [B, n, C], dk, dv [B, m, C] bf16.  n, m multiples of 32 (pad the keys and mask them with rdm_op_softmax otherwise). */
+int rdm_op_attention_bwd(rdm_ctx* ctx, const void* q, const void* k, const void* v, const void* o, const void* dout, int B, int n, int m, int heads,
+                         void* dq, void* dk, void* dv);
 int rdm_op_bmm(rdm_ctx* ctx, const void* a_bf16, const void* w_bf16, void* out_bf16_or_null, float* out_f32_or_null, int batch, int M, int N, int K,
                float alpha);
 int rdm_op_heads(rdm_ctx* ctx, const void* x_bf16, void* out_bf16, int B, int n, int H, int D, int ldx, int mode);

@@ -124,6 +124,7 @@ SIGNATURES = {
     "rdm_op_silu": (C.c_int, [_P, _P, _P, _P, C.c_longlong]),
     "rdm_op_sumpool2": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rdm_op_adamw": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]),
+    "rdm_op_attention_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "rdm_op_bmm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "rdm_op_heads": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rdm_op_transpose_batched": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int]),
@@ -676,6 +677,13 @@ class Context:
         """In-place AdamW step on fp32 tensors p / m / v with gradient g; p_bf16 (same shape, bf16) receives the rounded new parameters."""
         self._check(lib.rdm_op_adamw(self._h, _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(p_bf16) if p_bf16 is not None else None, p.numel(),
                                      float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step)))
+
+    def op_attention_bwd(self, q, k, v, o, dout, heads):
+        """fused attention backward (d_head 32): q / o / dout bf16 [B, n, C], k / v [B, m, C] -> dq, dk, dv."""
+        B, n, _ = q.shape; m = k.shape[1]
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        self._check(lib.rdm_op_attention_bwd(self._h, _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), B, n, m, heads, _ptr(dq), _ptr(dk), _ptr(dv)))
+        return dq, dk, dv
 
     def op_bmm(self, a, w, alpha=1.0, out_f32=False):
         """a bf16 [Z, M, K], w bf16 [Z, N, K] -> alpha * a w^T [Z, M, N] (bf16, or fp32 with out_f32)."""

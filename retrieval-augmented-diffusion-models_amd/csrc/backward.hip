@@ -535,3 +535,207 @@ hipError_t launch_ema(float* shadow, const float* p, long long n, float one_minu
     ema_kernel<<<dim3((unsigned)g), 256, 0, st>>>(shadow, p, n, one_minus_decay);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Fused attention backward for d_head = 32 (the UNet's self-attention; ldm CrossAttention, attention.py:52-72): no n x m score
+// matrix in memory.  Three kernels over (sample, head):
+//   attn_bwd_prep:  L[q] = log2-sum-exp of the scaled scores of row q (running max / sum like the forward), D[q] = dO[q] . O[q];
+//   attn_bwd_dkv:   a wave owns 32 keys and walks the query tiles: S = Q K^T (rows = queries), P = exp2(S c - L), dP = dO V^T,
+//                   dS = P (dP - D); dV^T += dO^T P, dK^T += Q^T dS -- P and dS stay in registers: the MFMA result layout (a lane = one
+//                   key column, 16 query rows) IS the B-operand layout of the next MFMA once the query rows of a tile are loaded in the
+//                   order pi (bits 2 and 3 of the position swapped), which makes a lane's 8 k-slots 8 CONSECUTIVE queries;
+//   attn_bwd_dq:    the mirror image: a wave owns 32 queries and walks the key tiles with S^T = K Q^T, dQ^T += K^T dS^T.
+// The operands read along the contraction index come from per-head transposed copies (Q^T, K^T, dO^T: [B H][32][n], made by
+// heads_kernel mode 3), exactly like the forward's V^T.  All bf16 in, fp32 accumulation, bf16 out.
+struct AttnBwdParams {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* o; const bf16_t* dout;     // [B, n|m, C], head h = columns [32 h, 32 h + 32)
+    const bf16_t* qT; const bf16_t* kT; const bf16_t* doT;                                       // [B H][32][n|m|n]
+    float* L; float* D;                                                                          // [B H][n]
+    bf16_t* dq; bf16_t* dk; bf16_t* dv;
+    int B, H, n, m, C; float scale, scale_log2e;
+};
+__device__ __forceinline__ int attn_pi(int p) { return (p & ~0xc) | ((p & 4) << 1) | ((p & 8) >> 1); }
+typedef __attribute__((ext_vector_type(16))) float ab_f32x16;
+
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnBwdParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int q0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
+    if (q0 >= p.n) return;
+    const long long qrow = (long long)b * p.n + q0 + l31;
+    bf16x8 qf[2];
+    qf[0] = *(const bf16x8*)(p.q + qrow * p.C + h * 32 + hf * 8); qf[1] = *(const bf16x8*)(p.q + qrow * p.C + h * 32 + 16 + hf * 8);
+    float mx = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < p.m; k0 += 32) {
+        const long long krow = (long long)b * p.m + k0 + l31;
+        const bf16x8 k0f = *(const bf16x8*)(p.k + krow * p.C + h * 32 + hf * 8), k1f = *(const bf16x8*)(p.k + krow * p.C + h * 32 + 16 + hf * 8);
+        ab_f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[r] = 0.f;
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0f, qf[0], s, 0, 0, 0);         // S^T[key][query]: lane = query column
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1f, qf[1], s, 0, 0, 0);
+        float t = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; r++) t = fmaxf(t, s[r]);
+        const float mn = fmaxf(mx, t * p.scale_log2e);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) ps += __builtin_amdgcn_exp2f(s[r] * p.scale_log2e - mn);
+        l = l * __builtin_amdgcn_exp2f(mx - mn) + ps;
+        mx = mn;
+    }
+    // the two half-waves hold the two 16-key halves of every tile: merge
+    const float mo = __shfl_xor(mx, 32), lo = __shfl_xor(l, 32);
+    const float mm = fmaxf(mx, mo);
+    const float lt = l * __builtin_amdgcn_exp2f(mx - mm) + lo * __builtin_amdgcn_exp2f(mo - mm);
+    // D = dO . O over the head's 32 channels (each half-wave 16 of them)
+    const bf16x8 o0 = *(const bf16x8*)(p.o + qrow * p.C + h * 32 + hf * 16), o1 = *(const bf16x8*)(p.o + qrow * p.C + h * 32 + hf * 16 + 8);
+    const bf16x8 d0 = *(const bf16x8*)(p.dout + qrow * p.C + h * 32 + hf * 16), d1 = *(const bf16x8*)(p.dout + qrow * p.C + h * 32 + hf * 16 + 8);
+    float dd = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) dd += bf2f((bf16_t)o0[e]) * bf2f((bf16_t)d0[e]) + bf2f((bf16_t)o1[e]) * bf2f((bf16_t)d1[e]);
+    dd += __shfl_xor(dd, 32);
+    if (hf == 0) {
+        const long long i = ((long long)b * p.H + h) * p.n + q0 + l31;
+        p.L[i] = mm + __log2f(lt); p.D[i] = dd;
+    }
+}
+
+// common: scores of a 32 x 32 tile -> P and dS as packed bf16 operand pairs (regs 0..7 -> first k-step, 8..15 -> second)
+__device__ __forceinline__ void attn_bwd_pds(const ab_f32x16& s, const ab_f32x16& dp, const float (&Lr)[16], const float (&Dr)[16], float c,
+                                             bf16x8 (&pf)[2], bf16x8 (&dsf)[2]) {
+    union { bf16x8 v; uint32_t u[4]; } a[2], g[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = t * 8 + 2 * i;
+            const float p0 = __builtin_amdgcn_exp2f(s[r] * c - Lr[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1] * c - Lr[r + 1]);
+            a[t].u[i] = cvt_pk_bf16(p0, p1);
+            g[t].u[i] = cvt_pk_bf16(p0 * (dp[r] - Dr[r]), p1 * (dp[r + 1] - Dr[r + 1]));
+        }
+    pf[0] = a[0].v; pf[1] = a[1].v; dsf[0] = g[0].v; dsf[1] = g[1].v;
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int k0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
+    if (k0 >= p.m) return;
+    const long long krow = (long long)b * p.m + k0 + l31;
+    bf16x8 kf[2], vf[2];                                     // B operands: column = key l31
+    kf[0] = *(const bf16x8*)(p.k + krow * p.C + h * 32 + hf * 8); kf[1] = *(const bf16x8*)(p.k + krow * p.C + h * 32 + 16 + hf * 8);
+    vf[0] = *(const bf16x8*)(p.v + krow * p.C + h * 32 + hf * 8); vf[1] = *(const bf16x8*)(p.v + krow * p.C + h * 32 + 16 + hf * 8);
+    ab_f32x16 dvT, dkT;                                      // [d rows][key column]
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dvT[r] = 0.f; dkT[r] = 0.f; }
+    const long long bh = (long long)b * p.H + h;
+    const bf16_t* qT = p.qT + (bh * 32 + l31) * p.n; const bf16_t* doT = p.doT + (bh * 32 + l31) * p.n;     // A operands: row = channel l31
+    const int pr = attn_pi(l31);
+    for (int q0 = 0; q0 < p.n; q0 += 32) {
+        const long long qrow = (long long)b * p.n + q0 + pr;                                  // A operands of S / dP: row position l31 holds query pi(l31)
+        const bf16x8 qa0 = *(const bf16x8*)(p.q + qrow * p.C + h * 32 + hf * 8), qa1 = *(const bf16x8*)(p.q + qrow * p.C + h * 32 + 16 + hf * 8);
+        const bf16x8 da0 = *(const bf16x8*)(p.dout + qrow * p.C + h * 32 + hf * 8), da1 = *(const bf16x8*)(p.dout + qrow * p.C + h * 32 + 16 + hf * 8);
+        const bf16x8 qt0 = *(const bf16x8*)(qT + q0 + hf * 8), qt1 = *(const bf16x8*)(qT + q0 + 16 + hf * 8);
+        const bf16x8 dt0 = *(const bf16x8*)(doT + q0 + hf * 8), dt1 = *(const bf16x8*)(doT + q0 + 16 + hf * 8);
+        float Lr[16], Dr[16];                                // regs 0..7 <-> queries q0 + 8 hf + 0..7, regs 8..15 <-> q0 + 16 + 8 hf + 0..7
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int e = 0; e < 8; e += 4) {
+                const float4 lv = *(const float4*)(p.L + bh * p.n + q0 + t * 16 + hf * 8 + e), dv4 = *(const float4*)(p.D + bh * p.n + q0 + t * 16 + hf * 8 + e);
+                Lr[t * 8 + e] = lv.x; Lr[t * 8 + e + 1] = lv.y; Lr[t * 8 + e + 2] = lv.z; Lr[t * 8 + e + 3] = lv.w;
+                Dr[t * 8 + e] = dv4.x; Dr[t * 8 + e + 1] = dv4.y; Dr[t * 8 + e + 2] = dv4.z; Dr[t * 8 + e + 3] = dv4.w;
+            }
+        ab_f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0, kf[0], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa1, kf[1], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, vf[0], dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, vf[1], dp, 0, 0, 0);
+        bf16x8 pf[2], dsf[2];
+        attn_bwd_pds(s, dp, Lr, Dr, p.scale_log2e, pf, dsf);
+        dvT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt0, pf[0], dvT, 0, 0, 0);
+        dvT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt1, pf[1], dvT, 0, 0, 0);
+        dkT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt0, dsf[0], dkT, 0, 0, 0);
+        dkT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt1, dsf[1], dkT, 0, 0, 0);
+    }
+    // lane = key column l31; reg r = channel 8 (r >> 2) + 4 hf + (r & 3)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        uint2 w;
+        w.x = cvt_pk_bf16(dvT[g * 4 + 0], dvT[g * 4 + 1]); w.y = cvt_pk_bf16(dvT[g * 4 + 2], dvT[g * 4 + 3]);
+        *(uint2*)(p.dv + krow * p.C + h * 32 + 8 * g + 4 * hf) = w;
+        w.x = cvt_pk_bf16(dkT[g * 4 + 0] * p.scale, dkT[g * 4 + 1] * p.scale); w.y = cvt_pk_bf16(dkT[g * 4 + 2] * p.scale, dkT[g * 4 + 3] * p.scale);
+        *(uint2*)(p.dk + krow * p.C + h * 32 + 8 * g + 4 * hf) = w;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hf = lane >> 5;
+    const int q0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
+    if (q0 >= p.n) return;
+    const long long qrow = (long long)b * p.n + q0 + l31;
+    bf16x8 qf[2], df[2];                                     // B operands: column = query l31
+    qf[0] = *(const bf16x8*)(p.q + qrow * p.C + h * 32 + hf * 8); qf[1] = *(const bf16x8*)(p.q + qrow * p.C + h * 32 + 16 + hf * 8);
+    df[0] = *(const bf16x8*)(p.dout + qrow * p.C + h * 32 + hf * 8); df[1] = *(const bf16x8*)(p.dout + qrow * p.C + h * 32 + 16 + hf * 8);
+    const long long bh = (long long)b * p.H + h;
+    const float Lq = p.L[bh * p.n + q0 + l31], Dq = p.D[bh * p.n + q0 + l31];
+    float Lr[16], Dr[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { Lr[r] = Lq; Dr[r] = Dq; }
+    ab_f32x16 dqT;
+#pragma unroll
+    for (int r = 0; r < 16; r++) dqT[r] = 0.f;
+    const bf16_t* kT = p.kT + (bh * 32 + l31) * p.m;
+    const int pr = attn_pi(l31);
+    for (int k0 = 0; k0 < p.m; k0 += 32) {
+        const long long krow = (long long)b * p.m + k0 + pr;
+        const bf16x8 ka0 = *(const bf16x8*)(p.k + krow * p.C + h * 32 + hf * 8), ka1 = *(const bf16x8*)(p.k + krow * p.C + h * 32 + 16 + hf * 8);
+        const bf16x8 va0 = *(const bf16x8*)(p.v + krow * p.C + h * 32 + hf * 8), va1 = *(const bf16x8*)(p.v + krow * p.C + h * 32 + 16 + hf * 8);
+        const bf16x8 kt0 = *(const bf16x8*)(kT + k0 + hf * 8), kt1 = *(const bf16x8*)(kT + k0 + 16 + hf * 8);
+        ab_f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qf[0], s, 0, 0, 0);          // S^T[key position][query]
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qf[1], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, df[0], dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, df[1], dp, 0, 0, 0);
+        bf16x8 pf[2], dsf[2];
+        attn_bwd_pds(s, dp, Lr, Dr, p.scale_log2e, pf, dsf);
+        dqT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt0, dsf[0], dqT, 0, 0, 0);
+        dqT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt1, dsf[1], dqT, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        uint2 w;
+        w.x = cvt_pk_bf16(dqT[g * 4 + 0] * p.scale, dqT[g * 4 + 1] * p.scale); w.y = cvt_pk_bf16(dqT[g * 4 + 2] * p.scale, dqT[g * 4 + 3] * p.scale);
+        *(uint2*)(p.dq + qrow * p.C + h * 32 + 8 * g + 4 * hf) = w;
+    }
+}
+
+// per-head transposes without padding: x [B, n, C] -> out [B H][32][n]
+__global__ __launch_bounds__(256) void head_transpose32_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int n, int H) {
+    __shared__ bf16_t tile[32][33];
+    const int h = blockIdx.y, b = blockIdx.z, r0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = (r0 + r < n) ? x[((long long)b * n + r0 + r) * (H * 32) + h * 32 + tx] : (bf16_t)0;
+    __syncthreads();
+    for (int d = ty; d < 32; d += 8) if (r0 + tx < n) out[(((long long)b * H + h) * 32 + d) * n + r0 + tx] = tile[tx][d];
+}
+size_t attn_bwd_scratch_bytes(int B, int H, int n, int m) { return ((size_t)B * H * 32 * (2 * (size_t)n + m)) * 2 + (size_t)B * H * n * 8 + 512; }
+hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* o, const bf16_t* dout, int B, int n, int m, int H,
+                                bf16_t* dq, bf16_t* dk, bf16_t* dv, char* scratch, hipStream_t st) {
+    if (n % 32 || m % 32) return hipErrorInvalidValue;
+    AttnBwdParams p{}; p.q = q; p.k = k; p.v = v; p.o = o; p.dout = dout; p.B = B; p.H = H; p.n = n; p.m = m; p.C = H * 32;
+    p.scale = 1.0f / sqrtf(32.f); p.scale_log2e = p.scale * 1.4426950408889634f;
+    bf16_t* qT = (bf16_t*)scratch; bf16_t* doT = qT + (size_t)B * H * 32 * n; bf16_t* kT = doT + (size_t)B * H * 32 * n;
+    float* L = (float*)(((uintptr_t)(kT + (size_t)B * H * 32 * m) + 255) & ~(uintptr_t)255); float* D = L + (size_t)B * H * n;
+    p.qT = qT; p.doT = doT; p.kT = kT; p.L = L; p.D = D; p.dq = dq; p.dk = dk; p.dv = dv;
+    head_transpose32_kernel<<<dim3((n + 31) / 32, H, B), 256, 0, st>>>(q, qT, B, n, H);
+    head_transpose32_kernel<<<dim3((n + 31) / 32, H, B), 256, 0, st>>>(dout, doT, B, n, H);
+    head_transpose32_kernel<<<dim3((m + 31) / 32, H, B), 256, 0, st>>>(k, kT, B, m, H);
+    attn_bwd_prep_kernel<<<dim3((n / 32 + 3) / 4, H, B), 256, 0, st>>>(p);
+    attn_bwd_dkv_kernel<<<dim3((m / 32 + 3) / 4, H, B), 256, 0, st>>>(p);
+    attn_bwd_dq_kernel<<<dim3((n / 32 + 3) / 4, H, B), 256, 0, st>>>(p);
+    return hipGetLastError();
+}

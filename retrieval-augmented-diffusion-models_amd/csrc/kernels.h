@@ -127,6 +127,10 @@ hipError_t launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* pb
 hipError_t launch_ema(float* shadow, const float* p, long long n, float one_minus_decay, hipStream_t st);
 hipError_t launch_silu(const float* x, const float* dy, bf16_t* ob, float* of, long long n, hipStream_t st);
 hipError_t launch_sumpool2(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t st);
+// fused attention backward, d_head = 32 (backward.hip): no score matrix in memory
+size_t attn_bwd_scratch_bytes(int B, int H, int n, int m);
+hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* o, const bf16_t* dout, int B, int n, int m, int H,
+                                bf16_t* dq, bf16_t* dk, bf16_t* dv, char* scratch, hipStream_t st);
 // attention backward helpers (backward.hip)
 hipError_t launch_heads(const bf16_t* x, bf16_t* out, int B, int n, int H, int D, int ldx, int mode, hipStream_t st);
 hipError_t launch_softmax_bwd(const bf16_t* P, const float* dP, bf16_t* dS, long long rows, int n, hipStream_t st);

@@ -1734,6 +1734,16 @@ int rdm_op_adamw(rdm_ctx* c, float* p, const float* g, float* m, float* v, void*
     RDM_CHECK_HIP(c, launch_adamw(p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay, step, c->stream));
     return 0;
 }
+int rdm_op_attention_bwd(rdm_ctx* c, const void* q, const void* k, const void* v, const void* o, const void* dout, int B, int n, int m, int heads,
+                         void* dq, void* dk, void* dv) {
+    RDM_ENTER(c);
+    if (!q || !k || !v || !o || !dout || !dq || !dk || !dv || B < 1 || heads < 1 || n < 32 || m < 32 || n % 32 || m % 32)
+        return c->fail(-1, "rdm_op_attention_bwd: bad argument (d_head = 32; n and m multiples of 32)");
+    RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, attn_bwd_scratch_bytes(B, heads, n, m)));
+    RDM_CHECK_HIP(c, launch_attention_bwd((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, B, n, m, heads,
+                                          (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, c->bwd_tmp, c->stream));
+    return 0;
+}
 int rdm_op_bmm(rdm_ctx* c, const void* a, const void* w, void* out_bf16, float* out_f32, int batch, int M, int N, int K, float alpha) {
     RDM_ENTER(c);
     if (!a || !w || (!out_bf16 && !out_f32) || batch < 1 || M < 1 || N < 2 || K < 64 || K % 64 || N % 2)

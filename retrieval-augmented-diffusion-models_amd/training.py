@@ -27,6 +27,9 @@ def _pad_rows(t, mult=64):
     return out
 
 
+_UNFUSED_ATTENTION_BWD = False       # tests flip this to reach the materialised-score path
+
+
 def _pad_keys(t, mult=64):
     """[B, m, C] -> [B, ceil(m / mult) * mult, C] with zero rows."""
     m = t.shape[1]
@@ -129,7 +132,8 @@ def attention_forward(ctx, q, k, v, heads):
     s = ctx.op_bmm(qp, kp, alpha=scale, out_f32=True)                                   # [BH, n, mp] fp32
     p = ctx.op_softmax(s, n_valid=m)
     o = ctx.op_bmm(p, vt)                                                               # [BH, n, 64]
-    return ctx.op_heads(o, heads, d, 2), {"p": p, "kpad": k, "vpad": v, "m": m}
+    out = ctx.op_heads(o, heads, d, 2)
+    return out, {"p": p, "kpad": k, "vpad": v, "m": m, "o": out}
 
 
 def attention_backward(ctx, q, k, v, heads, saved, dout):
@@ -137,6 +141,9 @@ def attention_backward(ctx, q, k, v, heads, saved, dout):
     B, n, C = q.shape
     d = C // heads
     scale = d ** -0.5
+    if d == 32 and n % 32 == 0 and k.shape[1] % 32 == 0 and "o" in saved and not _UNFUSED_ATTENTION_BWD:
+        dq, dk, dv = ctx.op_attention_bwd(q.contiguous(), k.contiguous(), v.contiguous(), saved["o"], dout.contiguous(), heads)     # fused: no score matrix
+        return {"q": dq, "k": dk, "v": dv}
     p, k, v, m = saved["p"], saved["kpad"], saved["vpad"], saved["m"]
     dop, dot_ = ctx.op_heads(dout, heads, d, 0), ctx.op_heads(dout, heads, d, 1)        # [BH, n, 64], [BH, 64, n]
     vp = ctx.op_heads(v, heads, d, 0)                                                   # [BH, m, 64]
