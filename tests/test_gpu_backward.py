@@ -395,13 +395,15 @@ def test_fused_and_unfused_attention_backward_agree(ctx):
     B, n, heads = 2, 1024, 12
     C = heads * 32
     q, k, v, dout = (bf16_round(_rand((B, n, C), 500 + i)).to(dev, torch.bfloat16) for i in range(4))
-    out, saved = training.attention_forward(ctx, q, k, v, heads)
+    out, saved = training.attention_forward(ctx, q, k, v, heads)          # flash forward
     fused = training.attention_backward(ctx, q, k, v, heads, saved, dout)
     training._UNFUSED_ATTENTION_BWD = True
     try:
-        plain = training.attention_backward(ctx, q, k, v, heads, saved, dout)
+        out_p, saved_p = training.attention_forward(ctx, q, k, v, heads)  # materialised scores
+        plain = training.attention_backward(ctx, q, k, v, heads, saved_p, dout)
     finally:
         training._UNFUSED_ATTENTION_BWD = False
+    assert "p" not in saved and "p" in saved_p and rel_l2(out.float(), out_p.float()) <= 6e-3
     for key in ("q", "k", "v"):
         e = rel_l2(fused[key].float(), plain[key].float())
         print(f"fused vs unfused d{key}: {e:.2e}")
