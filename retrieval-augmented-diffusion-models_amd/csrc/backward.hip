@@ -134,7 +134,17 @@ size_t conv_wgrad_scratch_bytes(int B, int H, int W, int C, int N, int* pWP, int
     const int margin = WP + 8;
     const long long P = (long long)B * (H + 2) * WP;
     // K' = P rounded up so that Z chunks of a multiple of 64 cover it
-    int Z = (int)((P + 8191) / 8192); if (Z < 1) Z = 1; if (Z > 64) Z = 64;
+    // K-chunks: enough of them that one tap's batched GEMM (ceil(N / 128) x ceil(C / 192) tiles per chunk) covers the chip twice, at
+    // least 1 k positions per chunk, at most 256 chunks and 256 MB of fp32 partial planes
+    const long long tiles = (long long)((N + 127) / 128) * ((C + 191) / 192);
+    long long Zl = (P + 8191) / 8192;
+    if (Zl < (512 + tiles - 1) / tiles) Zl = (512 + tiles - 1) / tiles;
+    if (Zl > P / 1024) Zl = P / 1024;
+    const long long plane = (long long)N * 9 * C * 4;
+    if (Zl > (256LL << 20) / plane) Zl = (256LL << 20) / plane;
+    if (Zl > 256) Zl = 256;
+    if (Zl < 1) Zl = 1;
+    int Z = (int)Zl;
     long long Kc = (P + Z - 1) / Z; Kc = (Kc + 63) & ~63LL;
     const long long K = Kc * Z;
     const long long PR = margin + K + margin;
@@ -173,7 +183,7 @@ hipError_t launch_conv_wgrad(const bf16_t* x, const bf16_t* dy, float* dw, int B
 // 256 CUs walking K' = M serially (0.2 ms each, a third of the training step).  Like the conv wgrad: row-major transposes dy^T [N][Mp],
 // a^T [K][Mp] (zero padded), Z K-chunks as a batched launch of fp32 planes, fixed-order sum.
 static void linear_wgrad_geom(long long M, int* pZ, long long* pKc) {
-    int Z = (int)((M + 2047) / 2048); if (Z < 1) Z = 1; if (Z > 64) Z = 64;
+    int Z = (int)((M + 1023) / 1024); if (Z < 1) Z = 1; if (Z > 128) Z = 128;
     long long Kc = (M + Z - 1) / Z; Kc = (Kc + 63) & ~63LL;
     *pZ = Z; *pKc = Kc;
 }
