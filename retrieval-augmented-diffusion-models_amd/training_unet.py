@@ -18,6 +18,52 @@ from . import parallel
 from . import training as T
 
 
+class TrainSpec:
+    """Layer plan of one UNetModel, derived from an `rdm_unet_cfg` (`_lib.make_unet_cfg`).  `blocks` lists the top-level modules in
+    state-dict order, each (name, [layers]) with layers ("conv_in", cin, cout) | ("res", cin, cout) | ("st", channels, heads) |
+    ("down", channels) | ("up", channels): the order the reference's constructor appends them in (openaimodel.py:144-305: one
+    ResBlock (+ SpatialTransformer where the downsampling factor is an attention resolution) per input block, a Downsample between
+    levels, res-st-res in the middle, num_res_blocks + 1 output blocks per level consuming the skip stack in reverse, the last of a
+    level carrying the Upsample)."""
+
+    def __init__(self, cfg):
+        self.in_channels, self.out_channels = int(cfg.in_channels), int(cfg.out_channels)
+        self.model_channels, self.context_dim = int(cfg.model_channels), int(cfg.context_dim)
+        mults = [int(cfg.channel_mult[i]) for i in range(cfg.n_channel_mult)]
+        attn = {int(cfg.attention_resolutions[i]) for i in range(cfg.n_attention_resolutions)}
+        nres, hc, mc = int(cfg.num_res_blocks), int(cfg.num_head_channels), self.model_channels
+
+        def level_layers(cin, cout, factor):
+            layers = [("res", cin, cout)]
+            if factor in attn:
+                layers.append(("st", cout, cout // hc))
+            return layers
+
+        blocks = [("input_blocks.0", [("conv_in", self.in_channels, mc)])]
+        skips, width, factor = [mc], mc, 1
+        for lvl, m in enumerate(mults):
+            for _ in range(nres):
+                blocks.append((f"input_blocks.{len(blocks)}", level_layers(width, m * mc, factor)))
+                width = m * mc
+                skips.append(width)
+            if lvl + 1 < len(mults):
+                blocks.append((f"input_blocks.{len(blocks)}", [("down", width)]))
+                skips.append(width)
+                factor *= 2
+        blocks.append(("middle_block", [("res", width, width), ("st", width, width // hc), ("res", width, width)]))
+        n_out = 0
+        for lvl in range(len(mults) - 1, -1, -1):
+            for i in range(nres + 1):
+                layers = level_layers(width + skips.pop(), mults[lvl] * mc, factor)
+                width = mults[lvl] * mc
+                if lvl > 0 and i == nres:
+                    layers.append(("up", width))
+                    factor //= 2
+                blocks.append((f"output_blocks.{n_out}", layers))
+                n_out += 1
+        self.blocks = blocks
+
+
 def timestep_embedding(t, dim, max_period=10000.0):
     """ldm `timestep_embedding` (openaimodel util): [cos | sin] of t * exp(-log(max_period) * i / half)."""
     half = dim // 2

@@ -578,3 +578,17 @@ def test_gradient_averaging_world2_gloo():
         assert o0[k].shape == g0[k].shape
         assert np.array_equal(o0[k], o1[k])
         assert np.allclose(o0[k], (g0[k] + g1[k]) / 2, rtol=0, atol=1e-7)
+
+
+def test_train_spec_matches_oracle_block_table():
+    """training_unet.TrainSpec (built from the C config) lists the same modules, in the same order, as the oracle's restatement of the
+    reference constructor (openaimodel.py:144-305) for the shipped and the reduced topology."""
+    from oracle import unet as ounet
+    from rdm_amd import _lib, synthetic, training_unet as TU
+    for kw, spec in (({}, ounet.shipped_spec()),
+                     (dict(model_channels=64, num_res_blocks=1, attention_resolutions=(2, 4), channel_mult=(1, 2, 3)), ounet.tiny_spec())):
+        cfg = _lib.make_unet_cfg(**kw)
+        t = TU.TrainSpec(cfg)
+        assert t.blocks == spec.blocks
+        assert (t.in_channels, t.out_channels, t.model_channels) == (spec.in_channels, spec.out_channels, spec.model_channels)
+        assert synthetic.unet_param_shapes(cfg) == ounet.param_shapes(spec)

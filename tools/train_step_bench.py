@@ -7,12 +7,13 @@ sys.path.insert(0, ROOT)
 import torch
 import rdm_amd
 from rdm_amd import _lib, training_unet as TU
-from oracle import unet as ounet            # state-dict shapes + synthetic weights only (test infrastructure; no arithmetic from it)
+from rdm_amd import synthetic
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ctx = _lib.Context(0); d = ctx.device
-spec = ounet.shipped_spec()
-sd = ounet.synth_state_dict(ounet.param_shapes(spec), seed=3)
+cfg = _lib.make_unet_cfg()                  # the shipped imagenet topology
+spec = TU.TrainSpec(cfg)
+sd = synthetic.unet_state_dict(cfg, seed=3)
 P = TU.params_from_state_dict(sd, d)
 nparam = sum(v.numel() for v in P.values())
 state = {"m": {k: torch.zeros_like(v) for k, v in P.items()}, "v": {k: torch.zeros_like(v) for k, v in P.items()}}
