@@ -296,6 +296,9 @@ int rdm_op_layernorm(rdm_ctx* ctx, const void* x, int in_is_f32, const float* ga
                      float eps, void* out_bf16);
 int rdm_op_self_attention(rdm_ctx* ctx, const void* qk_bf16, const void* vt_bf16, int B, int n, int heads,
                           void* out_bf16);
+/* the same attention from ONE fused projection qkv [B, n, 3C] = [q | k | v] (the UNet sampling path's form: V stays token-major and is
+ * transposed inside the kernel's LDS reads); n % 64 == 0 */
+int rdm_op_self_attention_qkv(rdm_ctx* ctx, const void* qkv_bf16, int B, int n, int heads, void* out_bf16);
 int rdm_op_small_attention(rdm_ctx* ctx, const void* q_bf16, int ldq, const void* k_bf16, const void* v_bf16, int ldkv,
                            int B, int nq, int nkv, int heads, int D, int causal, float scale, void* out_bf16, int ldo);
 

@@ -133,6 +133,7 @@ SIGNATURES = {
     "rdm_op_groupnorm": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_float, C.c_int, _P]),
     "rdm_op_layernorm": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "rdm_op_self_attention": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "rdm_op_self_attention_qkv": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_op_small_attention": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_float, _P, C.c_int]),
 }
@@ -746,6 +747,13 @@ class Context:
         B, n, C2 = qk.shape
         out = torch.empty((B, n, C2 // 2), device=self.device, dtype=torch.bfloat16)
         self._check(lib.rdm_op_self_attention(self._h, _ptr(qk), _ptr(vt), B, n, heads, _ptr(out)))
+        return out
+
+    def op_self_attention_qkv(self, qkv, heads):
+        """qkv bf16 [B, n, 3C] = [q | k | v] (one fused projection), n % 64 == 0 -> [B, n, C]."""
+        B, n, C3 = qkv.shape
+        out = torch.empty((B, n, C3 // 3), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_self_attention_qkv(self._h, _ptr(qkv), B, n, heads, _ptr(out)))
         return out
 
     def op_small_attention(self, q, k, v, heads, D, causal, scale):

@@ -98,8 +98,13 @@ __global__ __launch_bounds__(256) void flash_d32_kernel(FlashParams p) {
 // counted vmcnt waits (the K/V tensors of a layer do not fit L2, so a chunk pays a full HBM/MALL round trip: one chunk
 // of look-ahead left the kernel latency-bound).  The ring image is lane-linear, so the bank-conflict swizzle sits on
 // the source address and again on the ds_read_b128 fragment reads.
+// VROW: V arrives token-major (v / ldv: a column block of the fused q|k|v projection) and the slot's second half holds V [64 keys][32]
+// instead of V^T; the PV operand (8 consecutive keys of one channel per lane) is then gathered by the hardware transpose read
+// ds_read_b64_tr_b16: each 16-lane group reads a [4 keys][16 channels] block, lane i the 4 channels 4(i&3).. of key i>>2, and lane j
+// receives channel j of the 4 keys (probed in tools/ubench/tr_probe.hip).  No separate V^T GEMM per layer.
+template <bool VROW>
 __global__ __launch_bounds__(256, 2) void flash_d32_lds_kernel(FlashParams p) {
-    constexpr int DEPTH = 4, CH = 8192;                               // per slot: K [64][32] bf16 | V^T [32][64] bf16
+    constexpr int DEPTH = 4, CH = 8192;                               // per slot: K [64][32] bf16 | V^T [32][64] bf16 (VROW: V [64][32])
     __shared__ __attribute__((aligned(16))) char lds[DEPTH * CH];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -133,13 +138,17 @@ __global__ __launch_bounds__(256, 2) void flash_d32_lds_kernel(FlashParams p) {
     const int kr = tid >> 2, vr = tid >> 3;
     const int ksp = (tid & 3) ^ ((kr >> 2) & 3), vsp = (tid & 7) ^ ((vr >> 1) & 7);
     const bf16_t* kg = p.k + (tok0 + kr) * p.ldk + h * 32 + ksp * 8;
-    const bf16_t* vg = p.vt + ((long long)b * p.C + h * 32 + vr) * p.n + vsp * 8;
+    const bf16_t* vg = VROW ? p.v + (tok0 + kr) * p.ldv + h * 32 + (tid & 3) * 8          // V rows: same shape as K's, unswizzled
+                            : p.vt + ((long long)b * p.C + h * 32 + vr) * p.n + vsp * 8;
     const int nchunk = p.n >> 6;
     auto request = [&](int c) {
         char* slot = lds + (c & (DEPTH - 1)) * CH;
         glds16(kg + (long long)c * 64 * p.ldk, slot + wave * 1024);
-        glds16(vg + c * 64, slot + 4096 + wave * 1024);
+        if (VROW) glds16(vg + (long long)c * 64 * p.ldv, slot + 4096 + wave * 1024);
+        else glds16(vg + c * 64, slot + 4096 + wave * 1024);
     };
+    // transpose-read address of this lane inside a slot's V image: key 8 hf + (i >> 2), channels 16 g + 4 (i & 3)  (i = lane & 15, g = (lane >> 4) & 1)
+    const uint32_t vtr = 4096 + (8 * hf + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     const int pi = (l31 & ~0xc) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);   // key permutation inside a 32-key sub-tile
 
     f32x16 o;
@@ -163,9 +172,21 @@ __global__ __launch_bounds__(256, 2) void flash_d32_lds_kernel(FlashParams p) {
                 const int krow = sub * 32 + pi;
                 const bf16x8 k0 = *(const bf16x8*)(L + krow * 64 + (((0 + hf) ^ ((krow >> 2) & 3)) << 4));
                 const bf16x8 k1 = *(const bf16x8*)(L + krow * 64 + (((2 + hf) ^ ((krow >> 2) & 3)) << 4));
-                const int vch = sub * 4 + hf;                  // 16-byte piece index of keys sub*32 + j*16 + hf*8
-                const bf16x8 v0 = *(const bf16x8*)(L + 4096 + l31 * 128 + (((vch) ^ ((l31 >> 1) & 7)) << 4));
-                const bf16x8 v1 = *(const bf16x8*)(L + 4096 + l31 * 128 + (((vch + 2) ^ ((l31 >> 1) & 7)) << 4));
+                bf16x8 v0, v1;
+                if (VROW) {       // keys sub*32 + 8 hf + 0..7 (v0) and + 16 (v1) of channel l31: two 4-key transpose reads each
+                    typedef __attribute__((ext_vector_type(4))) short s16x4;
+                    const LDS_AS char* vb = (const LDS_AS char*)(L + vtr + sub * 2048);
+                    union { bf16x8 v; s16x4 h[2]; } a0, a1;
+                    a0.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(vb));
+                    a0.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(vb + 256));
+                    a1.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(vb + 1024));
+                    a1.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(vb + 1280));
+                    v0 = a0.v; v1 = a1.v;
+                } else {
+                    const int vch = sub * 4 + hf;                  // 16-byte piece index of keys sub*32 + j*16 + hf*8
+                    v0 = *(const bf16x8*)(L + 4096 + l31 * 128 + (((vch) ^ ((l31 >> 1) & 7)) << 4));
+                    v1 = *(const bf16x8*)(L + 4096 + l31 * 128 + (((vch + 2) ^ ((l31 >> 1) & 7)) << 4));
+                }
                 f32x16 s;
 #pragma unroll
                 for (int r = 0; r < 16; r++) s[r] = 0.f;
@@ -216,11 +237,13 @@ __global__ __launch_bounds__(256, 2) void flash_d32_lds_kernel(FlashParams p) {
 
 hipError_t launch_flash_d32(const FlashParams& p, int heads, int batch, hipStream_t st) {
     if (p.n % 32 != 0 || p.C != heads * 32) return hipErrorInvalidValue;
+    if (!p.vt && (!p.v || p.n % 64 != 0)) return hipErrorInvalidValue;          // token-major V: LDS-shared kernel only
     if (p.n % 64 == 0) {
         dim3 grid((p.n / 32 + 3) / 4, heads, batch);
         static const int old = getenv("RDM_FLASH_OLD") ? atoi(getenv("RDM_FLASH_OLD")) : 0;
         FlashParams q = p; q.xcd_remap = old ? 0 : 1;          // RDM_FLASH_OLD=1: plain blockIdx mapping (A/B)
-        flash_d32_lds_kernel<<<grid, 256, 0, st>>>(q);
+        if (q.v && !q.vt) flash_d32_lds_kernel<true><<<grid, 256, 0, st>>>(q);
+        else flash_d32_lds_kernel<false><<<grid, 256, 0, st>>>(q);
         return hipGetLastError();
     }
     int nw = p.n / 32; if (nw > 4) nw = 4;

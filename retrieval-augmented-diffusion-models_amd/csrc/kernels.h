@@ -16,11 +16,12 @@ struct GnParams {
 struct FlashParams {
     const bf16_t* q; int ldq;        // q[(b*n + i)*ldq + h*32 + d]
     const bf16_t* k; int ldk;        // k[(b*n + j)*ldk + h*32 + d]
-    const bf16_t* vt;                // vt[((b*C) + h*32 + d)*n + j]
+    const bf16_t* vt;                // vt[((b*C) + h*32 + d)*n + j]   (V transposed per sample), or null with:
+    const bf16_t* v; int ldv;        // v[(b*n + j)*ldv + h*32 + d]     (token-major V, n % 64 == 0 only: read through ds_read_b64_tr_b16)
     bf16_t* out; int ldo;            // out[(b*n + i)*ldo + h*32 + d]
     int n, C;                        // tokens, channels (= heads*32)
-    float scale_log2e;
-    int xcd_remap;                   // set by the launcher: XCD-aware (sample, head) grouping of the query blocks               // d^-0.5 * log2(e)
+    float scale_log2e;               // d^-0.5 * log2(e)
+    int xcd_remap;                   // set by the launcher: XCD-aware (sample, head) grouping of the query blocks
 };
 
 struct SmallAttnParams {

@@ -175,6 +175,7 @@ static void build_unet(UNet& u, const rdm_unet_cfg& c, Manifest& mf) {
         s.ln1g = vec(tb + ".norm1.weight", {S}); s.ln1b = vec(tb + ".norm1.bias", {S});
         s.wqk = mat("bf16", tb + ".attn1.to_q.weight," + tb + ".attn1.to_k.weight", {S, S}, {S});
         s.wv = mat("bf16", tb + ".attn1.to_v.weight", {S}, {S});
+        if (s.wv != s.wqk + (size_t)2 * ch * ch * 2) { fprintf(stderr, "build_unet: to_v must directly follow to_q | to_k in the blob (fused q|k|v projection)\n"); abort(); }
         s.wo1 = mat("bf16", tb + ".attn1.to_out.0.weight", {S}, {S}); s.bo1 = vec(tb + ".attn1.to_out.0.bias", {S});
         s.ln2g = vec(tb + ".norm2.weight", {S}); s.ln2b = vec(tb + ".norm2.bias", {S});
         s.wq2 = mat("bf16", tb + ".attn2.to_q.weight", {S}, {S});
@@ -698,10 +699,24 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         // --- attn1 (self)
         bf16_t* l1 = o.abf((size_t)M * C);
         o.layernorm(t0, 0, s.ln1g, s.ln1b, l1, 0, M, C, s.lc);
-        bf16_t* qk = o.abf((size_t)M * 2 * C);
-        o.linear(l1, nullptr, C, 0, s.wqk, 0, false, M, 2 * C, ACT_NONE, nullptr, qk);
+        // n % 64 == 0: q | k | v in ONE projection (to_v's rows follow to_q | to_k in the blob, asserted in build_unet); the flash kernel
+        // reads the token-major V block through transpose reads, so no per-layer V^T GEMM (6.8 % of the forward as a batched
+        // weights-as-A GEMM at 380 TFLOP/s)
+        static const int no_vrow = getenv("RDM_NO_VROW") ? atoi(getenv("RDM_NO_VROW")) : 0;
+        const bool vrow = (n % 64 == 0) && !no_vrow;
+        const int QW = vrow ? 3 * C : 2 * C;
+        bf16_t* qk = o.abf((size_t)M * QW);
+        o.linear(l1, nullptr, C, 0, s.wqk, 0, false, M, QW, ACT_NONE, nullptr, qk);
         bf16_t* ao = o.abf((size_t)M * C);
-        if (n % 32 == 0) {
+        if (vrow) {
+            if (!o.plan) {
+                FlashParams f{}; f.q = qk; f.ldq = QW; f.k = qk + C; f.ldk = QW; f.v = qk + 2 * C; f.ldv = QW; f.out = ao; f.ldo = C;
+                f.n = n; f.C = C; f.scale_log2e = (1.0f / sqrtf(32.f)) * 1.4426950408889634f;
+                o.prof_begin(RDM_PROF_ATTENTION, 4.0 * B * s.heads * (double)n * n * 32);
+                o.check(launch_flash_d32(f, s.heads, B, o.c->stream), "flash attention");
+                o.prof_end();
+            }
+        } else if (n % 32 == 0) {
             bf16_t* vt = o.abf((size_t)M * C);      // V^T per sample: [B][C][n] via swapped-operand GEMM
             if (!o.plan) {
                 IgemmParams p = o.base(C, n, C);
@@ -1808,6 +1823,16 @@ int rdm_op_self_attention(rdm_ctx* c, const void* qk, const void* vt, int B, int
     if (!c) return -1;
     const int C = heads * 32;
     FlashParams f{}; f.q = (const bf16_t*)qk; f.ldq = 2 * C; f.k = (const bf16_t*)qk + C; f.ldk = 2 * C; f.vt = (const bf16_t*)vt;
+    f.out = (bf16_t*)out; f.ldo = C; f.n = n; f.C = C; f.scale_log2e = (1.0f / sqrtf(32.f)) * 1.4426950408889634f;
+    RDM_CHECK_HIP(c, launch_flash_d32(f, heads, B, c->stream));
+    return 0;
+}
+int rdm_op_self_attention_qkv(rdm_ctx* c, const void* qkv, int B, int n, int heads, void* out) {
+    RDM_ENTER(c);
+    if (!c) return -1;
+    const int C = heads * 32;
+    if (n % 64 != 0) return c->fail(-3, "rdm_op_self_attention_qkv: n = %d must be a multiple of 64 (token-major V is read by the LDS-shared kernel only)", n);
+    FlashParams f{}; f.q = (const bf16_t*)qkv; f.ldq = 3 * C; f.k = f.q + C; f.ldk = 3 * C; f.v = f.q + 2 * C; f.ldv = 3 * C;
     f.out = (bf16_t*)out; f.ldo = C; f.n = n; f.C = C; f.scale_log2e = (1.0f / sqrtf(32.f)) * 1.4426950408889634f;
     RDM_CHECK_HIP(c, launch_flash_d32(f, heads, B, c->stream));
     return 0;

@@ -127,9 +127,9 @@ def attention_forward(ctx, q, k, v, heads):
     scale = d ** -0.5
     m = k.shape[1]
     if d == 32 and m == n and n % 64 == 0 and not _UNFUSED_ATTENTION_BWD:
-        # self-attention at the UNet's head width: the sampling path's flash kernel (q | k side by side, V transposed per sample);
-        # the fused backward needs only q, k, v, the output and its gradient
-        out = ctx.op_self_attention(torch.cat([q, k], dim=-1), ctx.op_transpose_batched(v.contiguous()), heads)
+        # self-attention at the UNet's head width: the sampling path's flash kernel on [q | k | v] (V token-major, transposed inside
+        # the kernel's LDS reads); the fused backward needs only q, k, v, the output and its gradient
+        out = ctx.op_self_attention_qkv(torch.cat([q, k, v], dim=-1), heads)
         return out, {"o": out}
     k, v = _pad_keys(k), _pad_keys(v)                                                   # key count -> multiple of 64 (a GEMM K unit); padding gets probability 0
     qp, kp = ctx.op_heads(q, heads, d, 0), ctx.op_heads(k, heads, d, 0)                # [BH, n|mp, 64]

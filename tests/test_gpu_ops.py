@@ -233,6 +233,10 @@ def test_flash_self_attention(ctx, B, n, heads):
     vt = v.permute(0, 2, 1).contiguous()                     # [B, C, n]
     out = ctx.op_self_attention(qk.to(d, torch.bfloat16), vt.to(d, torch.bfloat16), heads)
     _close(out, ref, tol=2 ** -6, what="flash attention")    # P is rounded to bf16 before the PV MFMA
+    if n % 64 == 0:      # the fused-projection form: token-major V through the kernel's transpose reads; same arithmetic, same bits
+        qkv = torch.cat([q, k, v], -1).contiguous().to(d, torch.bfloat16)
+        out2 = ctx.op_self_attention_qkv(qkv, heads)
+        assert torch.equal(out2, out), "token-major-V flash kernel differs from the V^T one"
 
 
 @pytest.mark.parametrize("B,nq,nkv,heads,D,causal", [(2, 64, 4, 4, 32, 0), (2, 77, 77, 2, 64, 1), (1, 50, 50, 3, 64, 0),
