@@ -299,6 +299,13 @@ int rdm_op_self_attention(rdm_ctx* ctx, const void* qk_bf16, const void* vt_bf16
 /* the same attention from ONE fused projection qkv [B, n, 3C] = [q | k | v] (the UNet sampling path's form: V stays token-major and is
  * transposed inside the kernel's LDS reads); n % 64 == 0 */
 int rdm_op_self_attention_qkv(rdm_ctx* ctx, const void* qkv_bf16, int B, int n, int heads, void* out_bf16);
+/* CrossAttention over k retrieved neighbours (rdm/modules/attention.py:52-72) in the re-associated per-sample form the UNet path uses:
+ *   out[b] = softmax_groups(x[b] G[b]^T) U[b]^T + bias + res[b]
+ * x / res / out bf16 [B, n, C], G bf16 [B, NP, C] (row h*k + j = key j restricted to head h, times W_q / sqrt(d)), U bf16 [B, C, NP]
+ * (column h*k + j = W_o applied to value j restricted to head h); softmax over groups of `group` (= k: 1, 2, 4) adjacent columns of
+ * the first ncols = heads * k columns.  n % 32 == 0, C % 64 == 0, NP % 32 == 0, ncols <= min(NP, 128).  bias / res may be null. */
+int rdm_op_xattn_fused(rdm_ctx* ctx, const void* x_bf16, const void* G_bf16, const void* U_bf16, const float* bias, const void* res_bf16,
+                       int B, int n, int C, int NP, int ncols, int group, void* out_bf16);
 int rdm_op_small_attention(rdm_ctx* ctx, const void* q_bf16, int ldq, const void* k_bf16, const void* v_bf16, int ldkv,
                            int B, int nq, int nkv, int heads, int D, int causal, float scale, void* out_bf16, int ldo);
 

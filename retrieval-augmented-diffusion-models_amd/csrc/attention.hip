@@ -252,6 +252,211 @@ hipError_t launch_flash_d32(const FlashParams& p, int heads, int batch, hipStrea
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------ fused skinny cross-attention
+// scores GEMM (K = C, N <= 128) + group softmax + output GEMM (K <= 128, N = C) + bias + residual in one launch: the probabilities
+// never leave registers.  As two batched GEMMs both halves were latency-bound (2 - 15 k-steps per tile behind a cold pipeline:
+// 78 / 54 / 56 us per layer at the 32x32 / 16x16 / 8x8 levels for 184 / 43 / 17 MB of traffic).
+// A block = 32 rows of one sample, 4 waves.  Phase 1 splits K: wave w forms the partial scores of channels [w C/4, (w+1) C/4); the
+// x rows are read straight from global memory in MFMA layout (16 bytes per lane and 16-k step), G comes FRAGMENT-ORDERED (xattn_pack_g:
+// one step's operand of a 32-row block = 1 KiB contiguous; row-major it was 64 cache lines per load instruction and the CU's address
+// path, not latency, set the time); the four partial tiles meet in LDS and every wave sums them (swapped product: lane = x row,
+// registers = score columns, so a softmax group is 1 / 2 / 4 adjacent registers of one lane).  Phase 2 splits N: wave w owns the
+// 32-channel blocks w, w+4, ..; the probabilities (bf16, the rounding the two-GEMM form had) are the B operand as they sit, U comes
+// fragment-ordered with the matching column order and with its rows permuted so that a lane ends up with 16 CONSECUTIVE channels of
+// its row (two 16-byte residual loads / stores instead of four 8-byte ones); the next block's operands are requested before the
+// current block's MFMAs.
+__device__ __forceinline__ int xattn_chan(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }   // MFMA row i -> channel inside a 32-block
+// Gp[b][ks][jb][lane][8] = G[b][32 jb + (lane & 31)][16 ks + 8 (lane >> 5) + e]
+__global__ void xattn_pack_g_kernel(const bf16_t* G, bf16_t* Gp, int B, int NP, int C) {
+    const long long total = (long long)B * NP * C / 8;
+    const int nj = NP / 32, nk = C / 16;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63); long long r = i >> 6;
+        const int jb = (int)(r % nj); r /= nj;
+        const int ks = (int)(r % nk); const int b = (int)(r / nk);
+        *(uint4*)(Gp + i * 8) = *(const uint4*)(G + ((long long)b * NP + 32 * jb + (lane & 31)) * C + 16 * ks + 8 * (lane >> 5));
+    }
+}
+// Up[b][cb][st][lane][8] = U[b][32 cb + chan(lane & 31)][16 st + 4 (lane >> 5) + {0..3, 8..11}]
+__global__ void xattn_pack_u_kernel(const bf16_t* U, bf16_t* Up, int B, int NP, int C) {
+    const long long total = (long long)B * NP * C / 8;
+    const int ns = NP / 16, nc = C / 32;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63); long long r = i >> 6;
+        const int st = (int)(r % ns); r /= ns;
+        const int cb = (int)(r % nc); const int b = (int)(r / nc);
+        const bf16_t* src = U + ((long long)b * C + 32 * cb + xattn_chan(lane & 31)) * NP + 16 * st + 4 * (lane >> 5);
+        uint4 v; const uint2 lo = *(const uint2*)src, hi = *(const uint2*)(src + 8);
+        v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
+        *(uint4*)(Up + i * 8) = v;
+    }
+}
+hipError_t launch_xattn_pack(const bf16_t* G, const bf16_t* U, bf16_t* Gp, bf16_t* Up, int B, int NP, int C, hipStream_t st) {
+    if (NP % 32 != 0 || C % 32 != 0) return hipErrorInvalidValue;
+    const long long total = (long long)B * NP * C / 8;
+    int grid = (int)((total + 255) / 256); if (grid > 16384) grid = 16384; if (grid < 1) grid = 1;
+    xattn_pack_g_kernel<<<grid, 256, 0, st>>>(G, Gp, B, NP, C);
+    xattn_pack_u_kernel<<<grid, 256, 0, st>>>(U, Up, B, NP, C);
+    return hipGetLastError();
+}
+
+template <int NB>        // 32-column score blocks in use: ceil(ncols / 32)
+__global__ __launch_bounds__(256) void xattn_fused_kernel(XattnParams p) {
+    __shared__ __attribute__((aligned(16))) float part[4 * NB * 4 * 64 * 4];       // [wave][jb*4 + q][lane][4]
+    constexpr int SB = NB == 4 ? 5 : 3;                                             // k-steps requested together
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = p.C, NJ = p.NP >> 5;
+    const long long row0 = (long long)blockIdx.x * 32;
+    const int b = (int)(row0 / p.n);
+    // ---- phase 1: partial scores over this wave's K quarter
+    const int nsteps = C >> 6;                               // 16-k steps in a quarter
+    const bf16_t* xr = p.x + (row0 + l31) * C + w * (C >> 2) + 8 * hf;
+    const bf16_t* gr = p.G + (((long long)b * (C >> 4) + (long long)w * nsteps) * NJ * 64 + lane) * 8;      // + (s * NJ + jb) * 512
+    f32x16 acc[NB];
+#pragma unroll
+    for (int jb = 0; jb < NB; jb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[jb][r] = 0.f;
+    int s0 = 0;
+    for (; s0 + SB <= nsteps; s0 += SB) {
+        bf16x8 xb[SB], gb[SB][NB];
+#pragma unroll
+        for (int u = 0; u < SB; u++) {
+            xb[u] = *(const bf16x8*)(xr + (s0 + u) * 16);
+#pragma unroll
+            for (int jb = 0; jb < NB; jb++) gb[u][jb] = *(const bf16x8*)(gr + ((long long)(s0 + u) * NJ + jb) * 512);
+        }
+#pragma unroll
+        for (int u = 0; u < SB; u++)
+#pragma unroll
+            for (int jb = 0; jb < NB; jb++) acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gb[u][jb], xb[u], acc[jb], 0, 0, 0);
+    }
+    for (; s0 < nsteps; s0++) {
+        const bf16x8 xb = *(const bf16x8*)(xr + s0 * 16);
+#pragma unroll
+        for (int jb = 0; jb < NB; jb++) {
+            const bf16x8 gb = *(const bf16x8*)(gr + ((long long)s0 * NJ + jb) * 512);
+            acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gb, xb, acc[jb], 0, 0, 0);
+        }
+    }
+    // first output block's operands: requested before the exchange so that their latency hides behind it
+    const int ncb = C >> 5;
+    const bf16_t* ub = p.U + ((long long)b * ncb * (2 * NJ) * 64 + lane) * 8;        // + (cb * 2 NJ + st) * 512
+    struct Blk { bf16x8 uf[2 * NB]; uint4 rv[2]; f32x4 bv[4]; };
+    auto request = [&](Blk& k, int cb) {
+#pragma unroll
+        for (int st = 0; st < 2 * NB; st++) k.uf[st] = *(const bf16x8*)(ub + ((long long)cb * (2 * NJ) + st) * 512);
+        const long long o = (row0 + l31) * C + cb * 32 + 16 * hf;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) k.rv[h2] = p.res ? *(const uint4*)(p.res + o + 8 * h2) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int q = 0; q < 4; q++) k.bv[q] = p.bias ? *(const f32x4*)(p.bias + cb * 32 + 16 * hf + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    Blk k0, k1;
+    if (w < ncb) request(k0, w);
+#pragma unroll
+    for (int jb = 0; jb < NB; jb++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            f32x4 v = {acc[jb][4 * q], acc[jb][4 * q + 1], acc[jb][4 * q + 2], acc[jb][4 * q + 3]};
+            *(f32x4*)(part + (((w * NB + jb) * 4 + q) * 64 + lane) * 4) = v;
+        }
+    __syncthreads();
+    // ---- sum of the four partials, group softmax, probabilities as the B operand of phase 2
+    bf16x8 pf[2 * NB];
+#pragma unroll
+    for (int jb = 0; jb < NB; jb++) {
+        float s[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            f32x4 t = *(const f32x4*)(part + (((0 * NB + jb) * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+            for (int ww = 1; ww < 4; ww++) t += *(const f32x4*)(part + (((ww * NB + jb) * 4 + q) * 64 + lane) * 4);
+            s[4 * q] = t[0]; s[4 * q + 1] = t[1]; s[4 * q + 2] = t[2]; s[4 * q + 3] = t[3];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float* g = s + 4 * q;
+            if (p.group == 4) {
+                const float m = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3]));
+                float e[4], sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { e[i] = __expf(g[i] - m); sum += e[i]; }
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int i = 0; i < 4; i++) g[i] = e[i] * inv;
+            } else if (p.group == 2) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++) {
+                    const float m = fmaxf(g[2 * h2], g[2 * h2 + 1]);
+                    const float e0 = __expf(g[2 * h2] - m), e1 = __expf(g[2 * h2 + 1] - m);
+                    const float inv = 1.0f / (e0 + e1);
+                    g[2 * h2] = e0 * inv; g[2 * h2 + 1] = e1 * inv;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) g[i] = 1.0f;
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+            for (int i = 0; i < 4; i++) pk.u[i] = cvt_pk_bf16(s[8 * half + 2 * i], s[8 * half + 2 * i + 1]);
+            pf[2 * jb + half] = pk.v;
+        }
+    }
+    // ---- phase 2: this wave's 32-channel output blocks, operands one block ahead
+    auto finish = [&](const Blk& k, int cb) {
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2 * NB; st++) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k.uf[st], pf[st], o, 0, 0, 0);
+        const long long ob = (row0 + l31) * C + cb * 32 + 16 * hf;          // registers r = 0..15 <-> channels 16 hf + r (xattn_chan)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+            const uint32_t rr[4] = {k.rv[h2].x, k.rv[h2].y, k.rv[h2].z, k.rv[h2].w};
+            uint32_t wv[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = 8 * h2 + 2 * i;
+                const float a0 = o[r] + k.bv[r >> 2][r & 3] + __uint_as_float(rr[i] << 16);
+                const float a1 = o[r + 1] + k.bv[(r + 1) >> 2][(r + 1) & 3] + __uint_as_float(rr[i] & 0xffff0000u);
+                wv[i] = cvt_pk_bf16(a0, a1);
+            }
+            *(uint4*)(p.out + ob + 8 * h2) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+        }
+    };
+    for (int cb = w; cb < ncb; cb += 8) {
+        if (cb + 4 < ncb) request(k1, cb + 4);
+        finish(k0, cb);
+        if (cb + 4 < ncb) {
+            if (cb + 8 < ncb) request(k0, cb + 8);
+            finish(k1, cb + 4);
+        }
+    }
+}
+
+bool xattn_fused_supported(const XattnParams& p) {
+    return p.n > 0 && p.n % 32 == 0 && p.rows % p.n == 0 && p.C % 64 == 0 && p.NP % 32 == 0 && p.ncols >= 1 && p.ncols <= p.NP && p.ncols <= 128 &&
+           (p.group == 1 || p.group == 2 || p.group == 4) && p.x && p.G && p.U && p.out;
+}
+// p.G / p.U: the fragment-ordered images written by launch_xattn_pack
+hipError_t launch_xattn_fused(const XattnParams& p, hipStream_t st) {
+    if (!xattn_fused_supported(p)) return hipErrorInvalidValue;
+    const int nb = (p.ncols + 31) / 32;
+    dim3 grid((unsigned)(p.rows / 32));
+    switch (nb) {
+        case 1: xattn_fused_kernel<1><<<grid, 256, 0, st>>>(p); break;
+        case 2: xattn_fused_kernel<2><<<grid, 256, 0, st>>>(p); break;
+        case 3: xattn_fused_kernel<3><<<grid, 256, 0, st>>>(p); break;
+        default: xattn_fused_kernel<4><<<grid, 256, 0, st>>>(p); break;
+    }
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------ small attention
 
 template <int D>

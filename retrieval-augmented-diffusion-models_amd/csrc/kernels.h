@@ -24,6 +24,18 @@ struct FlashParams {
     int xcd_remap;                   // set by the launcher: XCD-aware (sample, head) grouping of the query blocks
 };
 
+// cross-attention over k retrieved neighbours in the re-associated form (model.hip: unet_compute_xattn): per sample b
+//   out = softmax_groups(x G_b^T) U_b^T + bias + res      x [rows][C], G_b [NP][C], U_b [C][NP]  (all bf16, row-major)
+struct XattnParams {
+    const bf16_t* x; const bf16_t* G; const bf16_t* U;
+    const float* bias; const bf16_t* res; bf16_t* out;
+    int rows, n, C, NP;              // rows = samples * n (n rows per sample, n % 32 == 0); NP = row count of G (128)
+    int ncols, group;                // heads * k used score columns; softmax over groups of `group` (1, 2, 4) adjacent columns
+};
+bool xattn_fused_supported(const XattnParams& p);
+hipError_t launch_xattn_fused(const XattnParams& p, hipStream_t st);        // G / U: FRAGMENT-ORDERED images, written by:
+hipError_t launch_xattn_pack(const bf16_t* G, const bf16_t* U, bf16_t* Gp, bf16_t* Up, int B, int NP, int C, hipStream_t st);
+
 struct SmallAttnParams {
     const bf16_t* q; int ldq;        // q[(b*nq + i)*ldq + h*D + d]
     const bf16_t* k; int ldk; const bf16_t* v; int ldv;   // k[(b*nkv + j)*ldk + h*D + d]

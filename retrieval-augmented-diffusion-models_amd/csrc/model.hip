@@ -190,7 +190,7 @@ static void build_unet(UNet& u, const rdm_unet_cfg& c, Manifest& mf) {
         s.wfo = mat("fuse_w", tb + ".ff.net.2.weight," + pre + ".proj_out.weight", {S}, {F, S});
         s.bfo = mf.add("fuse_b" + seg_spec("R", {S}), tb + ".ff.net.2.bias," + pre + ".proj_out.weight," + pre + ".proj_out.bias", (size_t)ch * 4);
         s.kv_off = u.kv_total; u.kv_total += 2 * ch;
-        s.xa_unit = u.xa_total; u.xa_total += 2LL * XA_NP * ch;
+        s.xa_unit = u.xa_total; u.xa_total += 4LL * XA_NP * ch;      // G, U row-major + their fragment-ordered images (attention.hip: xattn_fused_kernel)
         if (!kv_srcs.empty()) kv_srcs += ",";
         kv_srcs += tb + ".attn2.to_k.weight," + tb + ".attn2.to_v.weight";
         add_seg(kv_rspec, kv_padded, lch, ch); add_seg(kv_rspec, kv_padded, lch, ch);
@@ -633,6 +633,7 @@ static void unet_compute_xattn(Ops& o, UNet& u, const bf16_t* kv, int B, int k, 
             p.out_bf16 = U; p.ldo = XA_NP;
             o.check(launch_igemm(p, false, B, o.c->stream), "xattn U");
         }
+        o.check(launch_xattn_pack(G, U, U + (size_t)B * C * XA_NP, U + (size_t)B * C * XA_NP + (size_t)B * XA_NP * C, B, XA_NP, C, o.c->stream), "xattn pack");
     }
 }
 
@@ -752,6 +753,14 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
             bf16_t* P = o.abf((size_t)M * XA_NP);
             if (!o.plan) {
                 const bf16_t* G = xa + (size_t)B * s.xa_unit; const bf16_t* U = G + (size_t)B * XA_NP * C;
+                static const int no_xfused = getenv("RDM_NO_XFUSED") ? atoi(getenv("RDM_NO_XFUSED")) : 0;
+                XattnParams xp{}; xp.x = l2; xp.G = U + (size_t)B * C * XA_NP; xp.U = xp.G + (size_t)B * XA_NP * C; xp.bias = o.w<float>(s.bo2); xp.res = t1; xp.out = t2;
+                xp.rows = Mx; xp.n = n; xp.C = C; xp.NP = XA_NP; xp.ncols = s.heads * k; xp.group = k;
+                if (!no_xfused && xattn_fused_supported(xp)) {       // both GEMMs, the softmax and the residual in one launch (attention.hip)
+                    o.prof_begin(RDM_PROF_LINEAR, 4.0 * Mx * XA_NP * (double)C);
+                    o.check(launch_xattn_fused(xp, o.c->stream), "fused cross attention");
+                    o.prof_end();
+                } else {
                 IgemmParams p = o.base(n, XA_NP, C);
                 p.A0 = l2; p.C0 = C; p.sA = (long long)n * C; p.W = G; p.sW = (long long)XA_NP * C; p.out_bf16 = P; p.sO = (long long)n * XA_NP;
                 p.act = ACT_SOFTMAXG; p.sm_group = k;
@@ -764,6 +773,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                 o.prof_begin(RDM_PROF_LINEAR, 2.0 * Mx * C * (double)XA_NP);
                 o.check(launch_igemm(q, false, Bx, o.c->stream), "xattn out");
                 o.prof_end();
+                }
             }
         } else {
             bf16_t* q2 = o.abf((size_t)M * C);
@@ -1835,6 +1845,21 @@ int rdm_op_self_attention_qkv(rdm_ctx* c, const void* qkv, int B, int n, int hea
     FlashParams f{}; f.q = (const bf16_t*)qkv; f.ldq = 3 * C; f.k = f.q + C; f.ldk = 3 * C; f.v = f.q + 2 * C; f.ldv = 3 * C;
     f.out = (bf16_t*)out; f.ldo = C; f.n = n; f.C = C; f.scale_log2e = (1.0f / sqrtf(32.f)) * 1.4426950408889634f;
     RDM_CHECK_HIP(c, launch_flash_d32(f, heads, B, c->stream));
+    return 0;
+}
+int rdm_op_xattn_fused(rdm_ctx* c, const void* x, const void* G, const void* U, const float* bias, const void* res, int B, int n, int C,
+                       int NP, int ncols, int group, void* out) {
+    RDM_ENTER(c);
+    if (!c) return -1;
+    XattnParams q{}; q.x = (const bf16_t*)x; q.G = (const bf16_t*)G; q.U = (const bf16_t*)U; q.bias = bias; q.res = (const bf16_t*)res;
+    q.out = (bf16_t*)out; q.rows = B * n; q.n = n; q.C = C; q.NP = NP; q.ncols = ncols; q.group = group;
+    if (!xattn_fused_supported(q)) return c->fail(-3, "rdm_op_xattn_fused: unsupported shape (n %% 32, C %% 64, NP %% 32, ncols <= min(NP, 128), group 1 / 2 / 4): n %d C %d NP %d ncols %d group %d", n, C, NP, ncols, group);
+    const size_t img = (size_t)B * NP * C * 2;          // the kernel reads fragment-ordered images of G and U
+    RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, 2 * img));
+    bf16_t* Gp = (bf16_t*)c->bwd_tmp; bf16_t* Up = Gp + (size_t)B * NP * C;
+    RDM_CHECK_HIP(c, launch_xattn_pack(q.G, q.U, Gp, Up, B, NP, C, c->stream));
+    q.G = Gp; q.U = Up;
+    RDM_CHECK_HIP(c, launch_xattn_fused(q, c->stream));
     return 0;
 }
 int rdm_op_small_attention(rdm_ctx* c, const void* q, int ldq, const void* k, const void* v, int ldkv, int B, int nq, int nkv,

@@ -239,6 +239,27 @@ def test_flash_self_attention(ctx, B, n, heads):
         assert torch.equal(out2, out), "token-major-V flash kernel differs from the V^T one"
 
 
+@pytest.mark.parametrize("B,n,heads,k", [(3, 1024, 12, 4), (2, 256, 18, 4), (4, 64, 30, 4), (2, 64, 4, 2), (2, 32, 2, 1), (2, 96, 6, 4)])
+def test_xattn_fused(ctx, B, n, heads, k):
+    """Fused skinny cross-attention (scores GEMM + group softmax + output GEMM + bias + residual) against fp32 torch on the same bf16 operands."""
+    d = ctx.device
+    C, NP, ncols = heads * 32, 128, heads * k
+    x, res = bf16_round(_rand((B, n, C), 40)), bf16_round(_rand((B, n, C), 41))
+    G = torch.zeros(B, NP, C); U = torch.zeros(B, C, NP)
+    G[:, :ncols] = _rand((B, ncols, C), 42) * (4.0 / C ** 0.5)       # logits of a few units
+    U[:, :, :ncols] = _rand((B, C, ncols), 43)
+    G, U = bf16_round(G), bf16_round(U)
+    bias = _rand((C,), 44)
+    sc = torch.einsum("bnc,bjc->bnj", x, G[:, :ncols])
+    pr = bf16_round(sc.reshape(B, n, heads, k).softmax(-1).reshape(B, n, ncols))     # the kernel rounds the probabilities to bf16 for the second MFMA
+    ref = torch.einsum("bnj,bcj->bnc", pr, U[:, :, :ncols]) + bias + res
+    dev = lambda t: t.to(d, torch.bfloat16).contiguous()
+    out = ctx.op_xattn_fused(dev(x), dev(G), dev(U), bias.to(d), dev(res), ncols, k)
+    _close(out, ref, tol=2 ** -6, what="fused cross attention")
+    out0 = ctx.op_xattn_fused(dev(x), dev(G), dev(U), None, None, ncols, k)
+    _close(out0, ref - bias - res, tol=2 ** -6, what="fused cross attention (no bias / residual)")
+
+
 @pytest.mark.parametrize("B,nq,nkv,heads,D,causal", [(2, 64, 4, 4, 32, 0), (2, 77, 77, 2, 64, 1), (1, 50, 50, 3, 64, 0),
                                                      (2, 16, 16, 2, 32, 0), (1, 1024, 16, 12, 32, 0)])
 def test_small_attention(ctx, B, nq, nkv, heads, D, causal):
