@@ -303,9 +303,13 @@ int rdm_op_self_attention_qkv(rdm_ctx* ctx, const void* qkv_bf16, int B, int n, 
  *   out[b] = softmax_groups(x[b] G[b]^T) U[b]^T + bias + res[b]
  * x / res / out bf16 [B, n, C], G bf16 [B, NP, C] (row h*k + j = key j restricted to head h, times W_q / sqrt(d)), U bf16 [B, C, NP]
  * (column h*k + j = W_o applied to value j restricted to head h); softmax over groups of `group` (= k: 1, 2, 4) adjacent columns of
- * the first ncols = heads * k columns.  n % 32 == 0, C % 64 == 0, NP % 32 == 0, ncols <= min(NP, 128).  bias / res may be null. */
-int rdm_op_xattn_fused(rdm_ctx* ctx, const void* x_bf16, const void* G_bf16, const void* U_bf16, const float* bias, const void* res_bf16,
-                       int B, int n, int C, int NP, int ncols, int group, void* out_bf16);
+ * the first ncols = heads * k columns.  n % 32 == 0, C % 64 == 0, NP % 32 == 0, ncols <= min(NP, 128).  bias / res may be null.
+ * With ln_gamma / ln_beta given (res null) the LayerNorm in front and the residual are folded in as well:
+ *   out[b] = softmax_groups(LayerNorm(x[b]) G[b]^T) U[b]^T + bias + x[b]      (norm2 + attn2 + residual of BasicTransformerBlock,
+ * attention.py:238). */
+int rdm_op_xattn_fused(rdm_ctx* ctx, const void* x_bf16, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* G_bf16,
+                       const void* U_bf16, const float* bias, const void* res_bf16, int B, int n, int C, int NP, int ncols, int group,
+                       void* out_bf16);
 int rdm_op_small_attention(rdm_ctx* ctx, const void* q_bf16, int ldq, const void* k_bf16, const void* v_bf16, int ldkv,
                            int B, int nq, int nkv, int heads, int D, int causal, float scale, void* out_bf16, int ldo);
 

@@ -134,7 +134,7 @@ SIGNATURES = {
     "rdm_op_layernorm": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "rdm_op_self_attention": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_op_self_attention_qkv": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
-    "rdm_op_xattn_fused": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "rdm_op_xattn_fused": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_op_small_attention": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_float, _P, C.c_int]),
 }
@@ -757,13 +757,16 @@ class Context:
         self._check(lib.rdm_op_self_attention_qkv(self._h, _ptr(qkv), B, n, heads, _ptr(out)))
         return out
 
-    def op_xattn_fused(self, x, G, U, bias, res, ncols, group):
-        """out = softmax_groups(x G^T) U^T + bias + res per sample: x / res bf16 [B, n, C], G bf16 [B, NP, C], U bf16 [B, C, NP]."""
+    def op_xattn_fused(self, x, G, U, bias, res, ncols, group, ln=None):
+        """out = softmax_groups(x G^T) U^T + bias + res per sample: x / res bf16 [B, n, C], G bf16 [B, NP, C], U bf16 [B, C, NP].
+        ln = (gamma, beta, eps): scores on LayerNorm(x), residual = x (res must be None)."""
         B, n, Cc = x.shape
         NP = G.shape[1]
         out = torch.empty((B, n, Cc), device=self.device, dtype=torch.bfloat16)
-        self._check(lib.rdm_op_xattn_fused(self._h, _ptr(x), _ptr(G), _ptr(U), _ptr(bias) if bias is not None else None,
-                                           _ptr(res) if res is not None else None, B, n, Cc, NP, ncols, group, _ptr(out)))
+        g, b_, eps = ln if ln is not None else (None, None, 0.0)
+        opt = lambda t: _ptr(t) if t is not None else None
+        self._check(lib.rdm_op_xattn_fused(self._h, _ptr(x), opt(g), opt(b_), float(eps), _ptr(G), _ptr(U), opt(bias), opt(res),
+                                           B, n, Cc, NP, ncols, group, _ptr(out)))
         return out
 
     def op_small_attention(self, q, k, v, heads, D, causal, scale):

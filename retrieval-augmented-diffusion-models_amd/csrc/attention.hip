@@ -300,6 +300,44 @@ hipError_t launch_xattn_pack(const bf16_t* G, const bf16_t* U, bf16_t* Gp, bf16_
     return hipGetLastError();
 }
 
+// XCD-aware block order: workgroups go round-robin over the 8 XCDs in id order, so the n / 32 blocks of ONE sample -- which all stream
+// that sample's G and U images -- would pull them through 8 different L2s (at the 16x16 level: 150 MB of fabric traffic for 38 MB of
+// activations).  Remapped so that a sample's blocks are consecutive slots of one XCD's queue.
+__device__ __forceinline__ int xattn_block(int n) {
+    const int bps = n >> 5, lin = blockIdx.x;
+    if (gridDim.x % (8 * bps) != 0) return lin;
+    const int xcd = lin & 7, slot = lin >> 3;
+    return (slot / bps) * (8 * bps) + xcd * bps + (slot % bps);
+}
+
+// softmax over groups of `group` (1, 2, 4) adjacent entries of the 16 scores a lane holds for one 32-column block
+__device__ __forceinline__ void xattn_group_softmax(float* s, int group) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        float* g = s + 4 * q;
+        if (group == 4) {
+            const float m = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3]));
+            float e[4], sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { e[i] = __expf(g[i] - m); sum += e[i]; }
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int i = 0; i < 4; i++) g[i] = e[i] * inv;
+        } else if (group == 2) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; h2++) {
+                const float m = fmaxf(g[2 * h2], g[2 * h2 + 1]);
+                const float e0 = __expf(g[2 * h2] - m), e1 = __expf(g[2 * h2 + 1] - m);
+                const float inv = 1.0f / (e0 + e1);
+                g[2 * h2] = e0 * inv; g[2 * h2 + 1] = e1 * inv;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) g[i] = 1.0f;
+        }
+    }
+}
+
 template <int NB>        // 32-column score blocks in use: ceil(ncols / 32)
 __global__ __launch_bounds__(256) void xattn_fused_kernel(XattnParams p) {
     __shared__ __attribute__((aligned(16))) float part[4 * NB * 4 * 64 * 4];       // [wave][jb*4 + q][lane][4]
@@ -307,7 +345,7 @@ __global__ __launch_bounds__(256) void xattn_fused_kernel(XattnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = p.C, NJ = p.NP >> 5;
-    const long long row0 = (long long)blockIdx.x * 32;
+    const long long row0 = (long long)xattn_block(p.n) * 32;
     const int b = (int)(row0 / p.n);
     // ---- phase 1: partial scores over this wave's K quarter
     const int nsteps = C >> 6;                               // 16-k steps in a quarter
@@ -375,30 +413,7 @@ __global__ __launch_bounds__(256) void xattn_fused_kernel(XattnParams p) {
             for (int ww = 1; ww < 4; ww++) t += *(const f32x4*)(part + (((ww * NB + jb) * 4 + q) * 64 + lane) * 4);
             s[4 * q] = t[0]; s[4 * q + 1] = t[1]; s[4 * q + 2] = t[2]; s[4 * q + 3] = t[3];
         }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            float* g = s + 4 * q;
-            if (p.group == 4) {
-                const float m = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3]));
-                float e[4], sum = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; i++) { e[i] = __expf(g[i] - m); sum += e[i]; }
-                const float inv = 1.0f / sum;
-#pragma unroll
-                for (int i = 0; i < 4; i++) g[i] = e[i] * inv;
-            } else if (p.group == 2) {
-#pragma unroll
-                for (int h2 = 0; h2 < 2; h2++) {
-                    const float m = fmaxf(g[2 * h2], g[2 * h2 + 1]);
-                    const float e0 = __expf(g[2 * h2] - m), e1 = __expf(g[2 * h2 + 1] - m);
-                    const float inv = 1.0f / (e0 + e1);
-                    g[2 * h2] = e0 * inv; g[2 * h2 + 1] = e1 * inv;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) g[i] = 1.0f;
-            }
-        }
+        xattn_group_softmax(s, p.group);
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             union { bf16x8 v; uint32_t u[4]; } pk;
@@ -439,15 +454,237 @@ __global__ __launch_bounds__(256) void xattn_fused_kernel(XattnParams p) {
     }
 }
 
+// ---- the same with the LayerNorm in front folded in (out = softmax_groups(LN(x) G^T) U^T + bias + x: norm2 + attn2 + the residual of
+// BasicTransformerBlock, rdm/modules/attention.py:238): the block's 32 raw rows arrive ONCE, coalesced, in an LDS tile (padded rows:
+// conflict-free 16-byte reads at one row per lane); the row statistics are two exchanges of per-wave partial sums (mean, then the
+// centred squares, as layernorm_bf16x8_kernel forms them); the normalised operand is formed in registers on the way to the MFMA; the
+// residual is read from the tile, the result written back into it, and the tile leaves coalesced.  Every global access of the
+// activations is now whole rows (the MFMA-layout accesses above touch 32 - 64 cache lines per instruction).  The score exchange goes
+// block by block through one 16 KiB buffer.
+template <int NB>
+__global__ __launch_bounds__(256) void xattn_ln_fused_kernel(XattnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char xsm[];
+    constexpr int SB = 3;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = p.C, NJ = p.NP >> 5, RS = 2 * C + 16;
+    char* T = xsm;                                           // [32 rows][RS bytes]
+    float* part = (float*)(xsm + 32 * RS);                   // [wave][q][lane][4]
+    float* stat = part + 4 * 4 * 64 * 4;                     // [wave][32 rows]
+    const long long row0 = (long long)xattn_block(p.n) * 32;
+    const int b = (int)(row0 / p.n);
+    // the first score operands are on their way while the tile arrives
+    const int nsteps = C >> 6;
+    const bf16_t* gr = p.G + (((long long)b * (C >> 4) + (long long)w * nsteps) * NJ * 64 + lane) * 8;
+    struct GB { bf16x8 g[SB][NB]; };
+    auto gload = [&](GB& t, int sb) {
+#pragma unroll
+        for (int u = 0; u < SB; u++)
+#pragma unroll
+            for (int jb = 0; jb < NB; jb++) t.g[u][jb] = *(const bf16x8*)(gr + ((long long)(sb + u) * NJ + jb) * 512);
+    };
+    GB gA, gB;
+    if (SB <= nsteps) gload(gA, 0);
+    // ---- the tile in: 16-byte pieces, consecutive threads along a row
+    const int ppr = C >> 3, npc = (32 * ppr) >> 8;
+    struct Piece { long long g; int l; };
+    auto piece = [&](int it) {       // piece `it` of this thread (clamped: a repeated piece is harmless)
+        const int id = min(it, npc - 1) * 256 + tid, row = id / ppr, pc = id - row * ppr;
+        return Piece{(row0 + row) * C + pc * 8, row * RS + pc * 16};
+    };
+    for (int it0 = 0; it0 < npc; it0 += 6) {                      // six requests in flight per thread
+        const Piece q0 = piece(it0), q1 = piece(it0 + 1), q2 = piece(it0 + 2), q3 = piece(it0 + 3), q4 = piece(it0 + 4), q5 = piece(it0 + 5);
+        const uint4 v0 = *(const uint4*)(p.x + q0.g), v1 = *(const uint4*)(p.x + q1.g), v2 = *(const uint4*)(p.x + q2.g);
+        const uint4 v3 = *(const uint4*)(p.x + q3.g), v4 = *(const uint4*)(p.x + q4.g), v5 = *(const uint4*)(p.x + q5.g);
+        *(uint4*)(T + q0.l) = v0; *(uint4*)(T + q1.l) = v1; *(uint4*)(T + q2.l) = v2;
+        *(uint4*)(T + q3.l) = v3; *(uint4*)(T + q4.l) = v4; *(uint4*)(T + q5.l) = v5;
+    }
+    __syncthreads();
+    // ---- row statistics over this wave's K quarter (lane = row, half-wave = 8-channel piece of every 16)
+    const char* xl = T + l31 * RS + (w * (C >> 2) + 8 * hf) * 2;
+    float sm = 0.f;
+    for (int s0 = 0; s0 < nsteps; s0++) {
+        const bf16x8 x8 = *(const bf16x8*)(xl + s0 * 32);
+#pragma unroll
+        for (int e = 0; e < 8; e++) sm += bf2f((bf16_t)x8[e]);
+    }
+    sm += __shfl_xor(sm, 32);
+    if (hf == 0) stat[w * 32 + l31] = sm;
+    __syncthreads();
+    const float mean = (stat[l31] + stat[32 + l31] + stat[64 + l31] + stat[96 + l31]) / (float)C;
+    __syncthreads();
+    float sq = 0.f;
+    for (int s0 = 0; s0 < nsteps; s0++) {
+        const bf16x8 x8 = *(const bf16x8*)(xl + s0 * 32);
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const float d = bf2f((bf16_t)x8[e]) - mean; sq += d * d; }
+    }
+    sq += __shfl_xor(sq, 32);
+    if (hf == 0) stat[w * 32 + l31] = sq;
+    __syncthreads();
+    const float rstd = rsqrtf((stat[l31] + stat[32 + l31] + stat[64 + l31] + stat[96 + l31]) / (float)C + p.ln_eps);
+    // ---- phase 1: partial scores of LayerNorm(x) over the quarter
+    const float* gk = p.ln_g + w * (C >> 2) + 8 * hf;
+    const float* bk = p.ln_b + w * (C >> 2) + 8 * hf;
+    f32x16 acc[NB];
+#pragma unroll
+    for (int jb = 0; jb < NB; jb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[jb][r] = 0.f;
+    auto normed = [&](int st) {
+        const bf16x8 x8 = *(const bf16x8*)(xl + st * 32);
+        const f32x4 g0 = *(const f32x4*)(gk + st * 16), g1 = *(const f32x4*)(gk + st * 16 + 4);
+        const f32x4 b0 = *(const f32x4*)(bk + st * 16), b1 = *(const f32x4*)(bk + st * 16 + 4);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            y[e] = (bf2f((bf16_t)x8[e]) - mean) * rstd * g0[e] + b0[e];
+            y[4 + e] = (bf2f((bf16_t)x8[4 + e]) - mean) * rstd * g1[e] + b1[e];
+        }
+        union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+        for (int i = 0; i < 4; i++) pk.u[i] = cvt_pk_bf16(y[2 * i], y[2 * i + 1]);
+        return pk.v;
+    };
+    auto batch = [&](const GB& t, int sb) {
+        bf16x8 xb[SB];
+#pragma unroll
+        for (int u = 0; u < SB; u++) xb[u] = normed(sb + u);
+#pragma unroll
+        for (int u = 0; u < SB; u++)
+#pragma unroll
+            for (int jb = 0; jb < NB; jb++) acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t.g[u][jb], xb[u], acc[jb], 0, 0, 0);
+    };
+    int s0 = 0;
+    for (; s0 + SB <= nsteps; s0 += 2 * SB) {
+        const bool two = s0 + 2 * SB <= nsteps;
+        if (two) gload(gB, s0 + SB);
+        batch(gA, s0);
+        if (two) {
+            if (s0 + 3 * SB <= nsteps) gload(gA, s0 + 2 * SB);
+            batch(gB, s0 + SB);
+        }
+    }
+    s0 = (nsteps / SB) * SB;
+    for (; s0 < nsteps; s0++) {
+        const bf16x8 xb = normed(s0);
+#pragma unroll
+        for (int jb = 0; jb < NB; jb++) {
+            const bf16x8 gb = *(const bf16x8*)(gr + ((long long)s0 * NJ + jb) * 512);
+            acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gb, xb, acc[jb], 0, 0, 0);
+        }
+    }
+    const int ncb = C >> 5;
+    const bf16_t* ub = p.U + ((long long)b * ncb * (2 * NJ) * 64 + lane) * 8;
+    struct Blk { bf16x8 uf[2 * NB]; f32x4 bv[4]; };
+    auto request = [&](Blk& k, int cb) {
+#pragma unroll
+        for (int st = 0; st < 2 * NB; st++) k.uf[st] = *(const bf16x8*)(ub + ((long long)cb * (2 * NJ) + st) * 512);
+#pragma unroll
+        for (int q = 0; q < 4; q++) k.bv[q] = p.bias ? *(const f32x4*)(p.bias + cb * 32 + 16 * hf + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    Blk k0, k1;
+    if (w < ncb) request(k0, w);
+    // ---- exchange + softmax, one 32-column block at a time
+    bf16x8 pf[2 * NB];
+#pragma unroll
+    for (int jb = 0; jb < NB; jb++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            f32x4 v = {acc[jb][4 * q], acc[jb][4 * q + 1], acc[jb][4 * q + 2], acc[jb][4 * q + 3]};
+            *(f32x4*)(part + ((w * 4 + q) * 64 + lane) * 4) = v;
+        }
+        __syncthreads();
+        float s[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            f32x4 t = *(const f32x4*)(part + ((0 * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+            for (int ww = 1; ww < 4; ww++) t += *(const f32x4*)(part + ((ww * 4 + q) * 64 + lane) * 4);
+            s[4 * q] = t[0]; s[4 * q + 1] = t[1]; s[4 * q + 2] = t[2]; s[4 * q + 3] = t[3];
+        }
+        __syncthreads();
+        xattn_group_softmax(s, p.group);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+            for (int i = 0; i < 4; i++) pk.u[i] = cvt_pk_bf16(s[8 * half + 2 * i], s[8 * half + 2 * i + 1]);
+            pf[2 * jb + half] = pk.v;
+        }
+    }
+    // ---- phase 2: residual from the tile, result into the tile
+    auto finish = [&](const Blk& k, int cb) {
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2 * NB; st++) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k.uf[st], pf[st], o, 0, 0, 0);
+        char* tp = T + l31 * RS + (cb * 32 + 16 * hf) * 2;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+            const uint4 rq = *(const uint4*)(tp + 16 * h2);
+            const uint32_t rr[4] = {rq.x, rq.y, rq.z, rq.w};
+            uint32_t wv[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = 8 * h2 + 2 * i;
+                const float a0 = o[r] + k.bv[r >> 2][r & 3] + __uint_as_float(rr[i] << 16);
+                const float a1 = o[r + 1] + k.bv[(r + 1) >> 2][(r + 1) & 3] + __uint_as_float(rr[i] & 0xffff0000u);
+                wv[i] = cvt_pk_bf16(a0, a1);
+            }
+            *(uint4*)(tp + 16 * h2) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+        }
+    };
+    for (int cb = w; cb < ncb; cb += 8) {
+        if (cb + 4 < ncb) request(k1, cb + 4);
+        finish(k0, cb);
+        if (cb + 4 < ncb) {
+            if (cb + 8 < ncb) request(k0, cb + 8);
+            finish(k1, cb + 4);
+        }
+    }
+    __syncthreads();
+    // ---- the tile out
+    for (int it0 = 0; it0 < npc; it0 += 3) {
+        const Piece q0 = piece(it0), q1 = piece(it0 + 1), q2 = piece(it0 + 2);
+        const uint4 v0 = *(const uint4*)(T + q0.l), v1 = *(const uint4*)(T + q1.l), v2 = *(const uint4*)(T + q2.l);
+        *(uint4*)(p.out + q0.g) = v0; *(uint4*)(p.out + q1.g) = v1; *(uint4*)(p.out + q2.g) = v2;
+    }
+}
+
 bool xattn_fused_supported(const XattnParams& p) {
     return p.n > 0 && p.n % 32 == 0 && p.rows % p.n == 0 && p.C % 64 == 0 && p.NP % 32 == 0 && p.ncols >= 1 && p.ncols <= p.NP && p.ncols <= 128 &&
-           (p.group == 1 || p.group == 2 || p.group == 4) && p.x && p.G && p.U && p.out;
+           (p.group == 1 || p.group == 2 || p.group == 4);
 }
 // p.G / p.U: the fragment-ordered images written by launch_xattn_pack
+static size_t xattn_ln_smem(int C) { return (size_t)32 * (2 * C + 16) + 4 * 4 * 64 * 4 * 4 + 4 * 32 * 4; }
 hipError_t launch_xattn_fused(const XattnParams& p, hipStream_t st) {
-    if (!xattn_fused_supported(p)) return hipErrorInvalidValue;
+    if (!xattn_fused_supported(p) || !p.x || !p.G || !p.U || !p.out) return hipErrorInvalidValue;
     const int nb = (p.ncols + 31) / 32;
     dim3 grid((unsigned)(p.rows / 32));
+    if (p.ln_g) {
+        if (!p.ln_b || xattn_ln_smem(p.C) > 160 * 1024) return hipErrorInvalidValue;
+        static bool attr[RDM_MAX_DEVICES] = {};
+        const int dev = rdm_cur_device();
+        if (!attr[dev]) {
+            hipError_t e = hipSuccess;
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xattn_ln_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xattn_ln_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xattn_ln_fused_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xattn_ln_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr[dev] = true;
+        }
+        const size_t smem = xattn_ln_smem(p.C);
+        switch (nb) {
+            case 1: xattn_ln_fused_kernel<1><<<grid, 256, smem, st>>>(p); break;
+            case 2: xattn_ln_fused_kernel<2><<<grid, 256, smem, st>>>(p); break;
+            case 3: xattn_ln_fused_kernel<3><<<grid, 256, smem, st>>>(p); break;
+            default: xattn_ln_fused_kernel<4><<<grid, 256, smem, st>>>(p); break;
+        }
+        return hipGetLastError();
+    }
     switch (nb) {
         case 1: xattn_fused_kernel<1><<<grid, 256, 0, st>>>(p); break;
         case 2: xattn_fused_kernel<2><<<grid, 256, 0, st>>>(p); break;

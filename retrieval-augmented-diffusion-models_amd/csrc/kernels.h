@@ -31,6 +31,7 @@ struct XattnParams {
     const float* bias; const bf16_t* res; bf16_t* out;
     int rows, n, C, NP;              // rows = samples * n (n rows per sample, n % 32 == 0); NP = row count of G (128)
     int ncols, group;                // heads * k used score columns; softmax over groups of `group` (1, 2, 4) adjacent columns
+    const float* ln_g; const float* ln_b; float ln_eps;   // given: x holds the RAW rows, the scores are taken on LayerNorm(x) and the residual is x itself (res unused)
 };
 bool xattn_fused_supported(const XattnParams& p);
 hipError_t launch_xattn_fused(const XattnParams& p, hipStream_t st);        // G / U: FRAGMENT-ORDERED images, written by:

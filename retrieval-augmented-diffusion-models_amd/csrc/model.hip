@@ -744,7 +744,17 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         // --- attn2 (cross over the k neighbours); samples >= Bx have all-zero neighbours: t2 = t1 + b_o exactly (see add_bias_rows_kernel)
         const int Mx = Bx * n;
         bf16_t* l2 = o.abf((size_t)M * C);
-        if (Mx > 0) o.layernorm(t1, 0, s.ln2g, s.ln2b, l2, 0, Mx, C, s.lc);
+        // norm2 + attn2 + residual in one kernel when the neighbours' operands are cached (xa) and no channel is padding
+        static const int no_xfused = getenv("RDM_NO_XFUSED") ? atoi(getenv("RDM_NO_XFUSED")) : 0;       // 1: two GEMMs; 2: fused without the LayerNorm
+        XattnParams xp{};
+        if (xa && Mx > 0) {
+            const bf16_t* G = xa + (size_t)B * s.xa_unit; const bf16_t* U = G + (size_t)B * XA_NP * C;
+            xp.x = l2; xp.G = U + (size_t)B * C * XA_NP; xp.U = xp.G + (size_t)B * XA_NP * C; xp.bias = o.w<float>(s.bo2); xp.res = t1; xp.out = nullptr;
+            xp.rows = Mx; xp.n = n; xp.C = C; xp.NP = XA_NP; xp.ncols = s.heads * k; xp.group = k;
+        }
+        const bool xfused = xa && Mx > 0 && no_xfused != 1 && xattn_fused_supported(xp);
+        const bool xln = xfused && no_xfused != 2 && s.lc == C && C <= 2048;
+        if (Mx > 0 && !xln) o.layernorm(t1, 0, s.ln2g, s.ln2b, l2, 0, Mx, C, s.lc);
         bf16_t* t2 = o.abf((size_t)M * C);
         if (Bx < B && !o.plan)
             o.check(launch_add_bias_rows(t1 + (size_t)Mx * C, o.w<float>(s.bo2), t2 + (size_t)Mx * C, (long long)(M - Mx), C, o.c->stream), "zero-context cross attention");
@@ -753,10 +763,9 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
             bf16_t* P = o.abf((size_t)M * XA_NP);
             if (!o.plan) {
                 const bf16_t* G = xa + (size_t)B * s.xa_unit; const bf16_t* U = G + (size_t)B * XA_NP * C;
-                static const int no_xfused = getenv("RDM_NO_XFUSED") ? atoi(getenv("RDM_NO_XFUSED")) : 0;
-                XattnParams xp{}; xp.x = l2; xp.G = U + (size_t)B * C * XA_NP; xp.U = xp.G + (size_t)B * XA_NP * C; xp.bias = o.w<float>(s.bo2); xp.res = t1; xp.out = t2;
-                xp.rows = Mx; xp.n = n; xp.C = C; xp.NP = XA_NP; xp.ncols = s.heads * k; xp.group = k;
-                if (!no_xfused && xattn_fused_supported(xp)) {       // both GEMMs, the softmax and the residual in one launch (attention.hip)
+                xp.out = t2;
+                if (xln) { xp.x = t1; xp.res = nullptr; xp.ln_g = o.w<float>(s.ln2g); xp.ln_b = o.w<float>(s.ln2b); xp.ln_eps = 1e-5f; }
+                if (xfused) {       // both GEMMs, the softmax and the residual (and norm2) in one launch (attention.hip)
                     o.prof_begin(RDM_PROF_LINEAR, 4.0 * Mx * XA_NP * (double)C);
                     o.check(launch_xattn_fused(xp, o.c->stream), "fused cross attention");
                     o.prof_end();
@@ -1847,12 +1856,14 @@ int rdm_op_self_attention_qkv(rdm_ctx* c, const void* qkv, int B, int n, int hea
     RDM_CHECK_HIP(c, launch_flash_d32(f, heads, B, c->stream));
     return 0;
 }
-int rdm_op_xattn_fused(rdm_ctx* c, const void* x, const void* G, const void* U, const float* bias, const void* res, int B, int n, int C,
-                       int NP, int ncols, int group, void* out) {
+int rdm_op_xattn_fused(rdm_ctx* c, const void* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* G, const void* U,
+                       const float* bias, const void* res, int B, int n, int C, int NP, int ncols, int group, void* out) {
     RDM_ENTER(c);
     if (!c) return -1;
     XattnParams q{}; q.x = (const bf16_t*)x; q.G = (const bf16_t*)G; q.U = (const bf16_t*)U; q.bias = bias; q.res = (const bf16_t*)res;
     q.out = (bf16_t*)out; q.rows = B * n; q.n = n; q.C = C; q.NP = NP; q.ncols = ncols; q.group = group;
+    q.ln_g = ln_gamma; q.ln_b = ln_beta; q.ln_eps = ln_eps;
+    if ((ln_gamma != nullptr) != (ln_beta != nullptr) || (ln_gamma && res)) return c->fail(-3, "rdm_op_xattn_fused: LayerNorm needs gamma and beta, and then the residual is x itself (res must be null)");
     if (!xattn_fused_supported(q)) return c->fail(-3, "rdm_op_xattn_fused: unsupported shape (n %% 32, C %% 64, NP %% 32, ncols <= min(NP, 128), group 1 / 2 / 4): n %d C %d NP %d ncols %d group %d", n, C, NP, ncols, group);
     const size_t img = (size_t)B * NP * C * 2;          // the kernel reads fragment-ordered images of G and U
     RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, 2 * img));

@@ -258,6 +258,15 @@ def test_xattn_fused(ctx, B, n, heads, k):
     _close(out, ref, tol=2 ** -6, what="fused cross attention")
     out0 = ctx.op_xattn_fused(dev(x), dev(G), dev(U), None, None, ncols, k)
     _close(out0, ref - bias - res, tol=2 ** -6, what="fused cross attention (no bias / residual)")
+    # LayerNorm in front and the residual folded in: raw rows with a mean and a scale, gamma / beta non-trivial
+    raw = bf16_round(_rand((B, n, C), 45) * 1.7 + 0.4)
+    g, be = 1 + 0.1 * _rand((C,), 46), 0.1 * _rand((C,), 47)
+    xn = bf16_round(F.layer_norm(raw, (C,), g, be, 1e-5))
+    sc = torch.einsum("bnc,bjc->bnj", xn, G[:, :ncols])
+    pr = bf16_round(sc.reshape(B, n, heads, k).softmax(-1).reshape(B, n, ncols))
+    ref_ln = torch.einsum("bnj,bcj->bnc", pr, U[:, :, :ncols]) + bias + raw
+    out_ln = ctx.op_xattn_fused(dev(raw), dev(G), dev(U), bias.to(d), None, ncols, k, ln=(g.to(d), be.to(d), 1e-5))
+    _close(out_ln, ref_ln, tol=2 ** -6, what="fused LayerNorm + cross attention + residual")
 
 
 @pytest.mark.parametrize("B,nq,nkv,heads,D,causal", [(2, 64, 4, 4, 32, 0), (2, 77, 77, 2, 64, 1), (1, 50, 50, 3, 64, 0),
