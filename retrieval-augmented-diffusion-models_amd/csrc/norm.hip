@@ -225,78 +225,56 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* x, const floa
 // bf16 -> bf16 rows with C % 8 == 0 (every LayerNorm of the UNet): 16-byte loads and stores, 8 channels per lane.  A store
 // costs ~70 cycles per wave-instruction whatever its width, so the 4-byte-per-lane kernel above is bound by its store COUNT
 // (256 B per instruction ~ 1.9 TB/s chip-wide); this one moves 1 KiB per instruction.
-// R rows per wave, all their loads issued before the first reduction: with one row per wave the kernel ran at 4 TB/s on latency
-// (one 16-byte load in flight per lane); per-row arithmetic and its order are unchanged.
-template <int NV, int R>
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(const bf16_t* x, const float* gamma, const float* beta,
                                                                bf16_t* out, int M, int C, float eps, int Clog) {
     // Clog <= C: the row's tail [Clog, C) is zero padding (Clog % 8 == 0): statistics over Clog values; the tail's gamma / beta
     // are zero, so it is written back as zero.
     const int lane = threadIdx.x & 63;
-    const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
-    if (row0 >= M) return;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bf16_t* xr = x + row * C;
     const int nvec = C >> 3, nlog = Clog >> 3;
-    float v[R][NV][8];
+    float v[NV][8];
+    float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        const long long row = row0 + r < M ? row0 + r : M - 1;           // clamped: a repeated row is computed and not stored
-        const bf16_t* xr = x + row * C;
+    for (int j = 0; j < NV; j++) {
+        const int vi = lane + j * 64;
+        if (vi < nvec) {
+            const bf16x8 d = *(const bf16x8*)(xr + vi * 8);
 #pragma unroll
-        for (int j = 0; j < NV; j++) {
-            const int vi = lane + j * 64;
-            if (vi < nvec) {
-                const bf16x8 d = *(const bf16x8*)(xr + vi * 8);
+            for (int e = 0; e < 8; e++) { v[j][e] = bf2f((bf16_t)d[e]); s += v[j][e]; }
+        } else {
 #pragma unroll
-                for (int e = 0; e < 8; e++) v[r][j][e] = bf2f((bf16_t)d[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; e++) v[r][j][e] = 0.f;
-            }
+            for (int e = 0; e < 8; e++) v[j][e] = 0.f;
         }
     }
-    float gg[NV][8], bb[NV][8];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / Clog;             // the padded tail contributed zeros to s
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+        if (lane + j * 64 < nlog) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float d = v[j][e] - mean; q += d * d; }
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / Clog + eps);
 #pragma unroll
     for (int j = 0; j < NV; j++) {
         const int vi = lane + j * 64;
         if (vi < nvec) {
             const float4 g0 = *(const float4*)(gamma + vi * 8), g1 = *(const float4*)(gamma + vi * 8 + 4);
             const float4 b0 = *(const float4*)(beta + vi * 8), b1 = *(const float4*)(beta + vi * 8 + 4);
-            gg[j][0] = g0.x; gg[j][1] = g0.y; gg[j][2] = g0.z; gg[j][3] = g0.w; gg[j][4] = g1.x; gg[j][5] = g1.y; gg[j][6] = g1.z; gg[j][7] = g1.w;
-            bb[j][0] = b0.x; bb[j][1] = b0.y; bb[j][2] = b0.z; bb[j][3] = b0.w; bb[j][4] = b1.x; bb[j][5] = b1.y; bb[j][6] = b1.z; bb[j][7] = b1.w;
-        }
-    }
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            uint32_t o[4];
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < NV; j++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) s += v[r][j][e];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const float mean = s / Clog;             // the padded tail contributed zeros to s
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < NV; j++)
-            if (lane + j * 64 < nlog) {
-#pragma unroll
-                for (int e = 0; e < 8; e++) { const float d = v[r][j][e] - mean; q += d * d; }
-            }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-        const float rstd = rsqrtf(q / Clog + eps);
-        if (row0 + r < M) {
-#pragma unroll
-            for (int j = 0; j < NV; j++) {
-                const int vi = lane + j * 64;
-                if (vi < nvec) {
-                    uint32_t o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        o[e] = pack2bf((v[r][j][2 * e] - mean) * rstd * gg[j][2 * e] + bb[j][2 * e], (v[r][j][2 * e + 1] - mean) * rstd * gg[j][2 * e + 1] + bb[j][2 * e + 1]);
-                    *(uint4*)(out + (row0 + r) * C + vi * 8) = make_uint4(o[0], o[1], o[2], o[3]);
-                }
-            }
+            for (int e = 0; e < 4; e++)
+                o[e] = pack2bf((v[j][2 * e] - mean) * rstd * gg[2 * e] + bb[2 * e], (v[j][2 * e + 1] - mean) * rstd * gg[2 * e + 1] + bb[2 * e + 1]);
+            *(uint4*)(out + row * C + vi * 8) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
 }
@@ -323,18 +301,9 @@ hipError_t launch_layernorm(const void* x, int in_is_f32, const float* gamma, co
     if (Clog != C && (no_vec || ((size_t)x % 16) || ((size_t)out % 16) || ((size_t)gamma % 16) || ((size_t)beta % 16))) return hipErrorInvalidValue;
     if (!no_vec && !in_is_f32 && !out_is_f32 && C % 8 == 0 && C <= 1024 && ((size_t)x % 16 == 0) && ((size_t)out % 16 == 0) &&
         ((size_t)gamma % 16 == 0) && ((size_t)beta % 16 == 0)) {
-        static const int rows_env = getenv("RDM_LN_ROWS") ? atoi(getenv("RDM_LN_ROWS")) : 0;
-        const int R = rows_env ? rows_env : (M >= 16384 ? 4 : 1);          // small M: one row per wave keeps every CU busy
-        const int grid = (M + 4 * R - 1) / (4 * R);
-        if (C <= 512) {
-            if (R == 4) layernorm_bf16x8_kernel<1, 4><<<grid, 256, 0, st>>>((const bf16_t*)x, gamma, beta, (bf16_t*)out, M, C, eps, Clog);
-            else if (R == 2) layernorm_bf16x8_kernel<1, 2><<<grid, 256, 0, st>>>((const bf16_t*)x, gamma, beta, (bf16_t*)out, M, C, eps, Clog);
-            else layernorm_bf16x8_kernel<1, 1><<<(M + 3) / 4, 256, 0, st>>>((const bf16_t*)x, gamma, beta, (bf16_t*)out, M, C, eps, Clog);
-        } else {
-            if (R == 4) layernorm_bf16x8_kernel<2, 4><<<grid, 256, 0, st>>>((const bf16_t*)x, gamma, beta, (bf16_t*)out, M, C, eps, Clog);
-            else if (R == 2) layernorm_bf16x8_kernel<2, 2><<<grid, 256, 0, st>>>((const bf16_t*)x, gamma, beta, (bf16_t*)out, M, C, eps, Clog);
-            else layernorm_bf16x8_kernel<2, 1><<<(M + 3) / 4, 256, 0, st>>>((const bf16_t*)x, gamma, beta, (bf16_t*)out, M, C, eps, Clog);
-        }
+        const int grid = (M + 3) / 4;
+        if (C <= 512) layernorm_bf16x8_kernel<1><<<grid, 256, 0, st>>>((const bf16_t*)x, gamma, beta, (bf16_t*)out, M, C, eps, Clog);
+        else layernorm_bf16x8_kernel<2><<<grid, 256, 0, st>>>((const bf16_t*)x, gamma, beta, (bf16_t*)out, M, C, eps, Clog);
         return hipGetLastError();
     }
     if (C <= 1024) ln_dispatch<8>(x, in_is_f32, gamma, beta, out, out_is_f32, M, C, eps, st);

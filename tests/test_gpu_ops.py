@@ -209,7 +209,7 @@ def test_groupnorm(ctx, B, HW, C0, C1, silu, eps):
 
 
 @pytest.mark.parametrize("M,C,f32", [(100, 384, False), (77, 512, True), (513, 960, False), (9, 768, True), (4, 128, False),
-                                     (16384 + 13, 384, False), (16384 + 2, 960, False)])        # >= 16384 rows: four rows per wave, ragged tail
+                                     (16384 + 13, 384, False), (16384 + 2, 960, False)])        # large ragged M
 def test_layernorm(ctx, M, C, f32):
     d = ctx.device
     x = _rand((M, C), 24) * 1.5 + 0.3
