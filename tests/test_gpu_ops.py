@@ -240,7 +240,8 @@ def test_flash_self_attention(ctx, B, n, heads):
         assert torch.equal(out2, out), "token-major-V flash kernel differs from the V^T one"
 
 
-@pytest.mark.parametrize("B,n,heads,k", [(3, 1024, 12, 4), (2, 256, 18, 4), (4, 64, 30, 4), (2, 64, 4, 2), (2, 32, 2, 1), (2, 96, 6, 4)])
+@pytest.mark.parametrize("B,n,heads,k", [(3, 1024, 12, 4), (2, 256, 18, 4), (4, 64, 30, 4), (2, 64, 4, 2), (2, 32, 2, 1), (2, 96, 6, 4),
+                                        (8, 64, 4, 4), (16, 256, 2, 2)])       # the last two: block counts that take the XCD-aware block order
 def test_xattn_fused(ctx, B, n, heads, k):
     """Fused skinny cross-attention (scores GEMM + group softmax + output GEMM + bias + residual) against fp32 torch on the same bf16 operands."""
     d = ctx.device
