@@ -310,6 +310,12 @@ int rdm_op_self_attention_qkv(rdm_ctx* ctx, const void* qkv_bf16, int B, int n, 
 int rdm_op_xattn_fused(rdm_ctx* ctx, const void* x_bf16, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* G_bf16,
                        const void* U_bf16, const float* bias, const void* res_bf16, int B, int n, int C, int NP, int ncols, int group,
                        void* out_bf16);
+/* The UNet's `out` head (openaimodel.py:307-311: GroupNorm32 + SiLU + 3x3 conv to out_channels) and the VQ decoder's norm_out + swish +
+ * conv_out as one statistics pass + one kernel: x bf16 NHWC [B, H, W, C] raw, 32 groups; gn_gamma / gn_beta null: no norm, x is convolved
+ * as is.  w fp32 [Cout, C, 3, 3], bias fp32 [Cout] or null, out fp32 NCHW [B, Cout, H, W].  C % 32 == 0, C <= 240, W % 32 == 0, H even,
+ * Cout <= 8. */
+int rdm_op_head_conv(rdm_ctx* ctx, const void* x_bf16, const float* gn_gamma, const float* gn_beta, float gn_eps, const float* w,
+                     const float* bias, int B, int H, int W, int C, int Cout, float* out_f32);
 int rdm_op_small_attention(rdm_ctx* ctx, const void* q_bf16, int ldq, const void* k_bf16, const void* v_bf16, int ldkv,
                            int B, int nq, int nkv, int heads, int D, int causal, float scale, void* out_bf16, int ldo);
 

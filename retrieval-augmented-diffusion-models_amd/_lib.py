@@ -134,6 +134,7 @@ SIGNATURES = {
     "rdm_op_layernorm": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "rdm_op_self_attention": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_op_self_attention_qkv": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "rdm_op_head_conv": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_op_xattn_fused": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_op_small_attention": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_float, _P, C.c_int]),
@@ -755,6 +756,17 @@ class Context:
         B, n, C3 = qkv.shape
         out = torch.empty((B, n, C3 // 3), device=self.device, dtype=torch.bfloat16)
         self._check(lib.rdm_op_self_attention_qkv(self._h, _ptr(qkv), B, n, heads, _ptr(out)))
+        return out
+
+    def op_head_conv(self, x, w, bias, gn=None):
+        """GroupNorm(32) + SiLU (gn = (gamma, beta, eps); None: no norm) + 3x3 conv to few channels: x bf16 [B, H, W, C], w fp32 [Cout, C, 3, 3]
+        -> fp32 [B, Cout, H, W]."""
+        B, H, W, Cc = x.shape
+        Cout = w.shape[0]
+        out = torch.empty((B, Cout, H, W), device=self.device, dtype=torch.float32)
+        g, b_, eps = gn if gn is not None else (None, None, 0.0)
+        opt = lambda t: _ptr(t) if t is not None else None
+        self._check(lib.rdm_op_head_conv(self._h, _ptr(x), opt(g), opt(b_), float(eps), _ptr(w), opt(bias), B, H, W, Cc, Cout, _ptr(out)))
         return out
 
     def op_xattn_fused(self, x, G, U, bias, res, ncols, group, ln=None):

@@ -13,6 +13,21 @@ struct GnParams {
     bf16_t* out;                          // [B, HW, C0+C1]
 };
 
+hipError_t launch_gn_stats(GnParams p, hipStream_t st);          // the statistics pass alone (p.partial), for consumers that apply the norm themselves
+
+// GroupNorm-apply + SiLU + 3x3 conv to a few output channels in one kernel (the UNet's `out` head, the VQ decoder's conv_out)
+struct HeadParams {
+    const bf16_t* x; int B, H, W, C;                  // NHWC bf16, raw (pre-norm) when partial is given
+    const float* partial; int nchunk, groups;         // GroupNorm statistics from launch_gn_stats ([B][nchunk][groups][2]) or null: x is used as is
+    const float* gamma; const float* beta; float eps;
+    const float* w;                                   // [Cout][C][3][3] fp32
+    bf16_t* wp;                                       // scratch for the packed weights: head_conv_wp_bytes(C)
+    const float* bias; float* out; int Cout;          // out NCHW fp32
+};
+size_t head_conv_wp_bytes(int C);
+bool head_conv_supported(const HeadParams& p);
+hipError_t launch_head_conv(const HeadParams& p, hipStream_t st);
+
 struct FlashParams {
     const bf16_t* q; int ldq;        // q[(b*n + i)*ldq + h*32 + d]
     const bf16_t* k; int ldk;        // k[(b*n + j)*ldk + h*32 + d]

@@ -146,6 +146,204 @@ hipError_t launch_conv_out(const bf16_t* x, const float* w, const float* bias, f
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ head conv on the matrix pipe, GroupNorm-apply + SiLU folded in
+// The VALU head conv above sits on the 9x tap re-read through L2 -> L1 (round 2: 26 B/clk/CU), and the GroupNorm-apply in front of it
+// writes and re-reads the whole tensor.  Here a block owns a 32-pixel-wide strip of one image and walks down its rows, two at a time:
+// raw rows arrive once (16-byte pieces, coalesced), are normalised (the per-channel a x + b of gn_apply_kernel, + SiLU, rounded to bf16
+// as the standalone pass rounds) on their way into a 6-row LDS ring (34 pixels x C channels per row, pixel stride 2C + 16 bytes:
+// conflict-free fragment reads), the rows of the NEXT pair being requested before the current pair's MFMAs.  The 3x3 conv is 9 C/32
+// MFMA 16x16x32 steps per 16-pixel tile (a wave: one tile of one of the two rows): A = 16 pixels x 32 channels of a tap from the ring,
+// B = the tap's weights from LDS, fragment-ordered, N padded to 16 -- and the padding is used: columns [0, Cout) hold the bf16 high
+// part of the fp32 weights, [Cout, 2 Cout) the low part, so one MFMA carries ~16 weight bits.  Output NCHW fp32.
+size_t head_conv_wp_bytes(int C) { return (size_t)9 * (C / 32) * 1024; }
+// wp[(tap * C/32 + cb)][lane][8]: k = 32 cb + 8 (lane >> 4) + e, n = lane & 15
+__global__ void head_conv_pack_kernel(const float* w, bf16_t* wp, int C, int Cout) {
+    const int total = 9 * (C / 32) * 64 * 8;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int e = i & 7, lane = (i >> 3) & 63, s = i >> 9;
+        const int cb = s % (C / 32), tap = s / (C / 32);
+        const int k = 32 * cb + 8 * (lane >> 4) + e, n = lane & 15;
+        float v = 0.f;
+        if (n < 2 * Cout) {
+            const float f = w[((n % Cout) * C + k) * 9 + tap];
+            const float hi = bf2f(f2bf(f));
+            v = n < Cout ? hi : f - hi;
+        }
+        wp[i] = f2bf(v);
+    }
+}
+
+constexpr int HC_RING = 6, HC_PX = 34;
+__global__ __launch_bounds__(512) void head_conv_kernel(HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) char hsm[];
+    const int C = p.C, PS = 2 * C + 16, ROWB = HC_PX * PS, NCB = C >> 5;
+    char* ring = hsm;                                            // [6][34][PS]
+    char* wl = hsm + HC_RING * ROWB;                             // [9 NCB][1024]
+    float* fab = (float*)(wl + 9 * NCB * 1024);                  // [C][2]: a, b of y = a x + b
+    float* gstat = fab + 2 * C;                                  // [groups][2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, x0 = blockIdx.x * 32;
+    const int band = (p.H + gridDim.z - 1) / gridDim.z, y0 = blockIdx.z * band, y1 = min(p.H, y0 + band);
+    // ---- one-time: weights, normalisation table
+    for (int i = tid; i < 9 * NCB * 64; i += 512) *(uint4*)(wl + i * 16) = *(const uint4*)((const char*)p.wp + (size_t)i * 16);
+    if (p.partial) {
+        const int cg = C / p.groups;
+        if (tid < p.groups) {
+            double a = 0.0, q = 0.0;
+            const float* pp = p.partial + ((long long)b * p.nchunk * p.groups + tid) * 2;
+            for (int k = 0; k < p.nchunk; k++) { a += pp[(long long)k * p.groups * 2]; q += pp[(long long)k * p.groups * 2 + 1]; }
+            const double n = (double)cg * p.H * p.W, mean = a / n;
+            double var = q / n - mean * mean;
+            if (var < 0) var = 0;
+            gstat[tid * 2] = (float)mean; gstat[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += 512) {
+            const int g = c / cg;
+            const float fa = gstat[g * 2 + 1] * p.gamma[c];
+            fab[2 * c] = fa; fab[2 * c + 1] = p.beta[c] - gstat[g * 2] * fa;
+        }
+    }
+    __syncthreads();
+    // ---- row staging: rows come in pairs; a thread's pieces of a pair are requested together and committed later.  A thread's NPC
+    // pieces sit at the same (row of the pair, pixel, channel piece) in every pair: located once.
+    const int ppx = C >> 3, per_pair = 2 * HC_PX * ppx;          // 16-byte pieces per pixel / per row pair
+    constexpr int NPC = 8;                                       // pieces per thread and pair (C <= 240)
+    int pr[NPC], ploff[NPC], ppc[NPC]; long long pgoff[NPC];     // row in the pair (or -1: no such piece / outside the image in x), LDS and global offsets
+    // waves 4-7 stage rows (loads, normalisation, LDS writes), waves 0-3 run the MFMAs: the two phases overlap instead of alternating
+    const bool stager = w >= 4;
+    const int stid = tid & 255;
+#pragma unroll
+    for (int u = 0; u < NPC; u++) {
+        const int i = u * 256 + stid;
+        const int ic = min(i, per_pair - 1);
+        const int r = ic / (HC_PX * ppx), rem = ic - r * (HC_PX * ppx), px = rem / ppx, pc = rem - px * ppx;
+        const int xx = x0 - 1 + px;
+        pr[u] = i < per_pair ? (xx >= 0 && xx < p.W ? r : 2 + r) : -1;          // 2 + r: a column outside the image (stored as zero)
+        ploff[u] = px * PS + pc * 16; ppc[u] = pc * 8;
+        pgoff[u] = (long long)xx * C + pc * 8;
+    }
+    struct Pair { uint4 v[NPC]; };
+    const bf16_t* xb = p.x + (long long)b * p.H * p.W * C;
+    auto request = [&](Pair& t, int ya) {                        // image rows ya, ya + 1 (anything outside the image is zero)
+#pragma unroll
+        for (int u = 0; u < NPC; u++) {
+            const int y = ya + (pr[u] & 1);
+            const bool in = pr[u] >= 0 && pr[u] < 2 && y >= 0 && y < p.H;
+            t.v[u] = in ? *(const uint4*)(xb + (long long)y * p.W * C + pgoff[u]) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto commit = [&](const Pair& t, int ya) {
+#pragma unroll
+        for (int u = 0; u < NPC; u++) {
+            if (pr[u] < 0) continue;
+            const int y = ya + (pr[u] & 1);
+            uint4 o = t.v[u];
+            if (p.partial && pr[u] < 2 && y >= 0 && y < p.H) {
+                const uint32_t in[4] = {o.x, o.y, o.z, o.w};
+                uint32_t ov[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const f32x4 ab = *(const f32x4*)(fab + 2 * (ppc[u] + 2 * e));            // a0 b0 a1 b1
+                    const float v0 = silu_f(__uint_as_float(in[e] << 16) * ab[0] + ab[1]);
+                    const float v1 = silu_f(__uint_as_float(in[e] & 0xffff0000u) * ab[2] + ab[3]);
+                    ov[e] = cvt_pk_bf16(v0, v1);
+                }
+                o = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+            }
+            const int slot = (y + HC_RING) % HC_RING;
+            *(uint4*)(ring + slot * ROWB + ploff[u]) = o;
+        }
+    };
+    Pair pa, pb;
+    if (stager) {
+        request(pa, y0 - 1); request(pb, y0 + 1);
+        commit(pa, y0 - 1); commit(pb, y0 + 1);
+    }
+    __syncthreads();
+    // ---- two output rows per round: wave w -> row ya + (w >> 1), 16-pixel tile w & 1.  Rows are requested TWO rounds ahead (one round
+    // of MFMAs does not cover an HBM round trip with four waves on the CU) and committed one round ahead.
+    const int m = lane & 15, kg = lane >> 4, tx = w & 1;
+    const int aoff = (1 + tx * 16 + m) * PS + kg * 16;           // this lane's pixel (centre tap) inside a ring row
+    const char* bl = wl + lane * 16;
+    auto compute = [&](int ya) {
+        const int yo = ya + (w >> 1);
+        if (yo >= y1) return;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};       // two chains: consecutive MFMAs do not wait on each other
+        const char* rowp[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) rowp[d] = ring + ((yo + d - 1 + HC_RING) % HC_RING) * ROWB + aoff;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const char* ar = rowp[tap / 3] + (tap % 3 - 1) * PS;
+            const char* br = bl + tap * NCB * 1024;
+            int cb = 0;
+            for (; cb + 2 <= NCB; cb += 2) {
+                const bf16x8 a0 = *(const bf16x8*)(ar + cb * 64), a1 = *(const bf16x8*)(ar + cb * 64 + 64);
+                const bf16x8 b0 = *(const bf16x8*)(br + cb * 1024), b1 = *(const bf16x8*)(br + cb * 1024 + 1024);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc1, 0, 0, 0);
+            }
+            if (cb < NCB) {
+                const bf16x8 a0 = *(const bf16x8*)(ar + cb * 64);
+                const bf16x8 b0 = *(const bf16x8*)(br + cb * 1024);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc0, 0, 0, 0);
+            }
+        }
+        const f32x4 acc = acc0 + acc1;
+        // lane (n = lane & 15, rows 4 kg + i): channel n's high-part sum; the low-part sum sits in lane + Cout
+        f32x4 lo;
+#pragma unroll
+        for (int i = 0; i < 4; i++) lo[i] = __shfl(acc[i], lane + p.Cout);
+        if (m < p.Cout) {
+            const float bs = p.bias ? p.bias[m] : 0.f;
+            f32x4 o = {acc[0] + lo[0] + bs, acc[1] + lo[1] + bs, acc[2] + lo[2] + bs, acc[3] + lo[3] + bs};
+            *(f32x4*)(p.out + (((long long)b * p.Cout + m) * p.H + yo) * p.W + x0 + tx * 16 + 4 * kg) = o;
+        }
+    };
+    if (stager && y0 + 2 < y1) request(pa, y0 + 3);
+    for (int ya = y0; ya < y1; ya += 4) {
+        if (stager) {
+            if (ya + 4 < y1) request(pb, ya + 5);
+            if (ya + 2 < y1) commit(pa, ya + 3);
+        } else compute(ya);
+        __syncthreads();
+        if (ya + 2 < y1) {
+            if (stager) {
+                if (ya + 6 < y1) request(pa, ya + 7);
+                if (ya + 4 < y1) commit(pb, ya + 5);
+            } else compute(ya + 2);
+            __syncthreads();
+        }
+    }
+}
+
+bool head_conv_supported(const HeadParams& p) {
+    return p.C % 32 == 0 && p.C >= 32 && p.C <= 240 && p.W % 32 == 0 && p.H % 2 == 0 && p.Cout >= 1 && p.Cout <= 8 &&
+           (!p.partial || (p.groups > 0 && p.groups <= 64 && p.C % p.groups == 0));
+}
+hipError_t launch_head_conv(const HeadParams& p, hipStream_t st) {
+    if (!head_conv_supported(p) || !p.x || !p.w || !p.wp || !p.out) return hipErrorInvalidValue;
+    const size_t smem = (size_t)HC_RING * HC_PX * (2 * p.C + 16) + head_conv_wp_bytes(p.C) + (size_t)p.C * 8 + 64 * 8;
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    static bool attr[RDM_MAX_DEVICES] = {};
+    const int dev = rdm_cur_device();
+    if (!attr[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)head_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr[dev] = true;
+    }
+    head_conv_pack_kernel<<<(9 * (p.C / 32) * 512 + 255) / 256, 256, 0, st>>>(p.w, p.wp, p.C, p.Cout);
+    // bands: enough blocks for the chip when the batch is small (a band re-reads one halo row above and below)
+    const int pairs = (p.W / 32) * p.B;
+    int bands = (512 + pairs - 1) / pairs; if (bands > p.H / 8) bands = p.H / 8; if (bands < 1) bands = 1;
+    int band = (p.H + bands - 1) / bands; band += band & 1;          // even band heights: rows are walked in pairs
+    bands = (p.H + band - 1) / band;
+    head_conv_kernel<<<dim3(p.W / 32, p.B, bands), 512, smem, st>>>(p);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ timestep embedding
 // ldm timestep_embedding: [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(1e4) * i / half). bf16 out.
 __global__ void timestep_embedding_kernel(const long long* t, bf16_t* out, int B, int dim, int ld) {

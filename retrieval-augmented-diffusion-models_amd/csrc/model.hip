@@ -574,6 +574,27 @@ struct Ops {
         check(launch_groupnorm(p, c->stream), "groupnorm");
         prof_end();
     }
+    // GroupNorm + SiLU + 3x3 conv to a few channels (UNet `out`, VQ decoder conv_out): one statistics pass + the fused MFMA head kernel
+    // (misc.hip), or GroupNorm-apply into `tmp` + the VALU head conv where the fused kernel does not apply
+    void head(const bf16_t* x, int B, int H, int W, int C, int Clog, size_t g, size_t b, float eps, size_t woff, size_t boff, int Cout,
+              float* out, bf16_t* tmp, bf16_t* wp) {
+        if (plan) return;
+        static const int off = getenv("RDM_NO_HEADFUSE") ? atoi(getenv("RDM_NO_HEADFUSE")) : 0;
+        HeadParams hp{}; hp.x = x; hp.B = B; hp.H = H; hp.W = W; hp.C = C; hp.groups = 32; hp.gamma = w<float>(g); hp.beta = w<float>(b); hp.eps = eps;
+        hp.w = w<float>(woff); hp.wp = wp; hp.bias = w<float>(boff); hp.out = out; hp.Cout = Cout;
+        int nchunk = H * W / 64; if (nchunk < 1) nchunk = 1; if (nchunk > 32) nchunk = 32;
+        hp.partial = c->gn_partial; hp.nchunk = nchunk;
+        if (!off && Clog == C && head_conv_supported(hp)) {
+            GnParams p{}; p.x0 = x; p.C0 = C; p.HW = H * W; p.B = B; p.groups = 32; p.L0 = C; p.nchunk = nchunk; p.partial = c->gn_partial;
+            prof_begin(RDM_PROF_GROUPNORM, (double)B * H * W * C * 2.0);
+            check(launch_gn_stats(p, c->stream), "head groupnorm statistics");
+            prof_end();
+            check(launch_head_conv(hp, c->stream), "head conv");
+            return;
+        }
+        groupnorm(x, nullptr, C, 0, B, H * W, g, b, eps, 1, tmp, Clog, 0);
+        check(launch_conv_out(tmp, w<float>(woff), w<float>(boff), out, B, H, W, C, Cout, c->stream), "conv_out");
+    }
     void layernorm(const void* x, int in_f32, size_t g, size_t b, void* out, int out_f32, int M, int C, int Clog = -1) {
         if (plan) return;
         prof_begin(RDM_PROF_LAYERNORM, (double)M * C * ((in_f32 ? 4.0 : 2.0) + (out_f32 ? 4.0 : 2.0)));
@@ -849,8 +870,8 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
     }
     if (B < Bfull) { expand(h); B = Bfull; }          // (a UNet without attention: the whole network was shared)
     bf16_t* no = o.abf((size_t)B * H * W * mc);
-    o.groupnorm(h.p, nullptr, mc, 0, B, H * W, u.outg, u.outb, 1e-5f, 1, no, mcl, 0);
-    if (!o.plan) o.check(launch_conv_out(no, o.w<float>(u.outw), o.w<float>(u.outbias), eps_out, B, H, W, mc, c.out_channels, o.c->stream), "conv_out");
+    bf16_t* hwp = o.abf(head_conv_wp_bytes(mc) / 2);
+    o.head(h.p, B, H, W, mc, mcl, u.outg, u.outb, 1e-5f, u.outw, u.outbias, c.out_channels, eps_out, no, hwp);
 }
 
 // plan (count bytes) -> ensure arena -> run
@@ -956,8 +977,8 @@ static void vq_trunk(Ops& o, VqModel& v, bf16_t* h, int B, int H, int W, float* 
         }
     }
     bf16_t* no = o.abf((size_t)B * H * W * bin);
-    o.groupnorm(h, nullptr, bin, 0, B, H * W, v.noutg, v.noutb, 1e-6f, 1, no);
-    if (!o.plan) o.check(launch_conv_out(no, o.w<float>(v.coutw), o.w<float>(v.coutb), img, B, H, W, bin, c.out_ch, o.c->stream), "vq conv_out");
+    bf16_t* hwp = o.abf(head_conv_wp_bytes(bin) / 2);
+    o.head(h, B, H, W, bin, bin, v.noutg, v.noutb, 1e-6f, v.coutw, v.coutb, c.out_ch, img, no, hwp);
 }
 
 // VQ-f4 (3-channel latent): quantise (or not) + post_quant_conv + conv_in as tiny fp32 stem kernels, then the trunk
@@ -1871,6 +1892,25 @@ int rdm_op_xattn_fused(rdm_ctx* c, const void* x, const float* ln_gamma, const f
     RDM_CHECK_HIP(c, launch_xattn_pack(q.G, q.U, Gp, Up, B, NP, C, c->stream));
     q.G = Gp; q.U = Up;
     RDM_CHECK_HIP(c, launch_xattn_fused(q, c->stream));
+    return 0;
+}
+int rdm_op_head_conv(rdm_ctx* c, const void* x, const float* gn_gamma, const float* gn_beta, float gn_eps, const float* w, const float* bias,
+                     int B, int H, int W, int C, int Cout, float* out) {
+    RDM_ENTER(c);
+    if (!c) return -1;
+    HeadParams hp{}; hp.x = (const bf16_t*)x; hp.B = B; hp.H = H; hp.W = W; hp.C = C; hp.groups = 32; hp.gamma = gn_gamma; hp.beta = gn_beta; hp.eps = gn_eps;
+    hp.w = w; hp.bias = bias; hp.out = out; hp.Cout = Cout;
+    if ((gn_gamma != nullptr) != (gn_beta != nullptr)) return c->fail(-3, "rdm_op_head_conv: GroupNorm needs gamma and beta");
+    int nchunk = H * W / 64; if (nchunk < 1) nchunk = 1; if (nchunk > 32) nchunk = 32;
+    if (gn_gamma) { RDM_TRY(ensure_gn_partial(c, B)); hp.partial = c->gn_partial; hp.nchunk = nchunk; }
+    if (!head_conv_supported(hp)) return c->fail(-3, "rdm_op_head_conv: unsupported shape (C %% 32, C <= 240, W %% 32, H %% 2, Cout <= 8, C %% 32 groups): C %d H %d W %d Cout %d", C, H, W, Cout);
+    RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, head_conv_wp_bytes(C)));
+    hp.wp = (bf16_t*)c->bwd_tmp;
+    if (gn_gamma) {
+        GnParams p{}; p.x0 = hp.x; p.C0 = C; p.HW = H * W; p.B = B; p.groups = 32; p.L0 = C; p.nchunk = nchunk; p.partial = c->gn_partial;
+        RDM_CHECK_HIP(c, launch_gn_stats(p, c->stream));
+    }
+    RDM_CHECK_HIP(c, launch_head_conv(hp, c->stream));
     return 0;
 }
 int rdm_op_small_attention(rdm_ctx* c, const void* q, int ldq, const void* k, const void* v, int ldkv, int B, int nq, int nkv,

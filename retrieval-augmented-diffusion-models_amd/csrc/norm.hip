@@ -143,7 +143,7 @@ __global__ void gn_apply_kernel(GnParams p) {
     }
 }
 
-hipError_t launch_groupnorm(GnParams p, hipStream_t st) {
+static hipError_t gn_geometry(GnParams& p, int& R, int& threads) {
     const int C = p.C0 + p.C1;
     if (p.L0 <= 0) p.L0 = p.C0;
     if (p.L1 <= 0) p.L1 = p.C1;
@@ -151,11 +151,23 @@ hipError_t launch_groupnorm(GnParams p, hipStream_t st) {
     if (C % 8 || p.groups > 64 || (p.C0 % 8) || (p.C1 % 8)) return hipErrorInvalidValue;
     const int VC = C / 8;
     if (VC > 1024) return hipErrorInvalidValue;
-    int R = 256 / VC; if (R < 1) R = 1;
-    const int threads = ((VC * R + 63) / 64) * 64;
-    const size_t sm1 = (size_t)(R + 1) * C * 2 * sizeof(float);
+    R = 256 / VC; if (R < 1) R = 1;
+    threads = ((VC * R + 63) / 64) * 64;
+    return hipSuccess;
+}
+hipError_t launch_gn_stats(GnParams p, hipStream_t st) {
+    int R, threads;
+    hipError_t e = gn_geometry(p, R, threads);
+    if (e != hipSuccess) return e;
+    const size_t sm1 = (size_t)(R + 1) * (p.C0 + p.C1) * 2 * sizeof(float);
     gn_stats_kernel<<<dim3(p.nchunk, p.B), threads, sm1, st>>>(p);
-    hipError_t e = hipGetLastError();
+    return hipGetLastError();
+}
+hipError_t launch_groupnorm(GnParams p, hipStream_t st) {
+    int R, threads;
+    hipError_t e = gn_geometry(p, R, threads);
+    if (e != hipSuccess) return e;
+    e = launch_gn_stats(p, st);
     if (e != hipSuccess) return e;
     // apply: ~64 rows per thread-row, at least ~2k blocks across the batch
     int nblk = (p.HW + 64 * R - 1) / (64 * R);

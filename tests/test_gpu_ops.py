@@ -240,6 +240,23 @@ def test_flash_self_attention(ctx, B, n, heads):
         assert torch.equal(out2, out), "token-major-V flash kernel differs from the V^T one"
 
 
+@pytest.mark.parametrize("B,H,W,C,Cout,norm", [(2, 64, 64, 192, 3, True), (1, 32, 96, 128, 3, True), (3, 16, 32, 64, 4, False), (2, 34, 64, 224, 3, True),
+                                               (70, 8, 32, 32, 1, True)])
+def test_head_conv(ctx, B, H, W, C, Cout, norm):
+    """GroupNorm + SiLU + 3x3 head conv in one kernel against fp32 torch (activations rounded to bf16 after the norm, as the two-kernel
+    form rounds them; weights fp32: the kernel carries them as bf16 high + low parts)."""
+    d = ctx.device
+    x = bf16_round(_rand((B, H, W, C), 50) * 1.3 + 0.2)
+    w = _rand((Cout, C, 3, 3), 51) / (3 * C ** 0.5)
+    bias = _rand((Cout,), 52)
+    g, be = 1 + 0.1 * _rand((C,), 53), 0.1 * _rand((C,), 54)
+    xc = x.permute(0, 3, 1, 2)
+    act = bf16_round(F.silu(F.group_norm(xc, 32, g, be, 1e-5))) if norm else xc
+    ref = F.conv2d(act, w, bias, padding=1)
+    out = ctx.op_head_conv(x.to(d, torch.bfloat16), w.to(d), bias.to(d), gn=(g.to(d), be.to(d), 1e-5) if norm else None)
+    _close(out, ref, tol=2e-3, what="head conv")
+
+
 @pytest.mark.parametrize("B,n,heads,k", [(3, 1024, 12, 4), (2, 256, 18, 4), (4, 64, 30, 4), (2, 64, 4, 2), (2, 32, 2, 1), (2, 96, 6, 4),
                                         (8, 64, 4, 4), (16, 256, 2, 2)])       # the last two: block counts that take the XCD-aware block order
 def test_xattn_fused(ctx, B, n, heads, k):
