@@ -84,6 +84,17 @@ struct RarmAttnParams {
     const int* pos;                           // device step counter (self-attention attends rows 0..*pos)
     float scale; bf16_t* out; int ldo;
 };
+// decode-step cross-attention over the k neighbours with the per-sequence operands re-associated once per sampling call (as the UNet's
+// xattn kernels): x += softmax_heads(LN(x) G_b^T) UT_b + bias for sequences b < Bc; x += bias for the others (zero neighbours)
+struct RarmXattnParams {
+    float* x;                                  // [B2][C] fp32 residual stream, updated in place
+    const float* ln_g; const float* ln_b; float ln_eps;
+    const bf16_t* G; const bf16_t* UT;         // [Bc][NP][C] each: G row h*k + j = scale * (key j restricted to head h) W_q;  UT row h*k + j = W_o (value j restricted to head h)
+    const float* bias;                         // [C]
+    int B2, Bc, C, NP, heads, k;
+};
+hipError_t launch_rarm_xattn_decode(const RarmXattnParams& p, hipStream_t st);
+
 struct RarmSampleParams {
     const float* logits; int vocab; int B; int cfg; float scale, temperature; int top_k;
     const float* uniforms;                    // [steps][B], row = *pos - pos0

@@ -381,6 +381,8 @@ struct RarmModel {
     char* cache = nullptr; size_t cache_bytes = 0;
     char* ctxkv = nullptr; size_t ctxkv_bytes = 0;
     char* state = nullptr; size_t state_bytes = 0;
+    // decode-step cross-attention operands per layer (rarm_prepare): [depth][2][Bc][128][C] bf16 (G, UT), valid for xa_B conditional sequences and xa_k neighbours
+    char* xa = nullptr; size_t xa_bytes = 0; int xa_B = 0, xa_k = 0;
 };
 static void build_rarm(RarmModel& m, const rdm_rarm_cfg& c, Manifest& mf) {
     m.cfg = c; m.blk.clear(); m.C = c.n_heads * c.d_head;
@@ -1098,7 +1100,7 @@ void rdm_ctx_destroy(rdm_ctx* c) {
     hipDeviceSynchronize();
     void* ptrs[] = {c->zero_page, c->unet.blob, c->unet.arena.base, c->unet.kv_cache, c->vq.blob, c->vq.arena.base,
                     c->clip.blob, c->clip.arena.base, c->gn_partial, c->samp, c->splitk_ws, c->unet.xa_cache,
-                    c->rarm.blob, c->rarm.arena.base, c->rarm.cache, c->rarm.ctxkv, c->rarm.state, c->wfrag_tmp, c->bwd_tmp};
+                    c->rarm.blob, c->rarm.arena.base, c->rarm.cache, c->rarm.ctxkv, c->rarm.state, c->rarm.xa, c->wfrag_tmp, c->bwd_tmp};
     for (void* p : ptrs) if (p) hipFree(p);
     c->drop_frags();
     knn_free(c->db);
@@ -1396,10 +1398,39 @@ static int rarm_prepare(rdm_ctx* c, int B2, int k, const float* context /*[B,k,c
     // neighbours' keys / values of every layer in one GEMM; the unconditional half of a guided batch attends to ZERO neighbours
     // (transformer.py:237-239), whose projections are zero (to_k / to_v have no bias)
     RDM_CHECK_HIP(c, hipMemsetAsync(m.ctxkv, 0, (size_t)B2 * k * m.kv_total * 2, c->stream));
+    static const int no_xf = getenv("RDM_NO_RARM_XFUSED") ? atoi(getenv("RDM_NO_RARM_XFUSED")) : 0;
+    const bool fuse = !no_xf && g.n_heads * k <= 128 && C <= 1024 && C % 64 == 0;
+    m.xa_B = 0; m.xa_k = 0;
+    if (fuse) {
+        RDM_TRY(ensure_bytes(c, &m.xa, &m.xa_bytes, (size_t)g.depth * 2 * B * 128 * C * 2));
+        m.xa_B = B; m.xa_k = k;
+    }
     return run_with_arena(c, m.arena, m.blob, [&](Ops& o) {
         bf16_t* cb = o.abf((size_t)B * k * g.context_dim);
         if (!o.plan) o.check(launch_cast_f32_bf16(context, cb, (long long)B * k * g.context_dim, c->stream), "cast ctx");
         o.linear(cb, nullptr, g.context_dim, 0, m.kvw, 0, false, B * k, m.kv_total, ACT_NONE, nullptr, (bf16_t*)m.ctxkv);
+        // the decode step's cross-attention re-associated per sequence (rarm.hip: rarm_xattn_decode_kernel):
+        //   G_l[b][(h,j)][:] = (K_bj restricted to head h) W_q / sqrt(d),   UT_l[b][(h,j)][:] = W_o (V_bj restricted to head h)
+        if (fuse) {
+            constexpr int NP = 128;
+            bf16_t* kexp = o.abf((size_t)B * NP * C); bf16_t* vexp = o.abf((size_t)B * NP * C); bf16_t* wqt = o.abf((size_t)C * C);
+            if (!o.plan) {
+                const bf16_t* kv = (const bf16_t*)m.ctxkv;
+                for (int l = 0; l < g.depth; l++) {
+                    const RarmBlk& bk = m.blk[l];
+                    bf16_t* G = (bf16_t*)m.xa + ((size_t)l * 2) * B * NP * C; bf16_t* UT = G + (size_t)B * NP * C;
+                    o.check(launch_expand_heads(kv + (size_t)l * 2 * C, m.kv_total, B, k, g.n_heads, g.d_head, NP, 1.0f / sqrtf((float)g.d_head), kexp, c->stream), "rarm expand K");
+                    o.check(launch_expand_heads(kv + (size_t)l * 2 * C + C, m.kv_total, B, k, g.n_heads, g.d_head, NP, 1.0f, vexp, c->stream), "rarm expand V");
+                    o.check(launch_transpose_bf16(o.w<bf16_t>(bk.wq2), wqt, C, C, c->stream), "rarm transpose Wq");
+                    IgemmParams p = o.base(B * NP, C, C);
+                    p.A0 = kexp; p.C0 = C; p.W = wqt; p.out_bf16 = G;
+                    o.check(launch_igemm(p, false, 1, c->stream), "rarm xattn G");
+                    IgemmParams q = o.base(B * NP, C, C);
+                    q.A0 = vexp; q.C0 = C; q.W = o.w<bf16_t>(bk.wo2); q.out_bf16 = UT;
+                    o.check(launch_igemm(q, false, 1, c->stream), "rarm xattn UT");
+                }
+            }
+        }
     });
 }
 // one decode step for B2 sequences: token at position *pos -> logits of the next token
@@ -1426,6 +1457,14 @@ static int rarm_step(rdm_ctx* c, int B2, int k) {
                 o.check(launch_rarm_decode_attention(p, g.n_heads, B2, c->stream), "rarm self attention");
             }
             o.linear(ao, nullptr, C, 0, b.wo1, b.bo1, true, B2, C, ACT_NONE, nullptr, nullptr, x, x);
+            if (m.xa_B > 0 && m.xa_k == k) {      // norm2 + to_q + attention over the neighbours + to_out + residual in one launch
+                if (!o.plan) {
+                    RarmXattnParams xp{}; xp.x = x; xp.ln_g = o.w<float>(b.ln2g); xp.ln_b = o.w<float>(b.ln2b); xp.ln_eps = 1e-5f;
+                    xp.G = (const bf16_t*)m.xa + ((size_t)l * 2) * m.xa_B * 128 * C; xp.UT = xp.G + (size_t)m.xa_B * 128 * C;
+                    xp.bias = o.w<float>(b.bo2); xp.B2 = B2; xp.Bc = m.xa_B; xp.C = C; xp.NP = 128; xp.heads = g.n_heads; xp.k = k;
+                    o.check(launch_rarm_xattn_decode(xp, c->stream), "rarm fused cross attention");
+                }
+            } else {
             if (!o.linear_ln(x, b.ln2g, b.ln2b, C, b.wq2, 0, false, B2, C, ACT_NONE, q2)) {
                 o.layernorm(x, 1, b.ln2g, b.ln2b, ln, 0, B2, C);
                 o.linear(ln, nullptr, C, 0, b.wq2, 0, false, B2, C, ACT_NONE, nullptr, q2);
@@ -1436,6 +1475,7 @@ static int rarm_step(rdm_ctx* c, int B2, int k) {
                 o.check(launch_rarm_decode_attention(p, g.n_heads, B2, c->stream), "rarm cross attention");
             }
             o.linear(ao, nullptr, C, 0, b.wo2, b.bo2, true, B2, C, ACT_NONE, nullptr, nullptr, x, x);
+            }
             if (!o.linear_ln(x, b.ln3g, b.ln3b, C, b.wff1, b.bff1, true, B2, 8 * C, ACT_GEGLU, ff)) {
                 o.layernorm(x, 1, b.ln3g, b.ln3b, ln, 0, B2, C);
                 o.linear(ln, nullptr, C, 0, b.wff1, b.bff1, true, B2, 8 * C, ACT_GEGLU, nullptr, ff);

@@ -123,6 +123,128 @@ hipError_t launch_rarm_decode_attention(const RarmAttnParams& p, int heads, int 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- decode-step cross-attention, one launch
+// norm2 + to_q + attention over the k neighbours + to_out + residual (RetrievalPatchTransformer block, rdm/modules/attention.py:238)
+// for ONE new token per sequence.  With the neighbours fixed for the whole sampling call, softmax(q K^T / sqrt d) V W_o^T is
+// re-associated per sequence (model.hip: rarm_prepare): scores = LN(x) G_b^T, out = P UT_b -- two matrix-vector products against 2 x
+// heads*k x C bf16 per sequence instead of two C x C projections and an attention launch (3 launches of ~9 us each, all latency).
+// One block per sequence: LayerNorm by block reduction (two-pass, rounded to bf16 as the GEMM operand was), a wave per group of
+// score rows (coalesced 16-byte pieces, wave reduction), per-head softmax, then 4 output channels per thread over the heads*k rows.
+__global__ __launch_bounds__(1024) void rarm_xattn_decode_kernel(RarmXattnParams p) {
+    // 16 waves per sequence: the two matrix-vector products are one batch of loads each (every row of G / UT a thread needs is
+    // requested before the first one is used) -- with 4 waves and batches of 4 - 8 rows the kernel was 15 dependent HBM round trips
+    __shared__ float xn[1024];            // LayerNorm(x), C <= 1024
+    __shared__ float sc[128];             // scores -> probabilities
+    __shared__ float red[32];
+    __shared__ __attribute__((aligned(16))) float part[4 * 1024];        // output partials [row group][C]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, C = p.C;
+    float* xr = p.x + (long long)b * C;
+    if (b >= p.Bc) {                      // zero neighbours: K = V = 0 -> the attention output is 0, to_out leaves its bias
+        if (tid < C) xr[tid] += p.bias[tid];
+        return;
+    }
+    // ---- LayerNorm (one channel per thread)
+    const float v = tid < C ? xr[tid] : 0.f;
+    float s = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) tot += red[i];
+    const float mean = tot / C;
+    const float d = tid < C ? v - mean : 0.f;
+    float q = d * d;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) red[16 + w] = q;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) tot += red[16 + i];
+    const float rstd = rsqrtf(tot / C + p.ln_eps);
+    if (tid < C) xn[tid] = bf2f(f2bf(d * rstd * p.ln_g[tid] + p.ln_b[tid]));
+    __syncthreads();
+    // ---- scores: wave w takes rows w, w + 16, ... (<= 8 rows); a row = C/8 16-byte pieces over the lanes (two rounds)
+    const int nrow = p.heads * p.k, npc = C >> 3;
+    const bf16_t* Gb = p.G + (long long)b * p.NP * C;
+    {
+        bf16x8 g[8][2];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = w + 16 * u;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int pc = lane + 64 * h;
+                g[u][h] = (j < nrow && pc < npc) ? *(const bf16x8*)(Gb + (long long)j * C + pc * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = w + 16 * u;
+            float a = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int pc = lane + 64 * h;
+                if (pc < npc) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) a += bf2f((bf16_t)g[u][h][e]) * xn[pc * 8 + e];
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            if (lane == 0 && j < nrow) sc[j] = a;
+        }
+    }
+    __syncthreads();
+    // ---- softmax over each head's k columns
+    float pr = 0.f;
+    if (tid < nrow) {
+        const int h0 = (tid / p.k) * p.k;
+        float m = -INFINITY;
+        for (int i = 0; i < p.k; i++) m = fmaxf(m, sc[h0 + i]);
+        float sum = 0.f;
+        for (int i = 0; i < p.k; i++) sum += __expf(sc[h0 + i] - m);
+        pr = __expf(sc[tid] - m) / sum;
+    }
+    __syncthreads();
+    if (tid < nrow) sc[tid] = pr;
+    __syncthreads();
+    // ---- output: thread = (4 channels, row group); NG = 4 row groups, each thread <= 32 rows, all requested at once
+    const bf16_t* Ub = p.UT + (long long)b * p.NP * C;
+    const int nc4 = C >> 2, c4 = tid % nc4, jg = tid / nc4;      // nc4 <= 256 -> at least 4 groups among the 1024 threads
+    if (jg < 4) {
+        uint2 u[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) { const int j = jg + 4 * i; u[i] = j < nrow ? *(const uint2*)(Ub + (long long)j * C + c4 * 4) : make_uint2(0u, 0u); }
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int j = jg + 4 * i;
+            const float pj = j < nrow ? sc[j] : 0.f;
+            a0 += pj * __uint_as_float(u[i].x << 16); a1 += pj * __uint_as_float(u[i].x & 0xffff0000u);
+            a2 += pj * __uint_as_float(u[i].y << 16); a3 += pj * __uint_as_float(u[i].y & 0xffff0000u);
+        }
+        *(float4*)(part + jg * 1024 + c4 * 4) = make_float4(a0, a1, a2, a3);
+    }
+    __syncthreads();
+    if (tid < nc4) {
+        float4 xo = *(float4*)(xr + tid * 4);
+        const float4 bb = *(const float4*)(p.bias + tid * 4);
+        float4 acc = bb;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) { const float4 t = *(const float4*)(part + g4 * 1024 + tid * 4); acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+        xo.x += acc.x; xo.y += acc.y; xo.z += acc.z; xo.w += acc.w;
+        *(float4*)(xr + tid * 4) = xo;
+    }
+}
+hipError_t launch_rarm_xattn_decode(const RarmXattnParams& p, hipStream_t st) {
+    if (p.C % 8 || p.C > 1024 || p.heads * p.k > 128 || p.heads * p.k > p.NP || p.k < 1) return hipErrorInvalidValue;
+    rarm_xattn_decode_kernel<<<p.B2, 1024, 0, st>>>(p);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- CFG + temperature + top-k filter + softmax + multinomial
 // transformer.py:250-270.  One block per sequence: logits = l_u + s (l_c - l_u) (rows b and b + B of the doubled batch),
 // / temperature, values below the k-th largest -> -inf (taming top_k_logits keeps ties with the k-th), softmax, then ONE draw by
