@@ -11,6 +11,7 @@ struct GnParams {
     const float* gamma; const float* beta;
     float eps; int silu;
     bf16_t* out;                          // [B, HW, C0+C1]
+    int x1_bmod;                          // > 0: x1 holds only x1_bmod samples and sample b reads b % x1_bmod (a shared-prefix skip tensor whose second half was never materialised)
 };
 
 hipError_t launch_gn_stats(GnParams p, hipStream_t st);          // the statistics pass alone (p.partial), for consumers that apply the norm themselves

@@ -59,10 +59,11 @@ __device__ __forceinline__ unsigned long long l4_uni64(unsigned long long v) {  
     return ((unsigned long long)hi << 32) | lo;
 }
 __device__ __forceinline__ ASrc l4_asrc(bool dead, int row0, int kc, int C0, const char* A0p, const char* A1p, unsigned ld0, unsigned ld1,
-                                        const char* zero, unsigned voffA0, unsigned voffA1, unsigned lane16) {
+                                        const char* zero, unsigned voffA0, unsigned voffA1, unsigned lane16, int wrap1) {
     ASrc s;
     const bool second = kc >= C0;
     const unsigned ld = second ? ld1 : ld0;
+    if (second && row0 >= wrap1) row0 -= wrap1;             // second source holds wrap1 rows only (IgemmParams::a1_wrap_rows; at most two copies)
     const char* b = (second ? A1p : A0p) + (unsigned long long)row0 * ld + (unsigned)((second ? kc - C0 : kc) * 2);
     s.base = (const char*)l4_uni64((unsigned long long)(dead ? zero : b));
     s.pstride = (unsigned)__builtin_amdgcn_readfirstlane((int)(dead ? 0u : 32u * ld));
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
     const char* const zero = (const char*)p.zero_page;
     const char* const Wf = (const char*)p.Wfrag;
     const unsigned ld0 = (unsigned)(p.lda > 0 ? p.lda : p.C0) * 2u, ld1 = (unsigned)p.C1 * 2u;     // row strides in bytes
+    const int wrap1 = p.a1_wrap_rows > 0 ? p.a1_wrap_rows : 0x7fffffff;
 
     // ---- per-lane constants
     unsigned vbase[FM];                                         // LDS offset of row `frow` of A fragment i, k-step 0, buffer 0
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
         return (const char*)l4_uni64((unsigned long long)(Wf + off));
     };
     auto a_src = [&](const Cur& c) __attribute__((always_inline)) {
-        return l4_asrc(VAR == 1 || c.tile >= t_end, c.bm * BM, c.sl * BK, C0, A0p, A1p, ld0, ld1, zero, voffA0, voffA1, lane16);
+        return l4_asrc(VAR == 1 || c.tile >= t_end, c.bm * BM, c.sl * BK, C0, A0p, A1p, ld0, ld1, zero, voffA0, voffA1, lane16, wrap1);
     };
 
     asm volatile("" ::: H4_ACC_CLOBBERS);                    // the kernel descriptor must allocate the accumulator AGPRs
@@ -438,6 +440,7 @@ bool lin4_supported(const IgemmParams& p, int batch) {
     const int No = geglu ? p.N / 2 : p.N;
     if (p.N > 8192 || p.ldo % 8 || p.ldo < No || (p.ldw > 0 && p.ldw != p.K)) return false;
     if (p.C1 > 0 && p.lda > 0) return false;
+    if (p.a1_wrap_rows > 0 && (p.C1 == 0 || p.a1_wrap_rows % (128 * wm) != 0 || 2LL * p.a1_wrap_rows < p.M)) return false;     // whole tiles, at most two copies
     static const int min_tiles = getenv("RDM_L4_MIN_TILES") ? atoi(getenv("RDM_L4_MIN_TILES")) : 128;
     if (!p.l4_any_tiles && (long long)(p.M / (128 * wm)) * (p.N / (wm == 1 ? 384 : 192)) < min_tiles) return false;     // far fewer tiles than CUs: the 128-row tiles of igemm.hip (160 tiles -- the 8x8-level projections -- still win here: 28 vs 32 us)
     return true;

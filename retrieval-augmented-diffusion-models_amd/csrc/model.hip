@@ -487,8 +487,15 @@ struct Ops {
         p.Hin = p.Win = p.Hout = p.Wout = 1; p.stride = 1; p.rows_per_sample = 1; return p;
     }
     // out[M,N] = act(A[M,K] W^T + bias) (+res)
+    // a1_wrap_rows > 0: A1 holds that many rows only, row m reads m % a1_wrap_rows (lin4 only: callers check lin4_takes first)
+    bool lin4_takes(int M, int N, int C0, int C1, int a1_wrap_rows) {
+        if (c->deterministic) return false;
+        IgemmParams t = base(M, N, C0 + C1);
+        t.C0 = C0; t.C1 = C1; t.W = (const bf16_t*)blob; t.Wfrag = t.W; t.out_bf16 = (bf16_t*)blob; t.a1_wrap_rows = a1_wrap_rows;
+        return lin4_supported(t, 1);
+    }
     void linear(const bf16_t* A0, const bf16_t* A1, int C0, int C1, size_t woff, size_t boff, bool has_bias, int M, int N,
-                int act, const bf16_t* res, bf16_t* out, float* out_f32 = nullptr, const float* res_f32 = nullptr) {
+                int act, const bf16_t* res, bf16_t* out, float* out_f32 = nullptr, const float* res_f32 = nullptr, int a1_wrap_rows = 0) {
         if (plan) return;
         // skinny (weight-streaming) kernel for decode-sized operands.  Fast mode: whenever M <= 128.  Deterministic mode: exactly for
         // the ops with ONE row per sample (`single_row`: time embedding, RARM decode step, CLIP projection), at any batch
@@ -505,7 +512,7 @@ struct Ops {
         }
         IgemmParams p = base(M, N, C0 + C1);
         p.A0 = A0; p.A1 = A1; p.C0 = C0; p.C1 = C1; p.W = w<bf16_t>(woff); p.bias = has_bias ? w<float>(boff) : nullptr;
-        p.act = act; p.res_bf16 = res; p.res_f32 = res_f32; p.out_bf16 = out; p.out_f32 = out_f32;
+        p.act = act; p.res_bf16 = res; p.res_f32 = res_f32; p.out_bf16 = out; p.out_f32 = out_f32; p.a1_wrap_rows = a1_wrap_rows;
         if (act == ACT_GEGLU) p.ldo = N / 2;
         // one-wave-per-SIMD kernel for the big-M projections (its tile choice follows M, so not in deterministic mode)
         // (deterministic mode: its use must not follow the batch -- exactly when the rows of ONE sample fill whole 128 / 256-row tiles,
@@ -565,9 +572,9 @@ struct Ops {
     }
     void prof_end() { if (prof_open) hipEventRecord(c->prof_recs.back().b, c->stream); prof_open = false; }
     void groupnorm(const bf16_t* x0, const bf16_t* x1, int C0, int C1, int B, int HW, size_t g, size_t b, float eps, int silu,
-                   bf16_t* out, int L0 = -1, int L1 = -1) {      // L0 / L1: logical channels of the (zero-padded) sources, default = all
+                   bf16_t* out, int L0 = -1, int L1 = -1, int x1_bmod = 0) {      // L0 / L1: logical channels of the (zero-padded) sources, default = all
         if (plan) return;
-        GnParams p{}; p.x0 = x0; p.x1 = x1; p.C0 = C0; p.C1 = C1; p.HW = HW; p.B = B; p.groups = 32;
+        GnParams p{}; p.x0 = x0; p.x1 = x1; p.C0 = C0; p.C1 = C1; p.HW = HW; p.B = B; p.groups = 32; p.x1_bmod = x1_bmod;
         p.L0 = L0 < 0 ? C0 : L0; p.L1 = L1 < 0 ? C1 : L1;
         int nchunk = HW / 64; if (nchunk < 1) nchunk = 1; if (nchunk > 32) nchunk = 32;
         p.nchunk = nchunk; p.partial = c->gn_partial; p.gamma = w<float>(g); p.beta = w<float>(b); p.eps = eps; p.silu = silu;
@@ -677,7 +684,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
     o.linear(semb, nullptr, ted, 0, u.embw, u.embb, true, B, u.emb_total, ACT_NONE, nullptr, nullptr, emb_all);
     o.single_row = false;
 
-    struct Act { bf16_t* p; int C, H, W, L; };          // C: padded channels (row stride), L: logical channels
+    struct Act { bf16_t* p; int C, H, W, L; bool half = false; };          // C: padded channels (row stride), L: logical channels; half: only samples [0, Bfull/2) exist (a shared-prefix skip tensor read with a batch wrap)
     std::vector<Act> hs;
     Act h{nullptr, 0, H, W, 0};
     // Shared guidance prefix: with classifier-free guidance the batch is [x | x] with the SAME x and t in both halves and different
@@ -689,16 +696,25 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
     // (block outputs produced inside the prefix are allocated for Bfull samples and written into the first half, so leaving the
     //  prefix costs one copy of B samples per tensor: first half -> second half)
     auto expand = [&](Act& a) {        // [B, H, W, C] in a [2B, H, W, C] allocation -> second half = copy of the first
-        const size_t n = (size_t)B * a.H * a.W * a.C;
+        const size_t n = (size_t)(Bfull / 2) * a.H * a.W * a.C;
         if (!o.plan) o.check(hipMemcpyAsync(a.p + n, a.p, n * 2, hipMemcpyDeviceToDevice, o.c->stream), "expand prefix");
+        a.half = false;
     };
+    // Skip tensors pushed inside the prefix are NOT duplicated when their readers can wrap the batch index instead (GroupNorm's and the
+    // skip_connection GEMM's second source: 4 of the 5 copies, 0.24 ms of a 34.5 ms forward); resblock() materialises one on demand.
+    static const int no_wrap = getenv("RDM_NO_SKIPWRAP") ? atoi(getenv("RDM_NO_SKIPWRAP")) : 0;
 
-    auto resblock = [&](const ResW& r, const Act& a, const Act* skip) -> Act {
+    auto resblock = [&](const ResW& r, const Act& a, Act* skip) -> Act {
         const int C0 = a.C, C1 = skip ? skip->C : 0, HW = a.H * a.W, M = B * HW;
         o.rows_hint = HW;
+        int wrap_b = 0;                                    // > 0: the skip tensor holds Bfull/2 samples, read with a batch wrap
+        if (skip && skip->half) {
+            if (B == Bfull && r.skip && o.lin4_takes(M, r.cout, C0, C1, (Bfull / 2) * HW)) wrap_b = Bfull / 2;
+            else expand(*skip);
+        }
         const bf16_t* x1 = skip ? skip->p : nullptr;
         bf16_t* n1 = o.abf((size_t)M * r.cin);
-        o.groupnorm(a.p, x1, C0, C1, B, HW, r.gn1g, r.gn1b, 1e-5f, 1, n1, a.L, skip ? skip->L : 0);
+        o.groupnorm(a.p, x1, C0, C1, B, HW, r.gn1g, r.gn1b, 1e-5f, 1, n1, a.L, skip ? skip->L : 0, wrap_b);
         bf16_t* h1 = o.abf((size_t)M * r.cout);
         o.conv3(n1, nullptr, r.cin, 0, r.w1, r.b1, B, a.H, a.W, r.cout, 1, 0, emb_all + r.emb_off, u.emb_total, nullptr, h1);
         bf16_t* n2 = o.abf((size_t)M * r.cout);
@@ -706,7 +722,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         const bf16_t* res = a.p;
         if (r.skip) {
             bf16_t* s = o.abf((size_t)M * r.cout);
-            o.linear(a.p, x1, C0, C1, r.wsk, r.bsk, true, M, r.cout, ACT_NONE, nullptr, s);
+            o.linear(a.p, x1, C0, C1, r.wsk, r.bsk, true, M, r.cout, ACT_NONE, nullptr, s, nullptr, nullptr, wrap_b * HW);
             res = s;
         }
         bf16_t* out = o.abf((size_t)Bfull * HW * r.cout);           // Bfull: see expand()
@@ -839,7 +855,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
     };
 
     for (const UBlock& blk : u.blocks) {
-        const Act* skip = nullptr; Act sk{};
+        Act* skip = nullptr; Act sk{};
         if (blk.where == 2) { sk = hs.back(); hs.pop_back(); skip = &sk; }
         bool first = true;
         for (const ULayer& L : blk.layers) {
@@ -851,7 +867,11 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                 } break;
                 case 1: h = resblock(u.res[L.idx], h, (first && skip) ? skip : nullptr); break;
                 case 2:
-                    if (B < Bfull) { expand(h); for (Act& a : hs) expand(a); B = Bfull; }     // first context-dependent layer: leave the shared prefix
+                    if (B < Bfull) {       // first context-dependent layer: leave the shared prefix
+                        expand(h);
+                        for (Act& a : hs) { if (no_wrap || o.c->deterministic) expand(a); else a.half = true; }
+                        B = Bfull;
+                    }
                     h = transformer(u.st[L.idx], h); break;
                 case 3: {
                     const ConvW& d = u.down[L.idx];

@@ -23,8 +23,9 @@ __device__ __forceinline__ int gn_logical(const GnParams& p, int c) {
 __device__ __forceinline__ int gn_physical(const GnParams& p, int l) { return l < p.L0 ? l : p.C0 + (l - p.L0); }
 
 __device__ __forceinline__ const bf16_t* gn_src(const GnParams& p, int b, int row, int c) {
-    return (c < p.C0) ? p.x0 + ((long long)(b * p.HW + row) * p.C0 + c)
-                      : p.x1 + ((long long)(b * p.HW + row) * p.C1 + (c - p.C0));
+    if (c < p.C0) return p.x0 + ((long long)(b * p.HW + row) * p.C0 + c);
+    const int b1 = p.x1_bmod > 0 ? b % p.x1_bmod : b;
+    return p.x1 + ((long long)(b1 * p.HW + row) * p.C1 + (c - p.C0));
 }
 
 // grid (nchunk, B); block = VC * R threads where VC = C/8 (16-byte vectors per row)
