@@ -139,3 +139,26 @@ def test_token_and_code_ids_out_of_range_are_refused(fresh):
     assert "[0, 514)" in _err(lambda: fresh.rarm_forward(torch.full((2, 3), 514, dtype=torch.long, device=d), ctx2))
     assert "[0, 514)" in _err(lambda: fresh.rarm_sample(torch.full((2, 1), -1, dtype=torch.long, device=d), ctx2, 4, torch.rand(4, 2, device=d), top_k=8))
     fresh.rarm_forward(torch.full((2, 3), 513, dtype=torch.long, device=d), ctx2)          # the last valid id passes
+
+
+def test_single_op_entry_points_reject_unsupported_shapes(fresh):
+    """The single-kernel ops added in round 3 state their shape contract instead of running something else."""
+    d = fresh.device
+    bf = lambda *s: torch.zeros(*s, device=d, dtype=torch.bfloat16)
+    # token-major-V flash attention: n must be a multiple of 64
+    assert "multiple of 64" in _err(lambda: fresh.op_self_attention_qkv(bf(1, 32, 3 * 64), 2))
+    # fused cross-attention: C % 64, softmax group in {1, 2, 4}, LayerNorm form takes no separate residual
+    G, U = bf(1, 128, 96), bf(1, 96, 128)
+    assert "unsupported shape" in _err(lambda: fresh.op_xattn_fused(bf(1, 32, 96), G, U, None, None, 12, 4))
+    G, U = bf(1, 128, 64), bf(1, 64, 128)
+    assert "unsupported shape" in _err(lambda: fresh.op_xattn_fused(bf(1, 32, 64), G, U, None, None, 6, 3))
+    g = torch.ones(64, device=d)
+    assert "res must be null" in _err(lambda: fresh.op_xattn_fused(bf(1, 32, 64), G, U, None, bf(1, 32, 64), 8, 4, ln=(g, g, 1e-5)))
+    # fused head: W % 32, C <= 240
+    w = torch.zeros(3, 64, 3, 3, device=d)
+    assert "unsupported shape" in _err(lambda: fresh.op_head_conv(bf(1, 8, 24, 64), w, None))
+    w = torch.zeros(3, 256, 3, 3, device=d)
+    assert "unsupported shape" in _err(lambda: fresh.op_head_conv(bf(1, 8, 32, 256), w, None))
+    # and the context still works
+    out = fresh.op_head_conv(bf(1, 8, 32, 64), torch.zeros(3, 64, 3, 3, device=d), None)
+    assert out.shape == (1, 3, 8, 32) and float(out.abs().max()) == 0.0
