@@ -231,6 +231,12 @@ int rdm_prof_reset(rdm_ctx* ctx);
 /* ---- operator-level entry points (used by the parity tests; thin wrappers over the kernels) ---- */
 int rdm_op_linear(rdm_ctx* ctx, const void* a_bf16, const void* w_bf16, const float* bias, const void* residual_bf16,
                   void* out_bf16, float* out_f32, int M, int N, int K, int act, float alpha);
+/* out = act(LayerNorm(x; gamma, beta, eps) W^T + bias) in ONE kernel: nn.LayerNorm followed by nn.Linear as in BasicTransformerBlock
+ * (rdm/modules/attention.py:147-168: `self.attn1(self.norm1(x))`, `self.ff(self.norm3(x))`), the LayerNorm folded into the GEMM
+ * (lin4.hip).  x bf16 [M, K] RAW rows, w bf16 [N, K] (GEGLU: rows in the packed [32 x | 32 gates] order), out bf16 [M, N] (GEGLU: [M, N/2]).
+ * Returns -5 when the shape is not one the folded kernel takes (the executors then run LayerNorm + Linear). */
+int rdm_op_linear_ln(rdm_ctx* ctx, const void* x_bf16, const void* w_bf16, const float* bias, const float* gamma, const float* beta,
+                     void* out_bf16, int M, int N, int K, int act, float eps);
 int rdm_op_conv3x3(rdm_ctx* ctx, const void* x0_bf16, const void* x1_bf16, int C0, int C1, const void* w_bf16,
                    const float* bias, const float* rowvec, int rowvec_ld, const void* residual_bf16, void* out_bf16,
                    int B, int Hin, int Win, int N, int stride, int ups);

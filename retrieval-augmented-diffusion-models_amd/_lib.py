@@ -119,6 +119,7 @@ SIGNATURES = {
     "rdm_op_transpose": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "rdm_op_add": (C.c_int, [_P, _P, _P, _P, C.c_longlong]),
     "rdm_op_geglu": (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_int]),
+    "rdm_op_linear_ln": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "rdm_op_linear_wgrad": (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_int, C.c_int]),
     "rdm_op_ema": (C.c_int, [_P, _P, _P, C.c_longlong, C.c_float]),
     "rdm_op_silu": (C.c_int, [_P, _P, _P, _P, C.c_longlong]),
@@ -585,6 +586,13 @@ class Context:
         self._check(lib.rdm_op_linear(self._h, _ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(ob), _ptr(of), M, N, K,
                                       act, float(alpha)))
         return of if out_f32 else ob
+
+    def op_linear_ln(self, x, w, bias, gamma, beta, act=ACT_NONE, eps=1e-5):
+        """act(LayerNorm(x) w^T + bias) with the LayerNorm folded into the GEMM (raises RdmError for shapes the folded kernel does not take)."""
+        M, K = x.shape; N = w.shape[0]
+        out = torch.empty((M, N // 2 if act == ACT_GEGLU else N), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_linear_ln(self._h, _ptr(x), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(out), M, N, K, act, float(eps)))
+        return out
 
     def op_conv3x3(self, x0, w, bias, x1=None, rowvec=None, residual=None, stride=1, ups=0):
         B, Hin, Win, C0 = x0.shape

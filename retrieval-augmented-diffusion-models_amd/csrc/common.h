@@ -102,5 +102,8 @@ struct IgemmParams {
     int l4_any_tiles;           // lin4: take the GEMM whatever its tile count (deterministic mode: the choice must not follow the batch)
     int a1_wrap_rows;           // lin4 only: > 0: A1 holds only that many rows and row m reads m % a1_wrap_rows (a multiple of the block tile's rows)
     const bf16_t* Wfrag;        // conv3x3: fragment-ordered copy of W (conv_halo4.hip, built by launch_conv_w_fragpack) or null
+    // lin4 only: LayerNorm folded into the GEMM.  A0 holds the RAW rows, Wfrag the gamma-scaled fragment copy, ln_sb[n] = (s[n], b'[n]) per
+    // stored weight row (launch_lin_ln_sb); the kernel takes the row statistics itself: out = rstd (A Wg^T - mean s) + b'
+    const float* ln_sb; float ln_inv_c, ln_eps;      // ln_inv_c = 1 / (logical row width): zero padding beyond it adds nothing to the sums
     int dbg;                    // debug ablation bits (env RDM_IGEMM_DBG): 1 no MFMA, 2 no in-loop staging, 4 no stores
 };

@@ -127,7 +127,8 @@ hipError_t launch_conv_halo4(const IgemmParams& p, hipStream_t st);
 // one-wave-per-SIMD linear GEMM (lin4.hip): needs p.Wfrag = the fragment-ordered copy of W built by launch_lin_w_fragpack
 bool lin4_supported(const IgemmParams& p, int batch);
 hipError_t launch_lin4(const IgemmParams& p, hipStream_t st);
-hipError_t launch_lin_w_fragpack(const bf16_t* W, bf16_t* dst, int N, int K, int ldw, int geglu, hipStream_t st);       // dst: N*K elements; geglu: W rows in packing.py's _geglu_perm order
+hipError_t launch_lin_w_fragpack(const bf16_t* W, bf16_t* dst, int N, int K, int ldw, int geglu, hipStream_t st, const float* gamma = nullptr);       // dst: N*K elements; geglu: W rows in packing.py's _geglu_perm order; gamma: dst = bf16(gamma[k] W[n][k]) (LayerNorm fold)
+hipError_t launch_lin_ln_sb(const bf16_t* W, const float* gamma, const float* beta, const float* bias, float* sb, int N, int K, hipStream_t st);   // sb[n] = (sum_k bf16(gamma W), bias + sum_k beta W), n = stored row
 hipError_t launch_conv_w_fragpack(const bf16_t* W, bf16_t* dst, int N, int Cin, hipStream_t st);   // dst: N*9*Cin elements
 // 3x3 conv dispatcher: input-stationary halo kernels when the geometry allows, else the generic implicit GEMM
 inline hipError_t launch_conv3x3(const IgemmParams& p, hipStream_t st) {

@@ -32,7 +32,9 @@ __host__ __device__ inline int l4_geglu_row(int n) {              // fragment-or
     const int nb = n >> 5, fr = n & 31;
     return 64 * (nb >> 1) + 16 * (nb & 1) + (fr < 16 ? fr : 32 + (fr - 16));
 }
-__global__ __launch_bounds__(256) void lin_w_fragpack_kernel(const bf16_t* __restrict__ W, bf16_t* __restrict__ dst, int N, int K, int ldw, int geglu) {
+// gamma given (LayerNorm folded into the GEMM, see lin4_kernel<.., LN>): the copy holds bf16(gamma[k] * W[n][k])
+__global__ __launch_bounds__(256) void lin_w_fragpack_kernel(const bf16_t* __restrict__ W, bf16_t* __restrict__ dst, int N, int K, int ldw, int geglu,
+                                                             const float* __restrict__ gamma) {
     const int KQ = K >> 4;
     const long long nvec = (long long)N * K / 8;
     for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
@@ -42,13 +44,41 @@ __global__ __launch_bounds__(256) void lin_w_fragpack_kernel(const bf16_t* __res
         int n = nb * 32 + (lane & 31);
         const int c = kq * 16 + (lane >> 5) * 8;
         if (geglu) n = l4_geglu_row(n);
-        *(uint4*)(dst + v * 8) = *(const uint4*)(W + (long long)n * ldw + c);
+        uint4 w = *(const uint4*)(W + (long long)n * ldw + c);
+        if (gamma) {
+            uint32_t* u = (uint32_t*)&w;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                u[e] = pack2bf(gamma[c + 2 * e] * __uint_as_float(u[e] << 16), gamma[c + 2 * e + 1] * __uint_as_float(u[e] & 0xffff0000u));
+        }
+        *(uint4*)(dst + v * 8) = w;
     }
 }
-hipError_t launch_lin_w_fragpack(const bf16_t* W, bf16_t* dst, int N, int K, int ldw, int geglu, hipStream_t st) {
+hipError_t launch_lin_w_fragpack(const bf16_t* W, bf16_t* dst, int N, int K, int ldw, int geglu, hipStream_t st, const float* gamma) {
     const long long nvec = (long long)N * K / 8;
     long long g = (nvec + 255) / 256; if (g > 8192) g = 8192;
-    lin_w_fragpack_kernel<<<dim3((unsigned)g), 256, 0, st>>>(W, dst, N, K, ldw > 0 ? ldw : K, geglu);
+    lin_w_fragpack_kernel<<<dim3((unsigned)g), 256, 0, st>>>(W, dst, N, K, ldw > 0 ? ldw : K, geglu, gamma);
+    return hipGetLastError();
+}
+// LayerNorm folded into the consuming GEMM:  LN(x) W^T + b = rstd (x (gamma o W)^T - mu s) + b'   per row, with
+//   s[n] = sum_k bf16(gamma[k] W[n][k])  (of the ROUNDED products the GEMM multiplies by: the mean term cancels exactly what the
+//   accumulator holds),  b'[n] = b[n] + sum_k beta[k] W[n][k].   sb[n] = (s[n], b'[n]), n = STORED row.  One wave per row.
+__global__ __launch_bounds__(256) void lin_ln_sb_kernel(const bf16_t* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ bias, float* __restrict__ sb, int N, int K) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float s = 0.f, b = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = bf2f(W[(long long)n * K + k]);
+        s += bf2f(f2bf(gamma[k] * w));
+        b += beta[k] * w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); b += __shfl_xor(b, o); }
+    if (lane == 0) { sb[2 * n] = s; sb[2 * n + 1] = b + (bias ? bias[n] : 0.f); }
+}
+hipError_t launch_lin_ln_sb(const bf16_t* W, const float* gamma, const float* beta, const float* bias, float* sb, int N, int K, hipStream_t st) {
+    lin_ln_sb_kernel<<<dim3((unsigned)((N + 3) / 4)), 256, 0, st>>>(W, gamma, beta, bias, sb, N, K);
     return hipGetLastError();
 }
 
@@ -74,7 +104,12 @@ __device__ __forceinline__ ASrc l4_asrc(bool dead, int row0, int kc, int C0, con
 // WM: wave arrangement.  2 = 2 x 2 waves, block tile 256 x 192; 1 = 1 x 4 waves, block tile 128 x 384 (N % 384 == 0): every wave
 // reads the same 128 rows of A from LDS and no weight fragment is loaded by two waves -- 64 instead of 80 KiB per K-slice through the
 // CU's vector-memory return path (which, not the matrix pipe, paces the loop), and A is read from HBM by ONE block when N = 384
-template <int VAR, bool GEGLU, int WM>       // VAR: dev-only ablations (RDM_L4_VAR): 1 = activation pieces from the zero page, 2 = no stores
+// LN: LayerNorm folded in (p.ln_sb).  A holds the RAW rows; the weights are the gamma-scaled copy; every row's sum and sum of squares
+// are taken from the activation pieces as they pass through registers on their way to LDS (v_dot2_f32_bf16 against ones / itself,
+// 8 lanes per row reduced by DPP once per tile), meet in LDS as (mean, rstd) one step before the tile's read-out, and the read-out
+// forms  rstd * (acc - mean * s[n]) + b'[n]  in fp32 (no bias in the accumulators, no residual).  The separate LayerNorm pass (one
+// read + one write of the tensor, 2.3 % of a sampling step) is gone; the statistics cost VALU slots beside the MFMAs.
+template <int VAR, bool GEGLU, int WM, bool LN>       // VAR: dev-only ablations (RDM_L4_VAR): 1 = activation pieces from the zero page, 2 = no stores
 __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
     constexpr int BM = 128 * WM, BK = 64, FM = 4, FN = 3, WN = FN * 32, BN = (4 / WM) * WN;
     constexpr int L4_ABUF = BM * 144;          // one staged K-slice: BM rows x (128 bytes of channels + 16 of padding)
@@ -144,7 +179,22 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
     asm volatile("" ::: H4_ACC_CLOBBERS);                    // the kernel descriptor must allocate the accumulator AGPRs
     bf16x8 fa[2][FM];                                       // activation fragments: k-step parity
     bf16x8 fb[2][4][FN];                                    // weight fragments: [step parity][k-step][column fragment]
-    bf16x8 hreg[2][NPC];                                      // activation pieces in flight: [step parity][piece]
+    h4_u32x4 hreg[2][NPC];                                    // activation pieces in flight: [step parity][piece]
+    // LN: per-lane partial (sum, sum of squares) of the 8 channels x all slices seen so far of piece q's row, current tile
+    float lsum[NPC], lsq[NPC];
+#pragma unroll
+    for (int q = 0; q < NPC; q++) { lsum[q] = 0.f; lsq[q] = 0.f; }
+    const unsigned ones_bf = (unsigned)__builtin_amdgcn_readfirstlane(0x3f803f80);
+    auto stat_half = [&](int q, const h4_u32x4& h, int half) __attribute__((always_inline)) {
+        if constexpr (LN) {
+            if (half == 0)
+                asm volatile("v_dot2_f32_bf16 %0, %2, %4, %0\n\tv_dot2_f32_bf16 %1, %2, %2, %1\n\tv_dot2_f32_bf16 %0, %3, %4, %0\n\tv_dot2_f32_bf16 %1, %3, %3, %1"
+                             : "+v"(lsum[q]), "+v"(lsq[q]) : "v"(h.x), "v"(h.y), "s"(ones_bf));
+            else
+                asm volatile("v_dot2_f32_bf16 %0, %2, %4, %0\n\tv_dot2_f32_bf16 %1, %2, %2, %1\n\tv_dot2_f32_bf16 %0, %3, %4, %0\n\tv_dot2_f32_bf16 %1, %3, %3, %1"
+                             : "+v"(lsum[q]), "+v"(lsq[q]) : "v"(h.z), "v"(h.w), "s"(ones_bf));
+        }
+    };
 
     Cur cc{tile0, tile0 / nbn, tile0 % nbn, 0};
     Cur cb = cc, ca = cc;
@@ -156,11 +206,17 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
     // activation pieces and weight fragments already in flight for the next steps.
     constexpr int L4_STG = 2 * L4_ABUF;                        // per-wave fp32 staging of one fragment row: 32 rows x 400 bytes
     constexpr int L4_BIAS = L4_STG + 4 * 32 * 400;
-    for (int n = tid; n < p.N; n += 256) {
-        const float bv = biasp ? biasp[GEGLU ? l4_geglu_row(n) : n] : 0.f;
-        const uint32_t hi = cvt_pk_bf16(bv, 0.f) & 0xffffu;
-        const uint32_t lo = cvt_pk_bf16(bv - __uint_as_float(hi << 16), 0.f) & 0xffffu;
-        *(uint32_t*)(smem + L4_BIAS + n * 4) = hi | (lo << 16);
+    const int L4_STAT = L4_BIAS + p.N * 8;                     // LN: (mean, rstd) of the tile's BM rows
+    if constexpr (LN) {                                        // (s, b') per column in FRAGMENT order; the accumulators start at zero
+        for (int n = tid; n < p.N; n += 256)
+            *(float2*)(smem + L4_BIAS + n * 8) = *(const float2*)(p.ln_sb + 2 * (GEGLU ? l4_geglu_row(n) : n));
+    } else {
+        for (int n = tid; n < p.N; n += 256) {
+            const float bv = biasp ? biasp[GEGLU ? l4_geglu_row(n) : n] : 0.f;
+            const uint32_t hi = cvt_pk_bf16(bv, 0.f) & 0xffffu;
+            const uint32_t lo = cvt_pk_bf16(bv - __uint_as_float(hi << 16), 0.f) & 0xffffu;
+            *(uint32_t*)(smem + L4_BIAS + n * 4) = hi | (lo << 16);
+        }
     }
     __syncthreads();
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
@@ -168,7 +224,8 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
     auto bias_frags = [&](int bn, int row, int half, bf16x8 (&bf)[FN], bf16x8& ones) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < FN; j++) {
-            const uint32_t w = *(const uint32_t*)(smem + L4_BIAS + (bn * BN + wn * WN + j * 32 + row) * 4);
+            uint32_t w = 0u;
+            if constexpr (!LN) w = *(const uint32_t*)(smem + L4_BIAS + (bn * BN + wn * WN + j * 32 + row) * 4);
             FragU t; t.u = (u32x4_t){half ? 0u : w, 0u, 0u, 0u};
             bf[j] = t.f;
         }
@@ -193,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
         for (int q = 0; q < NPC; q++) H4_GLOADB(hreg[0][q], s0.voff, s0.base + (unsigned)q * s0.pstride, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int q = 0; q < NPC; q++) H4_LDSWO(ldsw0, hreg[0][q], q * 4608);
+        for (int q = 0; q < NPC; q++) { H4_LDSWO(ldsw0, hreg[0][q], q * 4608); stat_half(q, hreg[0][q], 0); stat_half(q, hreg[0][q], 1); }
         ASrc s1 = a_src(ca); cur_adv(ca);
 #pragma unroll
         for (int q = 0; q < NPC; q++) H4_GLOADB(hreg[0][q], s1.voff, s1.base + (unsigned)q * s1.pstride, 0);
@@ -254,7 +311,9 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
             for (int q = q0; q < q0 + nq; q++) {
                 if (P == 0) H4_LDSWO(ldsw1, hreg[P][q], q * 4608); else H4_LDSWO(ldsw0, hreg[P][q], q * 4608);
             }
-            mfma(ks, 0); mfma(ks, 1); mfma(ks, 2); mfma(ks, 3);
+            // LN: the pieces just written also feed the row statistics, four dot products behind each of the next MFMAs
+            auto stat_at = [&](int m) __attribute__((always_inline)) { if (m < 2 * nq) stat_half(q0 + (m >> 1), hreg[P][q0 + (m >> 1)], m & 1); };
+            mfma(ks, 0); stat_at(0); mfma(ks, 1); stat_at(1); mfma(ks, 2); stat_at(2); mfma(ks, 3); stat_at(3);
             if (ks < 3) {
 #pragma unroll
                 for (int i = 0; i < FM; i++) H4_LDSR(fa[(ks + 1) & 1][i], vbase[i], RB + (ks + 1) * 32);
@@ -265,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
 #pragma unroll
                 for (int i = 0; i < FM; i++) H4_LDSR(fa[0][i], vbase[i], (P ^ 1) * L4_ABUF);
             }
-            mfma(ks, 4); mfma(ks, 5);
+            mfma(ks, 4); stat_at(4); mfma(ks, 5); stat_at(5);
             // ... and the pieces of slice X + 3 into the registers just written out
 #pragma unroll
             for (int q = q0; q < q0 + nq; q++) {
@@ -280,7 +339,32 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
     // after a step: the next slice, or the tile's epilogue.  Returns true when the block has no work left.
     auto advance = [&]() __attribute__((always_inline)) -> bool {
         const int sl_done = cc.sl;
-        if (sl_done + 1 < nslice) { cc.sl++; return false; }
+        if (sl_done + 1 < nslice) {
+            cc.sl++;
+            if constexpr (LN) {
+                // the step just done wrote (and summed) the pieces of the tile's LAST slice: statistics complete.  The barrier inside
+                // the coming step orders these LDS writes before the read-out; the previous tile's read-out finished at least one
+                // barrier ago (nslice >= 2)
+                if (cc.sl == nslice - 1) {
+#pragma unroll
+                    for (int q = 0; q < NPC; q++) {
+                        float sv = lsum[q], tv = lsq[q];
+                        sv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv), 0xB1, 0xf, 0xf, true));
+                        tv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tv), 0xB1, 0xf, 0xf, true));
+                        sv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv), 0x4E, 0xf, 0xf, true));
+                        tv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tv), 0x4E, 0xf, 0xf, true));
+                        sv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv), 0x141, 0xf, 0xf, true));   // row_half_mirror: lane i <-> 7 - i
+                        tv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tv), 0x141, 0xf, 0xf, true));
+                        const float mean = sv * p.ln_inv_c;
+                        const float var = fmaxf(tv * p.ln_inv_c - mean * mean, 0.f);
+                        const float rstd = __builtin_amdgcn_rsqf(var + p.ln_eps);
+                        if (lc == 0) *(float2*)(smem + L4_STAT + ((q * 4 + wave) * 8 + lp) * 8) = make_float2(mean, rstd);
+                        lsum[q] = 0.f; lsq[q] = 0.f;
+                    }
+                }
+            }
+            return false;
+        }
         const int em0 = cc.bm * BM, en0 = cc.bn * BN;
         Cur nx = cc; cur_adv(nx);
         const bool has_next = nx.tile < t_end;
@@ -318,12 +402,14 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
             // fragment channels 0..15 = x, 16..31 = the gates of the same 16 channels; 16 outputs per fragment, 48 per wave:
             // output channel 96 bn + 48 wn + 16 j + k.  Task idx = it 64 + lane: (row, j, half h) -> 8 outputs = one 16-byte store
             const int eno_o = (en0 >> 1) + wn * (WN / 2);
-            unsigned voffs[3], lrd[3];
+            unsigned voffs[3], lrd[3], sbo[3], srow[3];
 #pragma unroll
             for (int it = 0; it < 3; it++) {
                 const int idx = it * 64 + lane_e, row = idx / 6, c6 = idx - row * 6;
                 voffs[it] = (unsigned)(row * ldo + c6 * 8) * 2u;
                 lrd[it] = (unsigned)(row * 400 + ((c6 >> 1) * 32 + (c6 & 1) * 8) * 4);
+                sbo[it] = (unsigned)(L4_BIAS + (en0 + wn * WN + (c6 >> 1) * 32 + (c6 & 1) * 8) * 8);      // (s, b') of the 8 x columns; their gates: + 16 columns
+                srow[it] = (unsigned)(L4_STAT + (wm * 128 + row) * 8);
             }
             const char* const obase = (const char*)(ob + (long long)(em0 + wm * 128) * ldo + eno_o);
             const unsigned long long rowstep = (unsigned long long)(32 * ldo) * 2ull;
@@ -331,8 +417,23 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
                 const char* const op = (const char*)l4_uni64((unsigned long long)(obase + i * rowstep));
 #pragma unroll
                 for (int it = 0; it < 3; it++) {
-                    const float4 x0 = *(const float4*)(stgr + lrd[it]), x1 = *(const float4*)(stgr + lrd[it] + 16);
-                    const float4 g0 = *(const float4*)(stgr + lrd[it] + 64), g1 = *(const float4*)(stgr + lrd[it] + 80);
+                    float4 x0 = *(const float4*)(stgr + lrd[it]), x1 = *(const float4*)(stgr + lrd[it] + 16);
+                    float4 g0 = *(const float4*)(stgr + lrd[it] + 64), g1 = *(const float4*)(stgr + lrd[it] + 80);
+                    if constexpr (LN) {
+                        const float2 st = *(const float2*)(smem + srow[it] + i * 256);
+                        const float r = st.y, m2 = -st.x * st.y;
+                        const float4* const qx = (const float4*)(smem + sbo[it]); const float4* const qg = (const float4*)(smem + sbo[it] + 128);
+                        const float4 a = qx[0], b = qx[1], c = qx[2], d = qx[3];
+                        x0.x = fmaf(r, x0.x, fmaf(m2, a.x, a.y)); x0.y = fmaf(r, x0.y, fmaf(m2, a.z, a.w));
+                        x0.z = fmaf(r, x0.z, fmaf(m2, b.x, b.y)); x0.w = fmaf(r, x0.w, fmaf(m2, b.z, b.w));
+                        x1.x = fmaf(r, x1.x, fmaf(m2, c.x, c.y)); x1.y = fmaf(r, x1.y, fmaf(m2, c.z, c.w));
+                        x1.z = fmaf(r, x1.z, fmaf(m2, d.x, d.y)); x1.w = fmaf(r, x1.w, fmaf(m2, d.z, d.w));
+                        const float4 e = qg[0], f = qg[1], g = qg[2], h = qg[3];
+                        g0.x = fmaf(r, g0.x, fmaf(m2, e.x, e.y)); g0.y = fmaf(r, g0.y, fmaf(m2, e.z, e.w));
+                        g0.z = fmaf(r, g0.z, fmaf(m2, f.x, f.y)); g0.w = fmaf(r, g0.w, fmaf(m2, f.z, f.w));
+                        g1.x = fmaf(r, g1.x, fmaf(m2, g.x, g.y)); g1.y = fmaf(r, g1.y, fmaf(m2, g.z, g.w));
+                        g1.z = fmaf(r, g1.z, fmaf(m2, h.x, h.y)); g1.w = fmaf(r, g1.w, fmaf(m2, h.z, h.w));
+                    }
                     const f32x2_t r0 = (f32x2_t){x0.x, x0.y} * gelu_erf_f2((f32x2_t){g0.x, g0.y});
                     const f32x2_t r1 = (f32x2_t){x0.z, x0.w} * gelu_erf_f2((f32x2_t){g0.z, g0.w});
                     const f32x2_t r2 = (f32x2_t){x1.x, x1.y} * gelu_erf_f2((f32x2_t){g1.x, g1.y});
@@ -347,12 +448,13 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
             stage_row(3); store_row(3);
         } else {
             const int eno = en0 + wn * WN;
-            unsigned voffs[6], lrd[6];
+            unsigned voffs[6], lrd[6], sbo[3], srow[3];          // LN: tasks it and it + 3 share their 8 columns, 16 rows apart
 #pragma unroll
             for (int it = 0; it < 6; it++) {
                 const int idx = it * 64 + lane_e, row = idx / 12, ch = idx - row * 12;
                 voffs[it] = (unsigned)(row * ldo + ch * 8) * 2u;
                 lrd[it] = (unsigned)(row * 400 + ch * 32);
+                if (it < 3) { sbo[it] = (unsigned)(L4_BIAS + (en0 + wn * WN + ch * 8) * 8); srow[it] = (unsigned)(L4_STAT + (wm * 128 + row) * 8); }
             }
             const char* const obase = (const char*)(ob + (long long)(em0 + wm * 128) * ldo + eno);
             const char* const rbase = (const char*)(rb + (long long)(em0 + wm * 128) * ldo + eno);
@@ -371,7 +473,17 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
 #pragma unroll
                 for (int it = 0; it < 6; it++) {
                     float4 a0 = *(const float4*)(stgr + lrd[it]), a1 = *(const float4*)(stgr + lrd[it] + 16);
-                    if (rb) {                                  // added in fp32: one rounding
+                    if constexpr (LN) {
+                        const float2 st = *(const float2*)(smem + srow[it % 3] + i * 256 + (it / 3) * 128);
+                        const float r = st.y, m2 = -st.x * st.y;
+                        const float4* const qs = (const float4*)(smem + sbo[it % 3]);
+                        const float4 a = qs[0], b = qs[1], c = qs[2], d = qs[3];
+                        a0.x = fmaf(r, a0.x, fmaf(m2, a.x, a.y)); a0.y = fmaf(r, a0.y, fmaf(m2, a.z, a.w));
+                        a0.z = fmaf(r, a0.z, fmaf(m2, b.x, b.y)); a0.w = fmaf(r, a0.w, fmaf(m2, b.z, b.w));
+                        a1.x = fmaf(r, a1.x, fmaf(m2, c.x, c.y)); a1.y = fmaf(r, a1.y, fmaf(m2, c.z, c.w));
+                        a1.z = fmaf(r, a1.z, fmaf(m2, d.x, d.y)); a1.w = fmaf(r, a1.w, fmaf(m2, d.z, d.w));
+                    }
+                    if (!LN && rb) {                           // added in fp32: one rounding
                         const h4_u32x4 r4 = rr4[i & 1][it];
                         a0.x += __uint_as_float(r4.x << 16); a0.y += __uint_as_float(r4.x & 0xffff0000u);
                         a0.z += __uint_as_float(r4.y << 16); a0.w += __uint_as_float(r4.y & 0xffff0000u);
@@ -383,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
                 }
             };
             constexpr int NST = VAR == 2 ? 0 : 6;              // stores per fragment row
-            if (rb) {
+            if (!LN && rb) {
                 res_request(0, rr4[0]); res_request(1, rr4[1]);
                 stage_row(0);
                 asm volatile("s_waitcnt vmcnt(6)" : "+v"(rr4[0][0]), "+v"(rr4[0][1]), "+v"(rr4[0][2]), "+v"(rr4[0][3]), "+v"(rr4[0][4]), "+v"(rr4[0][5]) :: "memory");
@@ -428,6 +540,9 @@ static int lin4_wm(const IgemmParams& p) {        // wave arrangement: 1 x 4 wav
     if (p.N % 192 == 0 && p.M % 256 == 0) return 2;
     return 0;
 }
+static int lin4_smem_bytes(const IgemmParams& p, int wm) {
+    return 2 * (128 * wm * 144) + 4 * 32 * 400 + (p.ln_sb ? p.N * 8 + 128 * wm * 8 : p.N * 4);
+}
 bool lin4_supported(const IgemmParams& p, int batch) {
     static const int off = getenv("RDM_NO_LIN4") ? atoi(getenv("RDM_NO_LIN4")) : 0;
     if ((off & 1) || !p.Wfrag || batch != 1) return false;
@@ -441,18 +556,20 @@ bool lin4_supported(const IgemmParams& p, int batch) {
     if (p.N > 8192 || p.ldo % 8 || p.ldo < No || (p.ldw > 0 && p.ldw != p.K)) return false;
     if (p.C1 > 0 && p.lda > 0) return false;
     if (p.a1_wrap_rows > 0 && (p.C1 == 0 || p.a1_wrap_rows % (128 * wm) != 0 || 2LL * p.a1_wrap_rows < p.M)) return false;     // whole tiles, at most two copies
+    // LayerNorm folded in: one source of >= 2 slices, no residual (the bias rides in ln_sb), everything in 160 KiB of LDS
+    if (p.ln_sb && (p.C1 > 0 || p.K < 128 || p.res_bf16 || p.bias || lin4_smem_bytes(p, wm) > 160 * 1024 || !(p.ln_inv_c > 0.f))) return false;
     static const int min_tiles = getenv("RDM_L4_MIN_TILES") ? atoi(getenv("RDM_L4_MIN_TILES")) : 128;
     if (!p.l4_any_tiles && (long long)(p.M / (128 * wm)) * (p.N / (wm == 1 ? 384 : 192)) < min_tiles) return false;     // far fewer tiles than CUs: the 128-row tiles of igemm.hip (160 tiles -- the 8x8-level projections -- still win here: 28 vs 32 us)
     return true;
 }
 
-template <int VAR, bool GEGLU, int WM>
+template <int VAR, bool GEGLU, int WM, bool LN>
 static hipError_t launch_lin4_cfg(const IgemmParams& p, hipStream_t st) {
-    const int smem = 2 * (128 * WM * 144) + 4 * 32 * 400 + p.N * 4;
+    const int smem = lin4_smem_bytes(p, WM);
     static int ncu_dev[RDM_MAX_DEVICES] = {0};
     const int dev = rdm_cur_device();
     if (!ncu_dev[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)lin4_kernel<VAR, GEGLU, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)lin4_kernel<VAR, GEGLU, WM, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         hipDeviceGetAttribute(&ncu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev);
     }
@@ -464,23 +581,28 @@ static hipError_t launch_lin4_cfg(const IgemmParams& p, hipStream_t st) {
         IgemmParams q = p; q.dbg |= 16;
         unsigned long long z[4] = {0, 0, 0, 0}, r[4];
         hipMemcpyToSymbol(HIP_SYMBOL(g_lin4_prof), z, sizeof(z));
-        lin4_kernel<VAR, GEGLU, WM><<<dim3((unsigned)g), 256, smem, st>>>(q);
+        lin4_kernel<VAR, GEGLU, WM, LN><<<dim3((unsigned)g), 256, smem, st>>>(q);
         hipStreamSynchronize(st);
         hipMemcpyFromSymbol(r, HIP_SYMBOL(g_lin4_prof), sizeof(r));
-        fprintf(stderr, "[lin4<%d,%d> M=%d N=%d K=%d] blocks=%llu per-block cycles: main %.0f epilogue %.0f (tiles/block %.2f)\n", (int)GEGLU, WM, p.M, p.N, p.K,
+        fprintf(stderr, "[lin4<%d,%d,%d> M=%d N=%d K=%d] blocks=%llu per-block cycles: main %.0f epilogue %.0f (tiles/block %.2f)\n", (int)GEGLU, WM, (int)LN, p.M, p.N, p.K,
                 r[3], (double)r[0] / r[3], (double)r[1] / r[3], (double)ntiles / g);
         return hipGetLastError();
     }
-    lin4_kernel<VAR, GEGLU, WM><<<dim3((unsigned)g), 256, smem, st>>>(p);
+    lin4_kernel<VAR, GEGLU, WM, LN><<<dim3((unsigned)g), 256, smem, st>>>(p);
     return hipGetLastError();
 }
 template <int VAR>
 static hipError_t launch_lin4_var(const IgemmParams& p, hipStream_t st) {
     const int wm = lin4_wm(p);
-    if (p.act == ACT_GEGLU) return wm == 1 ? launch_lin4_cfg<VAR, true, 1>(p, st) : launch_lin4_cfg<VAR, true, 2>(p, st);
-    return wm == 1 ? launch_lin4_cfg<VAR, false, 1>(p, st) : launch_lin4_cfg<VAR, false, 2>(p, st);
+    if (p.act == ACT_GEGLU) return wm == 1 ? launch_lin4_cfg<VAR, true, 1, false>(p, st) : launch_lin4_cfg<VAR, true, 2, false>(p, st);
+    return wm == 1 ? launch_lin4_cfg<VAR, false, 1, false>(p, st) : launch_lin4_cfg<VAR, false, 2, false>(p, st);
 }
 hipError_t launch_lin4(const IgemmParams& p, hipStream_t st) {
     static const int var = getenv("RDM_L4_VAR") ? atoi(getenv("RDM_L4_VAR")) : 0;
+    if (p.ln_sb) {                                   // LayerNorm folded in (no dev ablations of these)
+        const int wm = lin4_wm(p);
+        if (p.act == ACT_GEGLU) return wm == 1 ? launch_lin4_cfg<0, true, 1, true>(p, st) : launch_lin4_cfg<0, true, 2, true>(p, st);
+        return wm == 1 ? launch_lin4_cfg<0, false, 1, true>(p, st) : launch_lin4_cfg<0, false, 2, true>(p, st);
+    }
     return var == 2 ? launch_lin4_var<2>(p, st) : var == 1 ? launch_lin4_var<1>(p, st) : launch_lin4_var<0>(p, st);
 }

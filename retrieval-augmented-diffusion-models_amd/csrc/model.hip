@@ -103,6 +103,7 @@ struct StW {
     int c, heads; size_t gng, gnb, win, bin, ln1g, ln1b, wqk, wv, wo1, bo1, ln2g, ln2b, wq2, wo2, bo2, ln3g, ln3b, wff1,
         bff1, wff2, bff2, wout, bout, wfo, bfo; int kv_off; long long xa_unit;   // xa_unit: per-sample element offset of this layer's (G, U) pair
     int lc;                           // logical channels (c is padded)
+    bool v_follows;
 };
 struct ConvW { int c; size_t w, b; int lc; };
 struct ULayer { int kind; int idx; };            // 0 conv_in, 1 res, 2 st, 3 down, 4 up
@@ -175,7 +176,7 @@ static void build_unet(UNet& u, const rdm_unet_cfg& c, Manifest& mf) {
         s.ln1g = vec(tb + ".norm1.weight", {S}); s.ln1b = vec(tb + ".norm1.bias", {S});
         s.wqk = mat("bf16", tb + ".attn1.to_q.weight," + tb + ".attn1.to_k.weight", {S, S}, {S});
         s.wv = mat("bf16", tb + ".attn1.to_v.weight", {S}, {S});
-        if (s.wv != s.wqk + (size_t)2 * ch * ch * 2) { fprintf(stderr, "build_unet: to_v must directly follow to_q | to_k in the blob (fused q|k|v projection)\n"); abort(); }
+        s.v_follows = s.wv == s.wqk + (size_t)2 * ch * ch * 2;      // to_v directly behind to_q | to_k in the blob: q | k | v is ONE projection (else the separate V path runs)
         s.wo1 = mat("bf16", tb + ".attn1.to_out.0.weight", {S}, {S}); s.bo1 = vec(tb + ".attn1.to_out.0.bias", {S});
         s.ln2g = vec(tb + ".norm2.weight", {S}); s.ln2b = vec(tb + ".norm2.bias", {S});
         s.wq2 = mat("bf16", tb + ".attn2.to_q.weight", {S}, {S});
@@ -422,29 +423,61 @@ struct rdm_ctx {
     float* gn_partial = nullptr; size_t gn_partial_bytes = 0;
     char* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;   // fp32 partial planes of the K-split halo convs
     char* samp = nullptr; size_t samp_bytes = 0;     // sampler scratch
-    // fragment-ordered copies of the 3x3 conv weights (conv_halo4.hip), built on first use per weight, dropped when a model is reloaded
-    std::unordered_map<unsigned long long, bf16_t*> wfrag;      // key: weight address mixed with (N, Cin)
+    // derived weight layouts, built on first use per weight and dropped when a model is reloaded: fragment-ordered copies of the 3x3 conv
+    // weights (conv_halo4.hip) and of the Linear / 1x1 weights (lin4.hip; optionally scaled by a LayerNorm's gamma, with the (s, b') table
+    // of the folded LayerNorm beside it).  Keyed on everything the copy depends on -- the entry is the copy of exactly that
+    // (weight, shape, kind, gamma): two weights can never alias one entry.
+    struct FragKey {
+        const void* W; int N, K, kind; const void* aux;       // kind: 0 conv3x3, 1 linear, 2 linear GEGLU-ordered, 3 / 4 = 1 / 2 with LayerNorm folded in (aux = gamma)
+        bool operator==(const FragKey& o) const { return W == o.W && N == o.N && K == o.K && kind == o.kind && aux == o.aux; }
+    };
+    struct FragKeyHash {
+        size_t operator()(const FragKey& k) const {
+            size_t h = std::hash<const void*>()(k.W);
+            for (size_t v : {(size_t)k.N, (size_t)k.K, (size_t)k.kind, (size_t)(uintptr_t)k.aux}) h = (h ^ v) * 0x9E3779B97F4A7C15ull + (h >> 29);
+            return h;
+        }
+    };
+    struct FragVal { bf16_t* frag; float* sb; };
+    std::unordered_map<FragKey, FragVal, FragKeyHash> wfrag;
     char* bwd_tmp = nullptr; size_t bwd_tmp_bytes = 0;          // scratch of the backward ops (backward.hip)
-    char* wfrag_tmp = nullptr; size_t wfrag_tmp_bytes = 0;      // rdm_op_conv3x3: caller-owned weights are re-packed per call
-    void drop_frags() { for (auto& kv : wfrag) (void)hipFree(kv.second); wfrag.clear(); }
+    char* wfrag_tmp = nullptr; size_t wfrag_tmp_bytes = 0;      // rdm_op_conv3x3 / rdm_op_linear: caller-owned weights are re-packed per call
+    void drop_frags() { for (auto& kv : wfrag) { (void)hipFree(kv.second.frag); if (kv.second.sb) (void)hipFree(kv.second.sb); } wfrag.clear(); }
+    // (the copies are packed on `stream`; rdm_set_stream synchronises the old stream before it installs another one, so a copy is
+    //  complete before any other stream can launch a kernel that reads it)
     const bf16_t* frag_for(const bf16_t* W, int N, int Cin) {
-        const unsigned long long key = (unsigned long long)(uintptr_t)W ^ ((unsigned long long)N << 48) ^ ((unsigned long long)Cin << 32);
+        const FragKey key{W, N, Cin, 0, nullptr};
         auto it = wfrag.find(key);
-        if (it != wfrag.end()) return it->second;
+        if (it != wfrag.end()) return it->second.frag;
         bf16_t* d = nullptr;
         if (hipMalloc((void**)&d, (size_t)N * 9 * Cin * 2) != hipSuccess) return nullptr;
         if (launch_conv_w_fragpack(W, d, N, Cin, stream) != hipSuccess) { (void)hipFree(d); return nullptr; }
-        wfrag[key] = d;
+        wfrag[key] = FragVal{d, nullptr};
         return d;
     }
     const bf16_t* frag_for_lin(const bf16_t* W, int N, int K, int geglu) {       // fragment-ordered copy of a Linear / 1x1 weight (lin4.hip)
-        const unsigned long long key = ~((unsigned long long)(uintptr_t)W ^ ((unsigned long long)N << 48) ^ ((unsigned long long)K << 32)) ^ (geglu ? 1ull << 63 : 0ull);
+        const FragKey key{W, N, K, geglu ? 2 : 1, nullptr};
         auto it = wfrag.find(key);
-        if (it != wfrag.end()) return it->second;
+        if (it != wfrag.end()) return it->second.frag;
         bf16_t* d = nullptr;
         if (hipMalloc((void**)&d, (size_t)N * K * 2) != hipSuccess) return nullptr;
         if (launch_lin_w_fragpack(W, d, N, K, K, geglu, stream) != hipSuccess) { (void)hipFree(d); return nullptr; }
-        wfrag[key] = d;
+        wfrag[key] = FragVal{d, nullptr};
+        return d;
+    }
+    // ... with LayerNorm(gamma, beta) folded in: the copy holds bf16(gamma[k] W[n][k]), *sb the (s, b') table (lin4.hip: lin_ln_sb_kernel)
+    const bf16_t* frag_for_lin_ln(const bf16_t* W, int N, int K, int geglu, const float* gamma, const float* beta, const float* bias, const float** sb) {
+        const FragKey key{W, N, K, geglu ? 4 : 3, gamma};
+        auto it = wfrag.find(key);
+        if (it != wfrag.end()) { *sb = it->second.sb; return it->second.frag; }
+        bf16_t* d = nullptr; float* t = nullptr;
+        if (hipMalloc((void**)&d, (size_t)N * K * 2) != hipSuccess) return nullptr;
+        if (hipMalloc((void**)&t, (size_t)N * 2 * sizeof(float)) != hipSuccess) { (void)hipFree(d); return nullptr; }
+        if (launch_lin_w_fragpack(W, d, N, K, K, geglu, stream, gamma) != hipSuccess || launch_lin_ln_sb(W, gamma, beta, bias, t, N, K, stream) != hipSuccess) {
+            (void)hipFree(d); (void)hipFree(t); return nullptr;
+        }
+        wfrag[key] = FragVal{d, t};
+        *sb = t;
         return d;
     }
     // batch-invariant execution (rdm_set_deterministic / env RDM_DETERMINISTIC): every kernel-selection decision (skinny vs tiled GEMM,
@@ -539,6 +572,25 @@ struct Ops {
         if (plan) return true;
         prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)C);
         check(launch_sgemm(q, c->stream), "skinny linear on a LayerNorm");
+        prof_end();
+        return true;
+    }
+    // out = act(LayerNorm(x) W^T + bias) for the big-M projections, with the LayerNorm folded into lin4's GEMM (lin4.hip, <.., LN>): x is
+    // the RAW bf16 tensor, the row statistics are taken inside the kernel.  false = not available for this shape / mode (the caller
+    // runs layernorm + linear).  Clog: logical row width (zero padding beyond it).
+    bool linear_ln_big(const bf16_t* x, size_t g, size_t b, int C, int Clog, size_t woff, size_t boff, bool has_bias, int M, int N, int act, bf16_t* out) {
+        static const int off = getenv("RDM_NO_LNFOLD") ? atoi(getenv("RDM_NO_LNFOLD")) : 0;
+        if (off || c->deterministic) return false;
+        IgemmParams p = base(M, N, C);
+        p.A0 = x; p.C0 = C; p.W = w<bf16_t>(woff); p.act = act; p.out_bf16 = out; if (act == ACT_GEGLU) p.ldo = N / 2;
+        p.ln_inv_c = 1.0f / (float)Clog; p.ln_eps = 1e-5f;
+        IgemmParams t = p; t.Wfrag = p.W; t.ln_sb = (const float*)blob;          // shape check only
+        if (!lin4_supported(t, 1)) return false;
+        if (plan) return true;
+        p.Wfrag = c->frag_for_lin_ln(p.W, N, C, act == ACT_GEGLU, w<float>(g), w<float>(b), has_bias ? w<float>(boff) : nullptr, &p.ln_sb);
+        if (!p.Wfrag) { if (rc == 0) rc = c->fail(-2, "out of memory for a LayerNorm-folded weight copy"); return true; }
+        prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)C);
+        check(launch_lin4(p, c->stream), "linear on a folded LayerNorm");
         prof_end();
         return true;
     }
@@ -738,15 +790,18 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         o.linear(xn, nullptr, C, 0, s.win, s.bin, true, M, C, ACT_NONE, nullptr, t0);
         // --- attn1 (self)
         bf16_t* l1 = o.abf((size_t)M * C);
-        o.layernorm(t0, 0, s.ln1g, s.ln1b, l1, 0, M, C, s.lc);
         // n % 64 == 0: q | k | v in ONE projection (to_v's rows follow to_q | to_k in the blob, asserted in build_unet); the flash kernel
         // reads the token-major V block through transpose reads, so no per-layer V^T GEMM (6.8 % of the forward as a batched
         // weights-as-A GEMM at 380 TFLOP/s)
         static const int no_vrow = getenv("RDM_NO_VROW") ? atoi(getenv("RDM_NO_VROW")) : 0;
-        const bool vrow = (n % 64 == 0) && !no_vrow;
+        const bool vrow = (n % 64 == 0) && !no_vrow && s.v_follows;
         const int QW = vrow ? 3 * C : 2 * C;
         bf16_t* qk = o.abf((size_t)M * QW);
-        o.linear(l1, nullptr, C, 0, s.wqk, 0, false, M, QW, ACT_NONE, nullptr, qk);
+        // norm1 folded into the q | k | v projection where lin4 takes it (only the fused form: the other paths read l1 again)
+        if (!(vrow && o.linear_ln_big(t0, s.ln1g, s.ln1b, C, s.lc, s.wqk, 0, false, M, QW, ACT_NONE, qk))) {
+            o.layernorm(t0, 0, s.ln1g, s.ln1b, l1, 0, M, C, s.lc);
+            o.linear(l1, nullptr, C, 0, s.wqk, 0, false, M, QW, ACT_NONE, nullptr, qk);
+        }
         bf16_t* ao = o.abf((size_t)M * C);
         if (vrow) {
             if (!o.plan) {
@@ -836,10 +891,12 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         }
         // --- GEGLU feed-forward
         bf16_t* l3 = o.abf((size_t)M * C);
-        o.layernorm(t2, 0, s.ln3g, s.ln3b, l3, 0, M, C, s.lc);
         const int FI = 4 * s.lc;                     // GEGLU hidden width: 4 x the LOGICAL channels (a multiple of 128, never padded)
         bf16_t* ff = o.abf((size_t)M * FI);
-        o.linear(l3, nullptr, C, 0, s.wff1, s.bff1, true, M, 2 * FI, ACT_GEGLU, nullptr, ff);
+        if (!o.linear_ln_big(t2, s.ln3g, s.ln3b, C, s.lc, s.wff1, s.bff1, true, M, 2 * FI, ACT_GEGLU, ff)) {       // norm3 folded into the GEGLU projection
+            o.layernorm(t2, 0, s.ln3g, s.ln3b, l3, 0, M, C, s.lc);
+            o.linear(l3, nullptr, C, 0, s.wff1, s.bff1, true, M, 2 * FI, ACT_GEGLU, nullptr, ff);
+        }
         bf16_t* out = o.abf((size_t)M * C);
         static const int no_ffout = getenv("RDM_NO_FFOUT") ? atoi(getenv("RDM_NO_FFOUT")) : 0;
         if (!no_ffout) {
@@ -1130,7 +1187,14 @@ void rdm_ctx_destroy(rdm_ctx* c) {
 const char* rdm_last_error(rdm_ctx* c) { return c ? c->err : "null context"; }
 int rdm_set_deterministic(rdm_ctx* c, int on) { if (!c) return -1; c->deterministic = on != 0; return 0; }
 int rdm_get_deterministic(rdm_ctx* c) { return c ? (c->deterministic ? 1 : 0) : -1; }
-int rdm_set_stream(rdm_ctx* c, void* s) { if (!c) return -1; c->stream = (hipStream_t)s; return 0; }
+int rdm_set_stream(rdm_ctx* c, void* s) {
+    RDM_ENTER(c);
+    if ((hipStream_t)s != c->stream) {      // work queued (and derived weight copies packed) on the old stream completes before the new one is used
+        RDM_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        c->stream = (hipStream_t)s;
+    }
+    return 0;
+}
 
 long long rdm_unet_manifest(const rdm_unet_cfg* cfg, char* buf, size_t buflen, size_t* blob_bytes) {
     if (cfg_check_unet(nullptr, cfg)) return -1;
@@ -1723,6 +1787,26 @@ int rdm_op_linear(rdm_ctx* c, const void* a, const void* w, const float* bias, c
         }
     }
     RDM_CHECK_HIP(c, launch_igemm(p, false, 1, c->stream));
+    return 0;
+}
+int rdm_op_linear_ln(rdm_ctx* c, const void* x, const void* w, const float* bias, const float* gamma, const float* beta, void* out,
+                     int M, int N, int K, int act, float eps) {
+    RDM_ENTER(c);
+    if (!x || !w || !gamma || !beta || !out) return c->fail(-1, "rdm_op_linear_ln: null argument");
+    IgemmParams p{}; p.M = M; p.N = N; p.K = K; p.alpha = 1.f; p.ldo = (act == ACT_GEGLU) ? N / 2 : N; p.zero_page = c->zero_page;
+    p.Hin = p.Win = p.Hout = p.Wout = 1; p.stride = 1; p.rows_per_sample = 1;
+    p.A0 = (const bf16_t*)x; p.C0 = K; p.W = (const bf16_t*)w; p.out_bf16 = (bf16_t*)out; p.act = act; p.l4_any_tiles = 1;
+    p.ln_inv_c = 1.0f / (float)K; p.ln_eps = eps;
+    IgemmParams t = p; t.Wfrag = p.W; t.ln_sb = gamma;
+    if (!lin4_supported(t, 1)) return c->fail(-5, "rdm_op_linear_ln: shape not taken by the folded-LayerNorm kernel (M %% 128/256, N %% 384/192, K %% 64, K >= 128)");
+    // caller-owned weights: packed per call into the scratch copy [fragments | (s, b') table]
+    const size_t wbytes = ((size_t)N * K * 2 + 255) & ~(size_t)255;
+    RDM_TRY(ensure_bytes(c, &c->wfrag_tmp, &c->wfrag_tmp_bytes, wbytes + (size_t)N * 8));
+    float* sb = (float*)(c->wfrag_tmp + wbytes);
+    RDM_CHECK_HIP(c, launch_lin_w_fragpack(p.W, (bf16_t*)c->wfrag_tmp, N, K, K, act == ACT_GEGLU, c->stream, gamma));
+    RDM_CHECK_HIP(c, launch_lin_ln_sb(p.W, gamma, beta, bias, sb, N, K, c->stream));
+    p.Wfrag = (const bf16_t*)c->wfrag_tmp; p.ln_sb = sb;
+    RDM_CHECK_HIP(c, launch_lin4(p, c->stream));
     return 0;
 }
 int rdm_op_conv3x3(rdm_ctx* c, const void* x0, const void* x1, int C0, int C1, const void* w, const float* bias,

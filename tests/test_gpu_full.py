@@ -95,42 +95,45 @@ def test_ddim_50_steps_shipped(shipped, tag):
 
 def test_ddim_50_steps_shipped_batch64(shipped):
     """The benchmark's own batch geometry (config #3: B = 64, CFG => UNet batch 128): tall tiles, K-split, wide GEGLU tiles, the shared
-    guidance prefix on 64 samples and the zero-context shortcut only run at this size.  Row 0 carries the golden trajectory's inputs,
-    rows 1..63 are random; samples are independent, so row 0 must track the reference trajectory within the same flat bound."""
+    guidance prefix on 64 samples and the zero-context shortcut only run at this size.  Rows 0 and 63 carry the inputs of two different
+    golden trajectories, rows 1..62 are random; samples are independent, so both must track their reference within the same flat bound."""
     ctx = shipped
-    g = golden("full_ddim_k4.npz")
+    g, g2 = golden("full_ddim_k4.npz"), golden("full_ddim_k4_b.npz")
     gen = torch.Generator().manual_seed(77)
-    x_T = torch.cat([torch.from_numpy(g["x_T"]), torch.randn(63, 3, 64, 64, generator=gen)])
-    cond = torch.cat([torch.from_numpy(g["cond"]), torch.randn(63, 4, 512, generator=gen) * 0.45])
+    # row 0 and row 63 (last tile, the wrapped-skip partner of row 63 - 64 in the doubled batch) carry two DIFFERENT reference trajectories
+    x_T = torch.cat([torch.from_numpy(g["x_T"]), torch.randn(62, 3, 64, 64, generator=gen), torch.from_numpy(g2["x_T"])])
+    cond = torch.cat([torch.from_numpy(g["cond"]), torch.randn(62, 4, 512, generator=gen) * 0.45, torch.from_numpy(g2["cond"])])
     sched = odiff.Schedule()
     z, xi, pi = ctx.ddim_sample(50, x_T, cond, torch.zeros_like(cond), sched.alphas_cumprod, eta=0.0, scale=float(g["scale"]), log_every_t=1,
                                 want_intermediates=True)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(z).all())
-    errs = {int(i): rel_l2(xi[int(i), :1], torch.from_numpy(g[f"x_{int(i)}"])) for i in g["steps"]}
-    ez = rel_l2(z[:1], torch.from_numpy(g["z"]))
-    print("[ddim_k4, batch 64] row 0 vs reference trajectory:", {i: f"{e:.3e}" for i, e in errs.items()}, f"final {ez:.3e}")
-    assert all(e <= DDIM_E0 for e in errs.values()) and ez <= DDIM_E0
+    for row, gg in ((0, g), (63, g2)):
+        errs = {int(i): rel_l2(xi[int(i), row:row + 1], torch.from_numpy(gg[f"x_{int(i)}"])) for i in gg["steps"]}
+        ez = rel_l2(z[row:row + 1], torch.from_numpy(gg["z"]))
+        print(f"[ddim_k4, batch 64] row {row} vs reference trajectory:", {i: f"{e:.3e}" for i, e in errs.items()}, f"final {ez:.3e}")
+        assert all(e <= DDIM_E0 for e in errs.values()) and ez <= DDIM_E0, f"row {row}"
 
 
 def test_ddpm_250_steps_shipped_k16_batch64(shipped):
     """Config #4 per-GPU geometry: B = 64, k = 16, 250 ancestral steps; row 0 = the golden trajectory's inputs and noise."""
     ctx = shipped
-    g = golden("full_ddpm_k16.npz")
+    g, g2 = golden("full_ddpm_k16.npz"), golden("full_ddpm_k16_b.npz")
     T = int(g["timesteps"])
     gen = torch.Generator().manual_seed(78)
-    x_T = torch.cat([torch.from_numpy(g["x_T"]), torch.randn(63, 3, 64, 64, generator=gen)])
-    cond = torch.cat([torch.from_numpy(g["cond"]), torch.randn(63, 16, 512, generator=gen) * 0.45])
+    x_T = torch.cat([torch.from_numpy(g["x_T"]), torch.randn(62, 3, 64, 64, generator=gen), torch.from_numpy(g2["x_T"])])
+    cond = torch.cat([torch.from_numpy(g["cond"]), torch.randn(62, 16, 512, generator=gen) * 0.45, torch.from_numpy(g2["cond"])])
     n0 = torch.from_numpy(np.random.default_rng(int(g["noise_seed"])).standard_normal((T, 1, 3, 64, 64)).astype(np.float32))
-    noise = torch.cat([n0, torch.randn(T, 63, 3, 64, 64, generator=gen)], dim=1)
+    n63 = torch.from_numpy(np.random.default_rng(int(g2["noise_seed"])).standard_normal((T, 1, 3, 64, 64)).astype(np.float32))
+    noise = torch.cat([n0, torch.randn(T, 62, 3, 64, 64, generator=gen), n63], dim=1)
     s = odiff.Schedule()
     sched = {n: getattr(s, n).numpy() for n in ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
                                                 "posterior_mean_coef2", "posterior_log_variance_clipped")}
     z = ctx.ddpm_sample(T, x_T, cond, noise, sched, clip_denoised=True)
     torch.cuda.synchronize()
-    ez = rel_l2(z[:1], torch.from_numpy(g["z"]))
-    print(f"[ddpm_k16, batch 64] row 0 final rel L2 {ez:.3e}")
-    assert bool(torch.isfinite(z).all()) and ez <= DDPM_FINAL
+    ez, ez63 = rel_l2(z[:1], torch.from_numpy(g["z"])), rel_l2(z[63:], torch.from_numpy(g2["z"]))
+    print(f"[ddpm_k16, batch 64] final rel L2: row 0 {ez:.3e}, row 63 (second reference trajectory) {ez63:.3e}")
+    assert bool(torch.isfinite(z).all()) and ez <= DDPM_FINAL and ez63 <= DDPM_FINAL
 
 
 def test_ddpm_250_steps_shipped_k16(shipped):
@@ -183,12 +186,19 @@ def test_vq_decode_shipped(ctx):
         e2 = rel_l2(ctx.vq_decode(z, force_not_quantize=True), ovq.vq_decode(sd, vs, z, force_not_quantize=True))
         print(f"[vq shipped] decoder only (no quantiser) rel L2 {e2:.3e}")
         assert e2 <= 2.5e-2
-    # batch of 64 (the benchmark's decode batch): rows are independent
-    zb = torch.cat([z, torch.randn(63, 3, 64, 64, generator=torch.Generator().manual_seed(1)) * 0.6])
-    imgb = ctx.vq_decode(zb)
+    # batch of 64 (the benchmark's decode batch): rows are independent; row 63 carries a SECOND reference latent / image
+    g2 = golden("full_vq_b.npz")
+    zb = torch.cat([z, torch.randn(62, 3, 64, 64, generator=torch.Generator().manual_seed(1)) * 0.6, torch.from_numpy(g2["z"])])
+    imgb, idxb = ctx.vq_decode(zb, return_indices=True)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(imgb).all())
     assert rel_l2(imgb[:1], img) <= 2.5e-2
+    agree63 = float((idxb.view(64, -1)[63].cpu().numpy() == g2["indices"]).mean())
+    e63 = rel_l2(imgb[63:], torch.from_numpy(g2["image"].astype(np.float32)))
+    print(f"[vq shipped, batch 64] row 63: code agreement {agree63:.5f}, image rel L2 {e63:.3e}")
+    assert agree63 >= 0.995
+    if agree63 == 1.0:
+        assert e63 <= 2.5e-2
 
 
 def test_clip_vitb32_full(ctx):

@@ -104,6 +104,57 @@ def test_linear_geglu_big_m(ctx, M, C):
         _close(out, ref, what=f"big-M geglu (run {rep})")
 
 
+# LayerNorm folded into the big-M projection (lin4.hip <.., LN>): norm1 -> q | k | v and norm3 -> GEGLU of BasicTransformerBlock
+# (rdm/modules/attention.py:147-168).  The reference is LayerNorm in fp32 on the bf16-rounded rows followed by the fp32 GEMM; rows carry a
+# per-row offset and scale so that mean and variance differ from row to row (a wrong row <-> statistic pairing cannot pass).  Both wave
+# arrangements, one / several tiles per block, the UNet's three widths, a few-tile case (M = 8192) and a 2-slice K.
+@pytest.mark.parametrize("M,N,K", [(32768, 1152, 384), (16384, 1728, 576), (8192, 2880, 960), (49152, 384, 128), (33024, 192, 192)])
+def test_linear_layernorm_folded(ctx, M, N, K):
+    d = ctx.device
+    x = _rand((M, K), 31) * (0.5 + _rand((M, 1), 32).abs() * 2.0) + _rand((M, 1), 33) * 1.5
+    x = bf16_round(x)
+    w = bf16_round(_rand((N, K), 34, K ** -0.5))
+    gamma, beta, b = 1.0 + _rand((K,), 35, 0.3), _rand((K,), 36, 0.3), _rand((N,), 37, 0.5)
+    ref = torch.empty(M, N)
+    for s0 in range(0, M, 8192):
+        ref[s0:s0 + 8192] = F.layer_norm(x[s0:s0 + 8192], (K,), gamma, beta, 1e-5) @ w.t() + b
+    xb, wb = x.to(d, torch.bfloat16), w.to(d, torch.bfloat16)
+    for rep in range(2):
+        out = ctx.op_linear_ln(xb, wb, b.to(d), gamma.to(d), beta.to(d))
+        assert torch.isfinite(out).all()
+        _close(out, ref, what=f"LayerNorm-folded linear (run {rep})")
+    out = ctx.op_linear_ln(xb, wb, None, gamma.to(d), beta.to(d))       # q | k | v has no bias
+    _close(out, ref - b, what="LayerNorm-folded linear, no bias")
+
+
+@pytest.mark.parametrize("M,C", [(32768, 384), (16384, 576), (8192, 960)])
+def test_linear_geglu_layernorm_folded(ctx, M, C):
+    from rdm_amd import _lib
+    from rdm_amd.packing import _geglu_perm
+    d = ctx.device
+    x = bf16_round(_rand((M, C), 41) * (0.5 + _rand((M, 1), 42).abs()) + _rand((M, 1), 43))
+    w, b = bf16_round(_rand((8 * C, C), 44, C ** -0.5)), _rand((8 * C,), 45, 0.3)
+    gamma, beta = 1.0 + _rand((C,), 46, 0.3), _rand((C,), 47, 0.3)
+    ref = torch.empty(M, 4 * C)
+    for s0 in range(0, M, 4096):
+        h, g = (F.layer_norm(x[s0:s0 + 4096], (C,), gamma, beta, 1e-5) @ w.t() + b).chunk(2, dim=-1)
+        ref[s0:s0 + 4096] = h * F.gelu(g)
+    perm = _geglu_perm(8 * C)
+    xb, wp, bp = x.to(d, torch.bfloat16), w[perm].contiguous().to(d, torch.bfloat16), b[perm].contiguous().to(d)
+    for rep in range(2):
+        out = ctx.op_linear_ln(xb, wp, bp, gamma.to(d), beta.to(d), act=_lib.ACT_GEGLU)
+        assert out.shape == (M, 4 * C) and torch.isfinite(out).all()
+        _close(out, ref, what=f"LayerNorm-folded geglu (run {rep})")
+
+
+def test_linear_layernorm_folded_refuses_other_shapes(ctx):
+    from rdm_amd._lib import RdmError
+    d = ctx.device
+    x, w = torch.zeros((100, 128), device=d, dtype=torch.bfloat16), torch.zeros((192, 128), device=d, dtype=torch.bfloat16)
+    with pytest.raises(RdmError):
+        ctx.op_linear_ln(x, w, None, torch.ones(128, device=d), torch.zeros(128, device=d))
+
+
 @pytest.mark.parametrize("M,N,K,act", [(1, 768, 768, 0), (2, 2304, 768, 0), (33, 768, 3072, 0), (64, 16384, 768, 0), (128, 2304, 768, 0),
                                        (128, 768, 768, 3), (96, 512, 256, 2), (64, 6144, 768, 1), (128, 6144, 768, 1), (3, 1024, 256, 1)])
 def test_skinny_linear(ctx, M, N, K, act):

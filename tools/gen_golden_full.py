@@ -12,6 +12,9 @@ What is written (tests/golden/full_*.npz; weights are NOT stored, they are re-de
                      x after loop iterations CHECK_DDPM, final latent                                      (config #4)
   full_vq.npz        shipped-spec VQ-f4 decode of a fixed latent: code indices + image (fp16)
   full_clip.npz      ViT-B/32 text embeddings of 3 captions and image embeddings of 2 seeded images
+  full_ddim_k4_b.npz / full_ddpm_k16_b.npz / full_vq_b.npz   (round 4; `ddim4b ddpm16b vqb`) a SECOND trajectory / latent from other
+                     seeds, stored lean (states after the check iterations + final): the golden row placed at batch index 63 of the
+                     batch-64 tests (last tile, wrapped-skip partner) beside row 0
 
 The eps-model of every trajectory is the REFERENCE class (rdm/modules/diffusionmodules/openaimodel.py:36-371) —
 the oracle UNet is additionally asserted equal on the first step.  DDIM update / schedule: oracle.diffusion (restates
@@ -67,7 +70,8 @@ def inputs(k, seed):
     return x_T, cond
 
 
-def gen_ddim(k, tag, seed):
+def gen_ddim(k, tag, seed, lean=False):
+    """lean: store only the states after CHECK_DDIM and the final latent (the second golden row of the batch-64 tests)"""
     m, sd, spec = ref_unet()
     apply_ref = lambda x, t, c: m(x, t, context=[c])
     x_T, cond = inputs(k, seed)
@@ -91,7 +95,9 @@ def gen_ddim(k, tag, seed):
         x_in = img
         img, pred_x0 = odiff.p_sample_ddim(apply_ref, img, cond, t, index, sch, scale=2.0, uc=uncond)
         if i in CHECK_DDIM:
-            keep[f"xin_{i}"] = x_in.numpy(); keep[f"x_{i}"] = img.numpy(); keep[f"px0_{i}"] = pred_x0.numpy()
+            keep[f"x_{i}"] = img.numpy()
+            if not lean:
+                keep[f"xin_{i}"] = x_in.numpy(); keep[f"px0_{i}"] = pred_x0.numpy()
         if i % 10 == 0:
             print(f"[{tag}] step {i} t={int(step)} |x|={img.norm():.3f} ({time.time() - t0:.0f} s)", flush=True)
     np.savez_compressed(os.path.join(OUT, f"full_{tag}.npz"), x_T=x_T.numpy(), cond=cond.numpy(), z=img.numpy(),
@@ -102,12 +108,12 @@ def ddpm_noise(T, shape):
     return torch.from_numpy(np.random.default_rng(NOISE_SEED).standard_normal((T,) + tuple(shape)).astype(np.float32))
 
 
-def gen_ddpm(k=16, T=250, seed=31):
+def gen_ddpm(k=16, T=250, seed=31, tag=None, noise_seed=NOISE_SEED):
     m, sd, spec = ref_unet()
     apply_ref = lambda x, t, c: m(x, t, context=[c])
     x_T, cond = inputs(k, seed)
     sched = odiff.Schedule()
-    noise = ddpm_noise(T, x_T.shape)
+    noise = torch.from_numpy(np.random.default_rng(noise_seed).standard_normal((T,) + tuple(x_T.shape)).astype(np.float32))
     img = x_T
     keep = {}
     t0 = time.time()
@@ -116,14 +122,15 @@ def gen_ddpm(k=16, T=250, seed=31):
         x_in = img
         img = odiff.p_sample_ddpm(apply_ref, sched, img, cond, t, noise[n], True)
         if n in CHECK_DDPM:
-            keep[f"xin_{n}"] = x_in.numpy(); keep[f"x_{n}"] = img.numpy()
+            keep[f"x_{n}"] = img.numpy()
+            if tag is None: keep[f"xin_{n}"] = x_in.numpy()
         if n % 25 == 0:
             print(f"[ddpm_k{k}] n={n} t={i} |x|={img.norm():.3f} ({time.time() - t0:.0f} s)", flush=True)
-    np.savez_compressed(os.path.join(OUT, f"full_ddpm_k{k}.npz"), x_T=x_T.numpy(), cond=cond.numpy(), z=img.numpy(),
-                        steps=np.asarray(CHECK_DDPM), noise_seed=np.int64(NOISE_SEED), timesteps=np.int64(T), **keep)
+    np.savez_compressed(os.path.join(OUT, f"full_ddpm_k{k}{tag or ''}.npz"), x_T=x_T.numpy(), cond=cond.numpy(), z=img.numpy(),
+                        steps=np.asarray(CHECK_DDPM), noise_seed=np.int64(noise_seed), timesteps=np.int64(T), **keep)
 
 
-def gen_vq(seed=55):
+def gen_vq(seed=55, tag=""):
     vs = ovq.shipped_vq_spec()
     sd = ounet.synth_state_dict(ovq.vq_param_shapes(vs), seed=VQ_SEED)
     rng = np.random.default_rng(seed)
@@ -136,7 +143,7 @@ def gen_vq(seed=55):
     top2 = d.topk(2, dim=1, largest=False).values
     print(f"[vq] image |.|max {img.abs().max():.3f}; distinct codes {idx.unique().numel()}; "
           f"min margin between best two codes {float((top2[:, 1] - top2[:, 0]).min()):.3e}")
-    np.savez_compressed(os.path.join(OUT, "full_vq.npz"), z=z.numpy(), indices=idx.numpy().astype(np.int32),
+    np.savez_compressed(os.path.join(OUT, f"full_vq{tag}.npz"), z=z.numpy(), indices=idx.numpy().astype(np.int32),
                         image=img.numpy().astype(np.float16), seed=np.int64(VQ_SEED))
 
 
@@ -177,5 +184,8 @@ if __name__ == "__main__":
     for w in what:
         t0 = time.time()
         {"clip": gen_clip, "vq": gen_vq, "ddim4": lambda: gen_ddim(4, "ddim_k4", 21),
-         "ddim1": lambda: gen_ddim(1, "ddim_k1", 22), "ddpm16": gen_ddpm}[w]()
+         "ddim1": lambda: gen_ddim(1, "ddim_k1", 22), "ddpm16": gen_ddpm,
+         # second golden rows (round 4): other inputs, placed at batch index 63 of the batch-64 tests (tests/test_gpu_full.py)
+         "ddim4b": lambda: gen_ddim(4, "ddim_k4_b", 23, lean=True), "ddpm16b": lambda: gen_ddpm(seed=33, tag="_b", noise_seed=NOISE_SEED + 1),
+         "vqb": lambda: gen_vq(seed=56, tag="_b")}[w]()
         print(f"== {w} done in {time.time() - t0:.0f} s", flush=True)
