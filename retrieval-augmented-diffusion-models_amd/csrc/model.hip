@@ -579,8 +579,12 @@ struct Ops {
     // the RAW bf16 tensor, the row statistics are taken inside the kernel.  false = not available for this shape / mode (the caller
     // runs layernorm + linear).  Clog: logical row width (zero padding beyond it).
     bool linear_ln_big(const bf16_t* x, size_t g, size_t b, int C, int Clog, size_t woff, size_t boff, bool has_bias, int M, int N, int act, bf16_t* out) {
-        static const int off = getenv("RDM_NO_LNFOLD") ? atoi(getenv("RDM_NO_LNFOLD")) : 0;
-        if (off || c->deterministic) return false;
+        // OFF by default (round 4, measured on the headline bench, same box): 38.50 img/s with the fold against 38.75 without.  The
+        // separate LayerNorm passes it removes are 42 ms of a 1650 ms step; the folded GEMMs cost 52 ms more -- every column block of a
+        // row block repeats the row statistics (64 v_dot2_f32_bf16 per K-slice at ~11 cycles each beside the MFMAs: K loop + 30 %), and
+        // the read-out gains 4 LDS reads + 16 FMAs per 8 outputs (GEGLU read-out + 50 %).  DESIGN.md section 8.  RDM_LNFOLD=1 enables it.
+        static const int on = getenv("RDM_LNFOLD") ? atoi(getenv("RDM_LNFOLD")) : 0;
+        if (!on || c->deterministic) return false;
         IgemmParams p = base(M, N, C);
         p.A0 = x; p.C0 = C; p.W = w<bf16_t>(woff); p.act = act; p.out_bf16 = out; if (act == ACT_GEGLU) p.ldo = N / 2;
         p.ln_inv_c = 1.0f / (float)Clog; p.ln_eps = 1e-5f;
