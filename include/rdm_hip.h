@@ -158,6 +158,13 @@ int rdm_vq_decode(rdm_ctx* ctx, const float* z, int b, int force_not_quantize, f
  * [dev] int64 [b, h*w] -> quantize.get_codebook_entry -> post_quant_conv -> Decoder -> img_out [dev] f32 [b,3,R,R].
  * For first stages with a wide latent (VQGAN-f16, z_channels % 64 == 0). */
 int rdm_vq_decode_indices(rdm_ctx* ctx, const int64_t* indices, int b, float* img_out);
+/* ---- first stage, encoder side (training input): LatentDiffusion.encode_first_stage -> VQModelInterface.encode = quant_conv(encoder(x))
+ *      under torch.no_grad(), reached from MinimalRETRODiffusion.shared_step -> get_input (rdm/models/diffusion/ddpm.py:390-391).
+ * Same rdm_vq_cfg as the decoder (the encoder mirrors it: ddconfig is shared); state_dict keys `encoder.*`, `quant_conv.*`.
+ * img [dev] f32 [b,out_ch,R,R] -> z_out [dev] f32 [b,embed_dim,R/f,R/f] (no quantisation: VQModelInterface quantises in decode). */
+long long rdm_vqenc_manifest(const rdm_vq_cfg* cfg, char* buf, size_t buflen, size_t* blob_bytes);
+int rdm_load_vqenc(rdm_ctx* ctx, const rdm_vq_cfg* cfg, const void* packed, size_t nbytes);
+int rdm_vq_encode(rdm_ctx* ctx, const float* img, int b, float* z_out);
 /* scripts/rdm_sample.py:203-214 custom_to_np/custom_to_pil: f32 NCHW [-1,1] -> uint8 NHWC (truncating). */
 int rdm_to_uint8(rdm_ctx* ctx, const float* img, int b, int c, int h, int w, uint8_t* out);
 
@@ -216,6 +223,9 @@ int rdm_db_gather(rdm_ctx* ctx, const uint32_t* idx, long long n_idx, float* out
 int rdm_comm_unique_id(rdm_ctx* ctx, void* id128 /*[host] 128 bytes*/);
 int rdm_comm_init(rdm_ctx* ctx, const void* id128 /*[host]*/, int rank, int world);
 int rdm_comm_all_gather(rdm_ctx* ctx, const void* send /*[dev]*/, void* recv /*[dev]*/, size_t nbytes);
+/* gradient all-reduce of data-parallel training (the reference: DDP inside pytorch_lightning's Trainer, main.py:783-785): buf [dev] f32
+ * [count] <- sum over ranks (average != 0: divided by the world size), in place, enqueued on the stream. */
+int rdm_comm_all_reduce_f32(rdm_ctx* ctx, float* buf /*[dev]*/, size_t count, int average);
 int rdm_comm_destroy(rdm_ctx* ctx);
 
 /* ---- measurement: optional HIP-event brackets around launches on the context stream, by kernel class.
@@ -267,6 +277,23 @@ int rdm_op_add(rdm_ctx* ctx, const void* a_bf16, const void* b_bf16, void* out_b
  * that is the gradient of Upsample's nearest-neighbour F.interpolate: x bf16 [B, 2H, 2W, C] -> out bf16 [B, H, W, C]. */
 int rdm_op_silu(rdm_ctx* ctx, const float* x, const float* dy_or_null, void* out_bf16_or_f32, long long n);
 int rdm_op_sumpool2(rdm_ctx* ctx, const void* x_bf16, void* out_bf16, int B, int H, int W, int C);
+/* The elementwise steps of MinimalRETRODiffusion.shared_step -> forward -> ldm p_losses around the UNet (rdm/models/diffusion/ddpm.py:390-443):
+ *   rdm_op_q_sample   LatentDiffusion.q_sample: x_t = sqrt_ac[b] x0 + sqrt_1mac[b] noise; x0 / noise / out f32 NCHW [B,C,H,W] (out may be
+ *                     NULL), out_nhwc bf16 [B,H,W,cpad] (may be NULL; channels >= C zero): the operand of the native training forward;
+ *   rdm_op_mse_loss   p_losses (l2, eps parameterisation): se[b] = mean_{chw} (eps - target)^2 and, when deps is given,
+ *                     deps = coef[b] (eps - target); eps / deps bf16 NHWC [B,H,W,ldc] (first C channels), target f32 NCHW;
+ *   rdm_op_where_rows out[b,:] = mask[b] ? a[b,:] : x[b,:] (the Bernoulli(p_uncond) conditioning switch, :393-396); mask uint8 [rows];
+ *   rdm_op_timestep_embedding  ldm timestep_embedding: t int64 [B] -> bf16 [B, ld] = [cos | sin | zero tail];
+ *   rdm_op_colsum_samples      x bf16 [B,HW,N] -> bf16 [B,N], sum over a sample's pixels (gradient of the time-embedding row a ResBlock adds);
+ *   rdm_op_expand2    x bf16 [B,H,W,C] -> [B,2H,2W,C]: mode 0 zero insertion (stride-2 conv gradient as a stride-1 one), mode 1 nearest copy. */
+int rdm_op_q_sample(rdm_ctx* ctx, const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac, float* out_or_null,
+                    void* out_nhwc_bf16_or_null, int B, int C, int H, int W, int cpad);
+int rdm_op_mse_loss(rdm_ctx* ctx, const void* eps_nhwc_bf16, const float* target, const float* coef_or_null, float* se, void* deps_nhwc_bf16_or_null,
+                    int B, int C, int H, int W, int ldc);
+int rdm_op_where_rows(rdm_ctx* ctx, const unsigned char* mask, const float* a, const float* x, float* out, long long rows, long long n);
+int rdm_op_timestep_embedding(rdm_ctx* ctx, const int64_t* t, void* out_bf16, int B, int dim, int ld);
+int rdm_op_colsum_samples(rdm_ctx* ctx, const void* x_bf16, void* out_bf16, int B, int HW, int N);
+int rdm_op_expand2(rdm_ctx* ctx, const void* x_bf16, void* out_bf16, int B, int H, int W, int C, int mode);
 /* LitEma.forward (ldm/modules/ema.py: `shadow.sub_(one_minus_decay * (shadow - param))`; the caller computes
  * decay = min(decay, (1 + num_updates) / (10 + num_updates)) like the reference) on fp32 tensors in place. */
 int rdm_op_ema(rdm_ctx* ctx, float* shadow, const float* param, long long n, float one_minus_decay);

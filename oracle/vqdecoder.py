@@ -174,3 +174,61 @@ def _decode_quantized(sd, spec: VQSpec, z):
             h = F.conv2d(h, sd[f"decoder.up.{lvl}.upsample.conv.weight"], sd[f"decoder.up.{lvl}.upsample.conv.bias"], padding=1)
     h = _swish(_gn(h, sd, "decoder.norm_out"))
     return F.conv2d(h, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
+
+
+# ------------------------------------------------------------------------------------------------ encoder side (round 4)
+# PARITY UNPINNED like the decoder: ldm Encoder / Downsample / VQModelInterface.encode are not vendored in the reference; restated from
+# the published ldm code (ldm/modules/diffusionmodules/model.py class Encoder, ldm/models/autoencoder.py VQModelInterface.encode:
+# `h = self.encoder(x); h = self.quant_conv(h); return h`).  Call site in the reference: MinimalRETRODiffusion.shared_step ->
+# get_input -> encode_first_stage (rdm/models/diffusion/ddpm.py:390-391), under torch.no_grad().
+
+def vq_encoder_param_shapes(s: VQSpec) -> Dict[str, tuple]:
+    """`encoder.*` and `quant_conv.*` of the first-stage state dict (in_channels = out_ch, double_z = False)."""
+    p: Dict[str, tuple] = {}
+    p["encoder.conv_in.weight"] = (s.ch, s.out_ch, 3, 3); p["encoder.conv_in.bias"] = (s.ch,)
+    block_in, curr_res = s.ch, s.resolution
+    for lvl in range(len(s.ch_mult)):
+        block_out = s.ch * s.ch_mult[lvl]
+        for i in range(s.num_res_blocks):
+            _res_shapes(p, f"encoder.down.{lvl}.block.{i}", block_in, block_out)
+            block_in = block_out
+            if curr_res in s.attn_resolutions:
+                a = f"encoder.down.{lvl}.attn.{i}"
+                p[a + ".norm.weight"] = (block_in,); p[a + ".norm.bias"] = (block_in,)
+                for n in ("q", "k", "v", "proj_out"):
+                    p[f"{a}.{n}.weight"] = (block_in, block_in, 1, 1); p[f"{a}.{n}.bias"] = (block_in,)
+        if lvl != len(s.ch_mult) - 1:
+            p[f"encoder.down.{lvl}.downsample.conv.weight"] = (block_in, block_in, 3, 3)
+            p[f"encoder.down.{lvl}.downsample.conv.bias"] = (block_in,)
+            curr_res //= 2
+    _res_shapes(p, "encoder.mid.block_1", block_in, block_in)
+    if s.mid_attn:
+        a = "encoder.mid.attn_1"
+        p[a + ".norm.weight"] = (block_in,); p[a + ".norm.bias"] = (block_in,)
+        for n in ("q", "k", "v", "proj_out"):
+            p[f"{a}.{n}.weight"] = (block_in, block_in, 1, 1); p[f"{a}.{n}.bias"] = (block_in,)
+    _res_shapes(p, "encoder.mid.block_2", block_in, block_in)
+    p["encoder.norm_out.weight"] = (block_in,); p["encoder.norm_out.bias"] = (block_in,)
+    p["encoder.conv_out.weight"] = (s.z_channels, block_in, 3, 3); p["encoder.conv_out.bias"] = (s.z_channels,)
+    p["quant_conv.weight"] = (s.embed_dim, s.z_channels, 1, 1); p["quant_conv.bias"] = (s.embed_dim,)
+    return p
+
+
+def vq_encode(sd, spec: VQSpec, x, scale_factor=1.0):
+    """encode_first_stage + get_first_stage_encoding for a VQModelInterface first stage: scale_factor * quant_conv(encoder(x)).
+    [ldm] Downsample(with_conv): F.pad(x, (0, 1, 0, 1)) then Conv2d(kernel 3, stride 2, padding 0)."""
+    h = F.conv2d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
+    for lvl in range(len(spec.ch_mult)):
+        for i in range(spec.num_res_blocks):
+            h = _resnet(sd, f"encoder.down.{lvl}.block.{i}", h)
+            if f"encoder.down.{lvl}.attn.{i}.q.weight" in sd:
+                h = _attn(sd, f"encoder.down.{lvl}.attn.{i}", h)
+        if lvl != len(spec.ch_mult) - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)
+            h = F.conv2d(h, sd[f"encoder.down.{lvl}.downsample.conv.weight"], sd[f"encoder.down.{lvl}.downsample.conv.bias"], stride=2, padding=0)
+    h = _resnet(sd, "encoder.mid.block_1", h)
+    if spec.mid_attn:
+        h = _attn(sd, "encoder.mid.attn_1", h)
+    h = _resnet(sd, "encoder.mid.block_2", h)
+    h = F.conv2d(_swish(_gn(h, sd, "encoder.norm_out")), sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+    return scale_factor * F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])

@@ -106,7 +106,17 @@ SIGNATURES = {
     "rdm_comm_unique_id": (C.c_int, [_P, _P]),
     "rdm_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "rdm_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "rdm_comm_all_reduce_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_int]),
     "rdm_comm_destroy": (C.c_int, [_P]),
+    "rdm_vqenc_manifest": (C.c_longlong, [_P, _P, C.c_size_t, _P]),
+    "rdm_load_vqenc": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "rdm_vq_encode": (C.c_int, [_P, _P, C.c_int, _P]),
+    "rdm_op_q_sample": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rdm_op_mse_loss": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rdm_op_where_rows": (C.c_int, [_P, _P, _P, _P, _P, C.c_longlong, C.c_longlong]),
+    "rdm_op_timestep_embedding": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "rdm_op_colsum_samples": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "rdm_op_expand2": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rdm_op_linear": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "rdm_op_conv3x3": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int]),
@@ -244,7 +254,8 @@ def make_clip_cfg(embed_dim=512, image_resolution=224, vision_layers=12, vision_
 
 def manifest(kind: str, cfg):
     """-> (list of (offset, nbytes, kind, [src...]), blob_bytes)"""
-    fn = {"unet": lib.rdm_unet_manifest, "vq": lib.rdm_vq_manifest, "clip": lib.rdm_clip_manifest, "rarm": lib.rdm_rarm_manifest}[kind]
+    fn = {"unet": lib.rdm_unet_manifest, "vq": lib.rdm_vq_manifest, "vqenc": lib.rdm_vqenc_manifest, "clip": lib.rdm_clip_manifest,
+          "rarm": lib.rdm_rarm_manifest}[kind]
     blob = C.c_size_t(0)
     n = fn(C.byref(cfg), None, 0, C.byref(blob))
     if n < 0:
@@ -274,7 +285,7 @@ class Context:
             raise RdmError(f"rdm_ctx_create failed ({rc}); no usable HIP device {device}")
         self._h = h
         self.device = torch.device("cuda", device)
-        self.unet_cfg = self.vq_cfg = self.clip_cfg = self.rarm_cfg = None
+        self.unet_cfg = self.vq_cfg = self.vqenc_cfg = self.clip_cfg = self.rarm_cfg = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -300,6 +311,21 @@ class Context:
 
     def load_vq(self, cfg: VqCfg, blob: np.ndarray):
         self._check(lib.rdm_load_vq(self._h, C.byref(cfg), blob.ctypes.data_as(_P), blob.nbytes)); self.vq_cfg = cfg
+
+    def load_vq_encoder(self, cfg: VqCfg, blob: np.ndarray):
+        """First-stage ENCODER weights (`encoder.*`, `quant_conv.*` of the first-stage state dict; packing.pack("vqenc", cfg, sd))."""
+        self._check(lib.rdm_load_vqenc(self._h, C.byref(cfg), blob.ctypes.data_as(_P), blob.nbytes)); self.vqenc_cfg = cfg
+
+    def vq_encode(self, img):
+        """VQModelInterface.encode: image f32 [b,out_ch,R,R] in [-1,1] -> latent f32 [b,embed_dim,R/f,R/f] (not quantised)."""
+        img = self._dev(img, torch.float32)
+        cfg = self._need("vq_encode", "vqenc")
+        if img.ndim != 4 or tuple(img.shape[1:]) != (cfg.out_ch, cfg.resolution, cfg.resolution):
+            raise RdmError(f"vq_encode: image must be [b,{cfg.out_ch},{cfg.resolution},{cfg.resolution}], got {tuple(img.shape)}")
+        zr = cfg.resolution >> (cfg.n_ch_mult - 1)
+        z = torch.empty((img.shape[0], cfg.embed_dim, zr, zr), device=self.device, dtype=torch.float32)
+        self._check(lib.rdm_vq_encode(self._h, _ptr(img), img.shape[0], _ptr(z)))
+        return z
 
     def load_clip(self, cfg: ClipCfg, blob: np.ndarray):
         self._check(lib.rdm_load_clip(self._h, C.byref(cfg), blob.ctypes.data_as(_P), blob.nbytes)); self.clip_cfg = cfg
@@ -566,6 +592,13 @@ class Context:
         self._check(lib.rdm_comm_all_gather(self._h, _ptr(local), _ptr(out), local.numel() * local.element_size()))
         return out
 
+    def comm_all_reduce(self, buf: torch.Tensor, average=True):
+        """In-place sum (mean) over the ranks of an fp32 device tensor through the context's RCCL communicator."""
+        if buf.dtype != torch.float32 or not buf.is_contiguous():
+            raise RdmError("comm_all_reduce: contiguous float32 tensor required")
+        self._check(lib.rdm_comm_all_reduce_f32(self._h, _ptr(buf), buf.numel(), int(bool(average))))
+        return buf
+
     def comm_destroy(self):
         self._check(lib.rdm_comm_destroy(self._h))
 
@@ -676,6 +709,51 @@ class Context:
         """x fp32: -> silu(x) bf16, or with dy (fp32) the gradient dy * silu'(x) fp32."""
         out = torch.empty(x.shape, device=self.device, dtype=torch.bfloat16 if dy is None else torch.float32)
         self._check(lib.rdm_op_silu(self._h, _ptr(x), _ptr(dy) if dy is not None else None, _ptr(out), x.numel()))
+        return out
+
+    # ---- training-step glue (include/rdm_hip.h: rdm_op_q_sample ...)
+    def op_q_sample(self, x0, noise, sqrt_ac, sqrt_1mac, want_nchw=True, cpad=0):
+        """x_t = sqrt_ac[b] x0 + sqrt_1mac[b] noise: -> (f32 NCHW or None, bf16 NHWC [B,H,W,cpad] or None)."""
+        B, Cc, H, W = x0.shape
+        out = torch.empty_like(x0) if want_nchw else None
+        onh = torch.empty((B, H, W, cpad), device=self.device, dtype=torch.bfloat16) if cpad else None
+        self._check(lib.rdm_op_q_sample(self._h, _ptr(x0), _ptr(noise), _ptr(sqrt_ac), _ptr(sqrt_1mac), _ptr(out), _ptr(onh), B, Cc, H, W, cpad))
+        return out, onh
+
+    def op_mse_loss(self, eps_nhwc, target, coef=None, C_=None):
+        """eps bf16 [B,H,W,ldc], target f32 [B,C,H,W] -> (se f32 [B], deps bf16 [B,H,W,ldc] = coef[b] (eps - target), or None without coef)."""
+        B, H, W, ldc = eps_nhwc.shape
+        Cc = target.shape[1] if C_ is None else C_
+        se = torch.empty((B,), device=self.device, dtype=torch.float32)
+        deps = torch.empty_like(eps_nhwc) if coef is not None else None
+        self._check(lib.rdm_op_mse_loss(self._h, _ptr(eps_nhwc), _ptr(target), _ptr(coef), _ptr(se), _ptr(deps), B, Cc, H, W, ldc))
+        return se, deps
+
+    def op_where_rows(self, mask, a, x):
+        """out[b] = a[b] if mask[b] else x[b]; mask uint8 / bool [B], a / x f32 [B, ...]."""
+        out = torch.empty_like(x)
+        m8 = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        self._check(lib.rdm_op_where_rows(self._h, _ptr(m8), _ptr(a), _ptr(x), _ptr(out), x.shape[0], x[0].numel()))
+        return out
+
+    def op_timestep_embedding(self, t, dim, ld=None):
+        ld = dim if ld is None else ld
+        out = torch.empty((t.shape[0], ld), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_timestep_embedding(self._h, _ptr(t), _ptr(out), t.shape[0], dim, ld))
+        return out
+
+    def op_colsum_samples(self, x):
+        """x bf16 [B, HW, N] -> bf16 [B, N]."""
+        B, HW, N = x.shape
+        out = torch.empty((B, N), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_colsum_samples(self._h, _ptr(x), _ptr(out), B, HW, N))
+        return out
+
+    def op_expand2(self, x, mode):
+        """x bf16 [B,H,W,C] -> [B,2H,2W,C]: mode 0 zero insertion, mode 1 nearest-neighbour copy."""
+        B, H, W, Cc = x.shape
+        out = torch.empty((B, 2 * H, 2 * W, Cc), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_expand2(self._h, _ptr(x), _ptr(out), B, H, W, Cc, mode))
         return out
 
     def op_sumpool2(self, x):

@@ -749,3 +749,122 @@ hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* 
     attn_bwd_dq_kernel<<<dim3((n / 32 + 3) / 4, H, B), 256, 0, st>>>(p);
     return hipGetLastError();
 }
+
+
+// ==================================================================================== training-step glue
+// The elementwise pieces around the UNet in MinimalRETRODiffusion.shared_step -> forward -> ldm p_losses
+// (rdm/models/diffusion/ddpm.py:390-443; ldm LatentDiffusion.q_sample / p_losses): noising, the squared-error loss and its gradient,
+// the Bernoulli(p_uncond) conditioning switch, the per-sample bias gradient of the time-embedding rows, the data movement of the
+// Downsample / Upsample gradients, and the scaling that turns an all-reduced sum into a mean.
+
+// q_sample: x_t = sqrt(abar_t) x_0 + sqrt(1 - abar_t) eps per sample, fp32 NCHW in; fp32 NCHW out (what the reference hands to the
+// UNet) and / or the bf16 NHWC [B, H, W, cpad] operand of the native training forward (channels beyond C zero)
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const float* __restrict__ a,
+                                                       const float* __restrict__ b, float* __restrict__ out, bf16_t* __restrict__ out_nhwc, int B, int C,
+                                                       int HW, int cpad) {
+    const long long n = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int bi = (int)(i / HW), r = (int)(i % HW);
+        const float av = a[bi], bv = b[bi];
+        for (int c = 0; c < cpad; c++) {
+            float v = 0.f;
+            if (c < C) {
+                const long long j = ((long long)bi * C + c) * HW + r;
+                v = av * x0[j] + bv * noise[j];
+                if (out) out[j] = v;
+            }
+            if (out_nhwc) out_nhwc[i * cpad + c] = f2bf(v);
+        }
+    }
+}
+hipError_t launch_q_sample(const float* x0, const float* noise, const float* a, const float* b, float* out, bf16_t* out_nhwc, int B, int C, int HW, int cpad,
+                           hipStream_t st) {
+    long long g = ((long long)B * HW + 255) / 256; if (g > 8192) g = 8192; if (g < 1) g = 1;
+    q_sample_kernel<<<dim3((unsigned)g), 256, 0, st>>>(x0, noise, a, b, out, out_nhwc, B, C, HW, cpad < C ? C : cpad);
+    return hipGetLastError();
+}
+
+// ldm p_losses, l2 / eps parameterisation: se[b] = mean over (C, H, W) of (eps_theta - target)^2 (the per-sample `loss_simple` before
+// the batch mean) and deps = coef[b] (eps_theta - target): the caller folds 2 / (C H W B) and the l_simple / elbo weights into coef.
+// eps bf16 NHWC [B, H, W, ldc] (the first C channels count), target fp32 NCHW.  One block per sample, fixed-order reduction.
+__global__ __launch_bounds__(256) void mse_loss_kernel(const bf16_t* __restrict__ eps, const float* __restrict__ target, const float* __restrict__ coef,
+                                                       float* __restrict__ se, bf16_t* __restrict__ deps, int C, int HW, int ldc) {
+    __shared__ float red[256];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int r = threadIdx.x; r < HW; r += 256) {
+        for (int c = 0; c < ldc; c++) {
+            float d = 0.f;
+            if (c < C) {
+                d = bf2f(eps[((long long)b * HW + r) * ldc + c]) - target[((long long)b * C + c) * HW + r];
+                s += d * d;
+            }
+            if (deps) deps[((long long)b * HW + r) * ldc + c] = f2bf(coef[b] * d);
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) se[b] = red[0] / (float)((long long)C * HW);
+}
+hipError_t launch_mse_loss(const bf16_t* eps, const float* target, const float* coef, float* se, bf16_t* deps, int B, int C, int HW, int ldc, hipStream_t st) {
+    mse_loss_kernel<<<dim3((unsigned)B), 256, 0, st>>>(eps, target, coef, se, deps, C, HW, ldc);
+    return hipGetLastError();
+}
+
+// out[b, :] = mask[b] ? a[b, :] : x[b, :]   (torch.where(repeat(mask, 'b -> b 1 1'), uncond_signal, r), ddpm.py:393-396)
+__global__ __launch_bounds__(256) void where_rows_kernel(const unsigned char* __restrict__ mask, const float* __restrict__ a, const float* __restrict__ x,
+                                                         float* __restrict__ out, long long rows, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows * n; i += (long long)gridDim.x * 256) out[i] = mask[i / n] ? a[i] : x[i];
+}
+hipError_t launch_where_rows(const unsigned char* mask, const float* a, const float* x, float* out, long long rows, long long n, hipStream_t st) {
+    long long g = (rows * n + 255) / 256; if (g > 8192) g = 8192; if (g < 1) g = 1;
+    where_rows_kernel<<<dim3((unsigned)g), 256, 0, st>>>(mask, a, x, out, rows, n);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ x, long long n, float s) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] *= s;
+}
+hipError_t launch_scale_f32(float* x, long long n, float s, hipStream_t st) {
+    long long g = (n + 255) / 256; if (g > 16384) g = 16384; if (g < 1) g = 1;
+    scale_f32_kernel<<<dim3((unsigned)g), 256, 0, st>>>(x, n, s);
+    return hipGetLastError();
+}
+
+// per-sample column sums of a bf16 [B, HW, N] tensor -> bf16 [B, N] (the gradient of the time-embedding row a ResBlock adds to every
+// pixel of a sample: h = conv(.) + emb_out[b]): one block per (sample, 64 columns), fixed-order tree over the pixels
+__global__ __launch_bounds__(256) void colsum_samples_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int HW, int N) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float s = 0.f;
+    if (col < N) for (int m = part; m < HW; m += 4) s += bf2f(x[((long long)b * HW + m) * N + col]);
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && col < N) out[(long long)b * N + col] = f2bf((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+hipError_t launch_colsum_samples(const bf16_t* x, bf16_t* out, int B, int HW, int N, hipStream_t st) {
+    colsum_samples_kernel<<<dim3((N + 63) / 64, B), 256, 0, st>>>(x, out, HW, N);
+    return hipGetLastError();
+}
+
+// mode 0: zero insertion  out[b, 2y, 2x, :] = x[b, y, x, :], zeros elsewhere (a stride-2 conv's output gradient seen as a stride-1 one);
+// mode 1: nearest-neighbour 2x copy out[b, Y, X, :] = x[b, Y / 2, X / 2, :] (what Upsample's fused conv read).  x [B, H, W, C], out [B, 2H, 2W, C], C % 8 == 0
+__global__ __launch_bounds__(256) void expand2_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int H, int W, int C, int mode) {
+    const int cv = C / 8;
+    const long long n = (long long)B * 2 * H * 2 * W * cv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % cv); long long r = i / cv;
+        const int X = (int)(r % (2 * W)); r /= 2 * W;
+        const int Y = (int)(r % (2 * H)); const int b = (int)(r / (2 * H));
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (mode == 1 || ((X & 1) == 0 && (Y & 1) == 0)) v = *(const uint4*)(x + (((long long)b * H + (Y >> 1)) * W + (X >> 1)) * C + c * 8);
+        *(uint4*)(out + i * 8) = v;
+    }
+}
+hipError_t launch_expand2(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, int mode, hipStream_t st) {
+    if (C % 8) return hipErrorInvalidValue;
+    long long g = ((long long)B * 4 * H * W * (C / 8) + 255) / 256; if (g > 16384) g = 16384; if (g < 1) g = 1;
+    expand2_kernel<<<dim3((unsigned)g), 256, 0, st>>>(x, out, B, H, W, C, mode);
+    return hipGetLastError();
+}

@@ -82,6 +82,7 @@ struct IgemmParams {
     int M, N, K;
     // conv3x3 geometry (conv mode): input [B, Hin, Win, C0(+C1)], output [B, Hout, Wout, N]
     int Hin, Win, Hout, Wout, stride, ups;
+    int asym;                   // generic implicit GEMM only: the 3x3 window of output (oy, ox) starts AT input (stride oy, stride ox) -- F.pad(x, (0, 1, 0, 1)) + an unpadded conv (ldm autoencoder Downsample)
     // epilogue
     float alpha;                // acc scale
     const float* bias;          // [N] (permuted for GEGLU) or null

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
                         }
                         mask |= (oy << 9) | (ox << 20);
                     } else {
-                        const int cy = oy * p.stride, cx = ox * p.stride;
+                        const int cy = oy * p.stride + p.asym, cx = ox * p.stride + p.asym;     // asym: zero padding (0, 1, 0, 1) instead of 1 all round
                         a_pix[i] = (b * p.Hin + cy) * p.Win + cx;
 #pragma unroll
                         for (int tp = 0; tp < 9; tp++) {

@@ -168,6 +168,13 @@ hipError_t launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* pb
                         hipStream_t st);
 hipError_t launch_ema(float* shadow, const float* p, long long n, float one_minus_decay, hipStream_t st);
 hipError_t launch_silu(const float* x, const float* dy, bf16_t* ob, float* of, long long n, hipStream_t st);
+// training-step glue (backward.hip, end): q_sample, squared-error loss + gradient, conditioning switch, scaling, per-sample column sums, 2x expansions
+hipError_t launch_q_sample(const float* x0, const float* noise, const float* a, const float* b, float* out, bf16_t* out_nhwc, int B, int C, int HW, int cpad, hipStream_t st);
+hipError_t launch_mse_loss(const bf16_t* eps, const float* target, const float* coef, float* se, bf16_t* deps, int B, int C, int HW, int ldc, hipStream_t st);
+hipError_t launch_where_rows(const unsigned char* mask, const float* a, const float* x, float* out, long long rows, long long n, hipStream_t st);
+hipError_t launch_scale_f32(float* x, long long n, float s, hipStream_t st);
+hipError_t launch_colsum_samples(const bf16_t* x, bf16_t* out, int B, int HW, int N, hipStream_t st);
+hipError_t launch_expand2(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, int mode, hipStream_t st);
 hipError_t launch_sumpool2(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t st);
 // fused attention backward, d_head = 32 (backward.hip): no score matrix in memory
 size_t attn_bwd_scratch_bytes(int B, int H, int n, int m);

@@ -383,7 +383,7 @@ hipError_t launch_cast_f32_bf16(const float* x, bf16_t* y, long long n, hipStrea
 // y[c][r] = x[r][c] (small weight matrices, once per sampling call)
 __global__ void transpose_bf16_kernel(const bf16_t* x, bf16_t* y, int rows, int cols, int ldy) {
     __shared__ bf16_t tile[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;      // row tiles on grid.x: a [millions of rows, N] operand (Linear weight gradients) has more than 65 535 of them
     x += (long long)blockIdx.z * rows * cols; y += (long long)blockIdx.z * cols * ldy;        // batch of matrices; ldy: output row pitch (>= rows)
     for (int i = threadIdx.y; i < 32; i += 8) {
         const int r = r0 + i, c = c0 + threadIdx.x;
@@ -396,7 +396,8 @@ __global__ void transpose_bf16_kernel(const bf16_t* x, bf16_t* y, int rows, int 
     }
 }
 hipError_t launch_transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st, int batch, int ldy) {
-    transpose_bf16_kernel<<<dim3((cols + 31) / 32, (rows + 31) / 32, batch < 1 ? 1 : batch), dim3(32, 8), 0, st>>>(x, y, rows, cols, ldy > 0 ? ldy : rows);
+    if ((cols + 31) / 32 > 65535) return hipErrorInvalidValue;
+    transpose_bf16_kernel<<<dim3((rows + 31) / 32, (cols + 31) / 32, batch < 1 ? 1 : batch), dim3(32, 8), 0, st>>>(x, y, rows, cols, ldy > 0 ? ldy : rows);
     return hipGetLastError();
 }
 

@@ -330,6 +330,67 @@ static void build_vq(VqModel& v, const rdm_vq_cfg& c, Manifest& mf) {
     v.coutw = f32("decoder.conv_out.weight", (size_t)c.out_ch * bin * 9); v.coutb = f32("decoder.conv_out.bias", c.out_ch);
 }
 
+// ------------------------------------------------------------------------------------ VQ-f4 first-stage ENCODER description (training input)
+// ldm Encoder (ldm/modules/diffusionmodules/model.py; un-vendored: restated from the published code, parity unpinned) as reached from
+// MinimalRETRODiffusion.get_input -> encode_first_stage -> VQModelInterface.encode = quant_conv(encoder(x)) under torch.no_grad()
+// (rdm/models/diffusion/ddpm.py:390-391): conv_in, per level num_res_blocks ResnetBlocks (+ AttnBlocks at attn_resolutions) and a
+// stride-2 Downsample conv with (0, 1, 0, 1) zero padding, mid res-attn-res, GroupNorm + swish + conv_out, quant_conv (1x1).
+struct VqEncModel {
+    rdm_vq_cfg cfg{}; bool loaded = false;
+    size_t cinw, cinb, noutg, noutb, coutw, coutb, qw, qb;
+    std::vector<std::vector<VqRes>> down; std::vector<std::vector<VqAttn>> down_attn; std::vector<ConvW> downsample;   // indexed by level
+    VqRes mid1, mid2; VqAttn attn;
+    char* blob = nullptr; size_t blob_bytes = 0; Arena arena;
+};
+static void build_vqenc(VqEncModel& v, const rdm_vq_cfg& c, Manifest& mf) {
+    v.cfg = c;
+    auto f32 = [&](const std::string& n, size_t numel) { return mf.add("f32", n, numel * 4); };
+    auto bf = [&](const std::string& n, size_t numel) { return mf.add("bf16", n, numel * 2); };
+    auto add_res = [&](const std::string& pre, int cin, int cout) {
+        VqRes r{}; r.cin = cin; r.cout = cout; r.skip = cin != cout;
+        r.n1g = f32(pre + ".norm1.weight", cin); r.n1b = f32(pre + ".norm1.bias", cin);
+        r.w1 = mf.add("conv3", pre + ".conv1.weight", (size_t)cout * cin * 9 * 2); r.b1 = f32(pre + ".conv1.bias", cout);
+        r.n2g = f32(pre + ".norm2.weight", cout); r.n2b = f32(pre + ".norm2.bias", cout);
+        r.w2 = mf.add("conv3", pre + ".conv2.weight", (size_t)cout * cout * 9 * 2); r.b2 = f32(pre + ".conv2.bias", cout);
+        if (r.skip) { r.wsk = bf(pre + ".nin_shortcut.weight", (size_t)cout * cin); r.bsk = f32(pre + ".nin_shortcut.bias", cout); }
+        return r;
+    };
+    auto add_attn = [&](const std::string& p, int ch) {
+        VqAttn a{}; a.c = ch;
+        a.ng = f32(p + ".norm.weight", ch); a.nb = f32(p + ".norm.bias", ch);
+        a.wq = bf(p + ".q.weight", (size_t)ch * ch); a.bq = f32(p + ".q.bias", ch);
+        a.wk = bf(p + ".k.weight", (size_t)ch * ch); a.bk = f32(p + ".k.bias", ch);
+        a.wv = bf(p + ".v.weight", (size_t)ch * ch); a.bv = f32(p + ".v.bias", ch);
+        a.wo = bf(p + ".proj_out.weight", (size_t)ch * ch); a.bo = f32(p + ".proj_out.bias", ch);
+        return a;
+    };
+    v.cinw = f32("encoder.conv_in.weight", (size_t)c.ch * c.out_ch * 9); v.cinb = f32("encoder.conv_in.bias", c.ch);
+    v.down.assign(c.n_ch_mult, {}); v.down_attn.assign(c.n_ch_mult, {}); v.downsample.assign(c.n_ch_mult, ConvW{});
+    int bin = c.ch, curr_res = c.resolution;
+    for (int lvl = 0; lvl < c.n_ch_mult; lvl++) {
+        const int bout = c.ch * c.ch_mult[lvl];
+        bool at = false;
+        for (int i = 0; i < c.n_attn_resolutions; i++) at = at || c.attn_resolutions[i] == curr_res;
+        for (int i = 0; i < c.num_res_blocks; i++) {
+            char pre[64]; snprintf(pre, sizeof pre, "encoder.down.%d.block.%d", lvl, i);
+            v.down[lvl].push_back(add_res(pre, bin, bout)); bin = bout;
+            if (at) { snprintf(pre, sizeof pre, "encoder.down.%d.attn.%d", lvl, i); v.down_attn[lvl].push_back(add_attn(pre, bin)); }
+        }
+        if (lvl != c.n_ch_mult - 1) {
+            char pre[64]; snprintf(pre, sizeof pre, "encoder.down.%d.downsample.conv", lvl);
+            ConvW d{}; d.c = bin; d.w = mf.add("conv3", std::string(pre) + ".weight", (size_t)bin * bin * 9 * 2);
+            d.b = f32(std::string(pre) + ".bias", bin); v.downsample[lvl] = d;
+            curr_res /= 2;
+        }
+    }
+    v.mid1 = add_res("encoder.mid.block_1", bin, bin);
+    if (c.mid_attn) v.attn = add_attn("encoder.mid.attn_1", bin);
+    v.mid2 = add_res("encoder.mid.block_2", bin, bin);
+    v.noutg = f32("encoder.norm_out.weight", bin); v.noutb = f32("encoder.norm_out.bias", bin);
+    v.coutw = f32("encoder.conv_out.weight", (size_t)c.z_channels * bin * 9); v.coutb = f32("encoder.conv_out.bias", c.z_channels);
+    v.qw = f32("quant_conv.weight", (size_t)c.embed_dim * c.z_channels); v.qb = f32("quant_conv.bias", c.embed_dim);
+}
+
 // ------------------------------------------------------------------------------------ CLIP description
 struct ClipBlk { size_t ln1g, ln1b, wqkv, bqkv, wo, bo, ln2g, ln2b, wfc, bfc, wpj, bpj; };
 struct ClipModel {
@@ -419,7 +480,7 @@ static void build_rarm(RarmModel& m, const rdm_rarm_cfg& c, Manifest& mf) {
 struct rdm_ctx {
     int device = 0; hipStream_t stream = nullptr; char err[512] = {0};
     void* zero_page = nullptr;
-    UNet unet; VqModel vq; ClipModel clip; RarmModel rarm; KnnDb db;
+    UNet unet; VqModel vq; VqEncModel vqenc; ClipModel clip; RarmModel rarm; KnnDb db;
     float* gn_partial = nullptr; size_t gn_partial_bytes = 0;
     char* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;   // fp32 partial planes of the K-split halo convs
     char* samp = nullptr; size_t samp_bytes = 0;     // sampler scratch
@@ -599,10 +660,11 @@ struct Ops {
         return true;
     }
     void conv3(const bf16_t* A0, const bf16_t* A1, int C0, int C1, size_t woff, size_t boff, int B, int Hin, int Win, int N,
-               int stride, int ups, const float* rowvec, int rowvec_ld, const bf16_t* res, bf16_t* out) {
+               int stride, int ups, const float* rowvec, int rowvec_ld, const bf16_t* res, bf16_t* out, int asym = 0) {
         if (plan) return;
         const int Hout = ups ? Hin * 2 : (stride == 2 ? Hin / 2 : Hin), Wout = ups ? Win * 2 : (stride == 2 ? Win / 2 : Win);
         IgemmParams p = base(B * Hout * Wout, N, 9 * (C0 + C1));
+        p.asym = asym;
         p.A0 = A0; p.A1 = A1; p.C0 = C0; p.C1 = C1; p.W = w<bf16_t>(woff); p.bias = w<float>(boff);
         p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.stride = stride; p.ups = ups;
         p.rowvec = rowvec; p.rowvec_ld = rowvec_ld; p.rows_per_sample = Hout * Wout; p.res_bf16 = res; p.out_bf16 = out;
@@ -1096,6 +1158,75 @@ static void vq_wide_body(Ops& o, VqModel& v, const long long* indices, int B, fl
     vq_trunk(o, v, h, B, zr, zr, img);
 }
 
+// VQ-f4 encode: image f32 [B, out_ch, R, R] -> z f32 [B, embed_dim, R / 2^(levels-1), ...]  (VQModelInterface.encode: no quantisation here)
+static void vqenc_body(Ops& o, VqEncModel& v, const float* img, int B, float* z) {
+    const rdm_vq_cfg& c = v.cfg;
+    int H = c.resolution, W = c.resolution;
+    bf16_t* h = o.abf((size_t)B * H * W * c.ch);
+    if (!o.plan) o.check(launch_conv_in(img, o.w<float>(v.cinw), o.w<float>(v.cinb), h, B, c.out_ch, H, W, c.ch, o.c->stream), "encoder conv_in");
+    auto res = [&](const VqRes& r, bf16_t* x) -> bf16_t* {
+        const int HW = H * W, M = B * HW;
+        bf16_t* n1 = o.abf((size_t)M * r.cin);
+        o.groupnorm(x, nullptr, r.cin, 0, B, HW, r.n1g, r.n1b, 1e-6f, 1, n1);
+        bf16_t* h1 = o.abf((size_t)M * r.cout);
+        o.conv3(n1, nullptr, r.cin, 0, r.w1, r.b1, B, H, W, r.cout, 1, 0, nullptr, 0, nullptr, h1);
+        bf16_t* n2 = o.abf((size_t)M * r.cout);
+        o.groupnorm(h1, nullptr, r.cout, 0, B, HW, r.n2g, r.n2b, 1e-6f, 1, n2);
+        const bf16_t* rs = x;
+        if (r.skip) { bf16_t* sk = o.abf((size_t)M * r.cout); o.linear(x, nullptr, r.cin, 0, r.wsk, r.bsk, true, M, r.cout, ACT_NONE, nullptr, sk); rs = sk; }
+        bf16_t* out = o.abf((size_t)M * r.cout);
+        o.conv3(n2, nullptr, r.cout, 0, r.w2, r.b2, B, H, W, r.cout, 1, 0, nullptr, 0, rs, out);
+        return out;
+    };
+    auto attn = [&](const VqAttn& a, bf16_t* x) -> bf16_t* {       // as vq_trunk's AttnBlock
+        const int C = a.c, n = H * W, M = B * n;
+        bf16_t* hn = o.abf((size_t)M * C);
+        o.groupnorm(x, nullptr, C, 0, B, n, a.ng, a.nb, 1e-6f, 0, hn);
+        bf16_t* q = o.abf((size_t)M * C); bf16_t* kk = o.abf((size_t)M * C); bf16_t* vt = o.abf((size_t)M * C);
+        o.linear(hn, nullptr, C, 0, a.wq, a.bq, true, M, C, ACT_NONE, nullptr, q);
+        o.linear(hn, nullptr, C, 0, a.wk, a.bk, true, M, C, ACT_NONE, nullptr, kk);
+        float* S = o.af32((size_t)B * n * n); bf16_t* P = o.abf((size_t)B * n * n); bf16_t* ao = o.abf((size_t)M * C);
+        if (!o.plan) {
+            IgemmParams p = o.base(C, n, C);
+            p.A0 = o.w<bf16_t>(a.wv); p.C0 = C; p.W = hn; p.sW = (long long)n * C; p.sO = (long long)C * n; p.out_bf16 = vt; p.ldo = n;
+            o.check(launch_igemm(p, false, B, o.c->stream), "enc v^T");
+            IgemmParams sc = o.base(n, n, C);
+            sc.A0 = q; sc.C0 = C; sc.W = kk; sc.sA = (long long)n * C; sc.sW = (long long)n * C; sc.sO = (long long)n * n; sc.out_f32 = S; sc.ldo = n;
+            sc.alpha = 1.0f / sqrtf((float)C);
+            o.check(launch_igemm(sc, false, B, o.c->stream), "enc qk^T");
+            o.check(launch_softmax_rows(S, P, (long long)B * n, n, o.c->stream), "enc softmax");
+            IgemmParams pv = o.base(n, C, n);
+            pv.A0 = P; pv.C0 = n; pv.W = vt; pv.sA = (long long)n * n; pv.sW = (long long)C * n; pv.sO = (long long)n * C; pv.out_bf16 = ao; pv.ldo = C;
+            pv.bias = o.w<float>(a.bv);
+            o.check(launch_igemm(pv, false, B, o.c->stream), "enc pv");
+        }
+        bf16_t* out = o.abf((size_t)M * C);
+        o.linear(ao, nullptr, C, 0, a.wo, a.bo, true, M, C, ACT_NONE, x, out);
+        return out;
+    };
+    int bin = c.ch;
+    for (int lvl = 0; lvl < c.n_ch_mult; lvl++) {
+        for (size_t i = 0; i < v.down[lvl].size(); i++) {
+            h = res(v.down[lvl][i], h); bin = v.down[lvl][i].cout;
+            if (i < v.down_attn[lvl].size()) h = attn(v.down_attn[lvl][i], h);
+        }
+        if (lvl != c.n_ch_mult - 1) {      // F.pad(x, (0, 1, 0, 1)) + Conv2d(stride 2, padding 0): window rows 2 oy .. 2 oy + 2, zero beyond the last row / column
+            const ConvW& d = v.downsample[lvl];
+            bf16_t* out = o.abf((size_t)B * (H / 2) * (W / 2) * d.c);
+            o.conv3(h, nullptr, d.c, 0, d.w, d.b, B, H, W, d.c, 2, 0, nullptr, 0, nullptr, out, /*asym=*/1);
+            h = out; H /= 2; W /= 2;
+        }
+    }
+    h = res(v.mid1, h);
+    if (c.mid_attn) h = attn(v.attn, h);
+    h = res(v.mid2, h);
+    bf16_t* no = o.abf((size_t)B * H * W * bin);
+    bf16_t* hwp = o.abf(head_conv_wp_bytes(bin) / 2);
+    float* ze = o.af32((size_t)B * c.z_channels * H * W);
+    o.head(h, B, H, W, bin, bin, v.noutg, v.noutb, 1e-6f, v.coutw, v.coutb, c.z_channels, ze, no, hwp);
+    if (!o.plan) o.check(launch_vq_quantize(ze, nullptr, 0, o.w<float>(v.qw), o.w<float>(v.qb), z, nullptr, B, H * W, 0, o.c->stream), "quant_conv");
+}
+
 // ------------------------------------------------------------------------------------ CLIP
 static void clip_tower(Ops& o, const std::vector<ClipBlk>& blks, float* x, int B, int L, int Wd, int heads, int causal) {
     const int M = B * L;
@@ -1181,7 +1312,8 @@ void rdm_ctx_destroy(rdm_ctx* c) {
     hipDeviceSynchronize();
     void* ptrs[] = {c->zero_page, c->unet.blob, c->unet.arena.base, c->unet.kv_cache, c->vq.blob, c->vq.arena.base,
                     c->clip.blob, c->clip.arena.base, c->gn_partial, c->samp, c->splitk_ws, c->unet.xa_cache,
-                    c->rarm.blob, c->rarm.arena.base, c->rarm.cache, c->rarm.ctxkv, c->rarm.state, c->rarm.xa, c->wfrag_tmp, c->bwd_tmp};
+                    c->rarm.blob, c->rarm.arena.base, c->rarm.cache, c->rarm.ctxkv, c->rarm.state, c->rarm.xa, c->wfrag_tmp, c->bwd_tmp,
+                    c->vqenc.blob, c->vqenc.arena.base};
     for (void* p : ptrs) if (p) hipFree(p);
     c->drop_frags();
     knn_free(c->db);
@@ -1231,6 +1363,31 @@ int rdm_load_vq(rdm_ctx* c, const rdm_vq_cfg* cfg, const void* packed, size_t nb
         return c->fail(-1, "unsupported vq cfg: ch %% 64 == 0 and either embed_dim == z_channels == 3 (VQ-f4 / KL-f4) or both multiples of 64 (VQGAN-f16)");
     Manifest mf; build_vq(c->vq, *cfg, mf);
     return load_blob(c, c->vq, mf, packed, nbytes);
+}
+static int cfg_check_vqenc(rdm_ctx* c, const rdm_vq_cfg* g) {
+    const bool ok = g && g->n_ch_mult >= 1 && g->n_ch_mult <= RDM_MAX_LEVELS && g->n_attn_resolutions >= 0 && g->n_attn_resolutions <= RDM_MAX_LEVELS &&
+                    g->ch % 64 == 0 && g->out_ch <= 4 && g->embed_dim == 3 && g->z_channels == 3 && !g->kl && g->resolution % (1 << (g->n_ch_mult - 1)) == 0;
+    if (!ok) return c ? c->fail(-1, "unsupported first-stage encoder cfg: VQ interface (kl = 0) with embed_dim == z_channels == 3, ch %% 64 == 0") : -1;
+    return 0;
+}
+long long rdm_vqenc_manifest(const rdm_vq_cfg* cfg, char* buf, size_t buflen, size_t* blob_bytes) {
+    if (cfg_check_vqenc(nullptr, cfg)) return -1;
+    VqEncModel v; Manifest mf; build_vqenc(v, *cfg, mf);
+    return write_manifest(mf, buf, buflen, blob_bytes);
+}
+int rdm_load_vqenc(rdm_ctx* c, const rdm_vq_cfg* cfg, const void* packed, size_t nbytes) {
+    RDM_ENTER(c);
+    if (!packed) return c->fail(-1, "null blob");
+    RDM_TRY(cfg_check_vqenc(c, cfg));
+    Manifest mf; build_vqenc(c->vqenc, *cfg, mf);
+    return load_blob(c, c->vqenc, mf, packed, nbytes);
+}
+int rdm_vq_encode(rdm_ctx* c, const float* img, int b, float* z_out) {
+    RDM_ENTER(c);
+    if (!img || !z_out || b < 1) return c->fail(-1, "rdm_vq_encode: bad argument");
+    if (!c->vqenc.loaded) return c->fail(-1, "first-stage encoder weights not loaded (rdm_load_vqenc)");
+    RDM_TRY(ensure_gn_partial(c, b));
+    return run_with_arena(c, c->vqenc.arena, c->vqenc.blob, [&](Ops& o) { vqenc_body(o, c->vqenc, img, b, z_out); });
 }
 int rdm_load_clip(rdm_ctx* c, const rdm_clip_cfg* cfg, const void* packed, size_t nbytes) {
     RDM_ENTER(c);
@@ -1683,9 +1840,10 @@ struct RcclId { char b[128]; };
 typedef int (*fn_get_id)(RcclId*);
 typedef int (*fn_init_rank)(void**, int, RcclId, int);
 typedef int (*fn_all_gather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_destroy)(void*);
 typedef const char* (*fn_errstr)(int);
-struct RcclFns { fn_get_id get_id; fn_init_rank init_rank; fn_all_gather all_gather; fn_destroy destroy; fn_errstr errstr; };
+struct RcclFns { fn_get_id get_id; fn_init_rank init_rank; fn_all_gather all_gather; fn_all_reduce all_reduce; fn_destroy destroy; fn_errstr errstr; };
 int rccl_load(rdm_ctx* c, RcclFns& f) {
     if (!c->rccl_lib) {
         c->rccl_lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -1694,6 +1852,7 @@ int rccl_load(rdm_ctx* c, RcclFns& f) {
     }
     f.get_id = (fn_get_id)dlsym(c->rccl_lib, "ncclGetUniqueId"); f.init_rank = (fn_init_rank)dlsym(c->rccl_lib, "ncclCommInitRank");
     f.all_gather = (fn_all_gather)dlsym(c->rccl_lib, "ncclAllGather"); f.destroy = (fn_destroy)dlsym(c->rccl_lib, "ncclCommDestroy");
+    f.all_reduce = (fn_all_reduce)dlsym(c->rccl_lib, "ncclAllReduce");
     f.errstr = (fn_errstr)dlsym(c->rccl_lib, "ncclGetErrorString");
     if (!f.get_id || !f.init_rank || !f.all_gather || !f.destroy) return c->fail(-5, "rdm_comm: librccl.so lacks the expected entry points");
     return 0;
@@ -1726,6 +1885,17 @@ int rdm_comm_all_gather(rdm_ctx* c, const void* send, void* recv, size_t nbytes)
     RcclFns f{}; RDM_TRY(rccl_load(c, f));
     const int r = f.all_gather(send, recv, nbytes, /*ncclInt8*/ 0, c->comm, c->stream);
     if (r != 0) return c->fail(-5, "ncclAllGather failed: %s", f.errstr ? f.errstr(r) : "?");
+    return 0;
+}
+int rdm_comm_all_reduce_f32(rdm_ctx* c, float* buf, size_t count, int average) {
+    RDM_ENTER(c);
+    if (!c->comm) return c->fail(-1, "rdm_comm_all_reduce_f32: no communicator (rdm_comm_init)");
+    if (!buf) return c->fail(-1, "rdm_comm_all_reduce_f32: null buffer");
+    RcclFns f{}; RDM_TRY(rccl_load(c, f));
+    if (!f.all_reduce) return c->fail(-5, "rdm_comm: librccl.so lacks ncclAllReduce");
+    const int r = f.all_reduce(buf, buf, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->stream);
+    if (r != 0) return c->fail(-5, "ncclAllReduce failed: %s", f.errstr ? f.errstr(r) : "?");
+    if (average && c->comm_world > 1) RDM_CHECK_HIP(c, launch_scale_f32(buf, (long long)count, 1.0f / (float)c->comm_world, c->stream));
     return 0;
 }
 int rdm_comm_destroy(rdm_ctx* c) {
@@ -1769,7 +1939,8 @@ int rdm_op_linear(rdm_ctx* c, const void* a, const void* w, const float* bias, c
                   int M, int N, int K, int act, float alpha) {
     RDM_ENTER(c);
     if (!c) return -1;
-    if (M <= 128 && alpha == 1.0f) {       // same dispatch as the executors (Ops::linear): decode-sized batches take the skinny kernel
+    if (M <= 128 && alpha == 1.0f && !c->deterministic) {       // same dispatch as the executors (Ops::linear): decode-sized batches take the skinny kernel.  Deterministic mode: the
+                                                                // op has no notion of "one row per sample", so it never takes the batch-dependent shortcut (the tiled kernel for every M)
         SgemmParams q{}; q.A = (const bf16_t*)a; q.lda = K; q.W = (const bf16_t*)w; q.M = M; q.N = N; q.K = K; q.bias = bias; q.act = act;
         q.res_bf16 = (const bf16_t*)res; q.out_f32 = out_f32; q.out_bf16 = (bf16_t*)out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
         if (sgemm_supported(q)) { RDM_CHECK_HIP(c, launch_sgemm(q, c->stream)); return 0; }
@@ -1922,6 +2093,43 @@ int rdm_op_silu(rdm_ctx* c, const float* x, const float* dy, void* out, long lon
     RDM_ENTER(c);
     if (!x || !out || n < 1) return c->fail(-1, "rdm_op_silu: bad argument");
     RDM_CHECK_HIP(c, launch_silu(x, dy, dy ? nullptr : (bf16_t*)out, dy ? (float*)out : nullptr, n, c->stream));
+    return 0;
+}
+int rdm_op_q_sample(rdm_ctx* c, const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac, float* out, void* out_nhwc, int B, int C,
+                    int H, int W, int cpad) {
+    RDM_ENTER(c);
+    if (!x0 || !noise || !sqrt_ac || !sqrt_1mac || (!out && !out_nhwc) || B < 1 || C < 1 || H < 1 || W < 1) return c->fail(-1, "rdm_op_q_sample: bad argument");
+    RDM_CHECK_HIP(c, launch_q_sample(x0, noise, sqrt_ac, sqrt_1mac, out, (bf16_t*)out_nhwc, B, C, H * W, cpad, c->stream));
+    return 0;
+}
+int rdm_op_mse_loss(rdm_ctx* c, const void* eps_nhwc, const float* target, const float* coef, float* se, void* deps_nhwc, int B, int C, int H, int W, int ldc) {
+    RDM_ENTER(c);
+    if (!eps_nhwc || !target || !se || (deps_nhwc && !coef) || B < 1 || C < 1 || ldc < C) return c->fail(-1, "rdm_op_mse_loss: bad argument");
+    RDM_CHECK_HIP(c, launch_mse_loss((const bf16_t*)eps_nhwc, target, coef, se, (bf16_t*)deps_nhwc, B, C, H * W, ldc, c->stream));
+    return 0;
+}
+int rdm_op_where_rows(rdm_ctx* c, const unsigned char* mask, const float* a, const float* x, float* out, long long rows, long long n) {
+    RDM_ENTER(c);
+    if (!mask || !a || !x || !out || rows < 1 || n < 1) return c->fail(-1, "rdm_op_where_rows: bad argument");
+    RDM_CHECK_HIP(c, launch_where_rows(mask, a, x, out, rows, n, c->stream));
+    return 0;
+}
+int rdm_op_timestep_embedding(rdm_ctx* c, const int64_t* t, void* out_bf16, int B, int dim, int ld) {
+    RDM_ENTER(c);
+    if (!t || !out_bf16 || B < 1 || dim < 2 || dim % 2 || ld < dim) return c->fail(-1, "rdm_op_timestep_embedding: bad argument");
+    RDM_CHECK_HIP(c, launch_timestep_embedding((const long long*)t, (bf16_t*)out_bf16, B, dim, ld, c->stream));
+    return 0;
+}
+int rdm_op_colsum_samples(rdm_ctx* c, const void* x, void* out, int B, int HW, int N) {
+    RDM_ENTER(c);
+    if (!x || !out || B < 1 || HW < 1 || N < 1) return c->fail(-1, "rdm_op_colsum_samples: bad argument");
+    RDM_CHECK_HIP(c, launch_colsum_samples((const bf16_t*)x, (bf16_t*)out, B, HW, N, c->stream));
+    return 0;
+}
+int rdm_op_expand2(rdm_ctx* c, const void* x, void* out, int B, int H, int W, int C, int mode) {
+    RDM_ENTER(c);
+    if (!x || !out || B < 1 || H < 1 || W < 1 || C < 8 || C % 8 || (mode != 0 && mode != 1)) return c->fail(-1, "rdm_op_expand2: bad argument (C %% 8 == 0, mode 0 / 1)");
+    RDM_CHECK_HIP(c, launch_expand2((const bf16_t*)x, (bf16_t*)out, B, H, W, C, mode, c->stream));
     return 0;
 }
 int rdm_op_sumpool2(rdm_ctx* c, const void* x, void* out, int B, int H, int W, int C) {

@@ -1,8 +1,9 @@
 """Native counterpart of the SAMPLING methods of rdm/models/diffusion/ddpm.py::MinimalRETRODiffusion
 (:445-458 apply_model, :662-686 get_unconditional_conditioning, :689-844 sample_with_query, :847-875 get_qids,
 :878-984 sample_from_rdata, :988-1011 sample_log) and of the un-vendored ldm LatentDiffusion it subclasses
-(register_schedule, sample / p_sample_loop, decode_first_stage, ema_scope).  Training, logging and the wrapper
-variants are out of scope.
+(register_schedule, sample / p_sample_loop, decode_first_stage, ema_scope), and -- SURVEY.md §8 f-4 -- of the TRAINING entry
+`shared_step` / `forward` (:390-443) with ldm's get_input / encode_first_stage / q_sample / p_losses / training_step /
+configure_optimizers / on_train_batch_end around it.  Logging, the Lightning loop and the wrapper variants are out of scope.
 
 The object holds no torch.nn weights: UNet and first-stage weights live in HBM inside the librdm_hip context
 (`self.ctx`), loaded from the reference's own state_dict keys.  Sampling runs on the EMA weights, which is what
@@ -98,17 +99,21 @@ class MinimalRETRODiffusion(object):
         if not unet_sd:
             unet_sd = sd                                           # already stripped
         self.ctx.load_unet(self.unet_cfg, packing.pack("unet", self.unet_cfg, unet_sd))
+        self._unet_sd = packing.strip_prefix(sd, "model.diffusion_model.") or unet_sd      # training starts from the LIVE weights, not the EMA copies
         if self.vq_cfg is not None:
             vq_sd = packing.strip_prefix(sd, "first_stage_model.")
             if vq_sd:
-                self.ctx.load_vq(self.vq_cfg, packing.pack("vq", self.vq_cfg, vq_sd))
+                self.load_first_stage_state_dict(vq_sd)
         return [], []
 
     def load_unet_state_dict(self, unet_sd):
         self.ctx.load_unet(self.unet_cfg, packing.pack("unet", self.unet_cfg, unet_sd))
+        self._unet_sd = unet_sd                                  # a reference (no copy): configure_optimizers() starts the masters from it
 
     def load_first_stage_state_dict(self, vq_sd):
         self.ctx.load_vq(self.vq_cfg, packing.pack("vq", self.vq_cfg, vq_sd))
+        if "encoder.conv_in.weight" in vq_sd:                   # the encoder side (training input): `encoder.*`, `quant_conv.*`
+            self.ctx.load_vq_encoder(self.vq_cfg, packing.pack("vqenc", self.vq_cfg, vq_sd))
 
     def eval(self): return self
     def to(self, device): return self
@@ -191,44 +196,123 @@ class MinimalRETRODiffusion(object):
         b = self.sqrt_one_minus_alphas_cumprod.to(x_start.device)[t].reshape(-1, 1, 1, 1)
         return a * x_start + b * noise
 
-    # ---- loss of a batch, forward only (SURVEY 8f-4's forward half: what validation_step evaluates under the EMA weights)
+    # ---- training surface.  ldm DDPM.get_input / LatentDiffusion.get_input, encode_first_stage, get_first_stage_encoding
     @torch.no_grad()
+    def encode_first_stage(self, x):
+        """ldm LatentDiffusion.encode_first_stage -> VQModelInterface.encode (no quantisation), on the native encoder."""
+        return self.ctx.vq_encode(x)
+
+    def get_first_stage_encoding(self, encoder_posterior):
+        return self.scale_factor * encoder_posterior             # a VQModelInterface posterior is the latent itself
+
+    @torch.no_grad()
+    def get_input(self, batch, k):
+        """ldm DDPM.get_input (`b h w c -> b c h w`, float) + LatentDiffusion.get_input (encode_first_stage ->
+        get_first_stage_encoding): batch[k] is the IMAGE [B,H,W,C] in [-1,1] as the datasets deliver it.  A tensor that already is a
+        latent [B,channels,h,w] (precomputed encodings) is passed through.  -> (z, None): no cond_stage conditioning in the RDM configs."""
+        x = torch.as_tensor(batch[k])
+        if x.ndim == 3:
+            x = x[..., None]
+        if x.ndim != 4:
+            raise ValueError(f"get_input: batch[{k!r}] must be an image [B,H,W,C] or a latent [B,{self.channels},h,w], got {tuple(x.shape)}")
+        v = self.vq_cfg
+        if v is not None and x.shape[-1] == v.out_ch and x.shape[1] == v.resolution and x.shape[2] == v.resolution:     # channel-last image
+            x = x.permute(0, 3, 1, 2).to(self.device).float().contiguous()
+            return self.get_first_stage_encoding(self.encode_first_stage(x)), None
+        if x.shape[1] == self.channels:                                                       # already a latent
+            return x.to(self.device).float().contiguous(), None
+        raise ValueError(f"get_input: batch[{k!r}] is neither a [B,R,R,C] image of the first stage's resolution nor a latent, got {tuple(x.shape)}")
+
+    def configure_optimizers(self, unet_sd=None, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, use_ema=True, ema_decay=0.9999):
+        """ldm LatentDiffusion.configure_optimizers (`torch.optim.AdamW(params, lr=self.learning_rate)` over the UNet parameters) +
+        the LitEma of DDPM.__init__(use_ema=True): fp32 master weights, AdamW moments, bf16 working copies and EMA shadows in HBM
+        (rdm_amd.training_unet.TrainState).  unet_sd: UNet state dict to start from (default: the one last loaded)."""
+        from ... import training_unet as TU
+        sd = unet_sd if unet_sd is not None else getattr(self, "_unet_sd", None)
+        if sd is None:
+            raise ValueError("configure_optimizers: load the UNet weights first (load_state_dict / load_unet_state_dict) or pass unet_sd")
+        if lr is not None:
+            self.learning_rate = float(lr)
+        self._opt = {"lr": float(getattr(self, "learning_rate", 1e-4)), "betas": tuple(betas), "eps": float(eps), "weight_decay": float(weight_decay)}
+        self._train_shapes = {k: tuple(v.shape) for k, v in sd.items()}
+        self.train_spec = TU.TrainSpec(self.unet_cfg)
+        self.train_state = TU.TrainState(TU.params_from_state_dict(sd, self.device), ema_decay=ema_decay if use_ema else None)
+        return self.train_state
+
+    def sync_sampling_weights(self, use_ema=True):
+        """What `ema_scope` arranges in the reference before sampling / validation: the sampler's weights in HBM <- the trained
+        weights (their EMA shadows by default)."""
+        from ... import training_unet as TU
+        st = self.train_state
+        src = st.ema.shadow if (use_ema and st.ema is not None) else st.P
+        self.ctx.load_unet(self.unet_cfg, packing.pack("unet", self.unet_cfg, TU.state_dict_from_params(src, self._train_shapes)))
+
+    def training_step(self, batch, batch_idx=0, **kwargs):
+        """ldm DDPM.training_step (`loss, loss_dict = self.shared_step(batch)`) + the optimiser step and on_train_batch_end's EMA update
+        that Lightning runs around it: one optimisation step of the UNet on the native path.  -> loss (before the update)."""
+        if getattr(self, "train_state", None) is None:
+            self.configure_optimizers()
+        loss, loss_dict = self.shared_step(batch, prefix="train", train=True, **kwargs)
+        self.last_loss_dict = loss_dict
+        return loss
+
+    def validation_step(self, batch, batch_idx=0, **kwargs):
+        return self.shared_step(batch, prefix="val", train=False, **kwargs)
+
     def shared_step(self, batch, t=None, noise=None, uncond_mask=None, first_stage_key="image", nn_key="nn_embeddings",
-                    l_simple_weight=1., original_elbo_weight=0., prefix="val", **kwargs):
-        """ddpm.py:390-443 (`shared_step` -> `forward`) + ldm `p_losses` (l2, eps parameterisation, logvar 0) WITHOUT gradients:
-        the noisy-latent UNet forward runs on the native path, the rest is elementwise.  `batch[first_stage_key]` is the LATENT
-        [B,C,H,W] (the first-stage encoder is not part of the native path: encode with the reference, or pass what
-        `get_first_stage_encoding` returned); `batch[nn_key]` [B,n,k,D] are the neighbours' embeddings the dataset supplies
-        (ddpm.py:360-365).  `t`, `noise` and the Bernoulli(p_uncond) conditioning-dropout draw `uncond_mask` may be given for
-        reproducibility; otherwise they are drawn like the reference does (:393-396, :406-413).  -> (loss, loss_dict)."""
-        x = torch.as_tensor(batch[first_stage_key]).to(self.device).float()
-        if x.ndim != 4 or x.shape[1] != self.channels:
-            raise ValueError(f"shared_step: batch[{first_stage_key!r}] must be the latent [B,{self.channels},H,W], got {tuple(x.shape)}")
-        nns = torch.as_tensor(batch[nn_key]).to(self.device).float()
-        r = nns.reshape(nns.shape[0], -1, nns.shape[-1])                                   # 'b n k d -> b (n k) d'
-        B = x.shape[0]
-        if self.p_uncond > 0. or uncond_mask is not None:
-            if uncond_mask is None:
-                uncond_mask = torch.distributions.Bernoulli(torch.full((B,), self.p_uncond)).sample().bool()
-            sig = self.get_unconditional_conditioning(shape=r.shape, k_nn=r.shape[1]).to(self.device).float()
-            if sig.ndim == 2:                       # a [D] guidance vector (created lazily): one copy per neighbour slot
-                sig = sig[:, None, :]
-            r = torch.where(torch.as_tensor(uncond_mask).to(self.device).reshape(-1, 1, 1), sig, r)
-        if t is None:
-            t = torch.randint(0, self.num_timesteps, (B,), device=self.device)
-        t = torch.as_tensor(t).to(self.device).long()
-        if noise is None:
-            noise = torch.randn_like(x)
-        noise = torch.as_tensor(noise).to(self.device).float()
-        x_noisy = self.q_sample(x, t, noise=noise)
-        out = self.apply_model(x_noisy, t, r.contiguous())
-        se = ((out - noise) ** 2).mean(dim=(1, 2, 3))
-        d = {f"{prefix}/loss_simple": se.mean()}
-        loss = l_simple_weight * se.mean()                                                 # logvar = 0: loss_simple / exp(0) + 0
-        loss_vlb = (self.lvlb_weights.to(self.device)[t] * se).mean()
-        d[f"{prefix}/loss_vlb"] = loss_vlb
-        loss = loss + original_elbo_weight * loss_vlb
-        d[f"{prefix}/loss"] = loss
+                    l_simple_weight=1., original_elbo_weight=0., prefix="val", train=False, **kwargs):
+        """ddpm.py:390-443 (`shared_step` -> `forward`) + ldm `p_losses` (l2, eps parameterisation, logvar 0).
+        `batch[first_stage_key]`: the image [B,H,W,C] in [-1,1] (encoded by the native first-stage encoder, `get_input`) or a
+        precomputed latent [B,C,h,w]; `batch[nn_key]` [B,n,k,D]: the neighbours' embeddings the dataset supplies (ddpm.py:360-365).
+        `t`, `noise` and the Bernoulli(p_uncond) conditioning-dropout draw `uncond_mask` may be given for reproducibility; otherwise
+        they are drawn like the reference does (:393-396, :406-413).
+        train=False: the loss without gradients on the sampler's weights (what validation_step logs under ema_scope).
+        train=True: forward with saved activations on the TRAINING weights, backward to every UNet parameter, gradient all-reduce,
+        AdamW, EMA (rdm_amd.training_unet) -- the noising, conditioning switch, loss and its gradient are HIP ops.  -> (loss, loss_dict)."""
+        with torch.no_grad():
+            x, _ = self.get_input(batch, first_stage_key)
+            if x.shape[1] != self.channels:
+                raise ValueError(f"shared_step: latent must be [B,{self.channels},H,W], got {tuple(x.shape)}")
+            nns = torch.as_tensor(batch[nn_key]).to(self.device).float()
+            r = nns.reshape(nns.shape[0], -1, nns.shape[-1]).contiguous()                      # 'b n k d -> b (n k) d'
+            B = x.shape[0]
+            if self.p_uncond > 0. or uncond_mask is not None:
+                if uncond_mask is None:
+                    uncond_mask = torch.distributions.Bernoulli(torch.full((B,), self.p_uncond)).sample().bool()
+                sig = self.get_unconditional_conditioning(shape=r.shape, k_nn=r.shape[1]).to(self.device).float()
+                if sig.ndim == 2:                   # a [D] guidance vector (created lazily): one copy per neighbour slot
+                    sig = sig[:, None, :]
+                sig = sig.expand_as(r).contiguous()
+                r = self.ctx.op_where_rows(torch.as_tensor(uncond_mask).reshape(-1), sig, r)
+            if t is None:
+                t = torch.randint(0, self.num_timesteps, (B,), device=self.device)
+            t = torch.as_tensor(t).to(self.device).long()
+            if noise is None:
+                noise = torch.randn_like(x)
+            noise = torch.as_tensor(noise).to(self.device).float().contiguous()
+            sa = self.sqrt_alphas_cumprod.to(self.device)[t].contiguous()
+            sb = self.sqrt_one_minus_alphas_cumprod.to(self.device)[t].contiguous()
+            lvlb = self.lvlb_weights.to(self.device)[t]
+            if not train:
+                x_noisy, _ = self.ctx.op_q_sample(x, noise, sa, sb, want_nchw=True)
+                out = self.apply_model(x_noisy, t, r)
+                se = ((out - noise) ** 2).mean(dim=(1, 2, 3))
+            else:
+                from ... import training_unet as TU
+                if getattr(self, "train_state", None) is None:
+                    raise RuntimeError("shared_step(train=True): call configure_optimizers() first")
+                _, x_nhwc = self.ctx.op_q_sample(x, noise, sa, sb, want_nchw=False, cpad=64)
+                n_el = float(B * x[0].numel())
+                coef = ((l_simple_weight + original_elbo_weight * lvlb) * (2.0 / n_el)).float().contiguous()
+                _, grads, se = TU.unet_loss_and_grads(self.ctx, self.train_state.params(), self.train_spec, x_nhwc, t,
+                                                      r.to(torch.bfloat16), noise, coef)
+                TU.apply_gradients(self.ctx, self.train_state, grads, group=getattr(self, "_group", None), **self._opt)
+            d = {f"{prefix}/loss_simple": se.mean()}
+            loss = l_simple_weight * se.mean()                                                 # logvar = 0: loss_simple / exp(0) + 0
+            loss_vlb = (lvlb * se).mean()
+            d[f"{prefix}/loss_vlb"] = loss_vlb
+            loss = loss + original_elbo_weight * loss_vlb
+            d[f"{prefix}/loss"] = loss
         return loss, d
 
     # ---- conditioning (ddpm.py:647-686)

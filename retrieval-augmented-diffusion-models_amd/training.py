@@ -8,9 +8,11 @@ sums, GEMMs for the time-embedding projection.  torch is used for device memory 
 The feed-forward sub-block of BasicTransformerBlock (`x + ff(norm3(x))`, ldm attention.py FeedForward / GEGLU) has its forward and
 backward here too (ff_forward / ff_backward).  Attention (ldm CrossAttention: softmax(q k^T scale) v per head) has an unfused forward / backward here as well (attention_forward /
 attention_backward: scores materialised per (sample, head), batched GEMMs on the MFMA kernel).  SpatialTransformer (GroupNorm -> proj_in -> block -> proj_out + x) and an AdamW step (rdm_op_adamw) close the loop for a small
-ResBlock + SpatialTransformer stack (training_step_demo).  What is NOT here yet: the whole-UNet graph in training form (down / up
-sampling, stem / head convs, time-embedding MLP backward), EMA, the first-stage encoder,
-the RCCL gradient all-reduce."""
+ResBlock + SpatialTransformer stack (training_step_demo).  The whole-UNet graph in training form (down / up sampling, stem / head
+convs, time-embedding MLP backward), LitEma and the optimisation step live in training_unet.py; the bucketed gradient all-reduce in
+parallel.average_gradients (RCCL through torch.distributed; rdm_comm_all_reduce_f32 for callers of the C ABI); the reference-surface
+entry (`MinimalRETRODiffusion.training_step`: first-stage encode -> q_sample -> conditioning dropout -> loss -> step) in
+models/diffusion/ddpm.py."""
 import torch
 
 from . import _lib
@@ -82,7 +84,7 @@ def resblock_backward(ctx, p, x, semb, saved, dout):
     # h1 = conv1(n1) + b1 + emb_out[b]
     g["w1"] = ctx.op_conv3x3_wgrad(saved["n1"], dh1)
     g["b1"] = ctx.op_colsum(dh1.reshape(M, Cout))
-    demb = torch.stack([ctx.op_colsum(dh1[b].reshape(HW, Cout)) for b in range(B)]).to(torch.bfloat16)      # [B, Cout]: sum over a sample's pixels
+    demb = ctx.op_colsum_samples(dh1.reshape(B, HW, Cout))                             # [B, Cout]: sum over a sample's pixels, one launch
     g["dsemb"], g["emb_w"], g["emb_b"] = linear_backward(ctx, semb, p["emb_w"], demb)
     dn1 = ctx.op_conv3x3_dgrad(dh1, p["w1"])
     # n1 = silu(gn1(x))

@@ -5,8 +5,11 @@ time-embedding MLP, the GroupNorm + SiLU + conv head).  This is what autograd do
 ldm `p_losses` in `main.py`'s training loop.
 
 Every arithmetic step is a C-ABI call (rdm_amd._lib / rdm_amd.training); torch holds device memory and does layout plumbing only
-(channel zero-padding, concatenation / slicing along channels, the zero insertion that turns a stride-2 gradient into a stride-1 one,
-the nearest-neighbour copy in front of Upsample's weight gradient, the sinusoidal timestep table).
+(channel zero-padding of the 3-channel stem / head, concatenation / slicing along channels).  Since round 4 the sinusoidal timestep
+table, the zero insertion that turns a stride-2 gradient into a stride-1 one, the nearest-neighbour copy in front of Upsample's weight
+gradient, the per-sample bias gradient of the time-embedding rows and the loss with its gradient are HIP ops too, and the bf16
+operands the kernels read are WORKING COPIES kept beside the fp32 masters (`TrainState.work`, refreshed by the optimiser kernel's bf16
+output) instead of being re-cast on every forward.
 
 Parameters live in a dict keyed by the reference's state-dict names, fp32 "master" tensors in the NATIVE layouts
 (`params_from_state_dict`: 3x3 conv weights [Cout, 3, 3, Cin], 1x1 convs [Cout, Cin]); `grads_to_state_dict_layout` maps gradients back."""
@@ -100,6 +103,27 @@ def _bf(t):
     return t.to(torch.bfloat16)
 
 
+class _Params:
+    """Parameter lookup of the training graph: `P` the fp32 masters, `W` (optional) bf16 working copies of the >= 2-D tensors.  w(k) is
+    what a kernel reads for a weight matrix (the working copy when there is one, else a cast of the master); 1-D tensors (biases, norm
+    affines) are read in fp32 straight from the masters."""
+
+    def __init__(self, P, W=None):
+        self.P, self.W = P, W
+
+    def __contains__(self, k): return k in self.P
+    def __getitem__(self, k): return self.P[k]
+
+    def w(self, k):
+        if self.W is not None and k in self.W:
+            return self.W[k]
+        return _bf(self.P[k])
+
+
+def _as_params(P):
+    return P if isinstance(P, _Params) else _Params(P)
+
+
 def _pad_channels(x, C):
     """[..., c] -> [..., C] with zero channels."""
     if x.shape[-1] == C:
@@ -110,12 +134,13 @@ def _pad_channels(x, C):
 
 
 def _res_params(P, pre):
-    p = {"gn1_g": P[pre + ".in_layers.0.weight"], "gn1_b": P[pre + ".in_layers.0.bias"], "w1": _bf(P[pre + ".in_layers.2.weight"]),
-         "b1": P[pre + ".in_layers.2.bias"], "emb_w": _bf(P[pre + ".emb_layers.1.weight"]), "emb_b": P[pre + ".emb_layers.1.bias"],
-         "gn2_g": P[pre + ".out_layers.0.weight"], "gn2_b": P[pre + ".out_layers.0.bias"], "w2": _bf(P[pre + ".out_layers.3.weight"]),
+    P = _as_params(P)
+    p = {"gn1_g": P[pre + ".in_layers.0.weight"], "gn1_b": P[pre + ".in_layers.0.bias"], "w1": P.w(pre + ".in_layers.2.weight"),
+         "b1": P[pre + ".in_layers.2.bias"], "emb_w": P.w(pre + ".emb_layers.1.weight"), "emb_b": P[pre + ".emb_layers.1.bias"],
+         "gn2_g": P[pre + ".out_layers.0.weight"], "gn2_b": P[pre + ".out_layers.0.bias"], "w2": P.w(pre + ".out_layers.3.weight"),
          "b2": P[pre + ".out_layers.3.bias"]}
     if pre + ".skip_connection.weight" in P:
-        p["skip_w"] = _bf(P[pre + ".skip_connection.weight"]); p["skip_b"] = P[pre + ".skip_connection.bias"]
+        p["skip_w"] = P.w(pre + ".skip_connection.weight"); p["skip_b"] = P[pre + ".skip_connection.bias"]
     return p
 
 
@@ -139,13 +164,14 @@ def _st_names(pre):
 
 
 def _gather(P, names, heads=None):
+    P = _as_params(P)
     out = {}
     for k, v in names.items():
         if isinstance(v, dict):
             out[k] = _gather(P, v, heads)
         else:
             t = P[v]
-            out[k] = _bf(t) if t.dim() >= 2 else t
+            out[k] = P.w(v) if t.dim() >= 2 else t
     if heads is not None and "wq" in out:
         out["heads"] = heads
     return out
@@ -161,12 +187,13 @@ def _scatter(grads, g, names):
 
 def unet_train_forward(ctx, P, spec, x, timesteps, context):
     """x bf16 [B, H, W, in_channels] (NHWC), timesteps int64 [B], context bf16 [B, k, context_dim] -> (eps bf16 [B, H, W, out_channels], tape)."""
+    P = _as_params(P)
     mc = spec.model_channels
-    tape = {"layers": [], "x": x}
-    t_emb = _bf(timestep_embedding(timesteps, mc))
-    e1 = ctx.op_linear(t_emb, _bf(P["time_embed.0.weight"]), P["time_embed.0.bias"], out_f32=True)
+    tape = {"layers": [], "x": x, "context": context}
+    t_emb = ctx.op_timestep_embedding(timesteps.to(x.device).long().contiguous(), mc)          # ldm timestep_embedding, [cos | sin]
+    e1 = ctx.op_linear(t_emb, P.w("time_embed.0.weight"), P["time_embed.0.bias"], out_f32=True)
     s1 = ctx.op_silu(e1)
-    emb = ctx.op_linear(s1, _bf(P["time_embed.2.weight"]), P["time_embed.2.bias"], out_f32=True)
+    emb = ctx.op_linear(s1, P.w("time_embed.2.weight"), P["time_embed.2.bias"], out_f32=True)
     semb = ctx.op_silu(emb)
     tape.update({"t_emb": t_emb, "e1": e1, "s1": s1, "emb": emb, "semb": semb})
 
@@ -189,11 +216,11 @@ def unet_train_forward(ctx, P, spec, x, timesteps, context):
                 tape["layers"].append(("st", pre, h, (p, saved)))
                 h = out
             elif l[0] == "down":
-                w = _bf(P[pre + ".op.weight"])
+                w = P.w(pre + ".op.weight")
                 tape["layers"].append(("down", pre, h, w))
                 h = ctx.op_conv3x3(h, w, P[pre + ".op.bias"], stride=2)
             elif l[0] == "up":
-                w = _bf(P[pre + ".conv.weight"])
+                w = P.w(pre + ".conv.weight")
                 tape["layers"].append(("up", pre, h, w))
                 h = ctx.op_conv3x3(h, w, P[pre + ".conv.bias"], ups=1)
         return h
@@ -223,6 +250,7 @@ def unet_train_forward(ctx, P, spec, x, timesteps, context):
 
 def unet_train_backward(ctx, P, spec, tape, deps):
     """deps bf16 [B, H, W, out_channels] -> {state-dict name: fp32 gradient in the native layout}."""
+    P = _as_params(P)
     grads = {}
     semb = tape["semb"]
     dsemb = None
@@ -259,14 +287,13 @@ def unet_train_backward(ctx, P, spec, tape, deps):
             d = g["x"]
         elif kind == "down":
             Bz, Hh, Wh, N = d.shape
-            z = torch.zeros((Bz, 2 * Hh, 2 * Wh, N), device=d.device, dtype=d.dtype)
-            z[:, ::2, ::2] = d                                                             # stride-2 gradient as a stride-1 one
+            z = ctx.op_expand2(d, 0)                                                       # stride-2 gradient as a stride-1 one (zero insertion)
             grads[pre + ".op.weight"] = ctx.op_conv3x3_wgrad(xin, z)
             grads[pre + ".op.bias"] = ctx.op_colsum(d.reshape(-1, N))
             d = ctx.op_conv3x3_dgrad(z, aux)
         elif kind == "up":
             N = d.shape[-1]
-            xu = xin.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).contiguous()   # what the fused conv read
+            xu = ctx.op_expand2(xin, 1)                                                     # what the fused conv read (nearest 2x)
             grads[pre + ".conv.weight"] = ctx.op_conv3x3_wgrad(xu, d)
             grads[pre + ".conv.bias"] = ctx.op_colsum(d.reshape(-1, N))
             d = ctx.op_sumpool2(ctx.op_conv3x3_dgrad(d, aux))
@@ -276,9 +303,9 @@ def unet_train_backward(ctx, P, spec, tape, deps):
             grads[pre + ".bias"] = ctx.op_colsum(d.reshape(-1, N))
     # time-embedding MLP: emb = W2 silu(W0 t + b0) + b2; every ResBlock read silu(emb)
     demb = ctx.op_silu(tape["emb"], dy=dsemb.contiguous())
-    ds1, grads["time_embed.2.weight"], grads["time_embed.2.bias"] = T.linear_backward(ctx, tape["s1"], _bf(P["time_embed.2.weight"]), _bf(demb))
+    ds1, grads["time_embed.2.weight"], grads["time_embed.2.bias"] = T.linear_backward(ctx, tape["s1"], P.w("time_embed.2.weight"), _bf(demb))
     de1 = ctx.op_silu(tape["e1"], dy=ds1.float().contiguous())
-    _, grads["time_embed.0.weight"], grads["time_embed.0.bias"] = T.linear_backward(ctx, tape["t_emb"], _bf(P["time_embed.0.weight"]), _bf(de1))
+    _, grads["time_embed.0.weight"], grads["time_embed.0.bias"] = T.linear_backward(ctx, tape["t_emb"], P.w("time_embed.0.weight"), _bf(de1))
     return grads
 
 
@@ -293,26 +320,78 @@ def g_named(g):
             "block": {"attn1": blk["attn1"], "attn2": blk["attn2"], "ff": blk["ff"]}}
 
 
-def unet_loss_and_grads(ctx, P, spec, x, timesteps, context, target):
-    """ldm p_losses' `loss_simple` (mean squared error of the predicted noise) and its gradient w.r.t. every UNet parameter."""
+def unet_loss_and_grads(ctx, P, spec, x, timesteps, context, target, coef=None):
+    """ldm p_losses' `loss_simple` (mean squared error of the predicted noise) and its gradient w.r.t. every UNet parameter.
+    target: bf16 / f32 NHWC [B,H,W,C] (as x) or f32 NCHW [B,C,H,W].  coef f32 [B] (optional): per-sample weight of (eps - target) in
+    the gradient -- default 2 / (B C H W), the gradient of the plain batch mean.  -> (loss, grads, se) with se the per-sample means."""
     eps, tape = unet_train_forward(ctx, P, spec, x, timesteps, context)
-    tape["context"] = context
-    diff = eps.float() - target.float()
-    loss = float((diff * diff).mean())
-    deps = (diff * (2.0 / diff.numel())).to(torch.bfloat16)
-    return loss, unet_train_backward(ctx, P, spec, tape, deps)
+    B, H, W, C = eps.shape
+    if target.dim() == 4 and target.shape[1] == C and target.shape[-1] != C:
+        tn = target.float().contiguous()
+    else:
+        tn = target.float().permute(0, 3, 1, 2).contiguous()
+    if coef is None:
+        coef = torch.full((B,), 2.0 / (B * C * H * W), device=eps.device, dtype=torch.float32)
+    se, deps = ctx.op_mse_loss(eps, tn, coef)
+    return float(se.mean()), unet_train_backward(ctx, P, spec, tape, deps), se
 
 
-def unet_training_step(ctx, P, state, spec, x, timesteps, context, target, step, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+class TrainState:
+    """What one optimisation step needs beside the batch: fp32 masters `P` (native layouts, `params_from_state_dict`), AdamW moments,
+    the bf16 working copies `work` of every >= 2-D tensor (written by the optimiser kernel: rdm_op_adamw's p_bf16), the step counter
+    and (optionally) LitEma's shadow weights."""
+
+    def __init__(self, P, ema_decay=None):
+        self.P = P
+        self.m = {k: torch.zeros_like(v) for k, v in P.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in P.items()}
+        self.work = {k: v.to(torch.bfloat16) for k, v in P.items() if v.dim() >= 2}
+        self.step = 0
+        self.ema = Ema(P, ema_decay) if ema_decay else None
+
+    def params(self):
+        return _Params(self.P, self.work)
+
+
+def unet_training_step(ctx, P, state, spec, x, timesteps, context, target, step=None, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                       coef=None):
     """One optimisation step of the UNet (what `trainer.fit` does per batch in the reference's main.py with ldm's AdamW): forward, MSE
-    loss, backward, AdamW on the fp32 masters `P` in place.  state = {"m": {...}, "v": {...}} fp32 moments keyed like P (zeros at
-    step 1).  -> loss value before the update."""
-    loss, grads = unet_loss_and_grads(ctx, P, spec, x, timesteps, context, target)
-    grads = parallel.average_gradients(grads)                  # data parallel: bucketed all-reduce (no-op on one rank)
+    loss, backward, bucketed gradient all-reduce, AdamW on the fp32 masters in place.  `state`: a TrainState (bf16 working copies, no
+    per-forward casts), or the round-3 form {"m": {...}, "v": {...}} with P the masters and `step` given.  -> loss before the update."""
+    if isinstance(state, TrainState):
+        loss, grads, _ = unet_loss_and_grads(ctx, state.params(), spec, x, timesteps, context, target, coef)
+        apply_gradients(ctx, state, grads, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        return loss
+    loss, grads, _ = unet_loss_and_grads(ctx, P, spec, x, timesteps, context, target, coef)
+    grads = parallel.average_gradients(grads)
     for k, p in P.items():
         ctx.op_adamw(p, grads[k].float().reshape(p.shape).contiguous(), state["m"][k], state["v"][k], step, lr=lr, betas=betas, eps=eps,
                      weight_decay=weight_decay)
     return loss
+
+
+def apply_gradients(ctx, state, grads, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, group=None):
+    """The optimiser half of a step on a TrainState: bucketed gradient all-reduce over the data-parallel group (no-op on one rank),
+    AdamW on the fp32 masters in place with the bf16 working copies refreshed by the same kernel, LitEma update."""
+    state.step += 1
+    grads = parallel.average_gradients(grads, group=group) if group is not None else parallel.average_gradients(grads)
+    for k, p in state.P.items():
+        ctx.op_adamw(p, grads[k].float().reshape(p.shape).contiguous(), state.m[k], state.v[k], state.step, lr=lr, betas=betas, eps=eps,
+                     weight_decay=weight_decay, p_bf16=state.work.get(k))
+    if state.ema is not None:
+        state.ema.update(ctx, state.P)
+
+
+def state_dict_from_params(P, like):
+    """native-layout masters -> tensors in the reference's state-dict layouts (`like`: name -> tensor or shape), on the host."""
+    out = {}
+    for k, v in P.items():
+        shape = tuple(like[k].shape) if hasattr(like[k], "shape") else tuple(like[k])
+        v = v.detach().float().cpu()
+        if len(shape) == 4 and shape[2:] == (3, 3):
+            v = v.reshape(shape[0], 3, 3, shape[1]).permute(0, 3, 1, 2)
+        out[k] = v.reshape(shape).contiguous()
+    return out
 
 
 class Ema:

@@ -334,7 +334,7 @@ def test_whole_unet_loss_gradients(ctx):
     loss_ref.backward()
     P = TU.params_from_state_dict(sd, dev)
     to_nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev, torch.bfloat16)
-    loss, grads = TU.unet_loss_and_grads(ctx, P, spec, to_nhwc(x), tsteps.to(dev), cx.to(dev, torch.bfloat16), to_nhwc(noise))
+    loss, grads, _ = TU.unet_loss_and_grads(ctx, P, spec, to_nhwc(x), tsteps.to(dev), cx.to(dev, torch.bfloat16), to_nhwc(noise))
     g = TU.grads_to_state_dict_layout({k: v.cpu() for k, v in grads.items()}, sd)
     missing = sorted(set(sd) - set(g))
     assert not missing, missing

@@ -76,6 +76,30 @@ def test_rarm_forward_shipped_deep_golden(ctx):
             assert e <= 2.5e-2
 
 
+def test_rarm_forward_shipped_deep_golden_batch64(ctx):
+    """The BENCHMARKED decode geometry (config #5: 64 sequences -- LN-folded skinny GEMMs with row blocks, the fused decode
+    cross-attention on 64 per-sequence operand sets): the golden's random-neighbour sequence sits at row 0 and its zero-neighbour
+    sequence at row 63 of a 64-sequence batch (rows 1..62 random tokens / neighbours); logits at positions 0, 31, 127, 255 against the
+    reference's in-tree RetrievalPatchTransformer, same bound as the 2-sequence run."""
+    g = golden("rarm_shipped_deep.npz")
+    spec = orarm.shipped_rarm_spec()
+    _load(ctx, spec, int(g["seed"]))
+    tok, cx = torch.from_numpy(g["tokens"]), torch.from_numpy(g["ctx"])
+    gen = torch.Generator().manual_seed(91)
+    T = tok.shape[1]
+    tokens = torch.cat([tok[:1], torch.randint(0, spec.vocab_out, (62, T), generator=gen), tok[1:2]])
+    context = torch.cat([cx[:1], torch.randn((62,) + tuple(cx.shape[1:]), generator=gen) * float(cx[0].std()), cx[1:2]])
+    logits = ctx.rarm_forward(tokens, context)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(logits).all())
+    ref = torch.from_numpy(g["logits_at"])
+    for row, r in ((0, 0), (63, 1)):
+        for j, p in enumerate(g["positions"].tolist()):
+            e = rel_l2(logits[row, p], ref[r, j])
+            print(f"rarm shipped, batch 64, row {row} ({'zero' if r else 'random'} neighbours), position {p}: rel L2 {e:.3e}")
+            assert e <= 2.5e-2
+
+
 def test_rarm_sampler_kernel_exact_at_vocab_16384(ctx):
     """The sampler kernel on STORED reference logits at the shipped vocabulary (16 384) and top-k 256, guided (scale 2.0): the tokens
     must EQUAL the reference run's (same uniforms), and with ties planted exactly at the top-k threshold (the 257th guided logit made
