@@ -593,7 +593,9 @@ struct Ops {
         if (plan) return;
         // skinny (weight-streaming) kernel for decode-sized operands.  Fast mode: whenever M <= 128.  Deterministic mode: exactly for
         // the ops with ONE row per sample (`single_row`: time embedding, RARM decode step, CLIP projection), at any batch
-        const bool skinny = c->deterministic ? single_row : (M <= 128);
+        // (one-row-per-sample operands of bigger batches -- RARM decode at 128+ sequences per GPU -- keep the skinny kernel: its row
+        //  blocks scale with M, while the tiled kernels would run a dozen 256-row tiles)
+        const bool skinny = c->deterministic ? single_row : (M <= 128 || (single_row && M <= 1024));
         if (skinny && !A1 && C1 == 0) {         // N/32 x ceil(M/32) blocks (sgemm.hip)
             SgemmParams q{}; q.A = A0; q.lda = C0; q.W = w<bf16_t>(woff); q.M = M; q.N = N; q.K = C0; q.bias = has_bias ? w<float>(boff) : nullptr;
             q.act = act; q.res_f32 = res_f32; q.res_bf16 = res; q.out_f32 = out_f32; q.out_bf16 = out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
@@ -626,7 +628,7 @@ struct Ops {
     // false = not available for this shape (the caller runs layernorm + linear)
     bool linear_ln(const float* x, size_t g, size_t b, int C, size_t woff, size_t boff, bool has_bias, int M, int N, int act, bf16_t* out) {
         static const int off = getenv("RDM_NO_LNFUSE") ? atoi(getenv("RDM_NO_LNFUSE")) : 0;
-        const bool skinny = c->deterministic ? single_row : (M <= 128);
+        const bool skinny = c->deterministic ? single_row : (M <= 128 || (single_row && M <= 1024));
         SgemmParams q{}; q.ln_x = x; q.ln_g = w<float>(g); q.ln_b = w<float>(b); q.ln_eps = 1e-5f; q.W = w<bf16_t>(woff); q.M = M; q.N = N; q.K = C;
         q.bias = has_bias ? w<float>(boff) : nullptr; q.act = act; q.out_bf16 = out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
         if (off || !skinny || !sgemm_supported(q)) return false;

@@ -91,7 +91,9 @@ def test_training_glue_ops(ctx):
 def _tiny_model(ctx, p_uncond=0.0, seed=21):
     from oracle import unet as ounet, vqdecoder as ovq
     from rdm_amd.models.diffusion.ddpm import MinimalRETRODiffusion
-    spec, vs = ounet.tiny_spec(), ovq.tiny_vq_spec()
+    # first stage with a 32 x 32 latent (two levels): the tiny UNet's attention then runs at 32^2 / 16^2 / 8^2 tokens (the backward's batched
+    # GEMMs contract over the token count, a multiple of 64 at every shipped resolution)
+    spec, vs = ounet.tiny_spec(), ovq.VQSpec(n_embed=512, ch=64, ch_mult=(1, 2), num_res_blocks=1, resolution=64)
     sd = {k: bf16_round(v) if v.dim() >= 2 else v for k, v in ounet.synth_state_dict(ounet.param_shapes(spec), seed=seed).items()}
     vsd = ounet.synth_state_dict({**ovq.vq_param_shapes(vs), **ovq.vq_encoder_param_shapes(vs)}, seed=seed + 1)
     up = dict(in_channels=spec.in_channels, out_channels=spec.out_channels, model_channels=spec.model_channels, num_res_blocks=spec.num_res_blocks,
