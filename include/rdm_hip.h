@@ -154,6 +154,10 @@ int rdm_ddpm_sample(rdm_ctx* ctx, const rdm_ddpm_args* args, const float* x_T, c
  *      (called at rdm/models/diffusion/ddpm.py:840, 981). z [dev] f32 [b,3,h,w] -> img [dev] f32 [b,3,H,W];
  * indices_out [dev] int32 [b*h*w] or NULL. */
 int rdm_vq_decode(rdm_ctx* ctx, const float* z, int b, int force_not_quantize, float* img_out, int32_t* indices_out);
+/* first_stage_model.quantize(z) (taming VectorQuantizer2.forward: nearest codebook entry, first minimum on ties, straight-through form
+ * z + (e - z)) WITHOUT post_quant_conv -- what DDIMSampler.p_sample_ddim applies to pred_x0 under quantize_x0 = True
+ * (rdm/models/diffusion/ddim.py:260-261).  z [dev] f32 [b,3,h,w] -> zq_out [dev] f32 [b,3,h,w]; indices_out [dev] int32 [b*h*w] or NULL. */
+int rdm_vq_quantize(rdm_ctx* ctx, const float* z, int b, float* zq_out, int32_t* indices_out);
 /* taming Net2NetTransformer.decode_to_img (reached from rdm/models/autoregression/transformer.py:296-312): code indices
  * [dev] int64 [b, h*w] -> quantize.get_codebook_entry -> post_quant_conv -> Decoder -> img_out [dev] f32 [b,3,R,R].
  * For first stages with a wide latent (VQGAN-f16, z_channels % 64 == 0). */

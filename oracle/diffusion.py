@@ -72,8 +72,9 @@ def ddim_schedule(sched: Schedule, S, eta):
     return ts, a_t, a_prev, sigma, sqrt_1m
 
 
-def p_sample_ddim(apply_model, x, c, t, index, sch, *, scale=1.0, uc=None, noise=None, temperature=1.0):
-    """ddim.py:217-268 with the options the native path supports."""
+def p_sample_ddim(apply_model, x, c, t, index, sch, *, scale=1.0, uc=None, noise=None, temperature=1.0, quantize=None):
+    """ddim.py:217-268 with the options the native path supports.  quantize: callable z -> z_q, the
+    `pred_x0, _, *_ = self.model.first_stage_model.quantize(pred_x0)` of quantize_denoised (:260-261)."""
     ts, a_t, a_prev, sigma, sqrt_1m = sch
     b = x.shape[0]
     assert scale >= 1.0
@@ -90,6 +91,8 @@ def p_sample_ddim(apply_model, x, c, t, index, sch, *, scale=1.0, uc=None, noise
     sg = torch.full_like(e_t, float(sigma[index]))
     s1m = torch.full_like(e_t, float(sqrt_1m[index]))
     pred_x0 = (x - s1m * e_t) / at.sqrt()
+    if quantize is not None:
+        pred_x0 = quantize(pred_x0)
     dir_xt = (1.0 - ap - sg ** 2).sqrt() * e_t
     nz = sg * noise * temperature
     x_prev = ap.sqrt() * pred_x0 + dir_xt + nz
@@ -98,7 +101,7 @@ def p_sample_ddim(apply_model, x, c, t, index, sch, *, scale=1.0, uc=None, noise
 
 def ddim_sample(apply_model, sched: Schedule, S, x_T, cond, *, eta=0.0, scale=1.0, uncond=None,
                 noise=None, log_every_t=100, temperature=1.0, mask=None, x0=None, q_noise=None, content_cond=None,
-                style_cond=None, timesteps=None, score_corrector=None):
+                style_cond=None, timesteps=None, score_corrector=None, quantize=None):
     """ddim.py:142-215. `noise` is an optional [S,B,...] stack consumed in loop order.  Optional loop-body options of the
     reference: inpainting (`mask`, `x0`; `q_noise` = explicit stack for the q_sample draw at :187), style / content conditioning
     by SNR band (:179-184), timestep subset (:158-160), score corrector (:239-241; a callable e_t, x, t, c -> e_t)."""
@@ -130,7 +133,7 @@ def ddim_sample(apply_model, sched: Schedule, S, x_T, cond, *, eta=0.0, scale=1.
         if score_corrector is not None:                               # corrector sees the guided e_t: wrap p_sample_ddim's pieces
             img, pred_x0 = _p_sample_ddim_corrected(apply_model, img, c_in, t, index, sch, scale, uncond, nz, temperature, score_corrector)
         else:
-            img, pred_x0 = p_sample_ddim(am, img, c_in, t, index, sch, scale=scale, uc=uncond, noise=nz, temperature=temperature)
+            img, pred_x0 = p_sample_ddim(am, img, c_in, t, index, sch, scale=scale, uc=uncond, noise=nz, temperature=temperature, quantize=quantize)
         if index % log_every_t == 0 or index == total - 1:
             inter["x_inter"].append(img)
             inter["pred_x0"].append(pred_x0)

@@ -87,6 +87,7 @@ SIGNATURES = {
     "rdm_ddim_sample": (C.c_int, [_P, C.POINTER(DdimArgs), _P, _P, _P, _P, _P, _P, _P]),
     "rdm_ddpm_sample": (C.c_int, [_P, C.POINTER(DdpmArgs), _P, _P, _P, _P]),
     "rdm_vq_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "rdm_vq_quantize": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "rdm_to_uint8": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_clip_encode_text": (C.c_int, [_P, _P, C.c_int, _P]),
     "rdm_clip_encode_image": (C.c_int, [_P, _P, C.c_int, _P]),
@@ -476,6 +477,18 @@ class Context:
         idx = torch.empty((b * z.shape[2] * z.shape[3],), device=self.device, dtype=torch.int32) if return_indices else None
         self._check(lib.rdm_vq_decode(self._h, _ptr(z), b, int(force_not_quantize), _ptr(img), _ptr(idx)))
         return (img, idx) if return_indices else img
+
+    def vq_quantize(self, z, return_indices=False):
+        """first_stage_model.quantize(z): z f32 [b,3,h,w] -> z_q (straight-through form), optionally the code indices."""
+        z = self._dev(z, torch.float32)
+        cfg = self._need("vq_quantize", "vq")
+        zr = cfg.resolution >> (cfg.n_ch_mult - 1)
+        if z.ndim != 4 or tuple(z.shape[1:]) != (cfg.embed_dim, zr, zr):
+            raise RdmError(f"vq_quantize: latent must be [b,{cfg.embed_dim},{zr},{zr}], got {tuple(z.shape)}")
+        zq = torch.empty_like(z)
+        idx = torch.empty((z.shape[0] * zr * zr,), device=self.device, dtype=torch.int32) if return_indices else None
+        self._check(lib.rdm_vq_quantize(self._h, _ptr(z), z.shape[0], _ptr(zq), _ptr(idx)))
+        return (zq, idx) if return_indices else zq
 
     def to_uint8(self, img):
         img = self._dev(img, torch.float32)

@@ -479,7 +479,7 @@ static void build_rarm(RarmModel& m, const rdm_rarm_cfg& c, Manifest& mf) {
 // ------------------------------------------------------------------------------------ context
 struct rdm_ctx {
     int device = 0; hipStream_t stream = nullptr; char err[512] = {0};
-    void* zero_page = nullptr;
+    void* zero_page = nullptr; float* eye3 = nullptr;
     UNet unet; VqModel vq; VqEncModel vqenc; ClipModel clip; RarmModel rarm; KnnDb db;
     float* gn_partial = nullptr; size_t gn_partial_bytes = 0;
     char* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;   // fp32 partial planes of the K-split halo convs
@@ -1315,7 +1315,7 @@ void rdm_ctx_destroy(rdm_ctx* c) {
     void* ptrs[] = {c->zero_page, c->unet.blob, c->unet.arena.base, c->unet.kv_cache, c->vq.blob, c->vq.arena.base,
                     c->clip.blob, c->clip.arena.base, c->gn_partial, c->samp, c->splitk_ws, c->unet.xa_cache,
                     c->rarm.blob, c->rarm.arena.base, c->rarm.cache, c->rarm.ctxkv, c->rarm.state, c->rarm.xa, c->wfrag_tmp, c->bwd_tmp,
-                    c->vqenc.blob, c->vqenc.arena.base};
+                    c->vqenc.blob, c->vqenc.arena.base, c->eye3};
     for (void* p : ptrs) if (p) hipFree(p);
     c->drop_frags();
     knn_free(c->db);
@@ -1584,6 +1584,21 @@ int rdm_vq_decode(rdm_ctx* c, const float* z, int b, int force_not_quantize, flo
     if (c->vq.wide) return c->fail(-1, "this first stage has a wide latent (VQGAN-f16): decode from code indices with rdm_vq_decode_indices");
     RDM_TRY(ensure_gn_partial(c, b));
     return run_with_arena(c, c->vq.arena, c->vq.blob, [&](Ops& o) { vq_body(o, c->vq, z, b, force_not_quantize, img_out, indices_out); });
+}
+int rdm_vq_quantize(rdm_ctx* c, const float* z, int b, float* zq_out, int32_t* indices_out) {
+    RDM_ENTER(c);
+    if (!z || !zq_out || b < 1) return c->fail(-1, "rdm_vq_quantize: bad argument");
+    VqModel& v = c->vq;
+    if (!v.loaded) return c->fail(-1, "vq weights not loaded");
+    if (v.wide || v.cfg.kl || v.cfg.embed_dim != 3) return c->fail(-1, "rdm_vq_quantize: needs a VQ first stage with a 3-channel latent (VQ-f4)");
+    if (!c->eye3) {       // the quantiser kernel ends in a 3 x 3 map (post_quant_conv in decode): identity + zero bias here
+        const float h[12] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};
+        RDM_CHECK_HIP(c, hipMalloc((void**)&c->eye3, sizeof h));
+        RDM_CHECK_HIP(c, hipMemcpy(c->eye3, h, sizeof h, hipMemcpyHostToDevice));
+    }
+    const int zr = v.cfg.resolution >> (v.cfg.n_ch_mult - 1);
+    RDM_CHECK_HIP(c, launch_vq_quantize(z, (const float*)(v.blob + v.codebook), v.cfg.n_embed, c->eye3, c->eye3 + 9, zq_out, indices_out, b, zr * zr, 1, c->stream));
+    return 0;
 }
 int rdm_vq_decode_indices(rdm_ctx* c, const int64_t* indices, int b, float* img_out) {
     RDM_ENTER(c);

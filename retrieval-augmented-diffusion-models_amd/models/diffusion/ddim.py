@@ -4,8 +4,10 @@ Same constructor, `make_schedule`, `sample`, `ddim_sampling`, `p_sample_ddim` si
 S-step loop itself runs inside librdm_hip (rdm_ddim_sample): UNet forward with CFG batch doubling + fused update
 per step, K/V of the neighbours projected once per call.  Options that change the loop body per step (callbacks, mask / x0
 inpainting, style_cond / content_cond by SNR band, timestep subset, noise_dropout, score_corrector) take the per-step path:
-native UNet forward, torch elementwise update.  quantize_x0 and ddim_use_original_steps raise NotImplementedError instead of
-being silently ignored.  Unlike the reference, nothing is forced
+native UNet forward, torch elementwise update.  quantize_x0 (round 4) also takes the per-step path: pred_x0 is snapped to the
+first stage's codebook by the native quantiser (rdm_vq_quantize).  ddim_use_original_steps raises NotImplementedError: in the
+reference that branch reads `self.model.ddim_sigmas_for_original_num_steps` (ddim.py:249), a buffer make_schedule registers on the
+SAMPLER (:52), so it ends in AttributeError there -- dead code, not a feature to mirror.  Unlike the reference, nothing is forced
 onto a "cuda" device string (ddim.py:21-25) and `--seed` style RNG comes from the caller's torch generator.
 """
 import numpy as np
@@ -79,12 +81,11 @@ class DDIMSampler(object):
                       noise_dropout=0., score_corrector=None, corrector_kwargs=None, unconditional_guidance_scale=1.,
                       unconditional_conditioning=None, random_guiding='none', content_cond=None, style_cond=None,
                       intermediates_to_cpu=False, S=None, eta=0., **kwargs):
-        unsupported = {"quantize_x0": quantize_denoised, "ddim_use_original_steps": ddim_use_original_steps}
-        bad = [k for k, v in unsupported.items() if v]
-        if bad:
-            raise NotImplementedError("native DDIM loop does not implement: " + ", ".join(bad))
+        if ddim_use_original_steps:
+            raise NotImplementedError("ddim_use_original_steps: dead in the reference (ddim.py:249 reads a buffer that lives on the sampler, "
+                                      "not on the model: AttributeError)")
         # options that change the loop body step by step run through the per-step path (native UNet forward per step)
-        per_step = (mask is not None or x0 is not None or noise_dropout > 0. or score_corrector is not None or
+        per_step = (quantize_denoised or mask is not None or x0 is not None or noise_dropout > 0. or score_corrector is not None or
                     content_cond is not None or style_cond is not None or random_guiding != 'none' or timesteps is not None)
         if isinstance(cond, dict):
             cond = cond[list(cond.keys())[0]]
@@ -109,7 +110,7 @@ class DDIMSampler(object):
                                      corrector_kwargs=corrector_kwargs, random_guiding=random_guiding, timesteps=timesteps,
                                      content_cond=None if content_cond is None else unwrap(content_cond),
                                      style_cond=None if style_cond is None else unwrap(style_cond),
-                                     noise=kwargs.get("noise"), q_noise=kwargs.get("q_noise"))
+                                     noise=kwargs.get("noise"), q_noise=kwargs.get("q_noise"), quantize_denoised=quantize_denoised)
         noise = kwargs.get("noise")             # [native] optional explicit per-step noise stack [S, B, C, H, W] (consumed in loop order)
         if eta != 0. and noise is None:
             noise = torch.randn((total_steps,) + tuple(shape), device=device)
@@ -122,7 +123,7 @@ class DDIMSampler(object):
 
     def _python_loop(self, cond, img, callback, img_callback, log_every_t, temperature, eta, scale, uc, to_cpu, mask=None,
                      x0=None, noise_dropout=0., score_corrector=None, corrector_kwargs=None, random_guiding='none',
-                     timesteps=None, content_cond=None, style_cond=None, noise=None, q_noise=None):
+                     timesteps=None, content_cond=None, style_cond=None, noise=None, q_noise=None, quantize_denoised=False):
         """Per-step path of ddim.py:143-209 (callbacks, inpainting mask, style / content conditioning by SNR band, timestep
         subset, noise dropout, score corrector): native UNet forward per step, torch elementwise update.  `noise` / `q_noise`
         [native]: optional explicit stacks [steps, B, C, H, W] for the update noise and for q_sample of the masked region."""
@@ -151,7 +152,7 @@ class DDIMSampler(object):
                 img = img_orig * mask + (1. - mask) * img
             if random_guiding == 'sampled':
                 random_guider = torch.clamp(torch.randn(img.shape, device=img.device), -1., 1.)
-            img, pred_x0 = self.p_sample_ddim(img, input_cond, ts, index=index, temperature=temperature,
+            img, pred_x0 = self.p_sample_ddim(img, input_cond, ts, index=index, temperature=temperature, quantize_denoised=quantize_denoised,
                                               noise_dropout=noise_dropout, score_corrector=score_corrector,
                                               corrector_kwargs=corrector_kwargs, unconditional_guidance_scale=scale,
                                               unconditional_conditioning=uc, noise=None if noise is None else noise[i],
@@ -169,8 +170,8 @@ class DDIMSampler(object):
                       unconditional_conditioning=None, noise=None, random_guider=None):
         b = x.shape[0]
         assert unconditional_guidance_scale >= 1.
-        if use_original_steps or quantize_denoised:
-            raise NotImplementedError
+        if use_original_steps:
+            raise NotImplementedError("use_original_steps: dead in the reference (ddim.py:249)")
         if noise is None:
             noise = torch.randn(x.shape, device=x.device)
         if unconditional_guidance_scale > 1.:
@@ -188,6 +189,8 @@ class DDIMSampler(object):
         sigma_t = torch.full_like(e_t, float(self.ddim_sigmas[index]))
         sqrt_one_minus_at = torch.full_like(e_t, float(self.ddim_sqrt_one_minus_alphas[index]))
         pred_x0 = (x - sqrt_one_minus_at * e_t) / a_t.sqrt()
+        if quantize_denoised:                     # ddim.py:260-261: pred_x0, _, *_ = self.model.first_stage_model.quantize(pred_x0)
+            pred_x0 = self.model.quantize_first_stage(pred_x0)
         dir_xt = (1. - a_prev - sigma_t ** 2).sqrt() * e_t
         noise = sigma_t * noise * temperature
         if noise_dropout > 0.:

@@ -190,6 +190,11 @@ class MinimalRETRODiffusion(object):
         return self.ctx.vq_decode(z / self.scale_factor if self.scale_factor != 1.0 else z, force_not_quantize=force_not_quantize)
 
     @torch.no_grad()
+    def quantize_first_stage(self, z):
+        """first_stage_model.quantize(z)[0] (taming VectorQuantizer2.forward) on the native quantiser."""
+        return self.ctx.vq_quantize(z)
+
+    @torch.no_grad()
     def q_sample(self, x_start, t, noise=None):
         noise = torch.randn_like(x_start) if noise is None else noise
         a = self.sqrt_alphas_cumprod.to(x_start.device)[t].reshape(-1, 1, 1, 1)

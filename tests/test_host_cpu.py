@@ -49,8 +49,11 @@ def test_ddim_timestep_quirks():
 def test_ddim_sampler_rejects_unsupported_options():
     from rdm_amd.models.diffusion.ddim import DDIMSampler
     s = DDIMSampler(_DummyModel())
+    s.make_schedule(5, verbose=False)
+    with pytest.raises(NotImplementedError):      # dead in the reference too (ddim.py:249 reads a sampler buffer off the model)
+        s.ddim_sampling(torch.zeros(1, 4, 512), (1, 3, 8, 8), ddim_use_original_steps=True)
     with pytest.raises(NotImplementedError):
-        s.sample(5, 1, (3, 8, 8), conditioning=torch.zeros(1, 4, 512), quantize_x0=True, verbose=False)
+        s.p_sample_ddim(torch.zeros(1, 3, 8, 8), torch.zeros(1, 4, 512), torch.zeros(1, dtype=torch.long), 0, use_original_steps=True)
     with pytest.raises(AssertionError):
         s.sample(5, 1, (3, 8, 8), conditioning=torch.zeros(1, 4, 512), unconditional_guidance_scale=0.5, verbose=False)
 
@@ -113,6 +116,29 @@ def test_ddim_per_step_options_match_oracle(case):
         assert torch.equal(a, b_)
     if case in ("callback", "all"):
         assert seen == list(range(11 if case == "all" else 20))
+
+
+def test_ddim_quantize_x0_matches_oracle():
+    """quantize_x0=True (ddim.py:260-261: pred_x0 snapped to the first stage's codebook every step) through the mirror's per-step
+    path, with a stand-in quantiser on the toy model, == the oracle's restatement bit for bit."""
+    from rdm_amd.models.diffusion.ddim import DDIMSampler
+    g = torch.Generator().manual_seed(9)
+    B, S = 2, 10
+    m = _ToyModel()
+    book = torch.randn(32, 3, generator=g)
+
+    def quant(z):                                     # nearest codebook entry, straight-through form (taming VectorQuantizer2)
+        zf = z.permute(0, 2, 3, 1)
+        idx = ((zf[..., None, :] - book) ** 2).sum(-1).argmin(-1)
+        return (zf + (book[idx] - zf)).permute(0, 3, 1, 2).contiguous()
+    m.quantize_first_stage = quant
+    x_T = torch.randn(B, 3, 8, 8, generator=g); c = torch.randn(B, 4, 16, generator=g); uc = torch.zeros(B, 4, 16)
+    z, inter = DDIMSampler(m).sample(S, B, (3, 8, 8), conditioning=c, eta=0.0, x_T=x_T, unconditional_guidance_scale=1.5,
+                                     unconditional_conditioning=uc, quantize_x0=True, log_every_t=2, verbose=False)
+    rz, rinter = odiff.ddim_sample(m.apply_model, odiff.Schedule(), S, x_T, c, scale=1.5, uncond=uc, log_every_t=2, quantize=quant)
+    assert torch.equal(z, rz)
+    for a, b_ in zip(inter["pred_x0"][1:], rinter["pred_x0"][1:]):
+        assert torch.equal(a, b_) and (a - quant(a)).abs().max().item() <= 1e-5        # every stored pred_x0 sits ON the codebook (z + (e - z): a few ulps off e)
 
 
 def test_tokenizer_matches_reference_golden():
