@@ -97,6 +97,9 @@ typedef struct {
 int rdm_ctx_create(int device_id, rdm_ctx** out);
 void rdm_ctx_destroy(rdm_ctx* ctx);
 const char* rdm_last_error(rdm_ctx* ctx);
+/* Frees the grow-only work buffers of the context (backward scratch incl. up to 256 MB of fp32 weight-gradient planes per conv,
+ * split-K planes, per-call weight re-packs, sampler scratch); they are re-created on demand.  Weights, caches and arenas stay. */
+int rdm_release_scratch(rdm_ctx* ctx);
 int rdm_set_stream(rdm_ctx* ctx, void* hip_stream);
 const char* rdm_version(void);
 /* Batch-invariant ("deterministic") execution: every kernel-selection decision of the library (skinny vs tiled GEMM, halo vs generic

@@ -87,6 +87,7 @@ SIGNATURES = {
     "rdm_ddim_sample": (C.c_int, [_P, C.POINTER(DdimArgs), _P, _P, _P, _P, _P, _P, _P]),
     "rdm_ddpm_sample": (C.c_int, [_P, C.POINTER(DdpmArgs), _P, _P, _P, _P]),
     "rdm_vq_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "rdm_release_scratch": (C.c_int, [_P]),
     "rdm_vq_quantize": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "rdm_to_uint8": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_clip_encode_text": (C.c_int, [_P, _P, C.c_int, _P]),
@@ -302,6 +303,10 @@ class Context:
     def _check(self, rc):
         if rc != 0:
             raise RdmError(f"librdm_hip error {rc}: {lib.rdm_last_error(self._h).decode()}")
+
+    def release_scratch(self):
+        """Hand the grow-only work buffers (training scratch, split-K planes, ...) back to the allocator; re-created on demand."""
+        self._check(lib.rdm_release_scratch(self._h))
 
     def use_current_stream(self):
         self._check(lib.rdm_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))

@@ -1323,6 +1323,19 @@ void rdm_ctx_destroy(rdm_ctx* c) {
 }
 
 const char* rdm_last_error(rdm_ctx* c) { return c ? c->err : "null context"; }
+
+// The grow-only work buffers (backward scratch: K-major operand copies + up to 256 MB of fp32 weight-gradient planes per conv -- over
+// 1 GB for the 576 -> 192 block at 64 x 64 and batch 64 --, split-K planes, per-call weight re-packs, sampler scratch) are kept between
+// calls so that steady-state steps allocate nothing; a caller switching from training back to sampling hands them back here.  They
+// are re-created on demand.
+int rdm_release_scratch(rdm_ctx* c) {
+    RDM_ENTER(c);
+    RDM_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    char** bufs[] = {&c->bwd_tmp, &c->wfrag_tmp, &c->splitk_ws, &c->samp};
+    size_t* sizes[] = {&c->bwd_tmp_bytes, &c->wfrag_tmp_bytes, &c->splitk_ws_bytes, &c->samp_bytes};
+    for (int i = 0; i < 4; i++) { if (*bufs[i]) { (void)hipFree(*bufs[i]); *bufs[i] = nullptr; } *sizes[i] = 0; }
+    return 0;
+}
 int rdm_set_deterministic(rdm_ctx* c, int on) { if (!c) return -1; c->deterministic = on != 0; return 0; }
 int rdm_get_deterministic(rdm_ctx* c) { return c ? (c->deterministic ? 1 : 0) : -1; }
 int rdm_set_stream(rdm_ctx* c, void* s) {
