@@ -153,6 +153,9 @@ def test_training_step_from_images_tracks_torch(ctx):
     print(f"training surface: validation loss before / after syncing the live weights {float(v0):.4f} / {float(v1):.4f}; torch after 3 steps {ref_after:.4f}")
     assert abs(float(v0) - curve[0][1]) <= 3e-2 * curve[0][1]             # still the initial weights
     assert abs(float(v1) - ref_after) <= 3e-2 * ref_after
+    ctx.release_scratch()                                                 # training scratch handed back; sampling re-creates what it needs
+    v2, _ = m.validation_step({"image": img, "nn_embeddings": nns}, 0, t=tsteps, noise=noise, uncond_mask=mask)
+    assert float(v2) == float(v1)
 
 
 def test_training_step_draws_like_the_reference_when_nothing_is_given(ctx):
