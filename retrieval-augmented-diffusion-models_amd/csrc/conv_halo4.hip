@@ -76,7 +76,12 @@ __host__ __device__ inline Halo4Geom halo4_geom(int H, int W) {
 }
 constexpr int H4_HALO_MAX = 66560;                 // largest HBYTES admitted (W = 8: 40 rows x 1664 bytes)
 
-template <int FN, int VAR>      // VAR: dev-only ablations (RDM_H4_VAR): 1 = no halo-piece address work (wrong results)
+// STRIP (round 4): images wider than 64 pixels (the first-stage decoder's 128- and 256-pixel levels).  A tile is still 256 output pixels
+// with the W = 64 halo geometry -- 4 rows of a 64-COLUMN STRIP -- but the strip's left / right halo columns are the neighbouring
+// strips' real pixels (zero only at the image border), rows of a tile are WI pixels apart in memory, and tile index -> (sample, row
+// group, strip).  Costs three VALU per halo piece (column = strip origin + halo column, its validity, the source column), so it is a
+// template variant: the UNet's kernels (W <= 64) are unchanged.
+template <int FN, int VAR, bool STRIP = false>      // VAR: dev-only ablations (RDM_H4_VAR): 1 = no halo-piece address work (wrong results)
 __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     constexpr int BM = 256, BK = 64, FM = 4, WN = FN * 32, BN = 2 * WN;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [halo0][halo1][dump: 1 KB per wave]
@@ -88,7 +93,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     const int lp = lane >> 3, lc = lane & 7;
 
     // ---- geometry (uniform)
-    const int H = p.Hout, W = p.Wout, HW = H * W;
+    const int H = p.Hout, WI = p.Wout, HW = H * WI;        // WI: image width; W: width of the halo geometry (a 64-column strip when STRIP)
+    const int W = STRIP ? 64 : WI;
     const Halo4Geom gm = halo4_geom(H, W);
     const int RS = gm.RS, HPW = gm.HPW, RSTR = gm.RSTR, NPR = gm.NPR, NPT = gm.NPT, HBYTES = gm.HBYTES;
     const int mNPR = 65536 / NPR + 1, mRS2 = 65536 / (RS + 2) + 1;     // x / d = (x * m) >> 16 for the small x met here (checked on the host)
@@ -144,12 +150,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     // LDS row address.  Rows outside the image and pieces beyond the halo read the zero page; columns outside the image are
     // redirected there per lane; positions past a row's end, and whole pieces beyond the halo, land in a wave-private dump area --
     // every k-step issues the same requests whether its piece is real or not, so the wait counts are compile-time constants.
+    // y0 | x0 << 16 in ONE register when STRIP (x0: first column of the tile's strip): the scalar file is full (hipcc already parks ~90
+    // uniform values in VGPR lanes; three more live scalars pushed those VGPRs into scratch, whose traffic would count in vmcnt)
     struct HaloTile { int b0, y0; };
+    auto ht_y0 = [](const HaloTile& h) { return STRIP ? (h.y0 & 0xffff) : h.y0; };
+    auto ht_x0 = [](const HaloTile& h) { return STRIP ? (int)((unsigned)h.y0 >> 16) : 0; };
     struct HaloSrc { const char* src; unsigned ldb; };                   // src: channel slice of pixel 0 in the slice's source tensor
     const int ups = p.ups ? 1 : 0;
     auto halo_tile = [&](int t) {
         const int tm0 = ((t % ntiles_mn) / nbn) * BM;
-        HaloTile h; h.b0 = tm0 / HW; h.y0 = (tm0 - h.b0 * HW) / W; return h;
+        HaloTile h;
+        if constexpr (STRIP) {              // tiles of an image: row groups of RS = 4 rows x strips of 64 columns, strips fastest
+            const int spr = WI >> 6, tpi = (H >> 2) * spr, tmi = tm0 >> 8;
+            h.b0 = tmi / tpi;
+            const int r = tmi - h.b0 * tpi, rg = r / spr;
+            h.y0 = (rg << 2) | (((r - rg * spr) << 6) << 16);
+        } else { h.b0 = tm0 / HW; h.y0 = (tm0 - h.b0 * HW) / W; }
+        return h;
     };
     auto halo_src = [&](int sl) {
         const int kc = sl * BK;
@@ -175,16 +192,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
         const unsigned xok = ((unsigned)x < (unsigned)W) ? 1u : 0u;
         const unsigned wr = (g < NPT && hx < HPW) ? 1u : 0u;
         const unsigned xs = xok ? (unsigned)(x >> ups) : 0u;
-        const unsigned e = ((rel >> 4) & 0x1fffu) | (xs << 13) | (xok << 19) | ((unsigned)(hy & 63) << 20) | ((unsigned)(sp & 3) << 26) | (wr << 28);
+        // STRIP: bits 13-19 hold the halo column hx (0 .. 65) itself: image column, validity and source column follow from the tile's strip
+        const unsigned e = STRIP ? (((rel >> 4) & 0x1fffu) | ((unsigned)(hx & 127) << 13) | ((unsigned)(hy & 63) << 20) | ((unsigned)(sp & 3) << 26) | (wr << 28))
+                                 : (((rel >> 4) & 0x1fffu) | (xs << 13) | (xok << 19) | ((unsigned)(hy & 63) << 20) | ((unsigned)(sp & 3) << 26) | (wr << 28));
         *(unsigned*)(smem + tbl + q * 256) = e;
     }
     const char* const zl = zero + lane * 16;                             // this lane's 16 bytes of the zero page
     // table entry e of a piece -> source address of this lane's 16 bytes (tile ht, slice source hs) and LDS destination.
     // `live` (uniform): the piece is one of this wave's (else: zero page -> dump area)
     auto halo_piece = [&](unsigned e, bool live, const HaloTile& ht, const HaloSrc& hs, unsigned hbase, const char*& gaddr, unsigned& ldst) {
-        const int hy = (int)((e >> 20) & 63u), sp = (int)((e >> 26) & 3u), xs = (int)((e >> 13) & 63u);
-        const int y = ht.y0 + hy - 1;
-        const bool ok = live & (((e >> 19) & 1u) != 0) & ((unsigned)y < (unsigned)H);
+        const int hy = (int)((e >> 20) & 63u), sp = (int)((e >> 26) & 3u);
+        int xs = (int)((e >> 13) & 63u);
+        bool xin = ((e >> 19) & 1u) != 0;
+        if constexpr (STRIP) { const int x = ht_x0(ht) + (int)((e >> 13) & 127u) - 1; xin = (unsigned)x < (unsigned)WI; xs = x >> ups; }
+        const int y = ht_y0(ht) + hy - 1;
+        const bool ok = live & xin & ((unsigned)y < (unsigned)H);
         const unsigned pix = (unsigned)__mul24(__mul24(ht.b0 + sp, p.Hin) + (y >> ups), p.Win) + (unsigned)xs;
         const char* const ga = hs.src + (unsigned long long)pix * hs.ldb + (unsigned)(lc * 16);
         const unsigned long long sel = ok ? (unsigned long long)ga : (unsigned long long)zl;
@@ -379,11 +401,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
             }
             asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(pe) :: "memory");   // the table entry (requested before the four A fragments)
             mfma(ks, 4);
-            int hy = (int)((pe >> 20) & 63u), sp = (int)((pe >> 26) & 3u), xs = (int)((pe >> 13) & 63u);
+            int hy = (int)((pe >> 20) & 63u), sp = (int)((pe >> 26) & 3u), xs = (int)((pe >> 13) & (STRIP ? 127u : 63u));
+            if constexpr (STRIP) xs += ht_x0(ht) - 1;                  // image column of this lane's halo position
             H4_PIN3(hy, sp, xs);
             mfma(ks, 5);
-            int y = ht.y0 + hy - 1;
-            unsigned okm = (live & (((pe >> 19) & 1u) != 0) & ((unsigned)y < (unsigned)H)) ? 0xffffffffu : 0u;
+            int y = ht_y0(ht) + hy - 1;
+            const bool xin = STRIP ? ((unsigned)xs < (unsigned)WI) : (((pe >> 19) & 1u) != 0);
+            unsigned okm = (live & xin & ((unsigned)y < (unsigned)H)) ? 0xffffffffu : 0u;
+            if constexpr (STRIP) xs >>= ups;                           // (an invalid column's address is discarded through okm)
             H4_PIN2(y, okm);
             mfma(ks, 6);
             int t = __mul24(ht.b0 + sp, p.Hin) + (y >> ups);
@@ -500,14 +525,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
                 lrd[it] = stg0 + (unsigned)(row * SROW) + (((c4 & ~7u) | ((c4 ^ fr) & 7u)) << 4);
             }
             const unsigned lx = swz ? 16u : 0u, la = swz ? 0u : 16u;   // second unit: XOR 16 (swizzled) / + 16 (padded)
-            const char* const obase = (const char*)(ob + (long long)(em0 + wm * 128) * p.ldo + eno);
-            const char* const rbase = (const char*)(rb + (long long)(em0 + wm * 128) * p.ldo + eno);
-            const unsigned long long rowstep = (unsigned long long)(32 * p.ldo) * 2ull;
+            // first output row (pixel index) of fragment row i of this wave: consecutive pixels of the tile, or -- STRIP -- half a strip row
+            auto frag_row0 = [&](int i) -> long long {
+                if constexpr (STRIP) {
+                    const int tp = wm * 128 + i * 32;
+                    return ((long long)(ht_tile.b0 * H + ht_y0(ht_tile) + (tp >> 6)) * WI + ht_x0(ht_tile) + (tp & 63));
+                } else return (long long)(em0 + wm * 128 + i * 32);
+            };
+            const char* const obase = (const char*)(ob + eno);
+            const char* const rbase = (const char*)(rb + eno);
+            const unsigned long long rowbytes = (unsigned long long)p.ldo * 2ull;
             // residual rows: asm loads (saddr form) with counted waits.  Program order of the vector-memory requests:
             // R0 R1 | S0 (NIT stores) R2 | S1 R3 | S2 | S3 -- the wait in front of row i's adds leaves exactly the younger ones in flight
             h4_u32x4 rr4[2][NIT];
             auto res_request = [&](int i, h4_u32x4 (&dst)[NIT]) {
-                const char* const rp = (const char*)h4_uni64((unsigned long long)(rbase + i * rowstep));
+                const char* const rp = (const char*)h4_uni64((unsigned long long)(rbase + (unsigned long long)frag_row0(i) * rowbytes));
 #pragma unroll
                 for (int it = 0; it < NIT; it++) H4_GLOADB(dst[it], voffs[it], rp, 0);
             };
@@ -520,7 +552,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
                 for (int it = 0; it < NIT; it++) asm volatile("" : "+v"(r[it]));
             };
             auto store_row = [&](int i) {
-                const char* const op = (const char*)h4_uni64((unsigned long long)(obase + i * rowstep));
+                const char* const op = (const char*)h4_uni64((unsigned long long)(obase + (unsigned long long)frag_row0(i) * rowbytes));
 #pragma unroll
                 for (int it = 0; it < NIT; it++) {
                     float4 a0 = *(const float4*)(smem + lrd[it]), a1 = *(const float4*)(smem + ((lrd[it] ^ lx) + la));
@@ -574,14 +606,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     }
 }
 
-template <int FN, int VAR>
+template <int FN, int VAR, bool STRIP = false>
 static hipError_t launch_halo4_cfg(const IgemmParams& p, hipStream_t st) {
     constexpr int smem = 2 * H4_HALO_MAX + 4096 + 4 * 21 * 256;       // halo x 2, dump, piece tables
     constexpr int BN = FN * 64;
     static int ncu_dev[RDM_MAX_DEVICES] = {0};
     const int dev = rdm_cur_device();
     if (!ncu_dev[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo4_kernel<FN, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo4_kernel<FN, VAR, STRIP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         hipDeviceGetAttribute(&ncu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev);
     }
@@ -594,15 +626,30 @@ static hipError_t launch_halo4_cfg(const IgemmParams& p, hipStream_t st) {
         IgemmParams q = p; q.dbg |= 16;
         unsigned long long z[4] = {0, 0, 0, 0}, r[4];
         hipMemcpyToSymbol(HIP_SYMBOL(g_halo4_prof), z, sizeof(z));
-        conv3x3_halo4_kernel<FN, VAR><<<dim3((unsigned)g), 256, smem, st>>>(q);
+        conv3x3_halo4_kernel<FN, VAR, STRIP><<<dim3((unsigned)g), 256, smem, st>>>(q);
         hipStreamSynchronize(st);
         hipMemcpyFromSymbol(r, HIP_SYMBOL(g_halo4_prof), sizeof(r));
         fprintf(stderr, "[halo4<%d> M=%d N=%d K=%d] blocks=%llu per-block cycles: main %.0f epilogue %.0f (tiles/block %.2f)\n", BN, p.M, p.N, p.K,
                 r[3], (double)r[0] / r[3], (double)r[1] / r[3], (double)ntiles / g);
         return hipGetLastError();
     }
-    conv3x3_halo4_kernel<FN, VAR><<<dim3((unsigned)g), 256, smem, st>>>(p);
+    conv3x3_halo4_kernel<FN, VAR, STRIP><<<dim3((unsigned)g), 256, smem, st>>>(p);
     return hipGetLastError();
+}
+
+// images wider than 64 pixels as 64-column strips (conv3x3_halo4_kernel<.., STRIP>): the first-stage decoder's 128- / 256-pixel levels
+bool conv_halo4_strip_supported(const IgemmParams& p) {
+    static const int off = getenv("RDM_NO_HALO4_STRIP") ? atoi(getenv("RDM_NO_HALO4_STRIP")) : 0;
+    if (off || getenv("RDM_NO_HALO4") || getenv("RDM_NO_HALO")) return false;
+    const int W = p.Wout, H = p.Hout;
+    if (p.stride != 1 || W <= 64 || W % 64 || H % 4 || W > 4096 || H > 4096) return false;
+    if (p.ups ? (p.Hout != 2 * p.Hin || p.Wout != 2 * p.Win) : (p.Hout != p.Hin || p.Wout != p.Win)) return false;
+    if (p.M % 256 != 0 || p.N % 128 != 0 || p.ksplit > 1) return false;
+    if (p.C0 % 64 || p.C1 % 64 || p.alpha != 1.0f || p.act != ACT_NONE || !p.out_bf16 || p.out_f32 || p.res_f32) return false;
+    if (p.ldo % 8 || p.K != 9 * (p.C0 + p.C1)) return false;
+    if (p.rowvec && p.rows_per_sample % 32 != 0) return false;
+    if ((long long)p.M * (p.C0 > p.C1 ? p.C0 : p.C1) >= 0x7fffffffLL || (long long)p.M * p.ldo >= 0x7fffffffLL) return false;
+    return true;
 }
 
 // the one-wave-per-SIMD kernel takes every conv the halo geometry admits once a fragment-ordered weight copy exists
@@ -623,6 +670,10 @@ bool conv_halo4_supported(const IgemmParams& p) {
 
 hipError_t launch_conv_halo4(const IgemmParams& p, hipStream_t st) {
     static const int var = getenv("RDM_H4_VAR") ? atoi(getenv("RDM_H4_VAR")) : 0;
+    if (p.Wout > 64) {
+        if (!p.Wfrag || !conv_halo4_strip_supported(p)) return hipErrorInvalidValue;
+        return launch_halo4_cfg<2, 0, true>(p, st);
+    }
     if (p.N % 192 == 0) {
         if (var == 1) return launch_halo4_cfg<3, 1>(p, st);
         if (var == 3) return launch_halo4_cfg<3, 3>(p, st);

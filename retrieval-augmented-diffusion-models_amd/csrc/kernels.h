@@ -123,6 +123,7 @@ int conv_halo_ksplit(const IgemmParams& p);                // K-split factor wor
 hipError_t launch_conv_halo(const IgemmParams& p, hipStream_t st);
 // one-wave-per-SIMD halo kernel (conv_halo4.hip): needs p.Wfrag, the fragment-ordered weight copy
 bool conv_halo4_supported(const IgemmParams& p);
+bool conv_halo4_strip_supported(const IgemmParams& p);     // output wider than 64 pixels: 64-column strips (N % 128 == 0, no K-split); needs p.Wfrag
 hipError_t launch_conv_halo4(const IgemmParams& p, hipStream_t st);
 // one-wave-per-SIMD linear GEMM (lin4.hip): needs p.Wfrag = the fragment-ordered copy of W built by launch_lin_w_fragpack
 bool lin4_supported(const IgemmParams& p, int batch);
@@ -132,6 +133,7 @@ hipError_t launch_lin_ln_sb(const bf16_t* W, const float* gamma, const float* be
 hipError_t launch_conv_w_fragpack(const bf16_t* W, bf16_t* dst, int N, int Cin, hipStream_t st);   // dst: N*9*Cin elements
 // 3x3 conv dispatcher: input-stationary halo kernels when the geometry allows, else the generic implicit GEMM
 inline hipError_t launch_conv3x3(const IgemmParams& p, hipStream_t st) {
+    if (p.Wfrag && p.Wout > 64 && conv_halo4_strip_supported(p)) return launch_conv_halo4(p, st);
     return conv_halo_supported(p) ? launch_conv_halo(p, st) : launch_igemm(p, true, 1, st);
 }
 // ---- backward pieces (backward.hip)

@@ -676,7 +676,7 @@ struct Ops {
         const bool det_generic = c->deterministic && ((Hout * Wout) % 256 != 0);
         const int ks = c->deterministic ? 1 : conv_halo_ksplit(p);
         if (ks > 1 && ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)ks * p.M * N * 4) == 0) { p.ksplit = ks; p.ws = (float*)c->splitk_ws; }
-        if (!det_generic && conv_halo_supported(p)) p.Wfrag = c->frag_for(p.W, N, C0 + C1);
+        if (!det_generic && (conv_halo_supported(p) || conv_halo4_strip_supported(p))) p.Wfrag = c->frag_for(p.W, N, C0 + C1);
         prof_begin(RDM_PROF_CONV3X3, 2.0 * p.M * N * (double)p.K);
         check(det_generic ? launch_igemm(p, true, 1, c->stream) : launch_conv3x3(p, c->stream), "conv3x3");
         prof_end();
@@ -2029,8 +2029,9 @@ int rdm_op_conv3x3(rdm_ctx* c, const void* x0, const void* x1, int C0, int C1, c
     const int ks = c->deterministic ? 1 : conv_halo_ksplit(p);
     if (ks > 1) { RDM_TRY(ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)ks * p.M * N * 4)); p.ksplit = ks; p.ws = (float*)c->splitk_ws; }
     static const int op_cache = getenv("RDM_OP_FRAG_CACHE") ? atoi(getenv("RDM_OP_FRAG_CACHE")) : 0;     // dev-only (tools/conv_bench.py): the caller promises constant weights
-    if (conv_halo_supported(p) && op_cache) p.Wfrag = c->frag_for(p.W, N, C0 + C1);
-    else if (conv_halo_supported(p)) {
+    const bool halo = conv_halo_supported(p) || conv_halo4_strip_supported(p);
+    if (halo && op_cache) p.Wfrag = c->frag_for(p.W, N, C0 + C1);
+    else if (halo) {
         RDM_TRY(ensure_bytes(c, &c->wfrag_tmp, &c->wfrag_tmp_bytes, (size_t)N * p.K * 2));
         RDM_CHECK_HIP(c, launch_conv_w_fragpack(p.W, (bf16_t*)c->wfrag_tmp, N, C0 + C1, c->stream));
         p.Wfrag = (const bf16_t*)c->wfrag_tmp;

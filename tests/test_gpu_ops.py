@@ -230,6 +230,33 @@ def test_conv3x3_halo_kernel(ctx, B, H, W, C0, C1, N):
     _close(out2, _conv_ref(xc, w, b), what="conv3x3 halo plain")
 
 
+# Images wider than 64 pixels: the one-wave-per-SIMD kernel on 64-column strips (conv_halo4.hip <.., STRIP>): the first-stage decoder's
+# 128- and 256-pixel levels (plain, dual source, residual + per-sample row, fused nearest-2x upsample 64 -> 128 and 128 -> 256,
+# non-square images, N = 128 / 256 / 512).  Random left / right neighbours make a strip that read zeros for its side halo fail.
+@pytest.mark.parametrize("B,H,W,C0,C1,N,ups", [(2, 128, 128, 128, 0, 128, 0), (1, 128, 128, 256, 0, 256, 0), (1, 256, 256, 128, 0, 128, 0),
+                                                (3, 64, 128, 64, 64, 256, 0), (1, 8, 192, 64, 0, 128, 0), (1, 4, 320, 64, 0, 128, 0),
+                                                (2, 64, 64, 128, 0, 128, 1), (1, 128, 128, 64, 0, 256, 1), (1, 32, 96, 64, 0, 512, 1)])
+def test_conv3x3_wide_images_as_strips(ctx, B, H, W, C0, C1, N, ups):
+    d = ctx.device
+    C = C0 + C1
+    x0 = bf16_round(_rand((B, H, W, C0), 50))
+    x1 = bf16_round(_rand((B, H, W, C1), 51)) if C1 else None
+    w, b = bf16_round(_rand((N, C, 3, 3), 52, (9 * C) ** -0.5)), _rand((N,), 53, 0.1)
+    xc = x0 if x1 is None else torch.cat([x0, x1], -1)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    ref = _conv_ref(xc, w, b, 1, bool(ups))
+    out = ctx.op_conv3x3(x0.to(d, torch.bfloat16), _pack_conv(w).to(d, torch.bfloat16), b.to(d),
+                         x1=None if x1 is None else x1.to(d, torch.bfloat16), ups=ups)
+    assert tuple(out.shape) == (B, Ho, Wo, N)
+    _close(out, ref, what="wide conv3x3")
+    temb, res = _rand((B, N), 54), bf16_round(_rand((B, Ho, Wo, N), 55))
+    out2 = ctx.op_conv3x3(x0.to(d, torch.bfloat16), _pack_conv(w).to(d, torch.bfloat16), b.to(d),
+                          x1=None if x1 is None else x1.to(d, torch.bfloat16), rowvec=temb.to(d), residual=res.to(d, torch.bfloat16), ups=ups)
+    _close(out2, ref + temb[:, None, None, :] + res, what="wide conv3x3 + row + residual")
+    # bitwise the same as the generic implicit GEMM?  No (other summation order): but both must sit within the tolerance of the reference,
+    # and the strip kernel must be the one that ran when it applies (env RDM_NO_HALO4_STRIP=1 switches it off for A/B)
+
+
 def test_conv3x3_dual_source_rowvec_residual(ctx):
     d = ctx.device
     B, H, W, C0, C1, N = 2, 8, 8, 128, 64, 192
