@@ -59,6 +59,7 @@ def parse():
     p.add_argument("--no-extras", action="store_true", help="skip the untimed extras (per-class roofline step, guidance-scale-1.0 step)")
     a = p.parse_args()
     a.k = a.k if a.k is not None else {2: 1, 3: 4, 4: 16, 5: 8}[a.config]
+    a.ddim_steps_given = a.ddim_steps is not None
     a.ddim_steps = a.ddim_steps if a.ddim_steps is not None else (250 if a.config == 4 else 50)
     a.steps = a.steps if a.steps is not None else (1 if a.config == 4 else 3)
     return a
@@ -163,7 +164,8 @@ def main():
         rcfg, vcfg = _lib.make_rarm_cfg(), _lib.make_vqgan_f16_cfg()
         ctx.load_rarm(rcfg, packing.pack("rarm", rcfg, synthetic.rarm_state_dict(rcfg)))
         ctx.load_vq(vcfg, packing.pack("vq", vcfg, synthetic.vq_state_dict(vcfg, synthetic.VQGAN_SEED)))
-        a.ddim_steps = 256                             # tokens per image (16 x 16 codes)
+        if not a.ddim_steps_given:
+            a.ddim_steps = 256                         # tokens per image (16 x 16 codes); fewer only for short profiling passes (the image is then incomplete)
     else:
         model.load_unet_state_dict(synthetic.unet_state_dict(model.unet_cfg))
         model.load_first_stage_state_dict(synthetic.vq_state_dict(model.vq_cfg))
@@ -213,6 +215,8 @@ def main():
             u = (0.5 * (1.0 + torch.erf(u * 0.7071067811865476))).clamp(0.0, 0.99999994).t().contiguous()
             sos = torch.full((B, 1), 16385, dtype=torch.long, device=dev)
             tok = ctx.rarm_sample(sos, nbrs, a.ddim_steps, u, temperature=1.0, top_k=256, guidance_scale=1.0)   # RARM: query NOT prepended
+            if tok.shape[1] < 256:                     # short profiling pass (--ddim-steps < 256): the remaining codes are padding
+                tok = torch.nn.functional.pad(tok, (0, 256 - tok.shape[1]))
             img = ctx.vq_decode_indices(tok)
             return parallel.all_gather_images(img, world * B)
         if a.config == 4:
@@ -275,7 +279,7 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process -- taken from the committed
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (gfx950 corrections applied; profiles/README.md)
     traffic, traffic_src = None, None
-    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_v4.json"):
+    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_v4.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 traffic = json.load(f)["hbm_bytes_per_launch"]; traffic_src = name
