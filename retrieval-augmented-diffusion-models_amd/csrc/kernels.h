@@ -93,6 +93,8 @@ struct RarmXattnParams {
     const bf16_t* G; const bf16_t* UT;         // [Bc][NP][C] each: G row h*k + j = scale * (key j restricted to head h) W_q;  UT row h*k + j = W_o (value j restricted to head h)
     const float* bias;                         // [C]
     int B2, Bc, C, NP, heads, k;
+    const float* ln3_g; const float* ln3_b; bf16_t* ln3_out;   // given: LayerNorm (gamma, beta) of the FINISHED rows leaves with them as bf16 [B2][C] (norm3: the operand of the feed-forward's first GEMM)
+    float* ws; int* ws_count;                  // four-blocks-per-sequence form: partial output rows [B2][4][C] fp32 and one arrival counter per sequence (zero between launches); null = one block per sequence
 };
 hipError_t launch_rarm_xattn_decode(const RarmXattnParams& p, hipStream_t st);
 

@@ -445,6 +445,7 @@ struct RarmModel {
     char* state = nullptr; size_t state_bytes = 0;
     // decode-step cross-attention operands per layer (rarm_prepare): [depth][2][Bc][128][C] bf16 (G, UT), valid for xa_B conditional sequences and xa_k neighbours
     char* xa = nullptr; size_t xa_bytes = 0; int xa_B = 0, xa_k = 0;
+    char* xws = nullptr; size_t xws_bytes = 0;          // split decode cross-attention: [B2][4][C] fp32 partial rows, then B2 arrival counters
 };
 static void build_rarm(RarmModel& m, const rdm_rarm_cfg& c, Manifest& mf) {
     m.cfg = c; m.blk.clear(); m.C = c.n_heads * c.d_head;
@@ -1314,7 +1315,7 @@ void rdm_ctx_destroy(rdm_ctx* c) {
     hipDeviceSynchronize();
     void* ptrs[] = {c->zero_page, c->unet.blob, c->unet.arena.base, c->unet.kv_cache, c->vq.blob, c->vq.arena.base,
                     c->clip.blob, c->clip.arena.base, c->gn_partial, c->samp, c->splitk_ws, c->unet.xa_cache,
-                    c->rarm.blob, c->rarm.arena.base, c->rarm.cache, c->rarm.ctxkv, c->rarm.state, c->rarm.xa, c->wfrag_tmp, c->bwd_tmp,
+                    c->rarm.blob, c->rarm.arena.base, c->rarm.cache, c->rarm.ctxkv, c->rarm.state, c->rarm.xa, c->rarm.xws, c->wfrag_tmp, c->bwd_tmp,
                     c->vqenc.blob, c->vqenc.arena.base, c->eye3};
     for (void* p : ptrs) if (p) hipFree(p);
     c->drop_frags();
@@ -1679,6 +1680,9 @@ static int rarm_prepare(rdm_ctx* c, int B2, int k, const float* context /*[B,k,c
     if (fuse) {
         RDM_TRY(ensure_bytes(c, &m.xa, &m.xa_bytes, (size_t)g.depth * 2 * B * 128 * C * 2));
         m.xa_B = B; m.xa_k = k;
+        const size_t pbytes = ((size_t)B2 * 4 * C * 4 + 255) & ~(size_t)255;
+        RDM_TRY(ensure_bytes(c, &m.xws, &m.xws_bytes, pbytes + (size_t)B2 * 4));
+        RDM_CHECK_HIP(c, hipMemsetAsync(m.xws + pbytes, 0, (size_t)B2 * 4, c->stream));       // arrival counters (every launch leaves them at zero)
     }
     return run_with_arena(c, m.arena, m.blob, [&](Ops& o) {
         bf16_t* cb = o.abf((size_t)B * k * g.context_dim);
@@ -1719,6 +1723,8 @@ static int rarm_step(rdm_ctx* c, int B2, int k) {
         bf16_t* q2 = o.abf((size_t)B2 * C); bf16_t* ff = o.abf((size_t)B2 * 4 * C);
         if (!o.plan) o.check(launch_rarm_embed(st.tokens, o.w<float>(m.emb), o.w<float>(m.pos), st.pos, x, B2, C, g.vocab_in, c->stream), "rarm embed");
         const float scale = 1.0f / sqrtf((float)g.d_head);
+        static const int no_ln3 = getenv("RDM_NO_RARM_LN3") ? atoi(getenv("RDM_NO_RARM_LN3")) : 0;
+        const bool ln3_fused = !no_ln3 && m.xa_B > 0 && m.xa_k == k;      // the fused cross-attention kernel also emits norm3 of its output rows
         for (int l = 0; l < g.depth; l++) {
             const RarmBlk& b = m.blk[l];
             if (!o.linear_ln(x, b.ln1g, b.ln1b, C, b.wqkv, 0, false, B2, 3 * C, ACT_NONE, qkv)) {
@@ -1737,6 +1743,8 @@ static int rarm_step(rdm_ctx* c, int B2, int k) {
                     RarmXattnParams xp{}; xp.x = x; xp.ln_g = o.w<float>(b.ln2g); xp.ln_b = o.w<float>(b.ln2b); xp.ln_eps = 1e-5f;
                     xp.G = (const bf16_t*)m.xa + ((size_t)l * 2) * m.xa_B * 128 * C; xp.UT = xp.G + (size_t)m.xa_B * 128 * C;
                     xp.bias = o.w<float>(b.bo2); xp.B2 = B2; xp.Bc = m.xa_B; xp.C = C; xp.NP = 128; xp.heads = g.n_heads; xp.k = k;
+                    xp.ws = (float*)m.xws; xp.ws_count = (int*)(m.xws + ((((size_t)B2 * 4 * C * 4) + 255) & ~(size_t)255));
+                    if (ln3_fused) { xp.ln3_g = o.w<float>(b.ln3g); xp.ln3_b = o.w<float>(b.ln3b); xp.ln3_out = ln; }
                     o.check(launch_rarm_xattn_decode(xp, c->stream), "rarm fused cross attention");
                 }
             } else {
@@ -1751,7 +1759,9 @@ static int rarm_step(rdm_ctx* c, int B2, int k) {
             }
             o.linear(ao, nullptr, C, 0, b.wo2, b.bo2, true, B2, C, ACT_NONE, nullptr, nullptr, x, x);
             }
-            if (!o.linear_ln(x, b.ln3g, b.ln3b, C, b.wff1, b.bff1, true, B2, 8 * C, ACT_GEGLU, ff)) {
+            if (ln3_fused) {      // norm3 left the cross-attention kernel with the finished rows: a plain GEGLU GEMM on the bf16 operand
+                o.linear(ln, nullptr, C, 0, b.wff1, b.bff1, true, B2, 8 * C, ACT_GEGLU, nullptr, ff);
+            } else if (!o.linear_ln(x, b.ln3g, b.ln3b, C, b.wff1, b.bff1, true, B2, 8 * C, ACT_GEGLU, ff)) {
                 o.layernorm(x, 1, b.ln3g, b.ln3b, ln, 0, B2, C);
                 o.linear(ln, nullptr, C, 0, b.wff1, b.bff1, true, B2, 8 * C, ACT_GEGLU, nullptr, ff);
             }

@@ -27,20 +27,26 @@ hipError_t launch_rarm_embed(const long long* tokens, const float* emb, const fl
 }
 
 // ---------------------------------------------------------------- decode-step attention against a K/V cache (d_head = 64)
-// One wave per (head, sequence).  Self-attention (attn1, causal): the new token's k / v rows are appended to the cache at
-// position *pos and the query attends to rows 0..*pos.  Cross-attention (attn2): k_new == null, the cache holds the
-// projected neighbours and all nkv rows are attended.  Phase 1: lane j scores keys j, j+64, ...; phase 2: lane d
-// accumulates sum_j p_j V[j][d] with coalesced 128-byte row reads.  CrossAttention.forward, attention.py:42-74.
-__global__ __launch_bounds__(64) void rarm_decode_attention_kernel(RarmAttnParams p) {
+// One BLOCK of four waves per (head, sequence) (round 4; one wave before: its 2 x 8 chunk loops were 16 serialised round trips to
+// the cache, 12.8 us at 256 cached rows -- four waves take every fourth 32-row chunk, and a wave's first K and V chunks are requested
+// together before anything is computed).  Self-attention (attn1, causal): the new token's k / v rows are appended to the cache at
+// position *pos and the query attends to rows 0..*pos.  Cross-attention (attn2): k_new == null, the cache holds the projected
+// neighbours and all nkv rows are attended.  Phase 1: scores of the wave's chunks into LDS; block-wide maximum and sum; phase 2: the
+// wave's chunks of sum_j p_j V[j][:], the four partial rows meet in LDS and are added in wave order.  CrossAttention.forward,
+// attention.py:42-74.
+__global__ __launch_bounds__(256) void rarm_decode_attention_kernel(RarmAttnParams p) {
     // Eight lanes per cache row (16 bytes each), eight rows per load instruction: an instruction touches 8 cache lines.  (One lane
     // per key row -- 64 rows, 64 lines per instruction -- in the score phase and one 128-byte row per instruction in the value
     // phase made this launch 11.5 us of mostly address traffic.)
     constexpr int D = 64;
     __shared__ float sc[1024];
-    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    __shared__ float red[8];
+    __shared__ float part[4][D];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int jr = lane >> 3, c8 = (lane & 7) * 8;
     const int t = p.pos ? *p.pos : 0;
     const int n = p.k_new ? t + 1 : p.nkv;
+    const int nc = p.k_new ? t : n;                     // rows read from the cache by the value phase
     bf16_t* Kc = p.Kc + (long long)b * p.batch_stride + h * D;
     bf16_t* Vc = p.Vc + (long long)b * p.batch_stride + h * D;
     const bf16_t* knew = p.k_new ? p.k_new + (long long)b * p.ldq + h * D : nullptr;
@@ -51,19 +57,29 @@ __global__ __launch_bounds__(64) void rarm_decode_attention_kernel(RarmAttnParam
 #pragma unroll
         for (int e = 0; e < 8; e++) qv[e] = bf2f((bf16_t)qq[e]) * p.scale;
     }
-    if (p.k_new && jr == 0) {       // append the new row (this wave reads it back from the projection output, never through the cache)
+    if (p.k_new && w == 0 && jr == 0) {       // append the new row (read back from the projection output below, never through the cache)
         *(bf16x8*)(Kc + (long long)t * p.row_stride + c8) = *(const bf16x8*)(knew + c8);
         *(bf16x8*)(Vc + (long long)t * p.row_stride + c8) = *(const bf16x8*)(vnew + c8);
     }
-    // ---- scores: rows j0 + jr, four row groups (32 rows) in flight
-    float m = -INFINITY;
-    for (int j0 = 0; j0 < n; j0 += 32) {
-        bf16x8 kk[4];
+    // ---- the wave's first chunk of keys AND values in one batch of requests (the values do not depend on the scores)
+    bf16x8 kk[4], vv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = j0 + u * 8 + jr;
-            const bf16_t* kr = (p.k_new && j == t) ? knew : Kc + (long long)(j < n ? j : 0) * p.row_stride;
-            kk[u] = *(const bf16x8*)(kr + c8);
+    for (int u = 0; u < 4; u++) {
+        const int j = w * 32 + u * 8 + jr;
+        const bf16_t* kr = (p.k_new && j == t) ? knew : Kc + (long long)(j < n ? j : 0) * p.row_stride;
+        kk[u] = *(const bf16x8*)(kr + c8);
+        vv[u] = *(const bf16x8*)(Vc + (long long)(j < nc ? j : 0) * p.row_stride + c8);
+    }
+    // ---- scores: rows j0 + 8 u + jr of chunks w, w + 4, ...
+    float m = -INFINITY;
+    for (int j0 = w * 32; j0 < n; j0 += 128) {
+        if (j0 != w * 32) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u * 8 + jr;
+                const bf16_t* kr = (p.k_new && j == t) ? knew : Kc + (long long)(j < n ? j : 0) * p.row_stride;
+                kk[u] = *(const bf16x8*)(kr + c8);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -77,21 +93,25 @@ __global__ __launch_bounds__(64) void rarm_decode_attention_kernel(RarmAttnParam
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[w] = m;
     __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float l = 0.f;
-    for (int j = lane; j < n; j += 64) { const float e = __expf(sc[j] - m); sc[j] = e; l += e; }
+    for (int j = tid; j < n; j += 256) { const float e = __expf(sc[j] - m); sc[j] = e; l += e; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+    if (lane == 0) red[4 + w] = l;
     __syncthreads();
-    // ---- values: cached rows, then the new token's row straight from the projection output
+    l = (red[4] + red[5]) + (red[6] + red[7]);
+    // ---- values: the wave's chunks of the cached rows
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int nc = p.k_new ? t : n;
-    for (int j0 = 0; j0 < nc; j0 += 32) {
-        bf16x8 vv[4];
+    for (int j0 = w * 32; j0 < nc; j0 += 128) {
+        if (j0 != w * 32) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = j0 + u * 8 + jr;
-            vv[u] = *(const bf16x8*)(Vc + (long long)(j < nc ? j : 0) * p.row_stride + c8);
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u * 8 + jr;
+                vv[u] = *(const bf16x8*)(Vc + (long long)(j < nc ? j : 0) * p.row_stride + c8);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -101,7 +121,7 @@ __global__ __launch_bounds__(64) void rarm_decode_attention_kernel(RarmAttnParam
             for (int e = 0; e < 8; e++) acc[e] += pj * bf2f((bf16_t)vv[u][e]);
         }
     }
-    if (p.k_new && jr == 0) {
+    if (p.k_new && w == 0 && jr == 0) {                   // ... and the new token's row straight from the projection output
         const bf16x8 vn = *(const bf16x8*)(vnew + c8);
         const float pt = sc[t];
 #pragma unroll
@@ -110,16 +130,21 @@ __global__ __launch_bounds__(64) void rarm_decode_attention_kernel(RarmAttnParam
 #pragma unroll
     for (int e = 0; e < 8; e++) { acc[e] += __shfl_xor(acc[e], 8); acc[e] += __shfl_xor(acc[e], 16); acc[e] += __shfl_xor(acc[e], 32); }
     if (jr == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) part[w][c8 + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < D / 2) {                                    // fixed order over the waves: deterministic
+        const int c = tid * 2;
         const float inv = 1.f / l;
-        uint4 w;
-        w.x = pack2bf(acc[0] * inv, acc[1] * inv); w.y = pack2bf(acc[2] * inv, acc[3] * inv);
-        w.z = pack2bf(acc[4] * inv, acc[5] * inv); w.w = pack2bf(acc[6] * inv, acc[7] * inv);
-        *(uint4*)(p.out + (long long)b * p.ldo + h * D + c8) = w;
+        const float o0 = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) * inv;
+        const float o1 = ((part[0][c + 1] + part[1][c + 1]) + (part[2][c + 1] + part[3][c + 1])) * inv;
+        *(uint32_t*)(p.out + (long long)b * p.ldo + h * D + c) = pack2bf(o0, o1);
     }
 }
 hipError_t launch_rarm_decode_attention(const RarmAttnParams& p, int heads, int batch, hipStream_t st) {
     if (p.nkv > 1024) return hipErrorInvalidValue;
-    rarm_decode_attention_kernel<<<dim3(heads, batch), 64, 0, st>>>(p);
+    rarm_decode_attention_kernel<<<dim3(heads, batch), 256, 0, st>>>(p);
     return hipGetLastError();
 }
 
@@ -130,6 +155,33 @@ hipError_t launch_rarm_decode_attention(const RarmAttnParams& p, int heads, int 
 // heads*k x C bf16 per sequence instead of two C x C projections and an attention launch (3 launches of ~9 us each, all latency).
 // One block per sequence: LayerNorm by block reduction (two-pass, rounded to bf16 as the GEMM operand was), a wave per group of
 // score rows (coalesced 16-byte pieces, wave reduction), per-head softmax, then 4 output channels per thread over the heads*k rows.
+// LayerNorm of ONE row spread one channel per thread over NW waves (two-pass, fp32), rounded to bf16: y[c] = (x - mean) rstd g[c] + b[c].
+// red: >= 2 NW floats of LDS.  Every thread of the block must call it.
+template <int NW>
+__device__ __forceinline__ void rarm_emit_ln(float xv, bool live, int c, int C, const float* g, const float* bta, float eps, bf16_t* y, float* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float s = live ? xv : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __syncthreads();                                   // red may still be read by the caller's previous phase
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; i++) tot += red[i];
+    const float mean = tot / C;
+    const float d = live ? xv - mean : 0.f;
+    float q = d * d;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) red[NW + w] = q;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; i++) tot += red[NW + i];
+    const float rstd = rsqrtf(tot / C + eps);
+    if (live) y[c] = f2bf(d * rstd * g[c] + bta[c]);
+}
 __global__ __launch_bounds__(1024) void rarm_xattn_decode_kernel(RarmXattnParams p) {
     // 16 waves per sequence: the two matrix-vector products are one batch of loads each (every row of G / UT a thread needs is
     // requested before the first one is used) -- with 4 waves and batches of 4 - 8 rows the kernel was 15 dependent HBM round trips
@@ -140,7 +192,9 @@ __global__ __launch_bounds__(1024) void rarm_xattn_decode_kernel(RarmXattnParams
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, C = p.C;
     float* xr = p.x + (long long)b * C;
     if (b >= p.Bc) {                      // zero neighbours: K = V = 0 -> the attention output is 0, to_out leaves its bias
-        if (tid < C) xr[tid] += p.bias[tid];
+        float xv = 0.f;
+        if (tid < C) { xv = xr[tid] + p.bias[tid]; xr[tid] = xv; }
+        if (p.ln3_out) rarm_emit_ln<16>(xv, tid < C, tid, C, p.ln3_g, p.ln3_b, p.ln_eps, p.ln3_out + (long long)b * C, red);
         return;
     }
     // ---- LayerNorm (one channel per thread)
@@ -237,10 +291,180 @@ __global__ __launch_bounds__(1024) void rarm_xattn_decode_kernel(RarmXattnParams
         for (int g4 = 0; g4 < 4; g4++) { const float4 t = *(const float4*)(part + g4 * 1024 + tid * 4); acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
         xo.x += acc.x; xo.y += acc.y; xo.z += acc.z; xo.w += acc.w;
         *(float4*)(xr + tid * 4) = xo;
+        if (p.ln3_out) *(float4*)(xn + tid * 4) = xo;          // the finished row, for norm3 below (xn is free: the scores are done)
     }
+    if (p.ln3_out) {       // the block holds the finished row: norm3 of the feed-forward that follows leaves with it (bf16 GEMM operand)
+        __syncthreads();
+        rarm_emit_ln<16>(tid < C ? xn[tid] : 0.f, tid < C, tid, C, p.ln3_g, p.ln3_b, p.ln_eps, p.ln3_out + (long long)b * C, red);
+    }
+}
+// Four blocks per sequence (round 4).  The one-block form asks ONE CU for a sequence's whole operand pair (heads k rows of G and of
+// UT: 295 KB at 12 heads x 8 neighbours x 768 channels) on 64 of 256 CUs: 16.4 us per layer.  The softmax is per head, so a block
+// that owns a QUARTER of the heads needs only their rows of G and UT (74 KB): scores, softmax and the partial output row of its
+// heads; the four partial rows meet in global memory -- written through to the coherence point (agent-scope stores), one
+// agent-scope arrival counter per sequence -- and the block that arrives last adds them IN BLOCK ORDER to bias and residual
+// (deterministic), and re-arms the counter.  heads % 4 == 0.
+// LayerNorm of one row held as channels tid + 256 i (i < 4) by a 256-thread block, rounded to bf16 (every thread calls it)
+__device__ __forceinline__ void rarm_emit_ln4(const float (&xv)[4], int tid, int C, const float* g, const float* bta, float eps, bf16_t* y, float* red) {
+    const int lane = tid & 63, w = tid >> 6;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) s += (tid + 256 * i < C) ? xv[i] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __syncthreads();
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const float d = (tid + 256 * i < C) ? xv[i] - mean : 0.f; q += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) red[4 + w] = q;
+    __syncthreads();
+    const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / C + eps);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int c = tid + 256 * i; if (c < C) y[c] = f2bf((xv[i] - mean) * rstd * g[c] + bta[c]); }
+}
+__global__ __launch_bounds__(256) void rarm_xattn_decode_split_kernel(RarmXattnParams p) {
+    __shared__ float xn[1024];
+    __shared__ float sc[32];
+    __shared__ float red[8];
+    __shared__ int s_last;
+    const int b = blockIdx.x >> 2, q = blockIdx.x & 3, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, C = p.C;
+    float* xr = p.x + (long long)b * C;
+    if (b >= p.Bc) {                      // zero neighbours: the attention output is 0, to_out leaves its bias (block 0 of the sequence)
+        if (q != 0) return;
+        float xv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int c = tid + 256 * i; xv[i] = 0.f; if (c < C) { xv[i] = xr[c] + p.bias[c]; xr[c] = xv[i]; } }
+        if (p.ln3_out) rarm_emit_ln4(xv, tid, C, p.ln3_g, p.ln3_b, p.ln_eps, p.ln3_out + (long long)b * C, red);
+        return;
+    }
+    // ---- every operand row this block will read, requested NOW: neither G nor UT depends on the LayerNorm or the scores, and the launch
+    // is a chain of dependent round trips -- wave w takes score rows w, w + 4, ... (<= 8 each; a row = C/8 16-byte pieces: two rounds of
+    // lanes), thread t the 4 output channels 4 t of all nr rows of UT
+    const int nr = (p.heads >> 2) * p.k, r0 = q * nr, npc = C >> 3;
+    const bf16_t* Gb = p.G + ((long long)b * p.NP + r0) * C;
+    const bf16_t* Ub = p.UT + ((long long)b * p.NP + r0) * C;
+    const int nc4 = C >> 2;
+    bf16x8 g[8][2];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int j = w + 4 * u;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int pc = lane + 64 * h;
+            g[u][h] = (j < nr && pc < npc) ? *(const bf16x8*)(Gb + (long long)j * C + pc * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    uint2 u[32];
+    if (tid < nc4) {
+#pragma unroll
+        for (int i = 0; i < 32; i++) u[i] = i < nr ? *(const uint2*)(Ub + (long long)i * C + tid * 4) : make_uint2(0u, 0u);
+    }
+    // ---- LayerNorm (two-pass; up to 4 channels per thread), rounded to bf16 as the GEMM operand was
+    float v[4]; float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int c = tid + 256 * i; v[i] = c < C ? xr[c] : 0.f; s += v[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / C;
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int c = tid + 256 * i; const float d = c < C ? v[i] - mean : 0.f; v[i] = d; qq += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o);
+    if (lane == 0) red[4 + w] = qq;
+    __syncthreads();
+    const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / C + p.ln_eps);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int c = tid + 256 * i; if (c < C) xn[c] = bf2f(f2bf(v[i] * rstd * p.ln_g[c] + p.ln_b[c])); }
+    __syncthreads();
+    // ---- scores of this block's rows [r0, r0 + nr)
+    {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = w + 4 * u;
+            float a = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int pc = lane + 64 * h;
+                if (pc < npc) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) a += bf2f((bf16_t)g[u][h][e]) * xn[pc * 8 + e];
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            if (lane == 0 && j < nr) sc[j] = a;
+        }
+    }
+    __syncthreads();
+    float pr = 0.f;
+    if (tid < nr) {
+        const int h0 = (tid / p.k) * p.k;
+        float m = -INFINITY;
+        for (int i = 0; i < p.k; i++) m = fmaxf(m, sc[h0 + i]);
+        float sum = 0.f;
+        for (int i = 0; i < p.k; i++) sum += __expf(sc[h0 + i] - m);
+        pr = __expf(sc[tid] - m) / sum;
+    }
+    __syncthreads();
+    if (tid < nr) sc[tid] = pr;
+    __syncthreads();
+    // ---- partial output row of this block's heads: thread = 4 channels over the nr rows requested above
+    float* const pw = p.ws + ((long long)b * 4 + q) * C;
+    if (tid < nc4) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const float pj = i < nr ? sc[i] : 0.f;
+            a0 += pj * __uint_as_float(u[i].x << 16); a1 += pj * __uint_as_float(u[i].x & 0xffff0000u);
+            a2 += pj * __uint_as_float(u[i].y << 16); a3 += pj * __uint_as_float(u[i].y & 0xffff0000u);
+        }
+        __hip_atomic_store(pw + tid * 4 + 0, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pw + tid * 4 + 1, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pw + tid * 4 + 2, a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pw + tid * 4 + 3, a3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // Every thread's partial stores are agent-scope write-through stores (sc1): once they have COMPLETED (vmcnt) they sit at the coherence
+    // point, so no cache-wide fence is needed -- an agent-scope release fence here is a write-back of the whole L2 (buffer_wbl2), and with
+    // the K/V caches of 18 layers dirty in it that made the launch 31 us instead of 16.  Then ONE relaxed agent-scope arrival per block;
+    // the last arriver reads the four rows with agent-scope (sc1) loads, which cannot hit a stale L2 copy of an earlier layer's rows.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(p.ws_count + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    const float* const pb = p.ws + (long long)b * 4 * C;
+    float xv[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = tid + 256 * i;
+        xv[i] = 0.f;
+        if (c < C) {
+            const float t0 = __hip_atomic_load(pb + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), t1 = __hip_atomic_load(pb + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float t2 = __hip_atomic_load(pb + 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), t3 = __hip_atomic_load(pb + 3 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xv[i] = xr[c] + (p.bias[c] + ((t0 + t1) + (t2 + t3)));
+            xr[c] = xv[i];
+        }
+    }
+    if (tid == 0) __hip_atomic_store(p.ws_count + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next layer's launch
+    // the last arriver holds the finished row: norm3 of the feed-forward that follows leaves with it (bf16 GEMM operand)
+    if (p.ln3_out) rarm_emit_ln4(xv, tid, C, p.ln3_g, p.ln3_b, p.ln_eps, p.ln3_out + (long long)b * C, red);
 }
 hipError_t launch_rarm_xattn_decode(const RarmXattnParams& p, hipStream_t st) {
     if (p.C % 8 || p.C > 1024 || p.heads * p.k > 128 || p.heads * p.k > p.NP || p.k < 1) return hipErrorInvalidValue;
+    static const int no_split = getenv("RDM_NO_RARM_XSPLIT") ? atoi(getenv("RDM_NO_RARM_XSPLIT")) : 0;
+    // (from 128 sequences on the one-block form already fills the chip: measured equal at 256)
+    if (!no_split && p.ws && p.ws_count && p.B2 <= 128 && p.heads % 4 == 0 && (p.heads / 4) * p.k <= 32 && p.C % 4 == 0) {
+        rarm_xattn_decode_split_kernel<<<p.B2 * 4, 256, 0, st>>>(p);
+        return hipGetLastError();
+    }
     rarm_xattn_decode_kernel<<<p.B2, 1024, 0, st>>>(p);
     return hipGetLastError();
 }
@@ -288,17 +512,22 @@ __global__ __launch_bounds__(256) void rarm_sample_kernel(RarmSampleParams p) {
         uint32_t key[KPT];
 #pragma unroll
         for (int u = 0; u < KPT; u++) { const int i = tid + u * 256; key[u] = i < V ? f2ord(logit(i)) : 0u; }      // 0 is below every real key
-        for (int bit = 31; bit >= 0; bit--) {
-            const uint32_t cand = prefix | (1u << bit);
-            int cnt = 0;
+        // TWO bits per round (round 4): a round is a block-wide count + one barrier whatever it counts, so three thresholds per round
+        // (prefix | 01, 10, 11 at the bit pair) halve the 32 rounds; counts of 01 / 10 ride in one register (<= 4096 per wave each)
+        for (int bit = 30; bit >= 0; bit -= 2) {
+            const uint32_t c1 = prefix | (1u << bit), c2 = prefix | (2u << bit), c3 = prefix | (3u << bit);
+            uint32_t n12 = 0, n3 = 0;
 #pragma unroll
-            for (int u = 0; u < KPT; u++) cnt += key[u] >= cand ? 1 : 0;
+            for (int u = 0; u < KPT; u++) { n12 += (key[u] >= c1 ? 1u : 0u) + (key[u] >= c2 ? 0x10000u : 0u); n3 += key[u] >= c3 ? 1u : 0u; }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-            if ((tid & 63) == 0) hist[(bit & 1) * 4 + (tid >> 6)] = (uint32_t)cnt;       // two alternating slots: one barrier per round
+            for (int o = 32; o > 0; o >>= 1) { n12 += __shfl_xor(n12, o); n3 += __shfl_xor(n3, o); }
+            const int slot = ((bit >> 1) & 1) * 8;                                       // two alternating slots: one barrier per round
+            if ((tid & 63) == 0) { hist[slot + (tid >> 6) * 2] = n12; hist[slot + (tid >> 6) * 2 + 1] = n3; }
             __syncthreads();
-            const int tot = (int)(hist[(bit & 1) * 4] + hist[(bit & 1) * 4 + 1] + hist[(bit & 1) * 4 + 2] + hist[(bit & 1) * 4 + 3]);
-            if (tot >= remaining0) prefix = cand;
+            const uint32_t t12 = hist[slot] + hist[slot + 2] + hist[slot + 4] + hist[slot + 6];          // <= 16384 per field
+            const int tot3 = (int)(hist[slot + 1] + hist[slot + 3] + hist[slot + 5] + hist[slot + 7]);
+            const int tot1 = (int)(t12 & 0xffffu), tot2 = (int)(t12 >> 16);
+            if (tot3 >= remaining0) prefix = c3; else if (tot2 >= remaining0) prefix = c2; else if (tot1 >= remaining0) prefix = c1;
         }
     } else {
         for (int bit = 31; bit >= 0; bit--) {

@@ -1,12 +1,15 @@
-// Skinny GEMM for decode-sized batches: out[M,N] = act(A[M,K] W[N,K]^T + bias) (+ residual) with M <= 128 rows.
+// Skinny GEMM for decode-sized batches: out[M,N] = act(A[M,K] W[N,K]^T + bias) (+ residual), M = one row per sequence / sample.
 //
-// The RARM decode step (rarm.hip) and the UNet's time-embedding MLP are M = B' <= 128 row GEMMs against 768..6144-row weight
-// matrices: pure weight streaming.  The tiled kernel (igemm.hip) gives such a launch N/192 blocks (12 of 256 CUs for the
-// 2304-wide qkv projection) each walking K serially -- 35 us per launch, ~100 GB/s of weights.  Here a block owns only 32
-// output columns (N/32 blocks: 72..512), its four waves split K and hold the whole M x 32 partial tile in MFMA accumulators
-// (32x32x16 bf16, fp32), every lane issues all of its 16-byte operand loads for a K quarter up front, and the four partial tiles
-// meet in LDS for a fused bias / activation / residual epilogue.  GEGLU: the packed weight rows interleave 32 x-rows with their
-// 32 gate rows (packing._geglu_perm), so a block owns a 64-row strip and emits x * gelu(gate) for 32 outputs.
+// The RARM decode step (rarm.hip) and the UNet's time-embedding MLP are M = B' row GEMMs against 768..16384-row weight matrices: pure
+// weight streaming, and a launch lasts as long as ONE block's dependent operand fetch -- what a CU can ingest (~25-35 GB/s) times the
+// bytes the block asks for.  The tiled kernel (igemm.hip) gives such a launch N/192 blocks walking K serially (35 us, ~100 GB/s).
+// Here a block owns a SMALL output tile -- 16 MA rows x 16 NB columns, chosen per shape so that the launch has >= ~192 blocks and
+// each asks for as few bytes as possible (round 4: the N = 768 projections of the decode step ran 48 blocks of 32 x 32 outputs on 48
+// of 256 CUs, 393 KB each at K = 3072: 10.9 us; as 192 blocks of 16 x 16 they ask for half) --, its four waves split K and hold the
+// partial tile in MFMA accumulators (16x16x32 bf16, fp32), every lane issues all of its 16-byte operand loads for a K quarter up front,
+// and the four partial tiles meet in LDS for a fused bias / activation / residual epilogue.  GEGLU: the packed weight rows interleave
+// 32 x-rows with their 32 gate rows (packing._geglu_perm); a block owns a whole 64-row strip (NB = 4: 32 outputs) or one half of it
+// (NB = 2: x rows [16 h, 16 h + 16) and their gates, 16 outputs) and emits x * gelu(gate).
 #include <stdlib.h>
 
 #include "kernels.h"
@@ -15,23 +18,35 @@
 // the RARM block, rdm/modules/attention.py:84-86, 199-272): a block needs its rows' whole K anyway (each wave one quarter), so the row
 // statistics cost one cross-wave exchange and the separate LayerNorm launch (~5 us of a ~8 us GEMM) disappears.  K / 4 = 32 U only
 // (one batch of loads holds a wave's whole K quarter in registers).
-template <int MF, int NF, int U, bool LN = false>   // MF: 32-row blocks of M (1..4); NF: 1 plain, 2 GEGLU (x strip + gate strip); U: k-steps of 32 per batch of loads
+// MA: 16-row fragments of M per block (1, 2, 4, 8); NB: 16-column fragments of the weight strip (plain: 1, 2; GEGLU: 2, 4 = x fragments
+// then their gate fragments); U: k-steps of 32 per batch of loads
+template <int MA, int NB, bool GEGLU, int U, bool LN = false>
 __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
     // 16x16x32 MFMAs, not 32x32x16: the operands come straight from global memory in fragment order, and what such a launch pays
     // for is the number of cache LINES its load instructions touch (phase clocks at M = 64, K = 768: 9.1 of the launch's ~12 us are
     // the load phase).  A 32x32x16 fragment is 32 rows x 32 bytes per instruction -- 32 lines for 1 KB --, a 16x16x32 fragment is
     // 16 rows x 64 bytes: half the lines for the same bytes and the same FLOPs per cycle.
-    extern __shared__ float part[];                       // [4 waves][MF][NF][32 rows][32 cols]
+    constexpr int RB = 16 * MA, CB = 16 * NB;             // rows / weight rows of the block tile
+    constexpr int OC = GEGLU ? CB / 2 : CB;               // output columns of the block
+    extern __shared__ float part[];                       // [4 waves][RB rows][CB cols]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q4 = lane >> 4;
-    const int n0 = blockIdx.x * 32 * NF;                  // first weight row of this block's strip
-    const int mb0 = blockIdx.y * 32 * MF;                 // first of this block's rows (grid.y row blocks: more, lighter blocks -- a launch is
-                                                          // as long as ONE block's dependent operand fetch, and 24 blocks left 232 CUs idle)
+    const int mb0 = blockIdx.y * RB;                      // first of this block's rows
+    // weight rows of fragment j; first OUTPUT column of the block
+    int wrow[NB], ncol0;
+    if constexpr (GEGLU && NB == 2) {                     // half a strip: x rows [16 h, +16) and their gates (32 rows further on)
+        const int strip = blockIdx.x >> 1, h = blockIdx.x & 1;
+        wrow[0] = strip * 64 + h * 16; wrow[1] = strip * 64 + 32 + h * 16;
+        ncol0 = strip * 32 + h * 16;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NB; j++) wrow[j] = blockIdx.x * CB + j * 16;
+        ncol0 = blockIdx.x * OC;
+    }
     const int kq = p.K >> 2, k0 = wave * kq;              // this wave's K quarter
-    constexpr int MA = 2 * MF, NB = 2 * NF;               // 16-row fragments of M, 16-column fragments of the strip(s)
     const bf16_t* wp[NB];
 #pragma unroll
-    for (int j = 0; j < NB; j++) wp[j] = p.W + (long long)(n0 + j * 16 + r16) * p.K + k0 + q4 * 8;
+    for (int j = 0; j < NB; j++) wp[j] = p.W + (long long)(wrow[j] + r16) * p.K + k0 + q4 * 8;
     const bf16_t* ap[MA];
 #pragma unroll
     for (int i = 0; i < MA; i++) { int m = mb0 + i * 16 + r16; if (m >= p.M) m = p.M - 1; ap[i] = LN ? nullptr : p.A + (long long)m * p.lda + k0 + q4 * 8; }
@@ -41,7 +56,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
 #pragma unroll
         for (int j = 0; j < NB; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (LN) {
-        float* const lnv = part + 4 * MF * NF * 1024;           // [gamma K][beta K][4 waves][MA * 16 rows][sum, sumsq]
+        float* const lnv = part + 4 * RB * CB;                  // [gamma K][beta K][4 waves][RB rows][sum, sumsq]
         float* const stat = lnv + 2 * p.K;
         for (int k = tid * 4; k < p.K; k += 1024) {
             *(float4*)(lnv + k) = *(const float4*)(p.ln_g + k);
@@ -130,20 +145,19 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
         for (int j = 0; j < NB; j++)
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                part[((((wave * MF + (i >> 1)) * NF + (j >> 1)) * 32) + ((i & 1) * 16 + q4 * 4 + r)) * 32 + (j & 1) * 16 + r16] = acc[i][j][r];
+                part[(wave * RB + i * 16 + q4 * 4 + r) * CB + j * 16 + r16] = acc[i][j][r];
     __syncthreads();
-    const int ncol0 = blockIdx.x * 32;                    // first OUTPUT column
     // Two phases: every residual / bias value this thread needs is requested first, THEN the results are formed and stored.  The
     // decode step accumulates in place (out == residual: x += ...), so inside a single loop no load may move above the previous
-    // iteration's store and the 4 * MF iterations cost one L2 round trip each (~5 of the launch's ~14 us).  A thread reads and
+    // iteration's store and the iterations cost one L2 round trip each (~5 of the launch's ~14 us).  A thread reads and
     // writes the same elements, so hoisting its own loads above its own stores is safe whatever aliases.
-    constexpr int IT = 4 * MF;
+    constexpr int NOUT = RB * OC, IT = (NOUT + 255) / 256;
     float acc_[IT], res_[IT]; long long oi_[IT]; bool ok_[IT];
 #pragma unroll
     for (int it = 0; it < IT; it++) {
         const int e = tid + it * 256;
-        const int i = e >> 10, row = (e >> 5) & 31, col = e & 31, m = mb0 + i * 32 + row;
-        ok_[it] = m < p.M;
+        const int row = e / OC, col = e - row * OC, m = mb0 + row;
+        ok_[it] = e < NOUT && m < p.M;
         oi_[it] = (long long)m * p.ldo + ncol0 + col;
         float r = 0.f;
         if (ok_[it]) {
@@ -155,17 +169,23 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
 #pragma unroll
     for (int it = 0; it < IT; it++) {
         const int e = tid + it * 256;
-        const int i = e >> 10, row = (e >> 5) & 31, col = e & 31;
-        float v[NF];
+        const int row = (e / OC) % RB, col = e % OC;
+        // column `col` of the block's outputs = weight-tile column col (x) and, GEGLU, col + OC (its gate)
+        float v[GEGLU ? 2 : 1];
 #pragma unroll
-        for (int j = 0; j < NF; j++) {
+        for (int j = 0; j < (GEGLU ? 2 : 1); j++) {
+            const int cc = col + j * OC;
             float s = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; w++) s += part[((((w * MF + i) * NF + j) * 32) + row) * 32 + col];
-            v[j] = s + (p.bias ? p.bias[n0 + j * 32 + col] : 0.f);
+            for (int w = 0; w < 4; w++) s += part[(w * RB + row) * CB + cc];
+            // weight row behind tile column cc (= wrow[cc >> 4] + (cc & 15), spelled without a run-time array index)
+            int wr;
+            if constexpr (GEGLU && NB == 2) wr = wrow[0] + (cc < 16 ? cc : cc + 16);
+            else wr = wrow[0] + cc;
+            v[j] = s + (p.bias ? p.bias[wr] : 0.f);
         }
         float o = v[0];
-        if (NF == 2) o = v[0] * gelu_erf_f(v[1]);
+        if (GEGLU) o = v[0] * gelu_erf_f(v[GEGLU ? 1 : 0]);
         else if (p.act == ACT_SILU) o = silu_f(o);
         else if (p.act == ACT_QUICKGELU) o = quickgelu_f(o);
         acc_[it] = o + res_[it];
@@ -180,42 +200,73 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
 
 bool sgemm_supported(const SgemmParams& p) {
     static const int off = getenv("RDM_NO_SGEMM") ? atoi(getenv("RDM_NO_SGEMM")) : 0;
-    if (off || p.M < 1 || p.K % 256 != 0 || (!p.ln_x && p.lda % 8 != 0)) return false;      // any M: rows beyond 128 run as 32-row blocks (grid.y)
+    if (off || p.M < 1 || p.K % 256 != 0 || (!p.ln_x && p.lda % 8 != 0)) return false;      // any M: 16 MA-row blocks on grid.y
     if (p.ln_x && (p.K != 768 || !p.ln_g || !p.ln_b)) return false;                          // LayerNorm-fused A: a K quarter = one batch of 6 k-steps
     if (p.act == ACT_GEGLU) return p.N % 64 == 0;
     return p.N % 32 == 0 && (p.act == ACT_NONE || p.act == ACT_SILU || p.act == ACT_QUICKGELU);
 }
 
-template <int MF, int NF, int U, bool LN = false>
-static hipError_t launch_one(const SgemmParams& p, int grid, hipStream_t st) {
-    const size_t sm = (size_t)4 * MF * NF * 1024 * sizeof(float) + (LN ? (size_t)(2 * p.K + 4 * 2 * MF * 16 * 2) * sizeof(float) : 0);
+template <int MA, int NB, bool GEGLU, int U, bool LN = false>
+static hipError_t launch_one(const SgemmParams& p, hipStream_t st) {
+    constexpr int RB = 16 * MA, CB = 16 * NB;
+    const size_t sm = (size_t)4 * RB * CB * sizeof(float) + (LN ? (size_t)(2 * p.K + 4 * RB * 2) * sizeof(float) : 0);
     static bool attr_dev[RDM_MAX_DEVICES] = {false};
     bool& attr = attr_dev[rdm_cur_device()];
     if (!attr && sm > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)sgemm_kernel<MF, NF, U, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipError_t e = hipFuncSetAttribute((const void*)sgemm_kernel<MA, NB, GEGLU, U, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    sgemm_kernel<MF, NF, U, LN><<<dim3(grid, (p.M + 32 * MF - 1) / (32 * MF)), 256, sm, st>>>(p);
+    const int gx = GEGLU ? (NB == 4 ? p.N / 64 : p.N / 32) : p.N / CB;
+    sgemm_kernel<MA, NB, GEGLU, U, LN><<<dim3(gx, (p.M + RB - 1) / RB), 256, sm, st>>>(p);
     return hipGetLastError();
 }
-template <int NF>
-static hipError_t launch_nf(const SgemmParams& p, int grid, hipStream_t st) {
-    // rows per block: all of them (<= 128) when the column strips alone fill the chip, else 32-row blocks (grid.y = ceil(M / 32))
-    static const int rowsplit = getenv("RDM_SGEMM_ROWSPLIT") ? atoi(getenv("RDM_SGEMM_ROWSPLIT")) : 1;
-    const int mf = ((rowsplit && grid < 256) || p.M > 128) ? 1 : (p.M + 31) / 32;
+
+// Block tile for a shape: among the compiled (MA, NB) pairs the one with the smallest  rounds x bytes-per-block  (a block's operand
+// fetch is what a launch lasts; rounds = how many blocks a CU gets).  Depends on (M, N, K, kind) only.
+template <bool GEGLU, bool LN>
+static void pick_tile(const SgemmParams& p, int& ma, int& nb) {
+    static const int force_ma = getenv("RDM_SGEMM_MA") ? atoi(getenv("RDM_SGEMM_MA")) : 0, force_nb = getenv("RDM_SGEMM_NB") ? atoi(getenv("RDM_SGEMM_NB")) : 0;
+    const int mas[3] = {1, 2, 4}, nbs[2] = {GEGLU ? 2 : 1, GEGLU ? 4 : 2};
+    double best = 1e30; ma = 2; nb = nbs[1];
+    for (int a : mas) for (int b : nbs) {
+        if (LN && a > 2) continue;                                    // the LayerNorm-fused variant holds fp32 rows in registers: <= 32 rows
+        const long long blocks = (long long)((p.M + 16 * a - 1) / (16 * a)) * (GEGLU ? (b == 4 ? p.N / 64 : p.N / 32) : p.N / (16 * b));
+        const double bytes = (double)p.K * (16.0 * a * (LN ? 4.0 : 2.0) + 16.0 * b * 2.0);
+        const double rounds = (double)((blocks + 255) / 256);
+        (void)rounds;
+        const double per_cu = blocks > 256 ? (double)blocks / 256.0 : 1.0;                      // blocks a CU's ingest path is shared by
+        const double cost = per_cu * (bytes + 8192.0);                                          // + a fixed per-block latency term
+        if ((force_ma == 0 || force_ma == a) && (force_nb == 0 || force_nb == b) && cost < best) { best = cost; ma = a; nb = b; }
+    }
+}
+
+template <bool GEGLU>
+static hipError_t launch_nf(const SgemmParams& p, hipStream_t st) {
     const bool deep = ((p.K >> 2) % 192) == 0;            // K quarter is a multiple of 6 k-steps of 32 (K = 768, 1536, 3072 ...)
-    if (p.ln_x) return (mf == 1 || p.M <= 32) ? launch_one<1, NF, 6, true>(p, grid, st) : launch_one<2, NF, 6, true>(p, grid, st);
-    switch (mf) {
-        case 1: return deep ? launch_one<1, NF, 6>(p, grid, st) : launch_one<1, NF, 2>(p, grid, st);
-        case 2: return deep ? launch_one<2, NF, 6>(p, grid, st) : launch_one<2, NF, 2>(p, grid, st);
-        case 3: return deep ? launch_one<3, NF, 3>(p, grid, st) : launch_one<3, NF, 2>(p, grid, st);
-        default: return deep ? launch_one<4, NF, 3>(p, grid, st) : launch_one<4, NF, 2>(p, grid, st);
+    constexpr int N1 = GEGLU ? 2 : 1, N2 = GEGLU ? 4 : 2;
+    int ma, nb;
+    if (p.ln_x) {
+        pick_tile<GEGLU, true>(p, ma, nb);
+        if (ma == 1) return nb == N1 ? launch_one<1, N1, GEGLU, 6, true>(p, st) : launch_one<1, N2, GEGLU, 6, true>(p, st);
+        return nb == N1 ? launch_one<2, N1, GEGLU, 6, true>(p, st) : launch_one<2, N2, GEGLU, 6, true>(p, st);
+    }
+    pick_tile<GEGLU, false>(p, ma, nb);
+    if (nb == N1) {
+        switch (ma) {
+            case 1: return deep ? launch_one<1, N1, GEGLU, 6>(p, st) : launch_one<1, N1, GEGLU, 2>(p, st);
+            case 2: return deep ? launch_one<2, N1, GEGLU, 6>(p, st) : launch_one<2, N1, GEGLU, 2>(p, st);
+            default: return deep ? launch_one<4, N1, GEGLU, 6>(p, st) : launch_one<4, N1, GEGLU, 2>(p, st);
+        }
+    }
+    switch (ma) {
+        case 1: return deep ? launch_one<1, N2, GEGLU, 6>(p, st) : launch_one<1, N2, GEGLU, 2>(p, st);
+        case 2: return deep ? launch_one<2, N2, GEGLU, 6>(p, st) : launch_one<2, N2, GEGLU, 2>(p, st);
+        default: return deep ? launch_one<4, N2, GEGLU, 6>(p, st) : launch_one<4, N2, GEGLU, 2>(p, st);
     }
 }
 
 hipError_t launch_sgemm(const SgemmParams& p, hipStream_t st) {
     if (!sgemm_supported(p)) return hipErrorInvalidValue;
-    if (p.act == ACT_GEGLU) return launch_nf<2>(p, p.N / 64, st);
-    return launch_nf<1>(p, p.N / 32, st);
+    return p.act == ACT_GEGLU ? launch_nf<true>(p, st) : launch_nf<false>(p, st);
 }
