@@ -57,19 +57,20 @@ __global__ void gn_stats_kernel(GnParams p) {
 #pragma unroll
             for (int i = 0; i < 8; i++) { const float f = bf2f((bf16_t)d[i]); s[i] += f; q[i] += f * f; }
         }
+        // partials as [element i of the vector][row lane rr][vector v]: consecutive threads (v) write consecutive float2 -- the
+        // [rr][channel] order put a thread's 8 channels 64 bytes apart from its neighbour's: a 16-way bank conflict on every one of the
+        // 16 writes (round-3 counters: LDS bank-conflict / LDS-active = 0.87 in this kernel)
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            sm[((rr * C) + v * 8 + i) * 2 + 0] = s[i];
-            sm[((rr * C) + v * 8 + i) * 2 + 1] = q[i];
-        }
+        for (int i = 0; i < 8; i++) *(float2*)(sm + ((i * R + rr) * VC + v) * 2) = make_float2(s[i], q[i]);
     }
     __syncthreads();
-    // per-channel reduce over R (fixed order)
+    // per-channel reduce over R (fixed order): thread -> (i, v), consecutive threads read consecutive float2
     float* ch = sm + R * C * 2;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    for (int idx = threadIdx.x; idx < C; idx += blockDim.x) {
+        const int i = idx / VC, vv = idx - i * VC;
         float a = 0.f, bq = 0.f;
-        for (int r = 0; r < R; r++) { a += sm[(r * C + c) * 2]; bq += sm[(r * C + c) * 2 + 1]; }
-        ch[c * 2] = a; ch[c * 2 + 1] = bq;
+        for (int r = 0; r < R; r++) { const float2 t = *(const float2*)(sm + ((i * R + r) * VC + vv) * 2); a += t.x; bq += t.y; }
+        ch[(vv * 8 + i) * 2] = a; ch[(vv * 8 + i) * 2 + 1] = bq;
     }
     __syncthreads();
     const int cg = (p.L0 + p.L1) / p.groups;

@@ -551,15 +551,37 @@ __global__ __launch_bounds__(256) void rarm_sample_kernel(RarmSampleParams p) {
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
     mx = red[0]; __syncthreads();
     const int chunk = (V + 255) / 256, i0 = tid * chunk, i1 = min(V, i0 + chunk);
+    // (round 4) the three scans below add in EXACTLY the order they always did -- the draw is defined by it -- but no longer wait for one
+    // LDS read / one exponential per addition: loads and exponentials are issued in batches of 16, the additions then run out of registers
+    // (the serial forms were ~30 of the kernel's 77 us: 256 + 64 + 64 dependent LDS round trips)
     float part = 0.f;
-    for (int i = i0; i < i1; i++) { const float v = logit(i); if (f2ord(v) >= kth) part += __expf(v - mx); }
+    for (int i = i0; i < i1; i += 16) {
+        float e[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const float v = (i + u < i1) ? logit(i + u) : 0.f; e[u] = (i + u < i1 && f2ord(v) >= kth) ? __expf(v - mx) : -1.f; }
+#pragma unroll
+        for (int u = 0; u < 16; u++) if (e[u] >= 0.f) part += e[u];
+    }
     red[tid] = part; __syncthreads();
     if (tid == 0) {
         float total = 0.f;
-        for (int j = 0; j < 256; j++) total += red[j];
+        for (int j = 0; j < 256; j += 16) {
+            float r[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) r[u] = red[j + u];
+#pragma unroll
+            for (int u = 0; u < 16; u++) total += r[u];
+        }
         const float target = p.uniforms[(long long)(t - p.pos0) * p.B + b] * total;
-        float run = 0.f; int c = 255;
-        for (int j = 0; j < 256; j++) { if (run + red[j] > target) { c = j; break; } run += red[j]; }
+        float run = 0.f; int c = -1;
+        for (int j = 0; j < 256; j += 16) {
+            float r[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) r[u] = red[j + u];
+#pragma unroll
+            for (int u = 0; u < 16; u++) { const float nr = run + r[u]; if (c < 0) { if (nr > target) c = j + u; else run = nr; } }
+        }
+        if (c < 0) c = 255;
         // (if rounding pushed the target past the total, fall into the last non-empty chunk)
         while (c > 0 && red[c] == 0.f) c--;
         chosen = c; red[0] = run; red[1] = target;
@@ -568,11 +590,14 @@ __global__ __launch_bounds__(256) void rarm_sample_kernel(RarmSampleParams p) {
     if (tid == chosen) {
         float run = red[0]; const float target = red[1];
         int pick = -1, last = -1;
-        for (int i = i0; i < i1; i++) {
-            const float v = logit(i);
-            if (f2ord(v) < kth) continue;
-            last = i; run += __expf(v - mx);
-            if (run > target) { pick = i; break; }
+        for (int i = i0; i < i1 && pick < 0; i += 16) {
+            float e[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) { const float v = (i + u < i1) ? logit(i + u) : 0.f; e[u] = (i + u < i1 && f2ord(v) >= kth) ? __expf(v - mx) : -1.f; }
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                if (e[u] >= 0.f && pick < 0) { last = i + u; run += e[u]; if (run > target) pick = i + u; }
+            }
         }
         if (pick < 0) pick = last;
         p.tokens_out[(long long)b * p.steps + (t - p.pos0)] = pick;
