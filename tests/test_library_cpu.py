@@ -140,3 +140,40 @@ def test_ema_key_mapping():
           "model.diffusion_model.out.2.bias": torch.zeros(1), "first_stage_model.x": torch.zeros(1)}
     sd = packing.ema_unet_state_dict(ck)
     assert sd["out.2.weight"].item() == 1.0 and sd["out.2.bias"].item() == 0.0 and len(sd) == 2
+
+
+def test_vq_encoder_manifest():
+    """First-stage ENCODER (`encoder.*`, `quant_conv.*` -- taming/ldm Encoder + quant_conv, ldm/models/autoencoder.py:96-110): every
+    reference tensor consumed once; the stride-2 Downsample conv is a 3x3 conv entry like the others ([N][ky][kx][C])."""
+    spec = ovq.tiny_vq_spec()
+    shapes = ovq.vq_encoder_param_shapes(spec)
+    entries, blob, sd = _check_manifest("vqenc", spec_to_vq_cfg(spec), shapes)
+    off, nb, kd, srcs = next(e for e in entries if e[3] == ["encoder.down.0.downsample.conv.weight"])
+    w = sd[srcs[0]]
+    got = torch.from_numpy(blob[off:off + nb].view(np.int16).copy()).view(torch.bfloat16).float().reshape(w.shape[0], 3, 3, -1)
+    assert torch.equal(got[..., :w.shape[1]], w.permute(0, 2, 3, 1).to(torch.bfloat16).float())
+    full = ovq.vq_encoder_param_shapes(ovq.shipped_vq_spec())
+    import rdm_amd  # noqa: F401
+    from rdm_amd import _lib
+    e2, _ = _lib.manifest("vqenc", spec_to_vq_cfg(ovq.shipped_vq_spec()))
+    assert sorted(s for e in e2 for s in e[3]) == sorted(full)
+
+
+def test_training_layout_round_trip():
+    """Masters in the native layouts ([N][ky][kx][C] convs, [N][C] 1x1 convs) and back: state_dict_from_params inverts
+    params_from_state_dict, and grads_to_state_dict_layout maps a native-layout gradient onto the reference's parameter shapes."""
+    import rdm_amd  # noqa: F401
+    from rdm_amd import training_unet as tu
+    spec = ounet.tiny_spec()
+    sd = ounet.synth_state_dict(ounet.param_shapes(spec), seed=3)
+    P = tu.params_from_state_dict(sd, "cpu")
+    k3 = next(k for k, v in sd.items() if v.dim() == 4 and v.shape[2:] == (3, 3))
+    assert P[k3].shape == (sd[k3].shape[0], 3, 3, sd[k3].shape[1]) and torch.equal(P[k3][:, 1, 2, :], sd[k3][:, :, 1, 2])
+    back = tu.state_dict_from_params(P, sd)
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k].float()) for k in sd)
+    g = tu.grads_to_state_dict_layout({k3: P[k3].reshape(P[k3].shape[0], -1)}, sd)
+    assert torch.equal(g[k3], sd[k3].float())
+    pr = tu._Params(P, {k3: P[k3].to(torch.bfloat16) * 0})
+    assert not pr.w(k3).any() and pr[k3] is P[k3] and k3 in pr
+    kb = next(k for k in sd if k.endswith(".bias"))
+    assert pr.w(kb).dtype == torch.bfloat16 and torch.equal(pr.w(kb).float(), P[kb].to(torch.bfloat16).float())
