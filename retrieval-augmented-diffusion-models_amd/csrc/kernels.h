@@ -151,6 +151,12 @@ hipError_t launch_colsum(const bf16_t* x, float* out, long long M, int N, hipStr
 size_t colsum_scratch_bytes(long long M, int N);
 // dW [N][K] fp32 = dy^T a for dy [M, N], a [M, K] bf16 (Linear weight gradient): K-split over the M rows, fp32 planes summed in fixed order
 size_t linear_wgrad_scratch_bytes(long long M, int N, int K);
+// wgrad.hip: dW = dY^T X read in the activation layout (no transposes), taps = 1 (linear) or 9 (conv3x3 over [B][H][W] images)
+bool wgrad_tn_supported(long long M, int N, int K, int lda, int ldb);
+bool conv_wgrad_tn_supported(int B, int H, int W, int C, int N);
+size_t wgrad_tn_scratch_bytes(long long M, int N, int K, int taps);
+hipError_t launch_wgrad_tn(const bf16_t* dy, int lda, const bf16_t* x, int ldb, float* dw, long long M, int N, int K, int taps, int H, int W, char* scratch,
+                           const void* zero_page, hipStream_t st);
 hipError_t launch_linear_wgrad(const bf16_t* dy, const bf16_t* a, float* dw, long long M, int N, int K, char* scratch, const void* zero_page, hipStream_t st);
 hipError_t launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* beta, int B, int HW, int C, int groups,
                                 float eps, int silu, float* scratch, bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st);

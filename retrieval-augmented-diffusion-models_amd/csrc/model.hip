@@ -2076,6 +2076,11 @@ int rdm_op_conv3x3_dgrad(rdm_ctx* c, const void* dy, const void* w, void* dx, in
 int rdm_op_conv3x3_wgrad(rdm_ctx* c, const void* x, const void* dy, float* dw, int B, int H, int W, int C, int N) {
     RDM_ENTER(c);
     if (!x || !dy || !dw || C % 2 || N < 1) return c->fail(-1, "rdm_op_conv3x3_wgrad: bad arguments");
+    if (conv_wgrad_tn_supported(B, H, W, C, N)) {
+        RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, wgrad_tn_scratch_bytes((long long)B * H * W, N, C, 9) + 256));
+        RDM_CHECK_HIP(c, launch_wgrad_tn((const bf16_t*)dy, N, (const bf16_t*)x, C, dw, (long long)B * H * W, N, C, 9, H, W, c->bwd_tmp, c->zero_page, c->stream));
+        return 0;
+    }
     const size_t need = conv_wgrad_scratch_bytes(B, H, W, C, N, nullptr, nullptr, nullptr, nullptr, nullptr);
     RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, need));
     RDM_CHECK_HIP(c, launch_conv_wgrad((const bf16_t*)x, (const bf16_t*)dy, dw, B, H, W, C, N, c->bwd_tmp, c->zero_page, c->stream));
@@ -2101,6 +2106,11 @@ int rdm_op_layernorm_bwd(rdm_ctx* c, const void* x, const void* dy, const float*
 int rdm_op_linear_wgrad(rdm_ctx* c, const void* dy, const void* a, float* dw, long long M, int N, int K) {
     RDM_ENTER(c);
     if (!dy || !a || !dw || M < 1 || M > 0x7fffffffLL || N < 2 || K < 2 || N % 2 || K % 2) return c->fail(-1, "rdm_op_linear_wgrad: bad argument (N, K even)");
+    if (wgrad_tn_supported(M, N, K, N, K)) {
+        RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, wgrad_tn_scratch_bytes(M, N, K, 1) + 256));
+        RDM_CHECK_HIP(c, launch_wgrad_tn((const bf16_t*)dy, N, (const bf16_t*)a, K, dw, M, N, K, 1, 1, 1, c->bwd_tmp, c->zero_page, c->stream));
+        return 0;
+    }
     RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, linear_wgrad_scratch_bytes(M, N, K)));
     RDM_CHECK_HIP(c, launch_linear_wgrad((const bf16_t*)dy, (const bf16_t*)a, dw, M, N, K, c->bwd_tmp, c->zero_page, c->stream));
     return 0;

@@ -24,6 +24,34 @@ def _rand(shape, seed, scale=1.0):
     return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
 
 
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 64, 64, 192, 384), (3, 8, 32, 224, 96), (5, 16, 8, 64, 576)])
+def test_conv3x3_wgrad_tn(ctx, B, H, W, C, N):
+    """The transpose-free wgrad kernel (csrc/wgrad.hip): row splits with the XCD queueing (first case: 24 planes) and without, rectangular
+    images, partial 192-wide tiles, a row count that is not a multiple of the chunk -- against the fp32 autograd of the same bf16 operands."""
+    d = ctx.device
+    x = bf16_round(_rand((B, H, W, C), 11))
+    w = torch.zeros((N, C, 3, 3), requires_grad=True)
+    dy = bf16_round(_rand((B, H, W, N), 13))
+    F.conv2d(x.permute(0, 3, 1, 2), w, None, padding=1).permute(0, 2, 3, 1).backward(dy)
+    dw = ctx.op_conv3x3_wgrad(x.to(d, torch.bfloat16), dy.to(d, torch.bfloat16))
+    e = rel_l2(dw, w.grad.permute(0, 2, 3, 1))
+    print(f"conv wgrad B={B} {H}x{W} {C}->{N}: rel L2 {e:.2e}")
+    assert e <= 1e-5          # exact bf16 products, fp32 sums in another order
+    assert torch.equal(dw, ctx.op_conv3x3_wgrad(x.to(d, torch.bfloat16), dy.to(d, torch.bfloat16)))     # fixed-order planes: bitwise repeatable
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 320, 96), (4096, 384, 1152), (300, 64, 512), (65536, 384, 384)])
+def test_linear_wgrad_tn(ctx, M, N, K):
+    d = ctx.device
+    a, dy = bf16_round(_rand((M, K), 21)), bf16_round(_rand((M, N), 22))
+    dw = ctx.op_linear_wgrad(dy.to(d, torch.bfloat16), a.to(d, torch.bfloat16))
+    ref = dy.double().t() @ a.double()
+    e = rel_l2(dw.double(), ref)
+    print(f"linear wgrad M={M} {K}->{N}: rel L2 {e:.2e}")
+    assert e <= 1e-5
+    assert torch.equal(dw, ctx.op_linear_wgrad(dy.to(d, torch.bfloat16), a.to(d, torch.bfloat16)))
+
+
 @pytest.mark.parametrize("B,H,C,N", [(2, 16, 64, 128), (3, 8, 128, 64), (1, 32, 64, 64), (4, 16, 192, 192)])
 def test_conv3x3_dgrad_wgrad(ctx, B, H, C, N):
     d = ctx.device
