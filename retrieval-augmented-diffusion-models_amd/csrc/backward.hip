@@ -82,48 +82,78 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 // 2-byte loads took 0.46 ms per call -- two thirds of a whole-UNet training step): (1) row chunks of 2048 x column blocks of 256, a
 // thread sums 8 columns (16-byte loads) of every 8th row of its chunk, the block's 8 row lanes meet in LDS; (2) the chunk partials are
 // added in chunk order.
-constexpr int CS_ROWS = 2048;                 // rows per chunk for tall matrices; 128 below 16 k rows (more blocks than columns allow alone)
-__global__ __launch_bounds__(256) void colsum_part_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, long long M, int N, int CS) {
-    __shared__ float red[8][256];
-    const int cv = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int col0 = blockIdx.y * 256 + cv * 8;
+// Column block = VCB 16-byte vectors (the N / 8 vectors of a row dealt evenly to ceil(N / 256) blocks), RL = 256 / VCB row lanes; the
+// row chunk is sized for >= 1024 blocks whatever the shape (round 3 used 2048-row chunks x 256-column blocks: 128 blocks for a
+// [262144, 192] gradient, half the chip idle, 0.5 TB/s).
+__global__ __launch_bounds__(256) void colsum_part_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, long long M, int N, int CS, int VCB) {
+    __shared__ float red[2048];                          // [8 elements][RL][VCB]
+    const int RL = 256 / VCB;
+    const int cv = threadIdx.x % VCB, rl = threadIdx.x / VCB;
+    const int v = blockIdx.y * VCB + cv;                 // vector index in the row
     const long long r0 = (long long)blockIdx.x * CS, r1 = r0 + CS < M ? r0 + CS : M;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (col0 < N)
-        for (long long m = r0 + rl; m < r1; m += 8) {
-            const uint4 v = *(const uint4*)(x + m * N + col0);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const bool act = rl < RL && v * 8 < N;
+    if (act) {
+        long long m = r0 + rl;
+        for (; m + 3 * RL < r1; m += 4 * RL) {           // four 16-byte loads in flight
+            uint4 d[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) d[u] = *(const uint4*)(x + (m + u * RL) * N + v * 8);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t w[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) { s[2 * e] += __uint_as_float(w[e] << 16); s[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+            }
+        }
+        for (; m < r1; m += RL) {
+            const uint4 d = *(const uint4*)(x + m * N + v * 8);
+            const uint32_t w[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
             for (int e = 0; e < 4; e++) { s[2 * e] += __uint_as_float(w[e] << 16); s[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
         }
 #pragma unroll
-    for (int e = 0; e < 8; e++) red[rl][cv * 8 + e] = s[e];
+        for (int e = 0; e < 8; e++) red[(e * RL + rl) * VCB + cv] = s[e];
+    }
     __syncthreads();
-    const int col = blockIdx.y * 256 + threadIdx.x;
-    if (col < N) {
-        float t = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; r++) t += red[r][threadIdx.x];
-        part[(long long)blockIdx.x * N + col] = t;
+    for (int idx = threadIdx.x; idx < VCB * 8; idx += 256) {
+        const int e = idx / VCB, vv = idx - e * VCB;
+        const int col = (blockIdx.y * VCB + vv) * 8 + e;
+        if (col < N) {
+            float t = 0.f;
+            for (int r = 0; r < RL; r++) t += red[(e * RL + r) * VCB + vv];
+            part[(long long)blockIdx.x * N + col] = t;
+        }
     }
 }
+// chunk partials added in four fixed quarters per column, the quarters in a fixed tree
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunk, int N) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= N) return;
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int per = (nchunk + 3) / 4, c0 = q * per, c1 = min(nchunk, c0 + per);
     float t = 0.f;
-    for (int c = 0; c < nchunk; c++) t += part[(long long)c * N + col];
-    out[col] = t;
+    if (col < N) for (int c = c0; c < c1; c++) t += part[(long long)c * N + col];
+    red[q][threadIdx.x & 63] = t;
+    __syncthreads();
+    if (q == 0 && col < N) out[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-size_t colsum_scratch_bytes(long long M, int N) { return (size_t)((M + 127) / 128) * N * sizeof(float); }
+static void colsum_geom(long long M, int N, int* pCS, int* pVCB, int* pcolblocks) {
+    const int nv = N / 8, colblocks = (nv + 31) / 32, VCB = (nv + colblocks - 1) / colblocks;
+    long long CS = (M * colblocks + 1023) / 1024; CS = (CS + 7) & ~7LL;
+    if (CS < 64) CS = 64;
+    if (CS > 4096) CS = 4096;
+    *pCS = (int)CS; *pVCB = VCB; *pcolblocks = colblocks;
+}
+size_t colsum_scratch_bytes(long long M, int N) { return (size_t)((M + 63) / 64) * N * sizeof(float); }
 hipError_t launch_colsum(const bf16_t* x, float* out, long long M, int N, hipStream_t st, float* scratch) {
     if (!scratch || N % 8 != 0 || M < 256) {
         colsum_kernel<<<dim3((N + 63) / 64), 256, 0, st>>>(x, out, M, N);
         return hipGetLastError();
     }
-    const int CS = M >= 16384 ? CS_ROWS : 128;
+    int CS, VCB, colblocks; colsum_geom(M, N, &CS, &VCB, &colblocks);
     const int nchunk = (int)((M + CS - 1) / CS);
-    colsum_part_kernel<<<dim3(nchunk, (N + 255) / 256), 256, 0, st>>>(x, scratch, M, N, CS);
-    colsum_finish_kernel<<<dim3((N + 255) / 256), 256, 0, st>>>(scratch, out, nchunk, N);
+    colsum_part_kernel<<<dim3(nchunk, colblocks), 256, 0, st>>>(x, scratch, M, N, CS, VCB);
+    colsum_finish_kernel<<<dim3((N + 63) / 64), 256, 0, st>>>(scratch, out, nchunk, N);
     return hipGetLastError();
 }
 
@@ -287,11 +317,173 @@ __global__ __launch_bounds__(256) void gn_bwd_affine_kernel(GnBwdParams p) {
     for (int b = 0; b < p.B; b++) { g += p.part_g[(long long)b * p.C + c]; bb += p.part_b[(long long)b * p.C + c]; }
     p.dgamma[c] = g; p.dbeta[c] = bb;
 }
+// ---- vectorised GroupNorm backward (C % 8 == 0, C <= 2048): the round-3 kernels above walk a (sample, group) with 2-byte loads and
+// a division per element (1.2 TB/s over the step's 61 layers).  Here every pass is the forward's 16-byte stream (thread = one
+// 8-channel vector for the whole launch, VC x R threads):
+//   1. launch_gn_stats (the forward's statistics kernel)                                   -> (sum, sumsq) per (sample, chunk, group)
+//   2. gn_bwd_chan_kernel: per-(sample, chunk, CHANNEL) sums  a_c = sum dz, b_c = sum dz xh -> cpart
+//   3. gn_bwd_group_kernel (one block per sample): chunk order sums; dbeta / dgamma partials ARE a_c / b_c; S1 = sum_c gamma_c a_c, S2 likewise
+//   4. gn_bwd_apply2_kernel: dx = rstd (dz gamma - S1 / n - xh S2 / n)
+//   5. gn_bwd_affine_kernel (as before): dgamma / dbeta = sample-order sums
+struct GnBwd2 {
+    const bf16_t* x; const bf16_t* dy; const float* gamma; const float* beta;
+    int B, HW, C, groups, silu, nchunk; float eps;
+    const float* fpart; float* cpart; float* stats; float* part_g; float* part_b; bf16_t* dx;
+};
+__device__ __forceinline__ float silu_grad_f(float z) { const float sg = 1.f / (1.f + __expf(-z)); return sg * (1.f + z * (1.f - sg)); }
+__device__ __forceinline__ void unpack8(const uint4 d, float* f) {
+    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) { f[2 * e] = __uint_as_float(w[e] << 16); f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+}
+__global__ void gn_bwd_chan_kernel(GnBwd2 p) {
+    extern __shared__ float sm[];                        // [8][R][VC] float2
+    __shared__ float gstat[64][2];
+    const int C = p.C, VC = C >> 3, cg = C / p.groups;
+    const int R = blockDim.x / VC;
+    const int v = threadIdx.x % VC, rr = threadIdx.x / VC;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    if (threadIdx.x < p.groups) {
+        double a = 0.0, q = 0.0;
+        const float* pp = p.fpart + ((long long)b * p.nchunk * p.groups + threadIdx.x) * 2;
+        for (int k = 0; k < p.nchunk; k++) { const float2 t = *(const float2*)(pp + (long long)k * p.groups * 2); a += t.x; q += t.y; }
+        const double n = (double)cg * p.HW, mean = a / n;
+        double var = q / n - mean * mean; if (var < 0) var = 0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        gstat[threadIdx.x][0] = (float)mean; gstat[threadIdx.x][1] = rstd;
+        if (chunk == 0) { float* st = p.stats + ((long long)b * p.groups + threadIdx.x) * 4; st[0] = (float)mean; st[1] = rstd; }
+    }
+    __syncthreads();
+    if (rr < R) {
+        float fa[8], fb[8], ga[8], be[8], sa[8], sb[8];
+        {
+            int g = (v * 8) / cg, r = v * 8 - g * cg;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                fa[e] = gstat[g][1]; fb[e] = -gstat[g][0] * gstat[g][1];
+                ga[e] = p.gamma[v * 8 + e]; be[e] = p.beta[v * 8 + e]; sa[e] = 0.f; sb[e] = 0.f;
+                if (++r == cg) { r = 0; g++; }
+            }
+        }
+        const int rows_per = (p.HW + p.nchunk - 1) / p.nchunk;
+        const int r0 = chunk * rows_per, r1 = min(p.HW, r0 + rows_per);
+        const bf16_t* xb = p.x + (long long)b * p.HW * C + v * 8; const bf16_t* db = p.dy + (long long)b * p.HW * C + v * 8;
+        int row = r0 + rr;
+        for (; row + R < r1; row += 2 * R) {
+            const uint4 x0 = *(const uint4*)(xb + (long long)row * C), d0 = *(const uint4*)(db + (long long)row * C);
+            const uint4 x1 = *(const uint4*)(xb + (long long)(row + R) * C), d1 = *(const uint4*)(db + (long long)(row + R) * C);
+            float xf[8], df[8];
+            unpack8(x0, xf); unpack8(d0, df);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float xh = xf[e] * fa[e] + fb[e]; float dz = df[e]; if (p.silu) dz *= silu_grad_f(xh * ga[e] + be[e]); sa[e] += dz; sb[e] += dz * xh; }
+            unpack8(x1, xf); unpack8(d1, df);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float xh = xf[e] * fa[e] + fb[e]; float dz = df[e]; if (p.silu) dz *= silu_grad_f(xh * ga[e] + be[e]); sa[e] += dz; sb[e] += dz * xh; }
+        }
+        for (; row < r1; row += R) {
+            float xf[8], df[8];
+            unpack8(*(const uint4*)(xb + (long long)row * C), xf); unpack8(*(const uint4*)(db + (long long)row * C), df);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float xh = xf[e] * fa[e] + fb[e]; float dz = df[e]; if (p.silu) dz *= silu_grad_f(xh * ga[e] + be[e]); sa[e] += dz; sb[e] += dz * xh; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) *(float2*)(sm + ((e * R + rr) * VC + v) * 2) = make_float2(sa[e], sb[e]);
+    }
+    __syncthreads();
+    float* out = p.cpart + ((long long)b * p.nchunk + chunk) * C * 2;
+    for (int idx = threadIdx.x; idx < C; idx += blockDim.x) {
+        const int e = idx / VC, vv = idx - e * VC;
+        float a = 0.f, q = 0.f;
+        for (int r = 0; r < R; r++) { const float2 t = *(const float2*)(sm + ((e * R + r) * VC + vv) * 2); a += t.x; q += t.y; }
+        *(float2*)(out + (vv * 8 + e) * 2) = make_float2(a, q);
+    }
+}
+__global__ __launch_bounds__(256) void gn_bwd_group_kernel(GnBwd2 p) {
+    __shared__ float ch[2048 * 2];
+    const int b = blockIdx.x, C = p.C, cg = C / p.groups;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, q = 0.f;
+        const float* pp = p.cpart + ((long long)b * p.nchunk * C + c) * 2;
+        for (int k = 0; k < p.nchunk; k++) { const float2 t = *(const float2*)(pp + (long long)k * C * 2); a += t.x; q += t.y; }
+        const float ga = p.gamma[c];
+        ch[c * 2] = a * ga; ch[c * 2 + 1] = q * ga;
+        p.part_b[(long long)b * C + c] = a; p.part_g[(long long)b * C + c] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x < p.groups) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; c++) { s1 += ch[c * 2]; s2 += ch[c * 2 + 1]; }
+        const float n = (float)cg * (float)p.HW;
+        float* st = p.stats + ((long long)b * p.groups + threadIdx.x) * 4;
+        st[2] = s1 / n; st[3] = s2 / n;
+    }
+}
+__global__ void gn_bwd_apply2_kernel(GnBwd2 p) {
+    __shared__ float gs[64][4];
+    const int C = p.C, VC = C >> 3, cg = C / p.groups;
+    const int R = blockDim.x / VC;
+    const int v = threadIdx.x % VC, rr = threadIdx.x / VC;
+    const int b = blockIdx.y;
+    if (threadIdx.x < p.groups * 4) gs[threadIdx.x >> 2][threadIdx.x & 3] = p.stats[(long long)b * p.groups * 4 + threadIdx.x];
+    __syncthreads();
+    if (rr >= R) return;
+    float fa[8], fb[8], ga[8], be[8], c1[8], c2[8], c3[8];
+    {
+        int g = (v * 8) / cg, r = v * 8 - g * cg;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float mean = gs[g][0], rstd = gs[g][1];
+            fa[e] = rstd; fb[e] = -mean * rstd; ga[e] = p.gamma[v * 8 + e]; be[e] = p.beta[v * 8 + e];
+            c1[e] = rstd * ga[e]; c2[e] = rstd * gs[g][2]; c3[e] = rstd * gs[g][3];
+            if (++r == cg) { r = 0; g++; }
+        }
+    }
+    const int rows_per = (p.HW + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows_per, r1 = min(p.HW, r0 + rows_per);
+    const long long base = (long long)b * p.HW * C + v * 8;
+    for (int row = r0 + rr; row < r1; row += R) {
+        float xf[8], df[8], o[8];
+        unpack8(*(const uint4*)(p.x + base + (long long)row * C), xf); unpack8(*(const uint4*)(p.dy + base + (long long)row * C), df);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float xh = xf[e] * fa[e] + fb[e]; float dz = df[e];
+            if (p.silu) dz *= silu_grad_f(xh * ga[e] + be[e]);
+            o[e] = dz * c1[e] - c2[e] - xh * c3[e];
+        }
+        *(uint4*)(p.dx + base + (long long)row * C) = make_uint4(cvt_pk_bf16(o[0], o[1]), cvt_pk_bf16(o[2], o[3]), cvt_pk_bf16(o[4], o[5]), cvt_pk_bf16(o[6], o[7]));
+    }
+}
+static int gn_bwd_nchunk(int B, int HW) { int n = 2048 / (B > 0 ? B : 1); if (n > HW / 32) n = HW / 32; if (n < 1) n = 1; if (n > 64) n = 64; return n; }
+static bool gn_bwd_vec_ok(int C, int groups) {
+    static const bool off = getenv("RDM_NO_GN_BWD_VEC") != nullptr;
+    return !off && C % 8 == 0 && C <= 2048 && groups <= 64 && C % groups == 0;
+}
+size_t groupnorm_bwd_scratch_bytes(int B, int HW, int C, int groups) {
+    const size_t nch = gn_bwd_nchunk(B, HW);
+    return ((size_t)B * groups * 4 + 2 * (size_t)B * C + (size_t)B * nch * groups * 2 + (size_t)B * nch * C * 2) * sizeof(float) + 256;
+}
 hipError_t launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* beta, int B, int HW, int C, int groups,
-                                float eps, int silu, float* scratch /* B*groups*4 + 2*B*C floats */, bf16_t* dx, float* dgamma, float* dbeta,
+                                float eps, int silu, float* scratch /* groupnorm_bwd_scratch_bytes */, bf16_t* dx, float* dgamma, float* dbeta,
                                 hipStream_t st) {
     GnBwdParams p{}; p.x = x; p.dy = dy; p.gamma = gamma; p.beta = beta; p.B = B; p.HW = HW; p.C = C; p.groups = groups; p.silu = silu; p.eps = eps;
     p.stats = scratch; p.part_g = scratch + (size_t)B * groups * 4; p.part_b = p.part_g + (size_t)B * C; p.dx = dx; p.dgamma = dgamma; p.dbeta = dbeta;
+    if (gn_bwd_vec_ok(C, groups)) {
+        GnBwd2 q{}; q.x = x; q.dy = dy; q.gamma = gamma; q.beta = beta; q.B = B; q.HW = HW; q.C = C; q.groups = groups; q.silu = silu; q.eps = eps;
+        q.nchunk = gn_bwd_nchunk(B, HW);
+        q.stats = p.stats; q.part_g = p.part_g; q.part_b = p.part_b; q.dx = dx;
+        float* fpart = p.part_b + (size_t)B * C;
+        q.fpart = fpart; q.cpart = fpart + (size_t)B * q.nchunk * groups * 2;
+        GnParams f{}; f.x0 = x; f.C0 = C; f.HW = HW; f.B = B; f.groups = groups; f.nchunk = q.nchunk; f.partial = fpart; f.eps = eps;
+        hipError_t e = launch_gn_stats(f, st); if (e != hipSuccess) return e;
+        const int VC = C / 8; int R = 256 / VC; if (R < 1) R = 1;
+        const int threads = ((VC * R + 63) / 64) * 64;
+        gn_bwd_chan_kernel<<<dim3(q.nchunk, B), threads, (size_t)R * C * 2 * sizeof(float), st>>>(q);
+        gn_bwd_group_kernel<<<B, 256, 0, st>>>(q);
+        int nblk = (2048 + B - 1) / B; if (nblk > HW / 8) nblk = HW / 8; if (nblk < 1) nblk = 1;
+        gn_bwd_apply2_kernel<<<dim3(nblk, B), threads, 0, st>>>(q);
+        gn_bwd_affine_kernel<<<(C + 255) / 256, 256, 0, st>>>(p);
+        return hipGetLastError();
+    }
     gn_bwd_stats_kernel<<<B * groups, 256, 0, st>>>(p);
     gn_bwd_apply_kernel<<<B * ((C + 63) / 64), 256, 0, st>>>(p);
     gn_bwd_affine_kernel<<<(C + 255) / 256, 256, 0, st>>>(p);
@@ -337,12 +529,104 @@ __global__ __launch_bounds__(256) void ln_bwd_affine_kernel(const float* part_g,
     for (int i = 0; i < nb; i++) { g += part_g[(long long)i * C + c]; b += part_b[(long long)i * C + c]; }
     dgamma[c] = g; dbeta[c] = b;
 }
+// vectorised LayerNorm backward (C % 8 == 0, C <= 1024): one wave per row, the row lives in registers as NV 16-byte vectors per lane, so
+// x and dy are read ONCE (the scalar kernel above walks each row three times with 2-byte loads: 0.6 TB/s); the dgamma / dbeta partials
+// of a wave stay in registers across its rows and meet in LDS once per block.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const float* __restrict__ gamma,
+                                                         int M, int C, float eps, bf16_t* __restrict__ dx, float* __restrict__ part_g,
+                                                         float* __restrict__ part_b, int rows_per_block) {
+    extern __shared__ float acc[];                      // [4 waves][2][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, VC = C >> 3;
+    float ga[NV][8], ag[NV][8], ab[NV][8];
+    bool on[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        on[j] = lane + 64 * j < VC;
+#pragma unroll
+        for (int e = 0; e < 8; e++) { ga[j][e] = on[j] ? gamma[(lane + 64 * j) * 8 + e] : 0.f; ag[j][e] = 0.f; ab[j][e] = 0.f; }
+    }
+    const float invC = 1.f / (float)C;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int r = r0 + wave; r < r1; r += 4) {
+        float xf[NV][8], df[NV][8];
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            if (on[j]) {
+                unpack8(*(const uint4*)(x + (long long)r * C + (lane + 64 * j) * 8), xf[j]);
+                unpack8(*(const uint4*)(dy + (long long)r * C + (lane + 64 * j) * 8), df[j]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++) { xf[j][e] = 0.f; df[j][e] = 0.f; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) { s += xf[j][e]; ss += xf[j][e] * xf[j][e]; }
+        }
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+        const float mean = s * invC, rstd = rsqrtf(fmaxf(ss * invC - mean * mean, 0.f) + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; j++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float xh = on[j] ? (xf[j][e] - mean) * rstd : 0.f, dxh = df[j][e] * ga[j][e];
+                xf[j][e] = xh; s1 += dxh; s2 += dxh * xh;
+            }
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        s1 *= invC; s2 *= invC;
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                o[e] = rstd * (df[j][e] * ga[j][e] - s1 - xf[j][e] * s2);
+                ag[j][e] += df[j][e] * xf[j][e]; ab[j][e] += df[j][e];
+            }
+            if (on[j])
+                *(uint4*)(dx + (long long)r * C + (lane + 64 * j) * 8) = make_uint4(cvt_pk_bf16(o[0], o[1]), cvt_pk_bf16(o[2], o[3]), cvt_pk_bf16(o[4], o[5]), cvt_pk_bf16(o[6], o[7]));
+        }
+    }
+    float* mine = acc + (size_t)wave * 2 * C;
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+        if (on[j])
+#pragma unroll
+            for (int e = 0; e < 8; e++) { mine[(lane + 64 * j) * 8 + e] = ag[j][e]; mine[C + (lane + 64 * j) * 8 + e] = ab[j][e]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        part_g[(long long)blockIdx.x * C + c] = (acc[c] + acc[2 * C + c]) + (acc[4 * C + c] + acc[6 * C + c]);
+        part_b[(long long)blockIdx.x * C + c] = (acc[C + c] + acc[3 * C + c]) + (acc[5 * C + c] + acc[7 * C + c]);
+    }
+}
+// block partials added in four fixed quarters per channel, the quarters in a fixed tree (the one-thread-per-channel loop above is a
+// serial walk over up to 1024 partials: 0.13 ms per call at the UNet's widths)
+__global__ __launch_bounds__(256) void ln_bwd_affine4_kernel(const float* part_g, const float* part_b, int nb, int C, float* dgamma, float* dbeta) {
+    __shared__ float rg[4][64], rb[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int per = (nb + 3) / 4, i0 = q * per, i1 = min(nb, i0 + per);
+    float g = 0.f, b = 0.f;
+    if (c < C) for (int i = i0; i < i1; i++) { g += part_g[(long long)i * C + c]; b += part_b[(long long)i * C + c]; }
+    rg[q][threadIdx.x & 63] = g; rb[q][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (q == 0 && c < C) {
+        const int l = threadIdx.x;
+        dgamma[c] = (rg[0][l] + rg[1][l]) + (rg[2][l] + rg[3][l]); dbeta[c] = (rb[0][l] + rb[1][l]) + (rb[2][l] + rb[3][l]);
+    }
+}
 hipError_t launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, int M, int C, float eps, float* scratch /* 2*nb*C */,
                                 int* nb_out, bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st) {
-    const int rows_per_block = M >= 16384 ? 64 : 16;      // (the fixed-order sum over the block partials is serial per channel: keep nb in the hundreds)
+    const int rows_per_block = M >= 16384 ? 64 : 16;      // nb <= M / 16: the scratch contract of the callers (2 * ceil(M / 16) * C floats)
     const int nb = (M + rows_per_block - 1) / rows_per_block;
     if (nb_out) *nb_out = nb;
     float* pg = scratch; float* pb = scratch + (size_t)nb * C;
+    static const bool novec = getenv("RDM_NO_LN_BWD_VEC") != nullptr;
+    if (!novec && C % 8 == 0 && C <= 1024) {
+        if (C <= 512) ln_bwd_vec_kernel<1><<<nb, 256, (size_t)8 * C * sizeof(float), st>>>(x, dy, gamma, M, C, eps, dx, pg, pb, rows_per_block);
+        else ln_bwd_vec_kernel<2><<<nb, 256, (size_t)8 * C * sizeof(float), st>>>(x, dy, gamma, M, C, eps, dx, pg, pb, rows_per_block);
+        ln_bwd_affine4_kernel<<<(C + 63) / 64, 256, 0, st>>>(pg, pb, nb, C, dgamma, dbeta);
+        return hipGetLastError();
+    }
     ln_bwd_kernel<<<nb, 256, (size_t)8 * C * sizeof(float), st>>>(x, dy, gamma, M, C, eps, dx, pg, pb, rows_per_block);
     ln_bwd_affine_kernel<<<(C + 255) / 256, 256, 0, st>>>(pg, pb, nb, C, dgamma, dbeta);
     return hipGetLastError();

@@ -158,6 +158,7 @@ size_t wgrad_tn_scratch_bytes(long long M, int N, int K, int taps);
 hipError_t launch_wgrad_tn(const bf16_t* dy, int lda, const bf16_t* x, int ldb, float* dw, long long M, int N, int K, int taps, int H, int W, char* scratch,
                            const void* zero_page, hipStream_t st);
 hipError_t launch_linear_wgrad(const bf16_t* dy, const bf16_t* a, float* dw, long long M, int N, int K, char* scratch, const void* zero_page, hipStream_t st);
+size_t groupnorm_bwd_scratch_bytes(int B, int HW, int C, int groups);
 hipError_t launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* beta, int B, int HW, int C, int groups,
                                 float eps, int silu, float* scratch, bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st);
 hipError_t launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, int M, int C, float eps, float* scratch, int* nb_out,

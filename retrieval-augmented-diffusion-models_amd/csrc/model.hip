@@ -2090,7 +2090,7 @@ int rdm_op_groupnorm_bwd(rdm_ctx* c, const void* x, const void* dy, const float*
                          void* dx, float* dgamma, float* dbeta) {
     RDM_ENTER(c);
     if (!x || !dy || !gamma || !beta || !dx || !dgamma || !dbeta || C % 32) return c->fail(-1, "rdm_op_groupnorm_bwd: bad arguments");
-    RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, ((size_t)B * 32 * 4 + 2 * (size_t)B * C) * 4));
+    RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, groupnorm_bwd_scratch_bytes(B, HW, C, 32)));
     RDM_CHECK_HIP(c, launch_groupnorm_bwd((const bf16_t*)x, (const bf16_t*)dy, gamma, beta, B, HW, C, 32, eps, silu, (float*)c->bwd_tmp, (bf16_t*)dx,
                                           dgamma, dbeta, c->stream));
     return 0;

@@ -36,6 +36,8 @@ struct WgradParams {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
+}  // namespace
+
 __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -142,6 +144,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
         }
     }
 }
+
+namespace {
 
 void wgrad_geom(long long M, int N, int K, int taps, int* pZ, int* pmz) {
     const long long tiles = (long long)((N + 191) / 192) * ((K + 191) / 192);
