@@ -358,6 +358,11 @@ int rdm_op_head_conv(rdm_ctx* ctx, const void* x_bf16, const float* gn_gamma, co
                      const float* bias, int B, int H, int W, int C, int Cout, float* out_f32);
 int rdm_op_small_attention(rdm_ctx* ctx, const void* q_bf16, int ldq, const void* k_bf16, const void* v_bf16, int ldkv,
                            int B, int nq, int nkv, int heads, int D, int causal, float scale, void* out_bf16, int ldo);
+/* Gradient of rdm_op_small_attention for the UNet's cross-attention (ldm CrossAttention, rdm/modules/attention.py:52-72, with the few
+ * retrieved-neighbour embeddings as keys): d_head = 32, 1..32 keys, not causal.  q [B, nq, ldq], k / v [B, nkv, ldkv], dout [B, nq, ldo]
+ * (head h = columns [32 h, 32 h + 32)) -> dq [B, nq, 32 heads], dk / dv [B, nkv, 32 heads], all bf16; sums in a fixed order. */
+int rdm_op_small_attention_bwd(rdm_ctx* ctx, const void* q_bf16, int ldq, const void* k_bf16, const void* v_bf16, int ldkv, const void* dout_bf16, int ldo,
+                               int B, int nq, int nkv, int heads, float scale, void* dq_bf16, void* dk_bf16, void* dv_bf16);
 
 #ifdef __cplusplus
 }

@@ -151,6 +151,7 @@ SIGNATURES = {
     "rdm_op_xattn_fused": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_op_small_attention": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_float, _P, C.c_int]),
+    "rdm_op_small_attention_bwd": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P]),
 }
 
 
@@ -884,6 +885,17 @@ class Context:
         self._check(lib.rdm_op_xattn_fused(self._h, _ptr(x), opt(g), opt(b_), float(eps), _ptr(G), _ptr(U), opt(bias), opt(res),
                                            B, n, Cc, NP, ncols, group, _ptr(out)))
         return out
+
+    def op_small_attention_bwd(self, q, k, v, dout, heads, scale):
+        """Gradient of op_small_attention at d_head 32 with 1..32 keys (the UNet's cross-attention): -> dq, dk, dv (bf16)."""
+        B, nq, Cc = q.shape
+        m = k.shape[1]
+        assert k.stride(-2) == v.stride(-2) and q.is_contiguous() and dout.is_contiguous()
+        dq = torch.empty((B, nq, heads * 32), device=self.device, dtype=torch.bfloat16)
+        dk = torch.empty((B, m, heads * 32), device=self.device, dtype=torch.bfloat16); dv = torch.empty_like(dk)
+        self._check(lib.rdm_op_small_attention_bwd(self._h, _ptr(q), Cc, _ptr(k), _ptr(v), k.shape[2], _ptr(dout), dout.shape[2], B, nq, m, heads, float(scale),
+                                                   _ptr(dq), _ptr(dk), _ptr(dv)))
+        return dq, dk, dv
 
     def op_small_attention(self, q, k, v, heads, D, causal, scale):
         B, nq, Cc = q.shape

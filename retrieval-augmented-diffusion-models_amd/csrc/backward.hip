@@ -126,16 +126,27 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const bf16_t* __restri
         }
     }
 }
-// chunk partials added in four fixed quarters per column, the quarters in a fixed tree
+// chunk partials added in sixteen fixed runs per column (16 columns x 16 runs per block), the runs in a fixed tree: a run is a chain of
+// dependent adds behind L2 round trips, so the chain length sets the kernel's time
+__device__ __forceinline__ float tree16(const float* r, int stride) {
+    float t[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) t[i] = r[i * stride];
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+        for (int i = 0; i < w; i++) t[i] += t[i + w];
+    return t[0];
+}
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunk, int N) {
-    __shared__ float red[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-    const int per = (nchunk + 3) / 4, c0 = q * per, c1 = min(nchunk, c0 + per);
+    __shared__ float red[16][16];
+    const int cl = threadIdx.x & 15, q = threadIdx.x >> 4, col = blockIdx.x * 16 + cl;
+    const int per = (nchunk + 15) / 16, c0 = q * per, c1 = min(nchunk, c0 + per);
     float t = 0.f;
     if (col < N) for (int c = c0; c < c1; c++) t += part[(long long)c * N + col];
-    red[q][threadIdx.x & 63] = t;
+    red[q][cl] = t;
     __syncthreads();
-    if (q == 0 && col < N) out[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (q == 0 && col < N) out[col] = tree16(&red[0][cl], 16);
 }
 static void colsum_geom(long long M, int N, int* pCS, int* pVCB, int* pcolblocks) {
     const int nv = N / 8, colblocks = (nv + 31) / 32, VCB = (nv + colblocks - 1) / colblocks;
@@ -153,7 +164,7 @@ hipError_t launch_colsum(const bf16_t* x, float* out, long long M, int N, hipStr
     int CS, VCB, colblocks; colsum_geom(M, N, &CS, &VCB, &colblocks);
     const int nchunk = (int)((M + CS - 1) / CS);
     colsum_part_kernel<<<dim3(nchunk, colblocks), 256, 0, st>>>(x, scratch, M, N, CS, VCB);
-    colsum_finish_kernel<<<dim3((N + 63) / 64), 256, 0, st>>>(scratch, out, nchunk, N);
+    colsum_finish_kernel<<<dim3((N + 15) / 16), 256, 0, st>>>(scratch, out, nchunk, N);
     return hipGetLastError();
 }
 
@@ -310,12 +321,18 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdParams p) {
         p.part_b[(long long)b * p.C + c] = (rb_[0][l] + rb_[1][l]) + (rb_[2][l] + rb_[3][l]);
     }
 }
-__global__ __launch_bounds__(256) void gn_bwd_affine_kernel(GnBwdParams p) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= p.C) return;
+__global__ __launch_bounds__(256) void gn_bwd_affine_kernel(GnBwdParams p) {          // 64 channels x 4 sample runs per block
+    __shared__ float rg[4][64], rb[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int per = (p.B + 3) / 4, b0 = q * per, b1 = min(p.B, b0 + per);
     float g = 0.f, bb = 0.f;
-    for (int b = 0; b < p.B; b++) { g += p.part_g[(long long)b * p.C + c]; bb += p.part_b[(long long)b * p.C + c]; }
-    p.dgamma[c] = g; p.dbeta[c] = bb;
+    if (c < p.C) for (int b = b0; b < b1; b++) { g += p.part_g[(long long)b * p.C + c]; bb += p.part_b[(long long)b * p.C + c]; }
+    rg[q][threadIdx.x & 63] = g; rb[q][threadIdx.x & 63] = bb;
+    __syncthreads();
+    if (q == 0 && c < p.C) {
+        const int l = threadIdx.x;
+        p.dgamma[c] = (rg[0][l] + rg[1][l]) + (rg[2][l] + rg[3][l]); p.dbeta[c] = (rb[0][l] + rb[1][l]) + (rb[2][l] + rb[3][l]);
+    }
 }
 // ---- vectorised GroupNorm backward (C % 8 == 0, C <= 2048): the round-3 kernels above walk a (sample, group) with 2-byte loads and
 // a division per element (1.2 TB/s over the step's 61 layers).  Here every pass is the forward's 16-byte stream (thread = one
@@ -481,12 +498,12 @@ hipError_t launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* 
         gn_bwd_group_kernel<<<B, 256, 0, st>>>(q);
         int nblk = (2048 + B - 1) / B; if (nblk > HW / 8) nblk = HW / 8; if (nblk < 1) nblk = 1;
         gn_bwd_apply2_kernel<<<dim3(nblk, B), threads, 0, st>>>(q);
-        gn_bwd_affine_kernel<<<(C + 255) / 256, 256, 0, st>>>(p);
+        gn_bwd_affine_kernel<<<(C + 63) / 64, 256, 0, st>>>(p);
         return hipGetLastError();
     }
     gn_bwd_stats_kernel<<<B * groups, 256, 0, st>>>(p);
     gn_bwd_apply_kernel<<<B * ((C + 63) / 64), 256, 0, st>>>(p);
-    gn_bwd_affine_kernel<<<(C + 255) / 256, 256, 0, st>>>(p);
+    gn_bwd_affine_kernel<<<(C + 63) / 64, 256, 0, st>>>(p);
     return hipGetLastError();
 }
 
@@ -599,20 +616,17 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const bf16_t* __restric
         part_b[(long long)blockIdx.x * C + c] = (acc[C + c] + acc[3 * C + c]) + (acc[5 * C + c] + acc[7 * C + c]);
     }
 }
-// block partials added in four fixed quarters per channel, the quarters in a fixed tree (the one-thread-per-channel loop above is a
-// serial walk over up to 1024 partials: 0.13 ms per call at the UNet's widths)
+// block partials added in sixteen fixed runs per channel (16 channels x 16 runs per block), the runs in a fixed tree (the
+// one-thread-per-channel loop above is a serial walk over up to 1024 partials: 0.13 ms per call at the UNet's widths)
 __global__ __launch_bounds__(256) void ln_bwd_affine4_kernel(const float* part_g, const float* part_b, int nb, int C, float* dgamma, float* dbeta) {
-    __shared__ float rg[4][64], rb[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-    const int per = (nb + 3) / 4, i0 = q * per, i1 = min(nb, i0 + per);
+    __shared__ float rg[16][16], rb[16][16];
+    const int cl = threadIdx.x & 15, q = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    const int per = (nb + 15) / 16, i0 = q * per, i1 = min(nb, i0 + per);
     float g = 0.f, b = 0.f;
     if (c < C) for (int i = i0; i < i1; i++) { g += part_g[(long long)i * C + c]; b += part_b[(long long)i * C + c]; }
-    rg[q][threadIdx.x & 63] = g; rb[q][threadIdx.x & 63] = b;
+    rg[q][cl] = g; rb[q][cl] = b;
     __syncthreads();
-    if (q == 0 && c < C) {
-        const int l = threadIdx.x;
-        dgamma[c] = (rg[0][l] + rg[1][l]) + (rg[2][l] + rg[3][l]); dbeta[c] = (rb[0][l] + rb[1][l]) + (rb[2][l] + rb[3][l]);
-    }
+    if (q == 0 && c < C) { dgamma[c] = tree16(&rg[0][cl], 16); dbeta[c] = tree16(&rb[0][cl], 16); }
 }
 hipError_t launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, int M, int C, float eps, float* scratch /* 2*nb*C */,
                                 int* nb_out, bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st) {
@@ -624,7 +638,7 @@ hipError_t launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* 
     if (!novec && C % 8 == 0 && C <= 1024) {
         if (C <= 512) ln_bwd_vec_kernel<1><<<nb, 256, (size_t)8 * C * sizeof(float), st>>>(x, dy, gamma, M, C, eps, dx, pg, pb, rows_per_block);
         else ln_bwd_vec_kernel<2><<<nb, 256, (size_t)8 * C * sizeof(float), st>>>(x, dy, gamma, M, C, eps, dx, pg, pb, rows_per_block);
-        ln_bwd_affine4_kernel<<<(C + 63) / 64, 256, 0, st>>>(pg, pb, nb, C, dgamma, dbeta);
+        ln_bwd_affine4_kernel<<<(C + 15) / 16, 256, 0, st>>>(pg, pb, nb, C, dgamma, dbeta);
         return hipGetLastError();
     }
     ln_bwd_kernel<<<nb, 256, (size_t)8 * C * sizeof(float), st>>>(x, dy, gamma, M, C, eps, dx, pg, pb, rows_per_block);
@@ -1150,5 +1164,125 @@ hipError_t launch_expand2(const bf16_t* x, bf16_t* out, int B, int H, int W, int
     if (C % 8) return hipErrorInvalidValue;
     long long g = ((long long)B * 4 * H * W * (C / 8) + 255) / 256; if (g > 16384) g = 16384; if (g < 1) g = 1;
     expand2_kernel<<<dim3((unsigned)g), 256, 0, st>>>(x, out, B, H, W, C, mode);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Cross-attention backward for FEW keys (the UNet's attn2: the conditioning is a handful of retrieved-neighbour embeddings, d_head =
+// 32, at most 32 keys): the partner of small_attention_kernel (attention.cpp forward).  Round 3 sent this through the generic unfused
+// path -- per-head padded copies of q / dO (D 32 -> 64), four batched GEMMs against 64 padded keys, a score matrix, two transposes:
+// 24 ms of a 125 ms step for 4 keys.  Here one thread owns a query row: it recomputes its m probabilities from K (LDS, fp32), forms
+// dP = dO V^T, dS = P (dP - sum P dP), dQ = scale dS K, and leaves P / dS in LDS; the block then contracts them with its 256 rows of
+// dO / q (dV = P^T dO, dK = scale dS^T q), one (which, key, channel) output per thread, and writes a partial per (sample, head, block).
+// small_attention_bwd_finish_kernel adds the block partials in block order.
+struct SmallAttnBwdParams {
+    const bf16_t* q; int ldq; const bf16_t* k; const bf16_t* v; int ldkv; const bf16_t* dout; int ldo;
+    bf16_t* dq; bf16_t* dk; bf16_t* dv; float* part;
+    int nq, nkv, H, nblk; float scale;
+};
+__global__ __launch_bounds__(256) void small_attention_bwd_kernel(SmallAttnBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    const int m = p.nkv, t = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+    float* Ks = (float*)smem_; float* Vs = Ks + m * 32;
+    float* Ps = Vs + m * 32; float* Ds = Ps + m * 256;                    // [m][256]: probabilities, then dS
+    bf16_t* qs = (bf16_t*)(Ds + m * 256); bf16_t* dos = qs + 256 * 32;     // [256][32] bf16 rows of q and dO
+    for (int i = t; i < m * 4; i += 256) {
+        const int j = i >> 2, c = (i & 3) * 8;
+        float kf[8], vf[8];
+        unpack8(*(const uint4*)(p.k + ((long long)b * m + j) * p.ldkv + h * 32 + c), kf);
+        unpack8(*(const uint4*)(p.v + ((long long)b * m + j) * p.ldkv + h * 32 + c), vf);
+#pragma unroll
+        for (int e = 0; e < 8; e++) { Ks[j * 32 + c + e] = kf[e]; Vs[j * 32 + c + e] = vf[e]; }
+    }
+    const int qi = blockIdx.x * 256 + t;
+    const bool on = qi < p.nq;
+    float qf[32], df[32];
+#pragma unroll
+    for (int c = 0; c < 32; c += 8) {
+        uint4 a = make_uint4(0, 0, 0, 0), d = a;
+        if (on) {
+            a = *(const uint4*)(p.q + ((long long)b * p.nq + qi) * p.ldq + h * 32 + c);
+            d = *(const uint4*)(p.dout + ((long long)b * p.nq + qi) * p.ldo + h * 32 + c);
+        }
+        *(uint4*)(qs + t * 32 + c) = a; *(uint4*)(dos + t * 32 + c) = d;
+        unpack8(a, qf + c); unpack8(d, df + c);
+    }
+    __syncthreads();
+    // probabilities of this row
+    float mx = -INFINITY;
+    for (int j = 0; j < m; j++) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; d++) s += qf[d] * Ks[j * 32 + d];
+        s *= p.scale;
+        Ps[j * 256 + t] = s; mx = fmaxf(mx, s);
+    }
+    float l = 0.f;
+    for (int j = 0; j < m; j++) { const float e = __expf(Ps[j * 256 + t] - mx); Ps[j * 256 + t] = e; l += e; }
+    const float inv = on ? 1.f / l : 0.f;
+    float delta = 0.f;
+    for (int j = 0; j < m; j++) {
+        const float pj = Ps[j * 256 + t] * inv;
+        float dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; d++) dp += df[d] * Vs[j * 32 + d];
+        Ps[j * 256 + t] = pj; Ds[j * 256 + t] = dp; delta += pj * dp;
+    }
+    float dq[32];
+#pragma unroll
+    for (int d = 0; d < 32; d++) dq[d] = 0.f;
+    for (int j = 0; j < m; j++) {
+        const float ds = Ps[j * 256 + t] * (Ds[j * 256 + t] - delta);
+        Ds[j * 256 + t] = ds;
+#pragma unroll
+        for (int d = 0; d < 32; d++) dq[d] += ds * Ks[j * 32 + d];
+    }
+    if (on) {
+        bf16_t* op = p.dq + ((long long)b * p.nq + qi) * (p.H * 32) + h * 32;
+#pragma unroll
+        for (int c = 0; c < 32; c += 8)
+            *(uint4*)(op + c) = make_uint4(cvt_pk_bf16(dq[c] * p.scale, dq[c + 1] * p.scale), cvt_pk_bf16(dq[c + 2] * p.scale, dq[c + 3] * p.scale),
+                                           cvt_pk_bf16(dq[c + 4] * p.scale, dq[c + 5] * p.scale), cvt_pk_bf16(dq[c + 6] * p.scale, dq[c + 7] * p.scale));
+    }
+    __syncthreads();
+    // dK[j][d] = scale sum_t dS[j][t] q[t][d],  dV[j][d] = sum_t P[j][t] dO[t][d]: one output per thread and pass, rows in thread order
+    float* part = p.part + (((long long)(b * p.H + h) * p.nblk + blockIdx.x) * 2) * m * 32;
+    for (int o = t; o < 2 * m * 32; o += 256) {
+        const int which = o / (m * 32), jd = o - which * m * 32, j = jd >> 5, d = jd & 31;
+        const float* A = (which ? Ps : Ds) + j * 256;
+        const bf16_t* X = (which ? dos : qs) + d;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 256; r++) acc += A[r] * bf2f(X[r * 32]);
+        part[o] = which ? acc : acc * p.scale;
+    }
+}
+__global__ __launch_bounds__(256) void small_attention_bwd_finish_kernel(SmallAttnBwdParams p) {
+    const int m = p.nkv, h = blockIdx.x, b = blockIdx.y;
+    const float* part = p.part + (long long)(b * p.H + h) * p.nblk * 2 * m * 32;
+    for (int o = threadIdx.x; o < 2 * m * 32; o += 256) {
+        float acc = 0.f;
+        for (int i = 0; i < p.nblk; i++) acc += part[(long long)i * 2 * m * 32 + o];
+        const int which = o / (m * 32), jd = o - which * m * 32, j = jd >> 5, d = jd & 31;
+        (which ? p.dv : p.dk)[((long long)b * m + j) * (p.H * 32) + h * 32 + d] = f2bf(acc);
+    }
+}
+size_t small_attention_bwd_scratch_bytes(int B, int heads, int nq, int nkv) { return (size_t)B * heads * ((nq + 255) / 256) * 2 * nkv * 32 * sizeof(float) + 256; }
+// q [B, nq, ldq], k / v [B, nkv, ldkv], dout [B, nq, ldo] (head h = columns [32 h, 32 h + 32)) -> dq [B, nq, 32 heads], dk / dv [B, nkv, 32 heads] bf16
+hipError_t launch_small_attention_bwd(const bf16_t* q, int ldq, const bf16_t* k, const bf16_t* v, int ldkv, const bf16_t* dout, int ldo, int B, int nq, int nkv,
+                                      int heads, float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv, char* scratch, hipStream_t st) {
+    if (nkv < 1 || nkv > 32 || ldq % 8 || ldkv % 8 || ldo % 8) return hipErrorInvalidValue;
+    SmallAttnBwdParams p{}; p.q = q; p.ldq = ldq; p.k = k; p.v = v; p.ldkv = ldkv; p.dout = dout; p.ldo = ldo; p.dq = dq; p.dk = dk; p.dv = dv;
+    p.part = (float*)scratch; p.nq = nq; p.nkv = nkv; p.H = heads; p.nblk = (nq + 255) / 256; p.scale = scale;
+    const size_t smem = (size_t)nkv * 64 * 4 + (size_t)nkv * 512 * 4 + 2 * 256 * 32 * 2;
+    static bool attr[RDM_MAX_DEVICES] = {};
+    const int dev = rdm_cur_device();
+    if (!attr[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)small_attention_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+        if (e != hipSuccess) return e;
+        attr[dev] = true;
+    }
+    small_attention_bwd_kernel<<<dim3(p.nblk, heads, B), 256, smem, st>>>(p);
+    small_attention_bwd_finish_kernel<<<dim3(heads, B), 256, 0, st>>>(p);
     return hipGetLastError();
 }

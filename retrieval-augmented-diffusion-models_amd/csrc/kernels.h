@@ -168,6 +168,9 @@ hipError_t launch_layernorm(const void* x, int in_is_f32, const float* gamma, co
                             int M, int C, float eps, hipStream_t st, int Clog = -1);   // Clog: logical width of zero-padded rows (statistics over Clog)
 hipError_t launch_flash_d32(const FlashParams& p, int heads, int batch, hipStream_t st);
 hipError_t launch_small_attention(const SmallAttnParams& p, int D, int heads, int batch, hipStream_t st);
+size_t small_attention_bwd_scratch_bytes(int B, int heads, int nq, int nkv);
+hipError_t launch_small_attention_bwd(const bf16_t* q, int ldq, const bf16_t* k, const bf16_t* v, int ldkv, const bf16_t* dout, int ldo, int B, int nq, int nkv,
+                                      int heads, float scale, bf16_t* dq, bf16_t* dk, bf16_t* dv, char* scratch, hipStream_t st);    // backward.hip: d_head 32, nkv <= 32
 hipError_t launch_conv_in(const float* x, const float* w, const float* bias, bf16_t* out, int B, int Cin, int H, int W,
                           int Cout, hipStream_t st);
 hipError_t launch_conv_out(const bf16_t* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin,

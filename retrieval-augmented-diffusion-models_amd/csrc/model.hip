@@ -2206,6 +2206,16 @@ int rdm_op_attention_bwd(rdm_ctx* c, const void* q, const void* k, const void* v
                                           (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, c->bwd_tmp, c->stream));
     return 0;
 }
+int rdm_op_small_attention_bwd(rdm_ctx* c, const void* q, int ldq, const void* k, const void* v, int ldkv, const void* dout, int ldo, int B, int nq, int nkv,
+                               int heads, float scale, void* dq, void* dk, void* dv) {
+    RDM_ENTER(c);
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || B < 1 || heads < 1 || nq < 1 || nkv < 1 || nkv > 32)
+        return c->fail(-1, "rdm_op_small_attention_bwd: bad argument (d_head = 32, 1..32 keys)");
+    RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, small_attention_bwd_scratch_bytes(B, heads, nq, nkv)));
+    RDM_CHECK_HIP(c, launch_small_attention_bwd((const bf16_t*)q, ldq, (const bf16_t*)k, (const bf16_t*)v, ldkv, (const bf16_t*)dout, ldo, B, nq, nkv, heads, scale,
+                                                (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, c->bwd_tmp, c->stream));
+    return 0;
+}
 int rdm_op_bmm(rdm_ctx* c, const void* a, const void* w, void* out_bf16, float* out_f32, int batch, int M, int N, int K, float alpha) {
     RDM_ENTER(c);
     if (!a || !w || (!out_bf16 && !out_f32) || batch < 1 || M < 1 || N < 2 || K < 64 || K % 64 || N % 2)

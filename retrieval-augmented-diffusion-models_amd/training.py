@@ -133,6 +133,11 @@ def attention_forward(ctx, q, k, v, heads):
         # the kernel's LDS reads); the fused backward needs only q, k, v, the output and its gradient
         out = ctx.op_self_attention_qkv(torch.cat([q, k, v], dim=-1), heads)
         return out, {"o": out}
+    if d == 32 and m <= 32 and not _UNFUSED_ATTENTION_BWD:
+        # cross-attention on a handful of conditioning tokens: one thread per query row, K / V in LDS (the sampling path's kernel); the
+        # backward recomputes the probabilities from q and K
+        out = ctx.op_small_attention(q.contiguous(), k.contiguous(), v.contiguous(), heads, 32, False, scale)
+        return out, {"small": True}
     k, v = _pad_keys(k), _pad_keys(v)                                                   # key count -> multiple of 64 (a GEMM K unit); padding gets probability 0
     qp, kp = ctx.op_heads(q, heads, d, 0), ctx.op_heads(k, heads, d, 0)                # [BH, n|mp, 64]
     vt = ctx.op_heads(v, heads, d, 1)                                                   # [BH, 64, mp]
@@ -150,6 +155,9 @@ def attention_backward(ctx, q, k, v, heads, saved, dout):
     scale = d ** -0.5
     if d == 32 and n % 32 == 0 and k.shape[1] % 32 == 0 and "o" in saved and not _UNFUSED_ATTENTION_BWD:
         dq, dk, dv = ctx.op_attention_bwd(q.contiguous(), k.contiguous(), v.contiguous(), saved["o"], dout.contiguous(), heads)     # fused: no score matrix
+        return {"q": dq, "k": dk, "v": dv}
+    if saved.get("small"):
+        dq, dk, dv = ctx.op_small_attention_bwd(q.contiguous(), k.contiguous(), v.contiguous(), dout.contiguous(), heads, scale)
         return {"q": dq, "k": dk, "v": dv}
     p, k, v, m = saved["p"], saved["kpad"], saved["vpad"], saved["m"]
     dop, dot_ = ctx.op_heads(dout, heads, d, 0), ctx.op_heads(dout, heads, d, 1)        # [BH, n, 64], [BH, 64, n]

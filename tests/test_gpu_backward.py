@@ -178,7 +178,7 @@ def test_feed_forward_block_backward(ctx, M, C):
     assert max(errs.values()) <= TOL
 
 
-@pytest.mark.parametrize("B,n,m,heads,d", [(2, 256, 256, 6, 32), (3, 64, 64, 4, 32), (2, 128, 64, 2, 64)])
+@pytest.mark.parametrize("B,n,m,heads,d", [(2, 256, 256, 6, 32), (3, 64, 64, 4, 32), (2, 128, 64, 2, 64), (3, 1024, 4, 12, 32), (2, 300, 20, 6, 32), (2, 64, 32, 3, 32)])
 def test_attention_forward_backward(ctx, B, n, m, heads, d):
     """softmax(q k^T / sqrt(d)) v per head (ldm CrossAttention core, self- and cross-shaped): output and dq / dk / dv vs autograd."""
     from rdm_amd import training
