@@ -24,10 +24,13 @@ def _rand(shape, seed, scale=1.0):
     return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
 
 
-@pytest.mark.parametrize("B,H,W,C,N", [(2, 64, 64, 192, 384), (3, 8, 32, 224, 96), (5, 16, 8, 64, 576)])
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 64, 64, 192, 384), (3, 8, 32, 224, 96), (5, 16, 8, 64, 576), (3, 32, 32, 128, 64), (5, 16, 16, 64, 128),
+                                       (2, 8, 64, 64, 64), (4, 16, 16, 576, 576), (1, 2, 16, 64, 64), (9, 4, 32, 192, 64)])
 def test_conv3x3_wgrad_tn(ctx, B, H, W, C, N):
-    """The transpose-free wgrad kernel (csrc/wgrad.hip): row splits with the XCD queueing (first case: 24 planes) and without, rectangular
-    images, partial 192-wide tiles, a row count that is not a multiple of the chunk -- against the fp32 autograd of the same bf16 operands."""
+    """The transpose-free wgrad kernels (csrc/wgrad.hip): the nine-tap kernel at widths 64 / 32 / 16 (row ring across sample boundaries:
+    blocks spanning several samples in the 576-channel case, a two-row image, odd sample counts) and the per-tap kernel (widths that are
+    not multiples of 64 channels, 8-pixel rows, partial 192-wide tiles, ragged row counts) -- against the fp32 autograd of the same bf16
+    operands."""
     d = ctx.device
     x = bf16_round(_rand((B, H, W, C), 11))
     w = torch.zeros((N, C, 3, 3), requires_grad=True)
