@@ -1132,6 +1132,41 @@ hipError_t launch_scale_f32(float* x, long long n, float s, hipStream_t st) {
 
 // per-sample column sums of a bf16 [B, HW, N] tensor -> bf16 [B, N] (the gradient of the time-embedding row a ResBlock adds to every
 // pixel of a sample: h = conv(.) + emb_out[b]): one block per (sample, 64 columns), fixed-order tree over the pixels
+// two stages like launch_colsum, per sample: 16-byte loads over (pixel chunk, column block, sample), then the chunk partials in chunk order
+__global__ __launch_bounds__(256) void colsum_samples_part_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, int HW, int N, int CS, int VCB) {
+    __shared__ float red[2048];
+    const int RL = 256 / VCB;
+    const int cv = threadIdx.x % VCB, rl = threadIdx.x / VCB, b = blockIdx.z;
+    const int v = blockIdx.y * VCB + cv;
+    const int r0 = blockIdx.x * CS, r1 = min(HW, r0 + CS);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (rl < RL && v * 8 < N) {
+        const bf16_t* xb = x + (long long)b * HW * N + v * 8;
+        for (int m = r0 + rl; m < r1; m += RL) {
+            float f[8]; unpack8(*(const uint4*)(xb + (long long)m * N), f);
+#pragma unroll
+            for (int e = 0; e < 8; e++) s[e] += f[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) red[(e * RL + rl) * VCB + cv] = s[e];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < VCB * 8; idx += 256) {
+        const int e = idx / VCB, vv = idx - e * VCB, col = (blockIdx.y * VCB + vv) * 8 + e;
+        if (col < N) {
+            float t = 0.f;
+            for (int r = 0; r < RL; r++) t += red[(e * RL + r) * VCB + vv];
+            part[((long long)b * gridDim.x + blockIdx.x) * N + col] = t;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void colsum_samples_finish_kernel(const float* __restrict__ part, bf16_t* __restrict__ out, int nchunk, int N) {
+    const int b = blockIdx.y, col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= N) return;
+    float t = 0.f;
+    for (int c = 0; c < nchunk; c++) t += part[((long long)b * nchunk + c) * N + col];
+    out[(long long)b * N + col] = f2bf(t);
+}
 __global__ __launch_bounds__(256) void colsum_samples_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int HW, int N) {
     __shared__ float red[4][64];
     const int b = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
@@ -1141,8 +1176,17 @@ __global__ __launch_bounds__(256) void colsum_samples_kernel(const bf16_t* __res
     __syncthreads();
     if (part == 0 && col < N) out[(long long)b * N + col] = f2bf((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
-hipError_t launch_colsum_samples(const bf16_t* x, bf16_t* out, int B, int HW, int N, hipStream_t st) {
-    colsum_samples_kernel<<<dim3((N + 63) / 64, B), 256, 0, st>>>(x, out, HW, N);
+static int colsum_samples_nchunk(int B, int HW) { int n = 1024 / (B > 0 ? B : 1); if (n > HW / 64) n = HW / 64; if (n > 32) n = 32; if (n < 1) n = 1; return n; }
+size_t colsum_samples_scratch_bytes(int B, int HW, int N) { return (size_t)B * colsum_samples_nchunk(B, HW) * N * sizeof(float) + 256; }
+hipError_t launch_colsum_samples(const bf16_t* x, bf16_t* out, int B, int HW, int N, hipStream_t st, float* scratch) {
+    if (!scratch || N % 8 || HW < 64) {
+        colsum_samples_kernel<<<dim3((N + 63) / 64, B), 256, 0, st>>>(x, out, HW, N);
+        return hipGetLastError();
+    }
+    const int nchunk = colsum_samples_nchunk(B, HW), CS = (HW + nchunk - 1) / nchunk;
+    const int nv = N / 8, colblocks = (nv + 31) / 32, VCB = (nv + colblocks - 1) / colblocks;
+    colsum_samples_part_kernel<<<dim3(nchunk, colblocks, B), 256, 0, st>>>(x, scratch, HW, N, CS, VCB);
+    colsum_samples_finish_kernel<<<dim3((N + 255) / 256, B), 256, 0, st>>>(scratch, out, nchunk, N);
     return hipGetLastError();
 }
 

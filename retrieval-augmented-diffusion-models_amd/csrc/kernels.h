@@ -187,7 +187,8 @@ hipError_t launch_q_sample(const float* x0, const float* noise, const float* a, 
 hipError_t launch_mse_loss(const bf16_t* eps, const float* target, const float* coef, float* se, bf16_t* deps, int B, int C, int HW, int ldc, hipStream_t st);
 hipError_t launch_where_rows(const unsigned char* mask, const float* a, const float* x, float* out, long long rows, long long n, hipStream_t st);
 hipError_t launch_scale_f32(float* x, long long n, float s, hipStream_t st);
-hipError_t launch_colsum_samples(const bf16_t* x, bf16_t* out, int B, int HW, int N, hipStream_t st);
+size_t colsum_samples_scratch_bytes(int B, int HW, int N);
+hipError_t launch_colsum_samples(const bf16_t* x, bf16_t* out, int B, int HW, int N, hipStream_t st, float* scratch = nullptr);
 hipError_t launch_expand2(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, int mode, hipStream_t st);
 hipError_t launch_sumpool2(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t st);
 // fused attention backward, d_head = 32 (backward.hip): no score matrix in memory

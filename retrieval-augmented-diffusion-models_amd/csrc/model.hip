@@ -2174,7 +2174,8 @@ int rdm_op_timestep_embedding(rdm_ctx* c, const int64_t* t, void* out_bf16, int 
 int rdm_op_colsum_samples(rdm_ctx* c, const void* x, void* out, int B, int HW, int N) {
     RDM_ENTER(c);
     if (!x || !out || B < 1 || HW < 1 || N < 1) return c->fail(-1, "rdm_op_colsum_samples: bad argument");
-    RDM_CHECK_HIP(c, launch_colsum_samples((const bf16_t*)x, (bf16_t*)out, B, HW, N, c->stream));
+    RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, colsum_samples_scratch_bytes(B, HW, N)));
+    RDM_CHECK_HIP(c, launch_colsum_samples((const bf16_t*)x, (bf16_t*)out, B, HW, N, c->stream, (float*)c->bwd_tmp));
     return 0;
 }
 int rdm_op_expand2(rdm_ctx* c, const void* x, void* out, int B, int H, int W, int C, int mode) {

@@ -82,6 +82,9 @@ def test_training_glue_ops(ctx):
     xs = bf16_round(_rand((B, 40, 192), 8)).to(d, torch.bfloat16)
     cs = ctx.op_colsum_samples(xs)
     assert (cs.float() - xs.float().sum(1)).abs().max().item() <= 2 ** -7 * float(xs.float().sum(1).abs().max())
+    xl = bf16_round(_rand((3, 1000, 320), 18)).to(d, torch.bfloat16)           # the two-stage path: ragged pixel chunks, two column blocks
+    cl = ctx.op_colsum_samples(xl)
+    assert (cl.float() - xl.float().sum(1)).abs().max().item() <= 2 ** -7 * float(xl.float().sum(1).abs().max())
     xe = bf16_round(_rand((2, 3, 5, 64), 9)).to(d, torch.bfloat16)
     z0, z1 = ctx.op_expand2(xe, 0), ctx.op_expand2(xe, 1)
     ref0 = torch.zeros((2, 6, 10, 64), device=d, dtype=torch.bfloat16); ref0[:, ::2, ::2] = xe
