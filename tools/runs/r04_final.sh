@@ -11,6 +11,9 @@ for c in 2 4; do timeout 900 python bench.py --config $c --no-cpu-baseline > "$O
 for b in 64 256; do timeout 600 python bench.py --config 5 --batch $b --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_config5_batch$b.json" 2> "$OUT/bench_config5_batch$b.err"; done
 timeout 1500 python bench.py --steps 3 --warmup 1 --full-cpu-baseline > "$OUT/bench_full_cpu_baseline.json" 2> "$OUT/bench_full_cpu_baseline.err"
 timeout 600 python tools/train_step_bench.py 64 4 > "$OUT/train_step_b64.log" 2>&1
+timeout 600 python tools/wgrad_bench.py > "$OUT/wgrad_shapes.log" 2>&1
+(cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_trace" -- python3 "$REPO/tools/train_step_bench.py" 64 3 > "$OUT/train_trace.log" 2>&1)
+python3 "$REPO/tools/pmc_sum.py" stats "$OUT/train_step_kernel_stats.csv" "$OUT/train_trace"; rm -rf "$OUT/train_trace"
 python - <<PY
 import json, glob
 for f in sorted(glob.glob("$OUT/bench*.json")):
