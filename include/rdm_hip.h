@@ -273,6 +273,12 @@ int rdm_op_groupnorm_bwd(rdm_ctx* ctx, const void* x_bf16, const void* dy_bf16, 
                          float eps, int silu, void* dx_bf16, float* dgamma, float* dbeta);
 int rdm_op_layernorm_bwd(rdm_ctx* ctx, const void* x_bf16, const void* dy_bf16, const float* gamma, int M, int C, float eps, void* dx_bf16,
                          float* dgamma, float* dbeta);
+/* The same two with the gradient of a residual path joined in the kernel: dx = (norm gradient) + residual (bf16, dx's shape; one rounding).
+ * Where autograd adds the branch's gradient to the skip connection's (x + f(norm(x)) in ResBlock / BasicTransformerBlock). */
+int rdm_op_groupnorm_bwd_add(rdm_ctx* ctx, const void* x_bf16, const void* dy_bf16, const float* gamma, const float* beta, int B, int HW, int C,
+                             float eps, int silu, const void* residual_bf16, void* dx_bf16, float* dgamma, float* dbeta);
+int rdm_op_layernorm_bwd_add(rdm_ctx* ctx, const void* x_bf16, const void* dy_bf16, const float* gamma, int M, int C, float eps,
+                             const void* residual_bf16, void* dx_bf16, float* dgamma, float* dbeta);
 /* nn.Linear weight gradient dW [N, K] fp32 = dy^T a for dy [M, N], a [M, K] bf16 (autograd of F.linear in the training step): K-split
  * over the M rows, deterministic fixed-order sum of the fp32 partial planes. */
 int rdm_op_linear_wgrad(rdm_ctx* ctx, const void* dy_bf16, const void* a_bf16, float* dw, long long M, int N, int K);

@@ -127,6 +127,8 @@ SIGNATURES = {
     "rdm_op_conv3x3_wgrad": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rdm_op_groupnorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P, _P, _P]),
     "rdm_op_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P]),
+    "rdm_op_groupnorm_bwd_add": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P, _P, _P, _P]),
+    "rdm_op_layernorm_bwd_add": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P]),
     "rdm_op_colsum": (C.c_int, [_P, _P, _P, C.c_longlong, C.c_int]),
     "rdm_op_transpose": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "rdm_op_add": (C.c_int, [_P, _P, _P, _P, C.c_longlong]),
@@ -685,16 +687,20 @@ class Context:
         self._check(lib.rdm_op_conv3x3_wgrad(self._h, _ptr(x), _ptr(dy), _ptr(dw), B, H, W, Cc, N))
         return dw
 
-    def op_groupnorm_bwd(self, x, dy, gamma, beta, eps, silu):
+    def op_groupnorm_bwd(self, x, dy, gamma, beta, eps, silu, residual=None):
+        """-> dx (+ residual when given: the skip path's gradient joins inside the kernel), dgamma, dbeta."""
         B, HW, Cc = x.shape
         dx = torch.empty_like(x); dg = torch.empty((Cc,), device=self.device, dtype=torch.float32); db = torch.empty_like(dg)
-        self._check(lib.rdm_op_groupnorm_bwd(self._h, _ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), B, HW, Cc, float(eps), int(silu), _ptr(dx), _ptr(dg), _ptr(db)))
+        assert residual is None or (residual.is_contiguous() and residual.numel() == x.numel())
+        self._check(lib.rdm_op_groupnorm_bwd_add(self._h, _ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), B, HW, Cc, float(eps), int(silu), _ptr(residual),
+                                                 _ptr(dx), _ptr(dg), _ptr(db)))
         return dx, dg, db
 
-    def op_layernorm_bwd(self, x, dy, gamma, eps=1e-5):
+    def op_layernorm_bwd(self, x, dy, gamma, eps=1e-5, residual=None):
         M, Cc = x.shape
         dx = torch.empty_like(x); dg = torch.empty((Cc,), device=self.device, dtype=torch.float32); db = torch.empty_like(dg)
-        self._check(lib.rdm_op_layernorm_bwd(self._h, _ptr(x), _ptr(dy), _ptr(gamma), M, Cc, float(eps), _ptr(dx), _ptr(dg), _ptr(db)))
+        assert residual is None or (residual.is_contiguous() and residual.numel() == x.numel())
+        self._check(lib.rdm_op_layernorm_bwd_add(self._h, _ptr(x), _ptr(dy), _ptr(gamma), M, Cc, float(eps), _ptr(residual), _ptr(dx), _ptr(dg), _ptr(db)))
         return dx, dg, db
 
     def op_colsum(self, x):

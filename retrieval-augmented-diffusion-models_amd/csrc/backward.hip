@@ -346,6 +346,7 @@ struct GnBwd2 {
     const bf16_t* x; const bf16_t* dy; const float* gamma; const float* beta;
     int B, HW, C, groups, silu, nchunk; float eps;
     const float* fpart; float* cpart; float* stats; float* part_g; float* part_b; bf16_t* dx;
+    const bf16_t* res;              // optional: dx = gradient + res (the residual path's gradient joins here instead of in a separate add pass)
 };
 __device__ __forceinline__ float silu_grad_f(float z) { const float sg = 1.f / (1.f + __expf(-z)); return sg * (1.f + z * (1.f - sg)); }
 __device__ __forceinline__ void unpack8(const uint4 d, float* f) {
@@ -467,6 +468,11 @@ __global__ void gn_bwd_apply2_kernel(GnBwd2 p) {
             if (p.silu) dz *= silu_grad_f(xh * ga[e] + be[e]);
             o[e] = dz * c1[e] - c2[e] - xh * c3[e];
         }
+        if (p.res) {
+            float rf[8]; unpack8(*(const uint4*)(p.res + base + (long long)row * C), rf);
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] += rf[e];
+        }
         *(uint4*)(p.dx + base + (long long)row * C) = make_uint4(cvt_pk_bf16(o[0], o[1]), cvt_pk_bf16(o[2], o[3]), cvt_pk_bf16(o[4], o[5]), cvt_pk_bf16(o[6], o[7]));
     }
 }
@@ -481,13 +487,13 @@ size_t groupnorm_bwd_scratch_bytes(int B, int HW, int C, int groups) {
 }
 hipError_t launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* beta, int B, int HW, int C, int groups,
                                 float eps, int silu, float* scratch /* groupnorm_bwd_scratch_bytes */, bf16_t* dx, float* dgamma, float* dbeta,
-                                hipStream_t st) {
+                                hipStream_t st, const bf16_t* residual) {
     GnBwdParams p{}; p.x = x; p.dy = dy; p.gamma = gamma; p.beta = beta; p.B = B; p.HW = HW; p.C = C; p.groups = groups; p.silu = silu; p.eps = eps;
     p.stats = scratch; p.part_g = scratch + (size_t)B * groups * 4; p.part_b = p.part_g + (size_t)B * C; p.dx = dx; p.dgamma = dgamma; p.dbeta = dbeta;
     if (gn_bwd_vec_ok(C, groups)) {
         GnBwd2 q{}; q.x = x; q.dy = dy; q.gamma = gamma; q.beta = beta; q.B = B; q.HW = HW; q.C = C; q.groups = groups; q.silu = silu; q.eps = eps;
         q.nchunk = gn_bwd_nchunk(B, HW);
-        q.stats = p.stats; q.part_g = p.part_g; q.part_b = p.part_b; q.dx = dx;
+        q.stats = p.stats; q.part_g = p.part_g; q.part_b = p.part_b; q.dx = dx; q.res = residual;
         float* fpart = p.part_b + (size_t)B * C;
         q.fpart = fpart; q.cpart = fpart + (size_t)B * q.nchunk * groups * 2;
         GnParams f{}; f.x0 = x; f.C0 = C; f.HW = HW; f.B = B; f.groups = groups; f.nchunk = q.nchunk; f.partial = fpart; f.eps = eps;
@@ -504,6 +510,7 @@ hipError_t launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* 
     gn_bwd_stats_kernel<<<B * groups, 256, 0, st>>>(p);
     gn_bwd_apply_kernel<<<B * ((C + 63) / 64), 256, 0, st>>>(p);
     gn_bwd_affine_kernel<<<(C + 63) / 64, 256, 0, st>>>(p);
+    if (residual) return launch_add_bf16(dx, residual, dx, (long long)B * HW * C, st);
     return hipGetLastError();
 }
 
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(256) void ln_bwd_affine_kernel(const float* part_g,
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const float* __restrict__ gamma,
                                                          int M, int C, float eps, bf16_t* __restrict__ dx, float* __restrict__ part_g,
-                                                         float* __restrict__ part_b, int rows_per_block) {
+                                                         float* __restrict__ part_b, int rows_per_block, const bf16_t* __restrict__ res) {
     extern __shared__ float acc[];                      // [4 waves][2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, VC = C >> 3;
     float ga[NV][8], ag[NV][8], ab[NV][8];
@@ -600,6 +607,11 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const bf16_t* __restric
                 o[e] = rstd * (df[j][e] * ga[j][e] - s1 - xf[j][e] * s2);
                 ag[j][e] += df[j][e] * xf[j][e]; ab[j][e] += df[j][e];
             }
+            if (on[j] && res) {
+                float rf[8]; unpack8(*(const uint4*)(res + (long long)r * C + (lane + 64 * j) * 8), rf);
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] += rf[e];
+            }
             if (on[j])
                 *(uint4*)(dx + (long long)r * C + (lane + 64 * j) * 8) = make_uint4(cvt_pk_bf16(o[0], o[1]), cvt_pk_bf16(o[2], o[3]), cvt_pk_bf16(o[4], o[5]), cvt_pk_bf16(o[6], o[7]));
         }
@@ -629,20 +641,21 @@ __global__ __launch_bounds__(256) void ln_bwd_affine4_kernel(const float* part_g
     if (q == 0 && c < C) { dgamma[c] = tree16(&rg[0][cl], 16); dbeta[c] = tree16(&rb[0][cl], 16); }
 }
 hipError_t launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, int M, int C, float eps, float* scratch /* 2*nb*C */,
-                                int* nb_out, bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st) {
+                                int* nb_out, bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st, const bf16_t* residual) {
     const int rows_per_block = M >= 16384 ? 64 : 16;      // nb <= M / 16: the scratch contract of the callers (2 * ceil(M / 16) * C floats)
     const int nb = (M + rows_per_block - 1) / rows_per_block;
     if (nb_out) *nb_out = nb;
     float* pg = scratch; float* pb = scratch + (size_t)nb * C;
     static const bool novec = getenv("RDM_NO_LN_BWD_VEC") != nullptr;
     if (!novec && C % 8 == 0 && C <= 1024) {
-        if (C <= 512) ln_bwd_vec_kernel<1><<<nb, 256, (size_t)8 * C * sizeof(float), st>>>(x, dy, gamma, M, C, eps, dx, pg, pb, rows_per_block);
-        else ln_bwd_vec_kernel<2><<<nb, 256, (size_t)8 * C * sizeof(float), st>>>(x, dy, gamma, M, C, eps, dx, pg, pb, rows_per_block);
+        if (C <= 512) ln_bwd_vec_kernel<1><<<nb, 256, (size_t)8 * C * sizeof(float), st>>>(x, dy, gamma, M, C, eps, dx, pg, pb, rows_per_block, residual);
+        else ln_bwd_vec_kernel<2><<<nb, 256, (size_t)8 * C * sizeof(float), st>>>(x, dy, gamma, M, C, eps, dx, pg, pb, rows_per_block, residual);
         ln_bwd_affine4_kernel<<<(C + 15) / 16, 256, 0, st>>>(pg, pb, nb, C, dgamma, dbeta);
         return hipGetLastError();
     }
     ln_bwd_kernel<<<nb, 256, (size_t)8 * C * sizeof(float), st>>>(x, dy, gamma, M, C, eps, dx, pg, pb, rows_per_block);
     ln_bwd_affine_kernel<<<(C + 255) / 256, 256, 0, st>>>(pg, pb, nb, C, dgamma, dbeta);
+    if (residual) return launch_add_bf16(dx, residual, dx, (long long)M * C, st);
     return hipGetLastError();
 }
 

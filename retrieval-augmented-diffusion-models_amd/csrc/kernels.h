@@ -160,9 +160,9 @@ hipError_t launch_wgrad_tn(const bf16_t* dy, int lda, const bf16_t* x, int ldb, 
 hipError_t launch_linear_wgrad(const bf16_t* dy, const bf16_t* a, float* dw, long long M, int N, int K, char* scratch, const void* zero_page, hipStream_t st);
 size_t groupnorm_bwd_scratch_bytes(int B, int HW, int C, int groups);
 hipError_t launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* beta, int B, int HW, int C, int groups,
-                                float eps, int silu, float* scratch, bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st);
+                                float eps, int silu, float* scratch, bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st, const bf16_t* residual = nullptr);    // residual: dx = gradient + residual
 hipError_t launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, int M, int C, float eps, float* scratch, int* nb_out,
-                                bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st);
+                                bf16_t* dx, float* dgamma, float* dbeta, hipStream_t st, const bf16_t* residual = nullptr);
 hipError_t launch_groupnorm(GnParams p, hipStream_t st);
 hipError_t launch_layernorm(const void* x, int in_is_f32, const float* gamma, const float* beta, void* out, int out_is_f32,
                             int M, int C, float eps, hipStream_t st, int Clog = -1);   // Clog: logical width of zero-padded rows (statistics over Clog)

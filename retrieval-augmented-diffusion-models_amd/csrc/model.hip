@@ -2086,22 +2086,30 @@ int rdm_op_conv3x3_wgrad(rdm_ctx* c, const void* x, const void* dy, float* dw, i
     RDM_CHECK_HIP(c, launch_conv_wgrad((const bf16_t*)x, (const bf16_t*)dy, dw, B, H, W, C, N, c->bwd_tmp, c->zero_page, c->stream));
     return 0;
 }
-int rdm_op_groupnorm_bwd(rdm_ctx* c, const void* x, const void* dy, const float* gamma, const float* beta, int B, int HW, int C, float eps, int silu,
-                         void* dx, float* dgamma, float* dbeta) {
+int rdm_op_groupnorm_bwd_add(rdm_ctx* c, const void* x, const void* dy, const float* gamma, const float* beta, int B, int HW, int C, float eps, int silu,
+                             const void* residual, void* dx, float* dgamma, float* dbeta) {
     RDM_ENTER(c);
     if (!x || !dy || !gamma || !beta || !dx || !dgamma || !dbeta || C % 32) return c->fail(-1, "rdm_op_groupnorm_bwd: bad arguments");
     RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, groupnorm_bwd_scratch_bytes(B, HW, C, 32)));
     RDM_CHECK_HIP(c, launch_groupnorm_bwd((const bf16_t*)x, (const bf16_t*)dy, gamma, beta, B, HW, C, 32, eps, silu, (float*)c->bwd_tmp, (bf16_t*)dx,
-                                          dgamma, dbeta, c->stream));
+                                          dgamma, dbeta, c->stream, (const bf16_t*)residual));
     return 0;
 }
-int rdm_op_layernorm_bwd(rdm_ctx* c, const void* x, const void* dy, const float* gamma, int M, int C, float eps, void* dx, float* dgamma, float* dbeta) {
+int rdm_op_groupnorm_bwd(rdm_ctx* c, const void* x, const void* dy, const float* gamma, const float* beta, int B, int HW, int C, float eps, int silu,
+                         void* dx, float* dgamma, float* dbeta) {
+    return rdm_op_groupnorm_bwd_add(c, x, dy, gamma, beta, B, HW, C, eps, silu, nullptr, dx, dgamma, dbeta);
+}
+int rdm_op_layernorm_bwd_add(rdm_ctx* c, const void* x, const void* dy, const float* gamma, int M, int C, float eps, const void* residual, void* dx,
+                             float* dgamma, float* dbeta) {
     RDM_ENTER(c);
     if (!x || !dy || !gamma || !dx || !dgamma || !dbeta) return c->fail(-1, "rdm_op_layernorm_bwd: null argument");
     RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, (size_t)2 * ((M + 15) / 16) * C * 4));
     RDM_CHECK_HIP(c, launch_layernorm_bwd((const bf16_t*)x, (const bf16_t*)dy, gamma, M, C, eps, (float*)c->bwd_tmp, nullptr, (bf16_t*)dx, dgamma, dbeta,
-                                          c->stream));
+                                          c->stream, (const bf16_t*)residual));
     return 0;
+}
+int rdm_op_layernorm_bwd(rdm_ctx* c, const void* x, const void* dy, const float* gamma, int M, int C, float eps, void* dx, float* dgamma, float* dbeta) {
+    return rdm_op_layernorm_bwd_add(c, x, dy, gamma, M, C, eps, nullptr, dx, dgamma, dbeta);
 }
 int rdm_op_linear_wgrad(rdm_ctx* c, const void* dy, const void* a, float* dw, long long M, int N, int K) {
     RDM_ENTER(c);

@@ -43,9 +43,10 @@ def _pad_keys(t, mult=64):
     return out
 
 
-def linear_backward(ctx, a, w, dy, bias=True):
-    """y = a w^T + b  (a [M,K], w [N,K], dy [M,N], all bf16)  ->  da bf16 [M,K], dw f32 [N,K], db f32 [N] (None for bias=False)."""
-    da = ctx.op_linear(dy, ctx.op_transpose(w))                                        # dy [M,N] . (w^T)^T
+def linear_backward(ctx, a, w, dy, bias=True, acc=None):
+    """y = a w^T + b  (a [M,K], w [N,K], dy [M,N], all bf16)  ->  da bf16 [M,K] (+ acc when given: another path's gradient w.r.t. the same
+    input joins in the GEMM's read-out), dw f32 [N,K], db f32 [N] (None for bias=False)."""
+    da = ctx.op_linear(dy, ctx.op_transpose(w), residual=acc)                          # dy [M,N] . (w^T)^T
     dw = ctx.op_linear_wgrad(dy, a)                                                    # dy^T a, K-split over the M rows
     return da, dw, (ctx.op_colsum(dy) if bias else None)
 
@@ -87,14 +88,15 @@ def resblock_backward(ctx, p, x, semb, saved, dout):
     demb = ctx.op_colsum_samples(dh1.reshape(B, HW, Cout))                             # [B, Cout]: sum over a sample's pixels, one launch
     g["dsemb"], g["emb_w"], g["emb_b"] = linear_backward(ctx, semb, p["emb_w"], demb)
     dn1 = ctx.op_conv3x3_dgrad(dh1, p["w1"])
-    # n1 = silu(gn1(x))
-    dx, g["gn1_g"], g["gn1_b"] = ctx.op_groupnorm_bwd(x.reshape(B, HW, Cin), dn1.reshape(B, HW, Cin), p["gn1_g"], p["gn1_b"], 1e-5, 1)
-    # skip path
+    # skip path first: its gradient joins the GroupNorm gradient inside the GroupNorm backward kernel
     if "skip_w" in p:
         dxs, g["skip_w"], g["skip_b"] = linear_backward(ctx, x.reshape(M, Cin), p["skip_w"], dflat)
     else:
         dxs = dflat
-    g["dx"] = ctx.op_add(dx.reshape(M, Cin), dxs.reshape(M, Cin)).reshape(B, H, W, Cin)
+    # n1 = silu(gn1(x))
+    dx, g["gn1_g"], g["gn1_b"] = ctx.op_groupnorm_bwd(x.reshape(B, HW, Cin), dn1.reshape(B, HW, Cin), p["gn1_g"], p["gn1_b"], 1e-5, 1,
+                                                      residual=dxs.reshape(B, HW, Cin).contiguous())
+    g["dx"] = dx.reshape(B, H, W, Cin)
     return g
 
 
@@ -116,8 +118,7 @@ def ff_backward(ctx, p, x, saved, dout):
     dh, g["w2"], g["b2"] = linear_backward(ctx, saved["h"], p["w2"], dout)              # out = h w2^T + b2 (+ x)
     dpre = ctx.op_geglu(saved["pre"], dh)                                               # [da | dg]
     dln, g["w1"], g["b1"] = linear_backward(ctx, saved["ln"], p["w1"], dpre)
-    dx_ln, g["ln_g"], g["ln_b"] = ctx.op_layernorm_bwd(x, dln, p["ln_g"])
-    g["x"] = ctx.op_add(dx_ln, dout)                                                    # + the residual path
+    g["x"], g["ln_g"], g["ln_b"] = ctx.op_layernorm_bwd(x, dln, p["ln_g"], residual=dout.contiguous())      # + the residual path, in the kernel
     return g
 
 
@@ -197,16 +198,16 @@ def attn_block_backward(ctx, p, x, saved, dout, context=None):
     d = attention_backward(ctx, saved["q"], saved["k"], saved["v"], p["heads"], saved, datt.reshape(B, n, C))
     c = saved["ln"] if context is None else context.reshape(-1, context.shape[-1])
     m = saved["k"].shape[1]
+    # the three projections' input gradients accumulate through the GEMMs' residual input (self-attention: all three read norm(x))
     dln, g["wq"], _ = linear_backward(ctx, saved["ln"], p["wq"], d["q"].reshape(B * n, C), bias=False)
-    dck, g["wk"], _ = linear_backward(ctx, c, p["wk"], d["k"].reshape(B * m, C), bias=False)
-    dcv, g["wv"], _ = linear_backward(ctx, c, p["wv"], d["v"].reshape(B * m, C), bias=False)
-    dc = ctx.op_add(dck, dcv)
+    dck, g["wk"], _ = linear_backward(ctx, c, p["wk"], d["k"].reshape(B * m, C), bias=False, acc=dln if context is None else None)
+    dc, g["wv"], _ = linear_backward(ctx, c, p["wv"], d["v"].reshape(B * m, C), bias=False, acc=dck)
     if context is None:
-        dln = ctx.op_add(dln, dc)
+        dln = dc
     else:
         g["context"] = dc.reshape(context.shape)
-    dx_ln, g["ln_g"], g["ln_b"] = ctx.op_layernorm_bwd(x.reshape(B * n, C), dln, p["ln_g"])
-    g["x"] = ctx.op_add(dx_ln, dflat).reshape(B, n, C)
+    dx, g["ln_g"], g["ln_b"] = ctx.op_layernorm_bwd(x.reshape(B * n, C), dln, p["ln_g"], residual=dflat.contiguous())
+    g["x"] = dx.reshape(B, n, C)
     return g
 
 
@@ -248,8 +249,9 @@ def spatial_transformer_backward(ctx, p, x, context, saved, dout):
     dhb, g["wout"], g["bout"] = linear_backward(ctx, saved["hb"].reshape(B * n, C), p["wout"], dflat)
     gb = transformer_block_backward(ctx, p["block"], saved["h"], context, saved["block"], dhb.reshape(B, n, C))
     dxn, g["win"], g["bin"] = linear_backward(ctx, saved["xn"].reshape(B * n, C), p["win"], gb["x"].reshape(B * n, C))
-    dx_gn, g["gn_g"], g["gn_b"] = ctx.op_groupnorm_bwd(x.reshape(B, n, C), dxn.reshape(B, n, C), p["gn_g"], p["gn_b"], 1e-6, 0)
-    g["x"] = ctx.op_add(dx_gn.reshape(B * n, C), dflat).reshape(B, H, W, C)
+    dx_gn, g["gn_g"], g["gn_b"] = ctx.op_groupnorm_bwd(x.reshape(B, n, C), dxn.reshape(B, n, C), p["gn_g"], p["gn_b"], 1e-6, 0,
+                                                        residual=dflat.reshape(B, n, C).contiguous())
+    g["x"] = dx_gn.reshape(B, H, W, C)
     g["context"] = gb["context"]
     g["block"] = gb
     return g
