@@ -315,6 +315,11 @@ int rdm_op_ema(rdm_ctx* ctx, float* shadow, const float* param, long long n, flo
  * the bf16 working copy the kernels read.  step counts from 1. */
 int rdm_op_adamw(rdm_ctx* ctx, float* p, const float* grad, float* exp_avg, float* exp_avg_sq, void* p_bf16_or_null, long long n, float lr,
                  float beta1, float beta2, float eps, float weight_decay, int step);
+/* The same two over LISTS of tensors (host arrays of n device pointers and element counts; p_bf16 may be null, or hold null entries): the
+ * UNet has 688 parameter tensors, most of them tiny -- 48 tensors per launch instead of one launch each.  Same arithmetic per element. */
+int rdm_op_adamw_multi(rdm_ctx* ctx, int n, float* const* p, const float* const* grad, float* const* exp_avg, float* const* exp_avg_sq,
+                       void* const* p_bf16_or_null, const long long* numel, float lr, float beta1, float beta2, float eps, float weight_decay, int step);
+int rdm_op_ema_multi(rdm_ctx* ctx, int n, float* const* shadow, const float* const* param, const long long* numel, float one_minus_decay);
 /* Attention backward, unfused first version (autograd through ldm CrossAttention.forward, attention.py:52-72:
  * sim = einsum(q, k) * scale; attn = sim.softmax(-1); out = einsum(attn, v)).  The scores are materialised per (sample, head):
  *   rdm_op_heads   x [B, n, ldx] (head h = columns [h D, (h+1) D)) <-> per-head matrices zero-padded to 64 columns:

@@ -153,6 +153,8 @@ SIGNATURES = {
     "rdm_op_xattn_fused": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_op_small_attention": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_float, _P, C.c_int]),
+    "rdm_op_adamw_multi": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]),
+    "rdm_op_ema_multi": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_float]),
     "rdm_op_small_attention_bwd": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P]),
 }
 
@@ -726,6 +728,32 @@ class Context:
         dw = torch.empty((N, K), device=self.device, dtype=torch.float32)
         self._check(lib.rdm_op_linear_wgrad(self._h, _ptr(dy), _ptr(a), _ptr(dw), M, N, K))
         return dw
+
+    @staticmethod
+    def _ptr_array(ts, optional=False):
+        arr = (C.c_void_p * len(ts))()
+        for i, t in enumerate(ts):
+            if t is None:
+                assert optional
+                arr[i] = None
+            else:
+                assert t.is_contiguous(), "tensor must be contiguous"
+                arr[i] = t.data_ptr()
+        return arr
+
+    def op_adamw_multi(self, ps, gs, ms, vs, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, p_bf16s=None):
+        """op_adamw over lists of fp32 tensors (48 tensors per launch); p_bf16s: list with None where a tensor has no bf16 working copy."""
+        n = len(ps)
+        assert n == len(gs) == len(ms) == len(vs) and all(g.numel() == p.numel() and g.dtype == torch.float32 for p, g in zip(ps, gs))
+        numel = (C.c_longlong * n)(*[p.numel() for p in ps])
+        self._check(lib.rdm_op_adamw_multi(self._h, n, self._ptr_array(ps), self._ptr_array(gs), self._ptr_array(ms), self._ptr_array(vs),
+                                           self._ptr_array(p_bf16s, True) if p_bf16s is not None else None, numel, float(lr), float(betas[0]),
+                                           float(betas[1]), float(eps), float(weight_decay), int(step)))
+
+    def op_ema_multi(self, shadows, ps, one_minus_decay):
+        n = len(ps)
+        numel = (C.c_longlong * n)(*[p.numel() for p in ps])
+        self._check(lib.rdm_op_ema_multi(self._h, n, self._ptr_array(shadows), self._ptr_array(ps), numel, float(one_minus_decay)))
 
     def op_ema(self, shadow, p, one_minus_decay):
         self._check(lib.rdm_op_ema(self._h, _ptr(shadow), _ptr(p), p.numel(), float(one_minus_decay)))

@@ -783,16 +783,18 @@ hipError_t launch_softmax_bwd(const bf16_t* P, const float* dP, bf16_t* dS, long
 // ---- AdamW step (torch.optim.AdamW semantics, decoupled weight decay, bias correction; ldm configure_optimizers in
 // rdm/models/diffusion/ddpm.py uses torch.optim.AdamW(params, lr)): fp32 master parameters and moments updated in place, optional
 // bf16 working copy of the new parameters for the next forward.
+__device__ __forceinline__ float adamw_elem(float pi, float gi, float& mi, float& vi, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
+    pi = pi * (1.f - lr * wd);
+    mi = __fmaf_rn(b1, mi, (1.f - b1) * gi);
+    vi = __fmaf_rn(b2, vi, (1.f - b2) * gi * gi);
+    return pi - (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+}
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                     bf16_t* __restrict__ pb, long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float gi = g[i];
-        float pi = p[i] * (1.f - lr * wd);
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        pi -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
-        p[i] = pi;
+        float mi = m[i], vi = v[i];
+        const float pi = adamw_elem(p[i], g[i], mi, vi, lr, b1, b2, eps, wd, bc1, bc2);
+        m[i] = mi; v[i] = vi; p[i] = pi;
         if (pb) pb[i] = f2bf(pi);
     }
 }
@@ -803,6 +805,58 @@ hipError_t launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* pb
     const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
     adamw_kernel<<<dim3((unsigned)grid), 256, 0, st>>>(p, g, m, v, pb, n, lr, b1, b2, eps, wd, bc1, bc2);
     return hipGetLastError();
+}
+
+// Multi-tensor form: the UNet has 688 parameter tensors, 450 of them a few hundred elements (biases, norm affines) -- one launch per tensor is
+// launch-bound (6 us each, 4.4 ms per step for 3 ms of memory traffic).  Up to 48 tensors per launch; a block owns 2048 consecutive elements
+// of one tensor and finds it by scanning the block-offset table in the kernel arguments.  ema = 1: shadow (p) <- shadow - omd (shadow - param (g)).
+struct MultiTensorArgs {
+    int n, ema; int blk[49];
+    float* p[48]; const float* g[48]; float* m[48]; float* v[48]; bf16_t* pb[48]; long long numel[48];
+    float lr, b1, b2, eps, wd, bc1, bc2, omd;
+};
+__global__ __launch_bounds__(256) void multi_tensor_kernel(MultiTensorArgs a) {
+    int t = 0;
+    while (t + 1 < a.n && (int)blockIdx.x >= a.blk[t + 1]) t++;
+    const long long base = (long long)((int)blockIdx.x - a.blk[t]) * 2048, n = a.numel[t];
+    float* __restrict__ p = a.p[t]; const float* __restrict__ g = a.g[t];
+    if (a.ema) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const long long i = base + u * 256 + threadIdx.x; if (i < n) { const float s = p[i]; p[i] = s - a.omd * (s - g[i]); } }
+        return;
+    }
+    float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t]; bf16_t* __restrict__ pb = a.pb[t];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const long long i = base + u * 256 + threadIdx.x;
+        if (i < n) {
+            float mi = m[i], vi = v[i];
+            const float pi = adamw_elem(p[i], g[i], mi, vi, a.lr, a.b1, a.b2, a.eps, a.wd, a.bc1, a.bc2);
+            m[i] = mi; v[i] = vi; p[i] = pi;
+            if (pb) pb[i] = f2bf(pi);
+        }
+    }
+}
+// host arrays of n pointers / element counts; ema: p = shadows, g = parameters, m / v / pb unused (may be null)
+hipError_t launch_multi_tensor(int n, float* const* p, const float* const* g, float* const* m, float* const* v, void* const* pb, const long long* numel, int ema,
+                               float lr, float b1, float b2, float eps, float wd, int step, float omd, hipStream_t st) {
+    if (!ema && step < 1) return hipErrorInvalidValue;
+    MultiTensorArgs a{};
+    a.ema = ema; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = wd; a.omd = omd;
+    a.bc1 = ema ? 1.f : 1.f - powf(b1, (float)step); a.bc2 = ema ? 1.f : 1.f - powf(b2, (float)step);
+    int i = 0;
+    while (i < n) {
+        int k = 0; long long blocks = 0;
+        while (i < n && k < 48 && blocks < (1 << 20)) {
+            if (numel[i] < 1) return hipErrorInvalidValue;
+            a.p[k] = p[i]; a.g[k] = g[i]; a.m[k] = m ? m[i] : nullptr; a.v[k] = v ? v[i] : nullptr; a.pb[k] = pb ? (bf16_t*)pb[i] : nullptr; a.numel[k] = numel[i];
+            a.blk[k] = (int)blocks; blocks += (numel[i] + 2047) / 2048; k++; i++;
+        }
+        a.n = k; a.blk[k] = (int)blocks;
+        multi_tensor_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(a);
+        hipError_t e = hipGetLastError(); if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // ---- SiLU on an fp32 vector (the time-embedding MLP: ldm TimestepEmbedSequential `nn.SiLU()` between / after the two Linear layers):

@@ -178,6 +178,8 @@ hipError_t launch_conv_out(const bf16_t* x, const float* w, const float* bias, f
 hipError_t launch_timestep_embedding(const long long* t, bf16_t* out, int B, int dim, int ld, hipStream_t st);   // rows of ld >= dim, tail zeroed
 hipError_t launch_cast_f32_bf16(const float* x, bf16_t* y, long long n, hipStream_t st);
 hipError_t launch_transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st, int batch = 1, int ldy = 0);       // y[c][r] = x[r][c] (batch contiguous matrices)
+hipError_t launch_multi_tensor(int n, float* const* p, const float* const* g, float* const* m, float* const* v, void* const* pb, const long long* numel, int ema,
+                               float lr, float b1, float b2, float eps, float wd, int step, float omd, hipStream_t st);      // AdamW / LitEma over a list of tensors, 48 per launch
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* pb, long long n, float lr, float b1, float b2, float eps, float wd, int step,
                         hipStream_t st);
 hipError_t launch_ema(float* shadow, const float* p, long long n, float one_minus_decay, hipStream_t st);

@@ -2205,6 +2205,21 @@ int rdm_op_adamw(rdm_ctx* c, float* p, const float* g, float* m, float* v, void*
     RDM_CHECK_HIP(c, launch_adamw(p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay, step, c->stream));
     return 0;
 }
+int rdm_op_adamw_multi(rdm_ctx* c, int n, float* const* p, const float* const* g, float* const* m, float* const* v, void* const* p_bf16, const long long* numel,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, int step) {
+    RDM_ENTER(c);
+    if (n < 1 || !p || !g || !m || !v || !numel || step < 1) return c->fail(-1, "rdm_op_adamw_multi: bad argument");
+    for (int i = 0; i < n; i++) if (!p[i] || !g[i] || !m[i] || !v[i] || numel[i] < 1) return c->fail(-1, "rdm_op_adamw_multi: null tensor in the list");
+    RDM_CHECK_HIP(c, launch_multi_tensor(n, p, g, m, v, p_bf16, numel, 0, lr, beta1, beta2, eps, weight_decay, step, 0.f, c->stream));
+    return 0;
+}
+int rdm_op_ema_multi(rdm_ctx* c, int n, float* const* shadow, const float* const* param, const long long* numel, float one_minus_decay) {
+    RDM_ENTER(c);
+    if (n < 1 || !shadow || !param || !numel) return c->fail(-1, "rdm_op_ema_multi: bad argument");
+    for (int i = 0; i < n; i++) if (!shadow[i] || !param[i] || numel[i] < 1) return c->fail(-1, "rdm_op_ema_multi: null tensor in the list");
+    RDM_CHECK_HIP(c, launch_multi_tensor(n, shadow, param, nullptr, nullptr, nullptr, numel, 1, 0.f, 0.f, 0.f, 0.f, 0.f, 1, one_minus_decay, c->stream));
+    return 0;
+}
 int rdm_op_attention_bwd(rdm_ctx* c, const void* q, const void* k, const void* v, const void* o, const void* dout, int B, int n, int m, int heads,
                          void* dq, void* dk, void* dv) {
     RDM_ENTER(c);

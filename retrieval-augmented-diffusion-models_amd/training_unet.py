@@ -375,9 +375,10 @@ def apply_gradients(ctx, state, grads, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, we
     AdamW on the fp32 masters in place with the bf16 working copies refreshed by the same kernel, LitEma update."""
     state.step += 1
     grads = parallel.average_gradients(grads, group=group) if group is not None else parallel.average_gradients(grads)
-    for k, p in state.P.items():
-        ctx.op_adamw(p, grads[k].float().reshape(p.shape).contiguous(), state.m[k], state.v[k], state.step, lr=lr, betas=betas, eps=eps,
-                     weight_decay=weight_decay, p_bf16=state.work.get(k))
+    keys = list(state.P)
+    gs = [grads[k].float().reshape(state.P[k].shape).contiguous() for k in keys]
+    ctx.op_adamw_multi([state.P[k] for k in keys], gs, [state.m[k] for k in keys], [state.v[k] for k in keys], state.step, lr=lr, betas=betas, eps=eps,
+                       weight_decay=weight_decay, p_bf16s=[state.work.get(k) for k in keys])          # 688 tensors in 15 launches
     if state.ema is not None:
         state.ema.update(ctx, state.P)
 
@@ -405,5 +406,5 @@ class Ema:
     def update(self, ctx, P):
         self.num_updates += 1
         decay = min(self.decay, (1 + self.num_updates) / (10 + self.num_updates))
-        for k, v in P.items():
-            ctx.op_ema(self.shadow[k], v, 1.0 - decay)
+        keys = list(P)
+        ctx.op_ema_multi([self.shadow[k] for k in keys], [P[k] for k in keys], 1.0 - decay)

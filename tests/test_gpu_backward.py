@@ -263,6 +263,29 @@ def test_adamw_step_matches_torch(ctx):
     assert torch.equal(pb.cpu(), p.cpu().to(torch.bfloat16))
 
 
+def test_adamw_and_ema_over_tensor_lists(ctx):
+    """rdm_op_adamw_multi / rdm_op_ema_multi: 120 tensors of 1 .. 300 k elements (three launches' worth, ragged last blocks, a tensor
+    without a bf16 copy) give bit for bit what the per-tensor entries give."""
+    d = ctx.device
+    sizes = [1, 7, 2048, 2049, 300001] + [int(3 + 37 * i ** 1.7) for i in range(115)]
+    mk = lambda seed, sc=1.0: [(_rand((n,), seed + i) * sc).to(d) for i, n in enumerate(sizes)]
+    p1, g, m1, v1 = mk(1000), mk(2000, 0.1), [t.abs() * 0.01 for t in mk(3000)], [t.abs() * 0.01 for t in mk(4000)]
+    p2, m2, v2 = [t.clone() for t in p1], [t.clone() for t in m1], [t.clone() for t in v1]
+    b1 = [None if i == 3 else torch.empty_like(t, dtype=torch.bfloat16) for i, t in enumerate(p1)]
+    b2 = [None if b is None else torch.empty_like(b) for b in b1]
+    for step in (1, 2):
+        for i in range(len(sizes)):
+            ctx.op_adamw(p1[i], g[i], m1[i], v1[i], step, lr=2e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.03, p_bf16=b1[i])
+        ctx.op_adamw_multi(p2, g, m2, v2, step, lr=2e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.03, p_bf16s=b2)
+    for a, b in zip(p1 + m1 + v1 + [x for x in b1 if x is not None], p2 + m2 + v2 + [x for x in b2 if x is not None]):
+        assert torch.equal(a, b)
+    s1 = mk(5000); s2 = [t.clone() for t in s1]
+    for i in range(len(sizes)):
+        ctx.op_ema(s1[i], p1[i], 0.25)
+    ctx.op_ema_multi(s2, p2, 0.25)
+    assert all(torch.equal(a, b) for a, b in zip(s1, s2))
+
+
 def _st_params(C, heads, Cc, seed):
     Fh = 4 * C
     def attn(sd, kc):
