@@ -259,14 +259,14 @@ def main():
     extras = {}
     if not a.no_extras:
         ctx.prof_reset()
-        ctx.prof_enable((_lib.PROF_LINEAR, _lib.PROF_KNN, _lib.PROF_ATTENTION, _lib.PROF_GROUPNORM, _lib.PROF_LAYERNORM))
+        ctx.prof_enable((_lib.PROF_LINEAR, _lib.PROF_KNN, _lib.PROF_ATTENTION, _lib.PROF_GROUPNORM, _lib.PROF_LAYERNORM, _lib.PROF_UPSCONV))
         torch.cuda.synchronize(); t1 = time.perf_counter()
         step(0)
         fence()
         t_prof_step = time.perf_counter() - t1
         ctx.prof_enable(())
         for name, kind in (("linear_gemm", _lib.PROF_LINEAR), ("knn", _lib.PROF_KNN), ("flash_attention", _lib.PROF_ATTENTION),
-                           ("groupnorm", _lib.PROF_GROUPNORM), ("layernorm", _lib.PROF_LAYERNORM)):
+                           ("groupnorm", _lib.PROF_GROUPNORM), ("layernorm", _lib.PROF_LAYERNORM), ("upsample_conv_by_phase", _lib.PROF_UPSCONV)):
             n_, ms_, w_ = ctx.prof_collect(kind)
             classes[name] = (n_, ms_, w_)
         extras["untimed_profiled_step_ms"] = t_prof_step * 1e3
@@ -302,6 +302,13 @@ def main():
                 "algorithmic_tflop_per_launch": fl_conv / max(n_conv, 1) / 1e12, "conv_time_frac_of_step": ms_conv * 1e-3 / dt}
         for name, (n_, ms_, w_) in classes.items():
             if n_ == 0:
+                continue
+            if name == "upsample_conv_by_phase":
+                # Upsample's nearest-2x + conv3x3 as four 2x2-tap convs at source resolution (igemm_kernel<.., 3>): EXECUTED FLOPs = 4/9 of the
+                # nine-tap count the reference's F.interpolate + conv2d performs
+                ach = w_ / (ms_ * 1e-3) / 1e12
+                roof[name] = {"kernel": "igemm_kernel<BM, BN, W, 3> (pre-summed phase weights)", "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s",
+                              "frac": ach / 2500.0, "launches": n_, "time_ms_per_step": ms_, "nine_tap_equivalent_tflops": ach * 2.25}
                 continue
             if name in ("linear_gemm", "flash_attention"):
                 roof[name] = {"bound": "mfma", "achieved": w_ / (ms_ * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",

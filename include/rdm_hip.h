@@ -240,7 +240,8 @@ int rdm_comm_destroy(rdm_ctx* ctx);
  * launches of one kind recorded since the last reset -- FLOPs (2*M*N*K; 4*n^2*d per attention head) for the MFMA-bound
  * kinds, bytes (minimal tensor / database passes) for the HBM-bound kinds.  Used by bench.py for the roofline objects. */
 enum { RDM_PROF_CONV3X3 = 0, RDM_PROF_LINEAR = 1, RDM_PROF_KNN = 2, RDM_PROF_ATTENTION = 3, RDM_PROF_GROUPNORM = 4,
-       RDM_PROF_LAYERNORM = 5 };
+       RDM_PROF_LAYERNORM = 5,
+       RDM_PROF_UPSCONV = 6 /* Upsample's nearest-2x + conv3x3 run by output phase (2 x 2 taps at source resolution): EXECUTED FLOPs, 4/9 of the nine-tap count */ };
 int rdm_prof_enable(rdm_ctx* ctx, int kind_mask);
 int rdm_prof_collect(rdm_ctx* ctx, int kind, long long* launches, double* ms, double* flops);
 int rdm_prof_reset(rdm_ctx* ctx);

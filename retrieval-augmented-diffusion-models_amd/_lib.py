@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("RDM_HIP_LIB") or os.path.join(_HERE, "librdm_hip.so")
 
 RDM_MAX_LEVELS = 8
 ACT_NONE, ACT_GEGLU, ACT_QUICKGELU, ACT_SILU = 0, 1, 2, 3
-PROF_CONV3X3, PROF_LINEAR, PROF_KNN, PROF_ATTENTION, PROF_GROUPNORM, PROF_LAYERNORM = range(6)
+PROF_CONV3X3, PROF_LINEAR, PROF_KNN, PROF_ATTENTION, PROF_GROUPNORM, PROF_LAYERNORM, PROF_UPSCONV = range(7)
 
 
 class UNetCfg(C.Structure):

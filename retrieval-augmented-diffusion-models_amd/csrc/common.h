@@ -82,6 +82,8 @@ struct IgemmParams {
     int M, N, K;
     // conv3x3 geometry (conv mode): input [B, Hin, Win, C0(+C1)], output [B, Hout, Wout, N]
     int Hin, Win, Hout, Wout, stride, ups;
+    int phase2;                 // generic implicit GEMM only: conv3x3 on a nearest-2x upsampled input by output phase (igemm.hip CONV == 3): W = the phase weights
+                                // [4][N][2][2][C0] (launch_conv_phase_weights), K = 4 C0, M = B Hin Win, launched with batch = 4
     int asym;                   // generic implicit GEMM only: the 3x3 window of output (oy, ox) starts AT input (stride oy, stride ox) -- F.pad(x, (0, 1, 0, 1)) + an unpadded conv (ldm autoencoder Downsample)
     // epilogue
     float alpha;                // acc scale

@@ -42,7 +42,12 @@ __device__ __forceinline__ void softmax_group16(float (&v)[16], int g) {
 // dev-only phase clock (env RDM_IGEMM_PROF=1): shader cycles spent by wave 0 of every block in [K loop, epilogue, wait at tile start]
 __device__ unsigned long long g_igemm_prof[5];
 
-template <int BM, int BN, int WAVES_M, int CONV, bool GEGLU>   // CONV: 0 linear, 1 conv3x3, 2 conv3x3 on a 2x nearest-upsampled input
+// CONV: 0 linear, 1 conv3x3, 2 conv3x3 on a 2x nearest-upsampled input, 3 the same conv by OUTPUT PHASE: output pixel (2y + a, 2x + b) of
+// conv3x3(nearest2x(src)) reads only the 2 x 2 source window rows {y - 1 + a, y + a} x columns {x - 1 + b, x + b} -- the taps that land
+// on one source pixel are pre-summed (launch_conv_phase_weights: [phase][N][2][2][C]) -- so a phase is a 4-tap conv at SOURCE resolution:
+// 16 tap-pixels per source pixel instead of 36 (2.25 x fewer FLOPs).  blockIdx.z = phase 2 a + b; rows m run over the B Hin Win source
+// pixels; the read-out scatters row (b, y, x) to output pixel (2y + a, 2x + b).
+template <int BM, int BN, int WAVES_M, int CONV, bool GEGLU>
 __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) {
     constexpr int BK = 64;
     constexpr int WAVES_N = 2, NW = WAVES_M * WAVES_N, NT = NW * 64;
@@ -74,11 +79,12 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
     if (tile >= t_end) return;
 
     const long long zb = blockIdx.z;
+    const int ph_a = CONV == 3 ? (int)(zb >> 1) : 0, ph_b = CONV == 3 ? (int)(zb & 1) : 0;
     const bf16_t* A0 = p.A0 + zb * p.sA;
     const bf16_t* A1 = p.A1;
     const bf16_t* W = p.W + zb * p.sW;
     const char* zero = (const char*)p.zero_page;
-    bf16_t* ob = p.out_bf16 ? p.out_bf16 + zb * p.sO : nullptr;
+    bf16_t* ob = p.out_bf16 ? p.out_bf16 + (CONV == 3 ? 0 : zb * p.sO) : nullptr;
     float* of = p.out_f32 ? p.out_f32 + zb * p.sO : nullptr;
     const bf16_t* rb = (p.res_bf16 && !p.res_k) ? p.res_bf16 + zb * p.sO : nullptr;
     const bf16_t* const rk = p.res_k ? p.res_bf16 + zb * p.sO : nullptr;
@@ -118,7 +124,19 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
             const int m = m0 + i * RPP + lrow;
             a_pix[i] = 0; a_mask[i] = 0;
             if (m < p.M) {
-                if (CONV) {
+                if (CONV == 3) {
+                    const int hw = p.Hin * p.Win;
+                    const int b = m / hw, rem = m - b * hw;
+                    const int y = rem / p.Win, x = rem - y * p.Win;
+                    a_pix[i] = (b * p.Hin + y) * p.Win + x;
+                    int mask = 0;
+#pragma unroll
+                    for (int tp = 0; tp < 4; tp++) {
+                        const int iy = y - 1 + ph_a + (tp >> 1), ix = x - 1 + ph_b + (tp & 1);
+                        if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) mask |= 1 << tp;
+                    }
+                    a_mask[i] = mask;
+                } else if (CONV) {
                     const int hw = p.Hout * p.Wout;
                     const int b = m / hw, rem = m - b * hw;
                     const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
@@ -171,7 +189,7 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
                 glds16(g, As + (i * RPP + wave * 8) * 128);
             }
         } else {
-            const int dpix = CONV ? (dy - 1) * p.Win + (dx - 1) : 0;
+            const int dpix = CONV == 3 ? (ph_a - 1 + (k_tap >> 1)) * p.Win + (ph_b - 1 + (k_tap & 1)) : CONV ? (dy - 1) * p.Win + (dx - 1) : 0;
 #pragma unroll
             for (int i = 0; i < AP; i++) {
                 const bool ok = (a_mask[i] >> k_tap) & 1;
@@ -425,6 +443,10 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
                     uint4 u = *(const uint4*)(stg + row * ROWB + ch * 16);
                     if (full || (m < p.M && col < No)) {
                         long long o = (long long)m * p.ldo + col;
+                        if constexpr (CONV == 3) {                      // source pixel (b, y, x) -> output pixel (2y + a, 2x + b)
+                            const int hw = p.Hin * p.Win, bb = m / hw, rem = m - bb * hw, yy = rem / p.Win, xx = rem - yy * p.Win;
+                            o = ((long long)(bb * p.Hout + 2 * yy + ph_a) * p.Wout + 2 * xx + ph_b) * p.ldo + col;
+                        }
                         if (rb) {
                             const uint4 r4 = *(const uint4*)(rb + o);
                             const uint32_t uu[4] = {u.x, u.y, u.z, u.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
@@ -591,6 +613,28 @@ static hipError_t launch_cfg(const IgemmParams& p, int batch, hipStream_t st) {
 }
 
 // Host entry: picks the tile. K must be a multiple of 64 (and C0, C1 multiples of 64 for conv / dual).
+// phase weights of conv3x3(nearest2x(.)):  Wp[2a + b][n][ty][tx][c] = sum of W[n][ky][kx][c] over the taps (ky, kx) that land on source
+// offset (a - 1 + ty, b - 1 + tx): rows a = 0: {0} | {1, 2}, a = 1: {0, 1} | {2}; columns likewise.  Summed in fp32, rounded once to bf16.
+__global__ __launch_bounds__(256) void conv_phase_weights_kernel(const bf16_t* __restrict__ W, bf16_t* __restrict__ Wp, int N, int C) {
+    const long long total = (long long)4 * N * 4 * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C); long long r = i / C;
+        const int tx = (int)(r & 1), ty = (int)((r >> 1) & 1); r >>= 2;
+        const int n = (int)(r % N), ph = (int)(r / N), a = ph >> 1, b = ph & 1;
+        const int ky0 = a == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), ky1 = a == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+        const int kx0 = b == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kx1 = b == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+        float s = 0.f;
+        for (int ky = ky0; ky <= ky1; ky++)
+            for (int kx = kx0; kx <= kx1; kx++) s += bf2f(W[((long long)n * 9 + ky * 3 + kx) * C + c]);
+        Wp[i] = f2bf(s);
+    }
+}
+hipError_t launch_conv_phase_weights(const bf16_t* W, bf16_t* Wp, int N, int C, hipStream_t st) {
+    long long g = ((long long)16 * N * C + 255) / 256; if (g > 8192) g = 8192;
+    conv_phase_weights_kernel<<<dim3((unsigned)g), 256, 0, st>>>(W, Wp, N, C);
+    return hipGetLastError();
+}
+
 hipError_t launch_igemm(const IgemmParams& p_in, bool conv, int batch, hipStream_t st) {
     static const int dbg = getenv("RDM_IGEMM_DBG") ? atoi(getenv("RDM_IGEMM_DBG")) : 0;
     IgemmParams p = p_in; p.dbg = dbg;
@@ -621,6 +665,14 @@ hipError_t launch_igemm(const IgemmParams& p_in, bool conv, int batch, hipStream
         if (tall && geglu_bn == 256 && p.N % 256 == 0 && (long long)((p.M + 255) / 256) * (p.N / 256) * batch >= 256)
             return launch_cfg<256, 256, 4, 0, true>(p, batch, st);
         return tall ? launch_cfg<256, 128, 4, 0, true>(p, batch, st) : launch_cfg<128, 128, 2, 0, true>(p, batch, st);
+    }
+    if (conv && p.phase2) {
+        // bf16 output through the LDS read-out only (it owns the row scatter); no residual / time row / activation at an Upsample conv
+        if (batch != 4 || !p.out_bf16 || p.out_f32 || p.res_bf16 || p.res_f32 || p.rowvec || p.act != ACT_NONE || p.alpha != 1.0f || p.ldo % 8 || p.N % 8 ||
+            p.C1 != 0 || p.K != 4 * p.C0 || p.M != (long long)(p.M / (p.Hin * p.Win)) * p.Hin * p.Win || p.Hout != 2 * p.Hin || p.Wout != 2 * p.Win)
+            return hipErrorInvalidValue;
+        if (wide) return tall ? launch_cfg<256, 192, 4, 3, false>(p, batch, st) : launch_cfg<128, 192, 2, 3, false>(p, batch, st);
+        return tall ? launch_cfg<256, 128, 4, 3, false>(p, batch, st) : launch_cfg<128, 128, 2, 3, false>(p, batch, st);
     }
     if (conv && p.ups) {
         if (wide) return tall ? launch_cfg<256, 192, 4, 2, false>(p, batch, st) : launch_cfg<128, 192, 2, 2, false>(p, batch, st);

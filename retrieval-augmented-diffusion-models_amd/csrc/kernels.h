@@ -134,6 +134,7 @@ hipError_t launch_lin_w_fragpack(const bf16_t* W, bf16_t* dst, int N, int K, int
 hipError_t launch_lin_ln_sb(const bf16_t* W, const float* gamma, const float* beta, const float* bias, float* sb, int N, int K, hipStream_t st);   // sb[n] = (sum_k bf16(gamma W), bias + sum_k beta W), n = stored row
 hipError_t launch_conv_w_fragpack(const bf16_t* W, bf16_t* dst, int N, int Cin, hipStream_t st);   // dst: N*9*Cin elements
 // 3x3 conv dispatcher: input-stationary halo kernels when the geometry allows, else the generic implicit GEMM
+hipError_t launch_conv_phase_weights(const bf16_t* W, bf16_t* Wp, int N, int C, hipStream_t st);     // igemm.hip: [N][3][3][C] -> [4 phases][N][2][2][C]
 inline hipError_t launch_conv3x3(const IgemmParams& p, hipStream_t st) {
     if (p.Wfrag && p.Wout > 64 && conv_halo4_strip_supported(p)) return launch_conv_halo4(p, st);
     return conv_halo_supported(p) ? launch_conv_halo(p, st) : launch_igemm(p, true, 1, st);

@@ -197,7 +197,9 @@ def _pack_conv(w):
 @pytest.mark.parametrize("B,H,W,C,N,stride,ups", [(2, 8, 8, 64, 192, 1, 0), (3, 16, 16, 128, 128, 1, 0), (2, 16, 16, 64, 64, 2, 0),
                                                   (2, 8, 8, 192, 192, 1, 1), (1, 32, 32, 64, 384, 1, 0), (5, 4, 4, 64, 64, 1, 0),
                                                   # fused nearest-2x upsample through the halo kernel (32x32 / 64x64 outputs) and the generic path (odd M)
-                                                  (2, 16, 16, 128, 192, 1, 1), (1, 32, 32, 64, 192, 1, 1), (3, 4, 4, 64, 128, 1, 1)])
+                                                  (2, 16, 16, 128, 192, 1, 1), (1, 32, 32, 64, 192, 1, 1), (3, 4, 4, 64, 128, 1, 1),
+                                                  # ... which now runs by output phase (four 2x2-tap convs on pre-summed weights): rectangular sources, tall / short tiles, N % 128 != 0
+                                                  (4, 32, 16, 128, 384, 1, 1), (1, 2, 8, 64, 72, 1, 1), (9, 16, 16, 64, 576, 1, 1)])
 def test_conv3x3(ctx, B, H, W, C, N, stride, ups):
     d = ctx.device
     x, w, b = bf16_round(_rand((B, H, W, C), 11)), bf16_round(_rand((N, C, 3, 3), 12, (9 * C) ** -0.5)), _rand((N,), 13, 0.1)
