@@ -57,6 +57,10 @@ def parse():
     p.add_argument("--full-cpu-baseline", action="store_true",
                    help="SURVEY 8d's protocol instead of the bounded sample: 1 warm-up + 3 FULL config-#1 runs (50 DDIM steps + decode), median; ~5 min on 32 cores")
     p.add_argument("--no-extras", action="store_true", help="skip the untimed extras (per-class roofline step, guidance-scale-1.0 step)")
+    p.add_argument("--gather", choices=("f32", "uint8"), default="f32",
+                   help="N > 1: what the one collective moves -- the decoded fp32 images [B,3,256,256] (50 MB per rank at B = 64, default) or their "
+                        "uint8 HWC form (rdm_to_uint8, the conversion of scripts/rdm_sample.py: 12.6 MB per rank; SURVEY 8e)")
+    p.add_argument("--dump-images", default=None, help="rank 0 writes the last timed step's gathered images to this .npy (parity tests of the N > 1 path)")
     a = p.parse_args()
     a.k = a.k if a.k is not None else {2: 1, 3: 4, 4: 16, 5: 8}[a.config]
     a.ddim_steps_given = a.ddim_steps is not None
@@ -157,6 +161,16 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ctx = _lib.Context(local)
+    # N > 1 on RCCL: the image all-gather runs through the library's own communicator (C ABI rdm_comm_all_gather); gloo test groups
+    # (ranks sharing one GPU) and a failed communicator keep torch.distributed
+    lib_comm = parallel.attach_library_comm(ctx) if world > 1 else False
+    collective = (None if world == 1 else "rdm_comm_all_gather (RCCL through the C ABI, library stream)" if lib_comm else
+                  f"torch.distributed all_gather ({torch.distributed.get_backend()})")
+
+    def gather(img):
+        if a.gather == "uint8":
+            img = ctx.to_uint8(img)                                                   # [b,256,256,3] uint8: clamp, (x+1)/2*255, truncation
+        return parallel.all_gather_images(img, world * B, ctx=ctx if lib_comm else None)      # no-op for one rank
 
     # ---- model: shipped architecture, seeded random weights; schedule from the product's register_schedule
     model = MinimalRETRODiffusion(unet_config={"params": {}}, first_stage_config={"params": {"ddconfig": {}}}, k_nn=a.k, ctx=ctx)
@@ -218,14 +232,14 @@ def main():
             if tok.shape[1] < 256:                     # short profiling pass (--ddim-steps < 256): the remaining codes are padding
                 tok = torch.nn.functional.pad(tok, (0, 256 - tok.shape[1]))
             img = ctx.vq_decode_indices(tok)
-            return parallel.all_gather_images(img, world * B)
+            return gather(img)
         if a.config == 4:
             noise = parallel.per_sample_noise(5000 + i, range(lo, hi), (a.ddim_steps, 3, 64, 64), device=dev).transpose(0, 1).contiguous()
             z = ctx.ddpm_sample(a.ddim_steps, x_Ts[i], cond, noise, sched_ddpm, clip_denoised=True)
         else:
             z, _, _ = ctx.ddim_sample(a.ddim_steps, x_Ts[i], cond, uncond if scale > 1 else None, model.alphas_cumprod, eta=0.0, scale=scale)
         img = ctx.vq_decode(z)
-        return parallel.all_gather_images(img, world * B)                            # no-op for one rank
+        return gather(img)
 
     def fence():
         if world > 1:
@@ -250,7 +264,9 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    assert img.shape[0] == world * B and bool(torch.isfinite(img).all()), "non-finite images"
+    assert img.shape[0] == world * B and bool(torch.isfinite(img.float()).all()), "non-finite images"
+    if a.dump_images and rank == 0:
+        np.save(a.dump_images, img.cpu().numpy())
     n_conv, ms_conv, fl_conv = ctx.prof_collect(_lib.PROF_CONV3X3)
 
     # ---- one extra UNTIMED step with events around every other kernel class (their event records would otherwise sit in
@@ -278,14 +294,15 @@ def main():
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process -- taken from the committed
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (gfx950 corrections applied; profiles/README.md)
-    traffic, traffic_src = None, None
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_v4.json"):
+    traffic, traffic_src, pmc = None, None, {}
+    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_v4.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch"]; traffic_src = name
+                pmc = json.load(f)
+            traffic = pmc["hbm_bytes_per_launch"]; traffic_src = name
             break
         except Exception:
-            pass
+            pmc = {}
 
     if rank == 0:
         images = world * B * a.steps
@@ -299,7 +316,7 @@ def main():
                 "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": traffic,
                 "traffic_note": f"bytes per launch of the dominant conv kernel from the committed rocprofv3 PMC passes (profiles/{traffic_src}), not collected in this run",
                 "launches": n_conv, "avg_launch_ms": ms_conv / max(n_conv, 1),
-                "algorithmic_tflop_per_launch": fl_conv / max(n_conv, 1) / 1e12, "conv_time_frac_of_step": ms_conv * 1e-3 / dt}
+                "algorithmic_tflop_per_launch": fl_conv / max(n_conv, 1) / 1e12, "conv_time_frac_of_step": ms_conv * 1e-3 / (dt / a.steps)}      # events cover the LAST timed step only
         for name, (n_, ms_, w_) in classes.items():
             if n_ == 0:
                 continue
@@ -315,10 +332,32 @@ def main():
                               "frac": w_ / (ms_ * 1e-3) / 1e12 / 2500.0, "launches": n_, "time_ms_per_step": ms_}
                 if name == "linear_gemm":
                     roof[name]["kernel"] = "lin4_kernel<GEGLU, WM> (big-M projections) + igemm_kernel / sgemm_kernel (the rest)"
+                # HBM bytes per launch and MFMA-busy share per kernel of the class, from the same committed PMC passes as `traffic`
+                per_kernel = pmc.get("linear" if name == "linear_gemm" else "flash_attention", {})
+                if per_kernel and a.config != 5:          # (the passes are of the default config: not the RARM decode's kernels)
+                    roof[name]["traffic"] = {k_: {"hbm_bytes_per_launch": v_.get("hbm_bytes_per_launch"), "mfma_busy_frac": v_.get("mfma_busy_frac")}
+                                             for k_, v_ in per_kernel.items()}
+                    roof[name]["traffic_note"] = f"per kernel, profiles/{traffic_src}"
             else:
                 roof[name] = {"bound": "hbm", "achieved": w_ / (ms_ * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                               "frac": w_ / (ms_ * 1e-3) / 1e9 / 8000.0, "launches": n_, "time_ms_per_step": ms_,
                               "algorithmic_bytes_per_launch": w_ / n_}
+        if a.config != 5:
+            # end to end: ALGORITHMIC FLOPs per image (g S F_unet(k) + F_dec + F_vq) x images/s against the dense bf16 peak
+            g_ = 2 if (a.config != 4 and a.scale > 1) else 1
+            flop_img = g_ * a.ddim_steps * (208.56e9 + (k - 4) * 0.034e9) + 670.58e9 + 0.20e9
+            roof["end_to_end_tflops"] = flop_img * images / dt / 1e12
+            roof["end_to_end_frac"] = roof["end_to_end_tflops"] / 2500.0
+            roof["algorithmic_tflop_per_image"] = flop_img / 1e12
+            # SpatialTransformer block (attention.py:122-196) as one class: its GEMMs (incl. the fused cross-attention and, not separable
+            # by the event kinds, the ResBlocks' 1x1 skip_connection GEMMs), self-attention and LayerNorms; its entry GroupNorm sits in `groupnorm`
+            st = [classes.get(n_) for n_ in ("linear_gemm", "flash_attention", "layernorm")]
+            if all(c_ is not None and c_[0] > 0 for c_ in st):
+                st_ms = sum(c_[1] for c_ in st)
+                st_fl = st[0][2] + st[1][2]
+                roof["spatial_transformer_block"] = {"bound": "mfma", "achieved": st_fl / (st_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                                                     "frac": st_fl / (st_ms * 1e-3) / 1e12 / 2500.0, "time_ms_per_step": st_ms,
+                                                     "classes": ["linear_gemm", "flash_attention", "layernorm"]}
         if a.config == 5 and "linear_gemm" in roof:
             # RARM: the step is ~200 skinny GEMMs per token (M = B rows against 768..6144-row weight matrices: pure weight streaming),
             # 70 % of the step; the 3x3 convs of the VQGAN decoder above are 3 %.  The dominant kernel's bound is HBM: a launch has to
@@ -345,13 +384,26 @@ def main():
                                     "(400.9M params, random weights) -> VQ-f4 decode to 256x256"),
                        "baseline_config": a.config, "batch_per_gpu": B, "global_batch": world * B, "sampler_steps": a.ddim_steps, "k": k,
                        "guidance_scale": None if a.config == 4 else (1.0 if a.config == 5 else a.scale), "db_rows": None if a.config == 2 else N,
-                       "parallelism": f"dp{world} (batch-sharded, weights + DB replicated, all-gather of images only)"},
+                       "parallelism": f"dp{world} (batch-sharded, weights + DB replicated, all-gather of images only)",
+                       "collective": collective, "gathered": None if world == 1 else f"{a.gather} images, {img.element_size() * img[0].numel() * B} bytes per rank",
+                       "deterministic_mode": bool(ctx.deterministic)},
             "roofline": roof,
         }
         if extras:
             out["extras"] = extras
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_full(a.scale) if a.full_cpu_baseline else cpu_baseline(a.scale)
+            if not a.full_cpu_baseline:
+                # the bounded sample above is an extrapolation; the full SURVEY-8d protocol (--full-cpu-baseline, ~5 min) as last committed
+                for name in ("r05_bench_full_cpu_baseline.json", "r04_bench_full_cpu_baseline.json"):
+                    try:
+                        with open(os.path.join(ROOT, "profiles", name)) as f:
+                            full = json.load(f)["cpu_baseline"]
+                        out["cpu_baseline"]["full_protocol_committed"] = {"value": full["value"], "unit": full["unit"], "cores": full["cores"],
+                                                                          "sample": full["sample"], "source": f"profiles/{name} (another box of the same pool)"}
+                        break
+                    except Exception:
+                        pass
         print(json.dumps(out), flush=True)
     ctx.close()
     parallel.shutdown()

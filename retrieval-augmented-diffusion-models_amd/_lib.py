@@ -293,9 +293,15 @@ class Context:
         self._h = h
         self.device = torch.device("cuda", device)
         self.unet_cfg = self.vq_cfg = self.vqenc_cfg = self.clip_cfg = self.rarm_cfg = None
+        self.comm_world = 0                   # ranks of the context's RCCL communicator (comm_init), 0 = none
 
     def close(self):
         if getattr(self, "_h", None):
+            if getattr(self, "comm_world", 0):
+                try:
+                    self.comm_destroy()
+                except Exception:
+                    pass
             lib.rdm_ctx_destroy(self._h)
             self._h = None
 
@@ -608,6 +614,7 @@ class Context:
         if len(uid) != 128:
             raise RdmError(f"comm_init: the unique id is 128 bytes, got {len(uid)}")
         self._check(lib.rdm_comm_init(self._h, C.create_string_buffer(uid, 128), int(rank), int(world)))
+        self.comm_world = int(world)
 
     def comm_all_gather(self, local: torch.Tensor, world: int) -> torch.Tensor:
         local = local.contiguous()
@@ -624,6 +631,7 @@ class Context:
 
     def comm_destroy(self):
         self._check(lib.rdm_comm_destroy(self._h))
+        self.comm_world = 0
 
     def prof_reset(self):
         self._check(lib.rdm_prof_reset(self._h))

@@ -442,7 +442,7 @@ __global__ void gn_bwd_apply2_kernel(GnBwd2 p) {
     const int R = blockDim.x / VC;
     const int v = threadIdx.x % VC, rr = threadIdx.x / VC;
     const int b = blockIdx.y;
-    if (threadIdx.x < p.groups * 4) gs[threadIdx.x >> 2][threadIdx.x & 3] = p.stats[(long long)b * p.groups * 4 + threadIdx.x];
+    for (int i = threadIdx.x; i < p.groups * 4; i += blockDim.x) gs[i >> 2][i & 3] = p.stats[(long long)b * p.groups * 4 + i];      // (a block may have fewer than groups * 4 threads: 192 at C = 1536)
     __syncthreads();
     if (rr >= R) return;
     float fa[8], fb[8], ga[8], be[8], c1[8], c2[8], c3[8];

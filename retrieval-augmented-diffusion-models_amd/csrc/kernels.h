@@ -156,6 +156,7 @@ size_t linear_wgrad_scratch_bytes(long long M, int N, int K);
 bool wgrad_tn_supported(long long M, int N, int K, int lda, int ldb);
 bool conv_wgrad_tn_supported(int B, int H, int W, int C, int N);
 size_t wgrad_tn_scratch_bytes(long long M, int N, int K, int taps);
+size_t conv_wgrad_tn_scratch_bytes(int B, int H, int W, int C, int N);
 hipError_t launch_wgrad_tn(const bf16_t* dy, int lda, const bf16_t* x, int ldb, float* dw, long long M, int N, int K, int taps, int H, int W, char* scratch,
                            const void* zero_page, hipStream_t st);
 hipError_t launch_linear_wgrad(const bf16_t* dy, const bf16_t* a, float* dw, long long M, int N, int K, char* scratch, const void* zero_page, hipStream_t st);

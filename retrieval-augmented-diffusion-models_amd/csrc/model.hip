@@ -2115,7 +2115,7 @@ int rdm_op_conv3x3_wgrad(rdm_ctx* c, const void* x, const void* dy, float* dw, i
     RDM_ENTER(c);
     if (!x || !dy || !dw || C % 2 || N < 1) return c->fail(-1, "rdm_op_conv3x3_wgrad: bad arguments");
     if (conv_wgrad_tn_supported(B, H, W, C, N)) {
-        RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, wgrad_tn_scratch_bytes((long long)B * H * W, N, C, 9) + 256));
+        RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, conv_wgrad_tn_scratch_bytes(B, H, W, C, N) + 256));
         RDM_CHECK_HIP(c, launch_wgrad_tn((const bf16_t*)dy, N, (const bf16_t*)x, C, dw, (long long)B * H * W, N, C, 9, H, W, c->bwd_tmp, c->zero_page, c->stream));
         return 0;
     }

@@ -327,6 +327,16 @@ __device__ __forceinline__ void rarm_emit_ln4(const float (&xv)[4], int tid, int
 #pragma unroll
     for (int i = 0; i < 4; i++) { const int c = tid + 256 * i; if (c < C) y[c] = f2bf((xv[i] - mean) * rstd * g[c] + bta[c]); }
 }
+// MEMORY-MODEL NOTE (the hand-over of the partial rows between the four blocks of a sequence): the partial rows are written with
+// agent-scope RELAXED atomic stores and the arrival counter is a RELAXED agent-scope RMW -- there is no release / acquire edge in the
+// C++ memory model.  What orders them is gfx950 hardware behaviour: agent-scope atomic stores are write-through (sc1) past the
+// per-XCD L2s to the coherence point, `s_waitcnt vmcnt(0)` + the workgroup barrier make every thread's stores COMPLETE before thread 0
+// arrives, and the last arriver's agent-scope atomic loads bypass its own L2.  (A release fence here is a whole-L2 write-back on this
+// multi-die part: 31 us per launch instead of 16.)  This is therefore a gfx950-only kernel: the build refuses any other target, and
+// tests/test_gpu_rarm.py::test_rarm_split_cross_attention_stress_bitwise compares repeated runs bit for bit against the one-block form.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "rarm_xattn_decode_split_kernel relies on gfx950's agent-scope write-through stores (see the note above)"
+#endif
 __global__ __launch_bounds__(256) void rarm_xattn_decode_split_kernel(RarmXattnParams p) {
     __shared__ float xn[1024];
     __shared__ float sc[32];

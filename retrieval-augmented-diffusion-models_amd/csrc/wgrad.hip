@@ -301,9 +301,7 @@ bool conv_wgrad_tn_supported(int B, int H, int W, int C, int N) {
 }
 size_t wgrad_tn_scratch_bytes(long long M, int N, int K, int taps) {
     int Z, mz; wgrad_geom(M, N, K, taps, &Z, &mz);
-    size_t b = Z > 1 ? (size_t)Z * N * taps * K * 4 : 0;
-    if (taps == 9) { const size_t cap = (size_t)(256LL << 20); if (b < cap) b = cap; }      // the nine-tap kernel picks its own Z (<= 256 MB of planes)
-    return b;
+    return Z > 1 ? (size_t)Z * N * taps * K * 4 : 0;      // (3x3 convs: conv_wgrad_tn_scratch_bytes below -- the nine-tap kernel picks its own Z)
 }
 
 // nine-tap kernel: W in {16, 32, 64}, H a power of two, channel counts multiples of 64
@@ -325,6 +323,14 @@ static void conv9_geom(int B, int H, int W, int C, int N, int* pZ, int* pcz) {
     const long long cz = (chunks + Z - 1) / Z;
     Z = (chunks + cz - 1) / cz;
     *pZ = (int)Z; *pcz = (int)cz;
+}
+// scratch of launch_wgrad_tn(taps = 9) for THIS geometry: the planes of the kernel that will run (nine-tap kernel: its own Z, at most
+// 256 MB; per-tap fallback: wgrad_geom's Z), nothing when one plane goes straight into dw
+size_t conv_wgrad_tn_scratch_bytes(int B, int H, int W, int C, int N) {
+    int Z, t;
+    if (conv9_ok(B, H, W, C, N)) conv9_geom(B, H, W, C, N, &Z, &t);
+    else wgrad_geom((long long)B * H * W, N, C, 9, &Z, &t);
+    return Z > 1 ? (size_t)Z * N * 9 * C * 4 : 0;
 }
 template <int LW>
 static hipError_t launch_conv9(WgradParams& p, int Z, hipStream_t st) {

@@ -100,6 +100,15 @@ class MinimalRETRODiffusion(object):
             unet_sd = sd                                           # already stripped
         self.ctx.load_unet(self.unet_cfg, packing.pack("unet", self.unet_cfg, unet_sd))
         self._unet_sd = packing.strip_prefix(sd, "model.diffusion_model.") or unet_sd      # training starts from the LIVE weights, not the EMA copies
+        # ... and resumes LitEma where the checkpoint left it (ldm LitEma registers the shadows, `num_updates` and `decay` as buffers, so
+        # the reference's load_state_dict restores them): configure_optimizers() seeds the shadows / counter from these
+        self._ema_sd, self._ema_num_updates, self._ema_decay = None, None, None
+        if any(k.startswith("model_ema.") and k not in ("model_ema.num_updates", "model_ema.decay") for k in sd):
+            self._ema_sd = packing.ema_unet_state_dict(sd)
+            if "model_ema.num_updates" in sd:
+                self._ema_num_updates = int(sd["model_ema.num_updates"])
+            if "model_ema.decay" in sd:
+                self._ema_decay = float(sd["model_ema.decay"])
         if self.vq_cfg is not None:
             vq_sd = packing.strip_prefix(sd, "first_stage_model.")
             if vq_sd:
@@ -109,6 +118,7 @@ class MinimalRETRODiffusion(object):
     def load_unet_state_dict(self, unet_sd):
         self.ctx.load_unet(self.unet_cfg, packing.pack("unet", self.unet_cfg, unet_sd))
         self._unet_sd = unet_sd                                  # a reference (no copy): configure_optimizers() starts the masters from it
+        self._ema_sd, self._ema_num_updates, self._ema_decay = None, None, None
 
     def load_first_stage_state_dict(self, vq_sd):
         self.ctx.load_vq(self.vq_cfg, packing.pack("vq", self.vq_cfg, vq_sd))
@@ -130,6 +140,9 @@ class MinimalRETRODiffusion(object):
         every rank searches its rows for the whole query batch and the per-rank top-k lists are merged in one exchange."""
         self.distributed, self._group = bool(enabled), group
         self.shard_db = bool(shard_db) and self.distributed
+        # on an RCCL group the image all-gather goes through the library's own communicator (C ABI rdm_comm_all_gather)
+        self._lib_comm = bool(self.distributed and self._ctx is not None and hasattr(self._ctx, "comm_init")
+                              and parallel.attach_library_comm(self._ctx, group))
         if self.retriever is not None and hasattr(self.retriever, "shard_rows") and \
                 bool(getattr(self.retriever, "_shard_rows", False)) != self.shard_db:
             self.retriever.shard_rows(self.shard_db, group)          # takes effect at the next train_searcher()
@@ -168,7 +181,7 @@ class MinimalRETRODiffusion(object):
             samples, _ = self.sample_log(cond=c, batch_size=hi - lo, unconditional_guidance_scale=scale,
                                          unconditional_conditioning=c_uncond, **kwargs)
         img = self.decode_first_stage(samples)
-        return parallel.all_gather_images(img, n_total, getattr(self, "_group", None))
+        return parallel.all_gather_images(img, n_total, getattr(self, "_group", None), ctx=self._ctx if getattr(self, "_lib_comm", False) else None)
 
     @contextmanager
     def ema_scope(self, context=None):
@@ -228,10 +241,13 @@ class MinimalRETRODiffusion(object):
             return x.to(self.device).float().contiguous(), None
         raise ValueError(f"get_input: batch[{k!r}] is neither a [B,R,R,C] image of the first stage's resolution nor a latent, got {tuple(x.shape)}")
 
-    def configure_optimizers(self, unet_sd=None, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, use_ema=True, ema_decay=0.9999):
+    def configure_optimizers(self, unet_sd=None, lr=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, use_ema=True, ema_decay=None):
         """ldm LatentDiffusion.configure_optimizers (`torch.optim.AdamW(params, lr=self.learning_rate)` over the UNet parameters) +
         the LitEma of DDPM.__init__(use_ema=True): fp32 master weights, AdamW moments, bf16 working copies and EMA shadows in HBM
-        (rdm_amd.training_unet.TrainState).  unet_sd: UNet state dict to start from (default: the one last loaded)."""
+        (rdm_amd.training_unet.TrainState).  unet_sd: UNet state dict to start from (default: the one last loaded).  When the weights
+        came from a checkpoint with `model_ema.*` entries (load_state_dict), the EMA shadows, `num_updates` and `decay` continue from
+        the checkpoint's (as LitEma's buffers do in the reference) instead of restarting the warm-up on a clone of the live weights;
+        ema_decay: None = the checkpoint's decay, else 0.9999."""
         from ... import training_unet as TU
         sd = unet_sd if unet_sd is not None else getattr(self, "_unet_sd", None)
         if sd is None:
@@ -241,7 +257,12 @@ class MinimalRETRODiffusion(object):
         self._opt = {"lr": float(getattr(self, "learning_rate", 1e-4)), "betas": tuple(betas), "eps": float(eps), "weight_decay": float(weight_decay)}
         self._train_shapes = {k: tuple(v.shape) for k, v in sd.items()}
         self.train_spec = TU.TrainSpec(self.unet_cfg)
+        resume = unet_sd is None and getattr(self, "_ema_sd", None) is not None          # the checkpoint's EMA belongs to the checkpoint's weights only
+        if ema_decay is None:
+            ema_decay = (self._ema_decay if resume and self._ema_decay is not None else 0.9999)
         self.train_state = TU.TrainState(TU.params_from_state_dict(sd, self.device), ema_decay=ema_decay if use_ema else None)
+        if use_ema and resume:
+            self.train_state.ema.resume(TU.params_from_state_dict(self._ema_sd, self.device), self._ema_num_updates or 0)
         return self.train_state
 
     def sync_sampling_weights(self, use_ema=True):

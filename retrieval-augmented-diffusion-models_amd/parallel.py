@@ -114,8 +114,47 @@ def per_sample_noise(seed: int, global_indices, shape, device="cpu", dtype=torch
     return torch.stack(out)
 
 
-def all_gather_images(local: torch.Tensor, n_total: int = None, group=None) -> torch.Tensor:
-    """Gather [b_rank, ...] shards into [n_total, ...] on every rank (shards may differ by one sample)."""
+def attach_library_comm(ctx, group=None) -> bool:
+    """Give the library context its own RCCL communicator over the ranks of the torch process group (C ABI: rdm_comm_unique_id on
+    rank 0 -> broadcast of the 128-byte id over the torch group -> rdm_comm_init on every rank), so that the data path's one
+    collective -- the all-gather of the finished images -- is `rdm_comm_all_gather` on the library's stream (`all_gather_images(...,
+    ctx=ctx)`).  Only for an RCCL ("nccl") group with one device per rank; on gloo (CPU tests, several ranks sharing one GPU: RCCL
+    refuses two ranks on one device) nothing is created.  -> True when the communicator exists.  A failure to create it is NOT fatal:
+    the torch.distributed collective stays in use (and the caller can report which one ran)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1 or dist.get_backend(group) != "nccl":
+        return False
+    if getattr(ctx, "comm_world", 0) == dist.get_world_size(group):
+        return True
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ok = torch.ones(1, dtype=torch.int32, device=ctx.device)
+    uid = torch.zeros(128, dtype=torch.uint8, device=ctx.device)
+    if rank == 0:
+        try:
+            uid = torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8).to(ctx.device)
+        except Exception:
+            ok.zero_()
+    dist.broadcast(uid, src=0, group=group)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0:
+        return False
+    try:
+        ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+    except Exception:
+        ok.zero_()
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)          # all ranks agree on which collective they will call
+    if int(ok.item()) == 0:
+        try:
+            ctx.comm_destroy()
+        except Exception:
+            pass
+        return False
+    return True
+
+
+def all_gather_images(local: torch.Tensor, n_total: int = None, group=None, ctx=None) -> torch.Tensor:
+    """Gather [b_rank, ...] shards into [n_total, ...] on every rank (shards may differ by one sample).
+    ctx: a library context with a communicator (attach_library_comm) -> the gather is rdm_comm_all_gather (RCCL through the C ABI, on
+    the library's stream) whenever the shards are equal-sized device tensors; otherwise torch.distributed."""
     if not dist.is_available() or not dist.is_initialized():
         return local
     world = dist.get_world_size(group)
@@ -125,6 +164,9 @@ def all_gather_images(local: torch.Tensor, n_total: int = None, group=None) -> t
         n_total = local.shape[0] * world
     counts = [shard_range(n_total, world, r)[1] - shard_range(n_total, world, r)[0] for r in range(world)]
     bmax = max(counts)
+    if ctx is not None and local.is_cuda and getattr(ctx, "comm_world", 0) == world and all(c == bmax for c in counts):
+        out = ctx.comm_all_gather(local, world)                                  # [world, b, ...]
+        return out.reshape((world * bmax,) + tuple(local.shape[1:]))
     if all(c == bmax for c in counts):
         out = torch.empty((world * bmax,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)

@@ -403,6 +403,15 @@ class Ema:
         self.decay, self.num_updates = decay, 0
         self.shadow = {k: v.clone() for k, v in P.items()}
 
+    def resume(self, shadow, num_updates):
+        """Continue from a checkpoint's LitEma buffers (`model_ema.*`, `model_ema.num_updates`): shadows in the native layouts of P."""
+        missing = set(self.shadow) - set(shadow)
+        if missing:
+            raise KeyError(f"Ema.resume: checkpoint shadows lack {sorted(missing)[:4]}...")
+        for k in self.shadow:
+            self.shadow[k].copy_(shadow[k])
+        self.num_updates = int(num_updates)
+
     def update(self, ctx, P):
         self.num_updates += 1
         decay = min(self.decay, (1 + self.num_updates) / (10 + self.num_updates))

@@ -1,0 +1,62 @@
+"""`bench.py --gpus N` end to end BEFORE an 8-GPU node runs it (verdict round 4, item 2): the N > 1 branch of the benchmark -- the
+torchrun self-launch, shard_range / per_sample_noise inputs by GLOBAL row, the all-gather, the max-over-ranks timing, the one JSON
+line of rank 0 -- executed on the box's ONE GPU with 2 and 4 processes over gloo (RDM_DIST_BACKEND=gloo RDM_DIST_DEVICE=0: RCCL
+refuses two ranks on one device, so the collective here is torch.distributed's; on a real multi-GPU node the same code path attaches
+the library's RCCL communicator, `config.collective` says which one ran).  In deterministic (batch-invariant) mode the gathered
+images of a global batch of 8 must be BIT-IDENTICAL for 1 x 8, 2 x 4 and 4 x 2 rows per rank.
+
+SURVEY.md 8e; /root/reference/scripts/rdm_sample.py:181-185 is single-GPU: everything here is new functionality."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GLOBAL_BATCH = 8
+
+
+def _run_bench(n, tmp_path, tag, extra=(), port=29700):
+    dump = tmp_path / f"img_{tag}.npy"
+    env = dict(os.environ, RDM_DIST_BACKEND="gloo", RDM_DIST_DEVICE="0", RDM_DETERMINISTIC="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MASTER_PORT=str(port))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--batch", str(GLOBAL_BATCH // n), "--db-rows", "200000",
+           "--ddim-steps", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--dump-images", str(dump)] + list(extra)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, f"expected ONE JSON line from rank 0, got {len(lines)}:\n{r.stdout[-2000:]}"
+    return json.loads(lines[0]), np.load(dump)
+
+
+def test_bench_gpus_2_and_4_on_one_gpu_match_the_single_rank_run(tmp_path):
+    one, img1 = _run_bench(1, tmp_path, "w1")
+    assert one["n_gpus"] == 1 and one["config"]["global_batch"] == GLOBAL_BATCH and one["config"]["deterministic_mode"] is True
+    assert img1.shape == (GLOBAL_BATCH, 3, 256, 256) and img1.dtype == np.float32 and np.isfinite(img1).all()
+    assert not np.array_equal(img1[0], img1[GLOBAL_BATCH - 1])                      # different global rows are different samples
+    for n in (2, 4):
+        line, img = _run_bench(n, tmp_path, f"w{n}", port=29700 + n)
+        assert line["n_gpus"] == n and line["steps"] == 1 and line["warmup"] == 1 and line["scaling"] == "weak"
+        assert line["config"]["global_batch"] == GLOBAL_BATCH and line["config"]["batch_per_gpu"] == GLOBAL_BATCH // n
+        assert line["config"]["parallelism"].startswith(f"dp{n}") and "gloo" in line["config"]["collective"]
+        assert np.isfinite(line["value"]) and line["value"] > 0 and abs(line["value"] - GLOBAL_BATCH / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+        assert line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
+        assert img.shape == img1.shape and img.dtype == np.float32
+        assert np.array_equal(img, img1), f"{n} ranks: gathered images differ from the 1-rank run (max |d| {np.abs(img - img1).max():.3e})"
+
+
+def test_bench_uint8_all_gather(tmp_path):
+    """--gather uint8: the collective moves rdm_to_uint8's HWC bytes (12.6 MB per rank at B = 64 instead of 50 MB); equal to
+    the conversion of the fp32 images of the same run configuration (scripts/rdm_sample.py:203-214: clamp, (x + 1) / 2 * 255, truncation)."""
+    _, img_f = _run_bench(2, tmp_path, "f32", port=29710)
+    line, img_u = _run_bench(2, tmp_path, "u8", extra=("--gather", "uint8"), port=29711)
+    assert "uint8" in line["config"]["gathered"] and str(256 * 256 * 3 * (GLOBAL_BATCH // 2)) in line["config"]["gathered"]
+    assert img_u.shape == (GLOBAL_BATCH, 256, 256, 3) and img_u.dtype == np.uint8
+    v = np.clip(img_f, np.float32(-1), np.float32(1))
+    ref = (np.float32(255.0) * ((v + np.float32(1.0)) / np.float32(2.0))).astype(np.uint8).transpose(0, 2, 3, 1)
+    assert np.array_equal(img_u, ref)

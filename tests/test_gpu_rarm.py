@@ -100,6 +100,44 @@ def test_rarm_forward_shipped_deep_golden_batch64(ctx):
             assert e <= 2.5e-2
 
 
+def test_rarm_split_cross_attention_stress_bitwise(ctx, tmp_path):
+    """The split decode cross-attention (four blocks per sequence, partial rows handed over through agent-scope write-through stores and
+    one relaxed arrival counter: rarm.hip's memory-model note) must behave like a deterministic function: 40 repeated 24-token decodes of
+    a 64-sequence batch at the shipped size (18 layers x 24 positions x 64 sequences x 40 = 1.1 M hand-overs) are compared BIT FOR BIT
+    with the first one -- a last arriver that read a stale partial row would show up as a differing run -- and the result agrees with the
+    one-block form of the kernel (RDM_NO_RARM_XSPLIT=1, another summation order: a bound, not bits) run in a child process."""
+    import os
+    import subprocess
+    import sys
+    spec = orarm.shipped_rarm_spec()
+    _load(ctx, spec, 77)
+    gen = torch.Generator().manual_seed(5)
+    tokens = torch.randint(0, spec.vocab_out, (64, 24), generator=gen)
+    context = torch.randn((64, 8, spec.context_dim), generator=gen) * 0.45
+    first = ctx.rarm_forward(tokens, context).cpu()
+    assert bool(torch.isfinite(first).all())
+    for rep in range(39):
+        again = ctx.rarm_forward(tokens, context).cpu()
+        assert torch.equal(again, first), f"repeat {rep + 1}: the split cross-attention gave different bits"
+    out = tmp_path / "oneblock.npy"
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})\n"
+        "import rdm_amd\nfrom rdm_amd import _lib, packing\nfrom oracle import rarm as orarm, unet as ounet\n"
+        "import test_gpu_rarm as T\n"
+        "torch.set_grad_enabled(False)\nctx = _lib.Context(0)\nspec = orarm.shipped_rarm_spec()\nT._load(ctx, spec, 77)\n"
+        "gen = torch.Generator().manual_seed(5)\ntokens = torch.randint(0, spec.vocab_out, (64, 24), generator=gen)\n"
+        "context = torch.randn((64, 8, spec.context_dim), generator=gen) * 0.45\n"
+        f"np.save({str(out)!r}, ctx.rarm_forward(tokens, context).cpu().numpy())\n")
+    env = dict(os.environ, RDM_NO_RARM_XSPLIT="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    one = torch.from_numpy(np.load(out))
+    e = rel_l2(first, one)
+    print("split vs one-block decode cross-attention, rel L2:", e)
+    assert e <= 2e-3
+
+
 def test_rarm_sampler_kernel_exact_at_vocab_16384(ctx):
     """The sampler kernel on STORED reference logits at the shipped vocabulary (16 384) and top-k 256, guided (scale 2.0): the tokens
     must EQUAL the reference run's (same uniforms), and with ties planted exactly at the top-k threshold (the 257th guided logit made

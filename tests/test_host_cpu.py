@@ -279,6 +279,7 @@ def _worker(rank, world, port, n_total, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from rdm_amd import parallel
     assert parallel.init_distributed("gloo") == (rank, rank)
+    assert parallel.attach_library_comm(FakeCtx()) is False           # the library's RCCL communicator is for RCCL groups only
     out = _dist_run(n_total)
     if rank == 0:
         q.put(out)
@@ -618,3 +619,37 @@ def test_train_spec_matches_oracle_block_table():
         assert t.blocks == spec.blocks
         assert (t.in_channels, t.out_channels, t.model_channels) == (spec.in_channels, spec.out_channels, spec.model_channels)
         assert synthetic.unet_param_shapes(cfg) == ounet.param_shapes(spec)
+
+
+def test_configure_optimizers_resumes_litema_from_checkpoint():
+    """A checkpoint's LitEma buffers (`model_ema.<name without dots>`, `model_ema.num_updates`, `model_ema.decay`) are restored by the
+    reference's load_state_dict; configure_optimizers must continue from them, not restart the warm-up on a clone of the live weights
+    (the first update would then pull the average onto the live weights with decay 2/11)."""
+    from oracle import unet as ounet
+    from rdm_amd.models.diffusion.ddpm import MinimalRETRODiffusion
+    from _util import spec_to_unet_cfg
+
+    class Ctx:
+        device = torch.device("cpu")
+        def load_unet(self, cfg, blob): self.loaded = len(blob)
+
+    spec = ounet.tiny_spec()
+    cfg = spec_to_unet_cfg(spec)
+    live = ounet.synth_state_dict(ounet.param_shapes(spec), seed=3)
+    ema = ounet.synth_state_dict(ounet.param_shapes(spec), seed=4)
+    ckpt = {"model.diffusion_model." + k: v for k, v in live.items()}
+    ckpt.update({"model_ema." + ("diffusion_model." + k).replace(".", ""): v for k, v in ema.items()})
+    ckpt["model_ema.num_updates"] = torch.tensor(12345, dtype=torch.int)
+    ckpt["model_ema.decay"] = torch.tensor(0.999, dtype=torch.float32)
+    m = MinimalRETRODiffusion(unet_config={"params": {}}, ctx=Ctx())
+    m.unet_cfg = cfg
+    m.load_state_dict(ckpt)
+    st = m.configure_optimizers()
+    k0 = "input_blocks.1.0.in_layers.2.weight"
+    assert st.ema.num_updates == 12345 and abs(st.ema.decay - 0.999) < 1e-7
+    assert torch.equal(st.ema.shadow[k0], ema[k0].permute(0, 2, 3, 1).contiguous())          # native conv layout, EMA values
+    assert torch.equal(st.P[k0], live[k0].permute(0, 2, 3, 1).contiguous())                  # masters = the LIVE weights
+    # a checkpoint without EMA entries (or explicit weights) starts a fresh average on the live weights
+    m.load_state_dict({"model.diffusion_model." + k: v for k, v in live.items()})
+    st = m.configure_optimizers()
+    assert st.ema.num_updates == 0 and st.ema.decay == 0.9999 and torch.equal(st.ema.shadow[k0], st.P[k0])
