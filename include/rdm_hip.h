@@ -245,6 +245,10 @@ enum { RDM_PROF_CONV3X3 = 0, RDM_PROF_LINEAR = 1, RDM_PROF_KNN = 2, RDM_PROF_ATT
 int rdm_prof_enable(rdm_ctx* ctx, int kind_mask);
 int rdm_prof_collect(rdm_ctx* ctx, int kind, long long* launches, double* ms, double* flops);
 int rdm_prof_reset(rdm_ctx* ctx);
+/* one CSV row per recorded launch since the last reset: kind, the op's role in the executor's graph ("st.proj_in", "res.conv1", ...; the
+ * reference modules behind the roles: rdm/modules/attention.py:122-196, ldm ResBlock), its shape (M, N, K | rows, channels | B, n, C),
+ * elapsed ms and algorithmic work -- the per-op table behind DESIGN.md's level-by-level costs (tools/op_trace.py). */
+int rdm_prof_dump(rdm_ctx* ctx, const char* path);
 
 /* ---- operator-level entry points (used by the parity tests; thin wrappers over the kernels) ---- */
 int rdm_op_linear(rdm_ctx* ctx, const void* a_bf16, const void* w_bf16, const float* bias, const void* residual_bf16,

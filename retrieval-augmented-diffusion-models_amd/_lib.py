@@ -105,6 +105,7 @@ SIGNATURES = {
     "rdm_prof_enable": (C.c_int, [_P, C.c_int]),
     "rdm_prof_collect": (C.c_int, [_P, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rdm_prof_reset": (C.c_int, [_P]),
+    "rdm_prof_dump": (C.c_int, [_P, C.c_char_p]),
     "rdm_comm_unique_id": (C.c_int, [_P, _P]),
     "rdm_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "rdm_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -635,6 +636,10 @@ class Context:
 
     def prof_reset(self):
         self._check(lib.rdm_prof_reset(self._h))
+
+    def prof_dump(self, path):
+        """One CSV row per recorded launch (kind, role tag, shape, ms, work): tools/op_trace.py."""
+        self._check(lib.rdm_prof_dump(self._h, os.fsencode(path)))
 
     def prof_collect(self, kind):
         n, ms, fl = C.c_longlong(0), C.c_double(0), C.c_double(0)

@@ -560,7 +560,7 @@ struct rdm_ctx {
     void* rccl_lib = nullptr; void* comm = nullptr; int comm_world = 0;
     // optional per-launch HIP-event profiler for the GEMM-class kernels (bench.py roofline)
     unsigned prof = 0;           // bit k set: record HIP events around launches of kind k (RDM_PROF_* in rdm_hip.h)
-    struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+    struct ProfRec { hipEvent_t a, b; int kind; double flops; const char* tag; int d0, d1, d2; };      // tag: the op's role in the graph (string literal), d*: its shape
     std::vector<ProfRec> prof_recs; std::vector<hipEvent_t> prof_pool;
     hipEvent_t prof_event() {
         if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
@@ -611,7 +611,7 @@ struct Ops {
             SgemmParams q{}; q.A = A0; q.lda = C0; q.W = w<bf16_t>(woff); q.M = M; q.N = N; q.K = C0; q.bias = has_bias ? w<float>(boff) : nullptr;
             q.act = act; q.res_f32 = res_f32; q.res_bf16 = res; q.out_f32 = out_f32; q.out_bf16 = out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
             if (sgemm_supported(q)) {
-                prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)C0);
+                prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)C0, M, N, C0);
                 check(launch_sgemm(q, c->stream), "skinny linear");
                 prof_end();
                 return;
@@ -631,7 +631,7 @@ struct Ops {
             if (c->deterministic) t.l4_any_tiles = p.l4_any_tiles = 1;
             if ((!c->deterministic || det_ok) && lin4_supported(t, 1)) p.Wfrag = c->frag_for_lin(p.W, N, C0 + C1, act == ACT_GEGLU);
         }
-        prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)(C0 + C1));
+        prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)(C0 + C1), M, N, C0 + C1);
         check(launch_igemm(p, false, 1, c->stream), "linear");
         prof_end();
     }
@@ -644,7 +644,7 @@ struct Ops {
         q.bias = has_bias ? w<float>(boff) : nullptr; q.act = act; q.out_bf16 = out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
         if (off || !skinny || !sgemm_supported(q)) return false;
         if (plan) return true;
-        prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)C);
+        prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)C, M, N, C);
         check(launch_sgemm(q, c->stream), "skinny linear on a LayerNorm");
         prof_end();
         return true;
@@ -667,7 +667,7 @@ struct Ops {
         if (plan) return true;
         p.Wfrag = c->frag_for_lin_ln(p.W, N, C, act == ACT_GEGLU, w<float>(g), w<float>(b), has_bias ? w<float>(boff) : nullptr, &p.ln_sb);
         if (!p.Wfrag) { if (rc == 0) rc = c->fail(-2, "out of memory for a LayerNorm-folded weight copy"); return true; }
-        prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)C);
+        prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)C, M, N, C);
         check(launch_lin4(p, c->stream), "linear on a folded LayerNorm");
         prof_end();
         return true;
@@ -694,7 +694,7 @@ struct Ops {
                 q.A0 = A0; q.C0 = C0; q.W = wp; q.bias = w<float>(boff); q.out_bf16 = out; q.phase2 = 1;
                 q.Hin = Hin; q.Win = Win; q.Hout = Hout; q.Wout = Wout; q.stride = 1; q.rows_per_sample = Hin * Win;
                 q.sA = 0; q.sW = (long long)N * 4 * C0; q.sO = 0;
-                prof_begin(RDM_PROF_UPSCONV, 2.0 * 4.0 * q.M * N * (double)q.K);
+                prof_begin(RDM_PROF_UPSCONV, 2.0 * 4.0 * q.M * N * (double)q.K, 4 * q.M, N, q.K);
                 check(launch_igemm(q, true, 4, c->stream), "conv3x3 on a 2x upsample, by phase");
                 prof_end();
                 return;
@@ -704,17 +704,18 @@ struct Ops {
         const int ks = c->deterministic ? 1 : conv_halo_ksplit(p);
         if (ks > 1 && ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)ks * p.M * N * 4) == 0) { p.ksplit = ks; p.ws = (float*)c->splitk_ws; }
         if (!det_generic && (conv_halo_supported(p) || conv_halo4_strip_supported(p))) p.Wfrag = c->frag_for(p.W, N, C0 + C1);
-        prof_begin(RDM_PROF_CONV3X3, 2.0 * p.M * N * (double)p.K);
+        prof_begin(RDM_PROF_CONV3X3, 2.0 * p.M * N * (double)p.K, p.M, N, p.K);
         check(det_generic ? launch_igemm(p, true, 1, c->stream) : launch_conv3x3(p, c->stream), "conv3x3");
         prof_end();
     }
     bool single_row = false;     // set by callers around ops whose operand has one row per sample (see linear)
     int rows_hint = 0;           // rows per sample of the operand of the linear ops that follow (0 = unknown); set by the UNet block executors
     bool prof_open = false;
-    void prof_begin(int kind, double work) {       // work: FLOPs (GEMM-class kinds) or bytes (bandwidth-class kinds)
+    const char* tag = "";        // role of the ops that follow in the graph ("st.proj_in", "res.conv1", ...): rdm_prof_dump groups by it
+    void prof_begin(int kind, double work, int d0 = 0, int d1 = 0, int d2 = 0) {       // work: FLOPs (GEMM-class kinds) or bytes (bandwidth-class kinds)
         prof_open = (c->prof >> kind) & 1u;
         if (!prof_open) return;
-        rdm_ctx::ProfRec r; r.a = c->prof_event(); r.b = c->prof_event(); r.kind = kind; r.flops = work;
+        rdm_ctx::ProfRec r; r.a = c->prof_event(); r.b = c->prof_event(); r.kind = kind; r.flops = work; r.tag = tag; r.d0 = d0; r.d1 = d1; r.d2 = d2;
         hipEventRecord(r.a, c->stream); c->prof_recs.push_back(r);
     }
     void prof_end() { if (prof_open) hipEventRecord(c->prof_recs.back().b, c->stream); prof_open = false; }
@@ -726,7 +727,7 @@ struct Ops {
         int nchunk = HW / 64; if (nchunk < 1) nchunk = 1; if (nchunk > 32) nchunk = 32;
         p.nchunk = nchunk; p.partial = c->gn_partial; p.gamma = w<float>(g); p.beta = w<float>(b); p.eps = eps; p.silu = silu;
         p.out = out;
-        prof_begin(RDM_PROF_GROUPNORM, (double)B * HW * (C0 + C1) * 6.0);       // two reads + one write of the bf16 tensor
+        prof_begin(RDM_PROF_GROUPNORM, (double)B * HW * (C0 + C1) * 6.0, B * HW, C0 + C1, silu);       // two reads + one write of the bf16 tensor
         check(launch_groupnorm(p, c->stream), "groupnorm");
         prof_end();
     }
@@ -742,7 +743,7 @@ struct Ops {
         hp.partial = c->gn_partial; hp.nchunk = nchunk;
         if (!off && Clog == C && head_conv_supported(hp)) {
             GnParams p{}; p.x0 = x; p.C0 = C; p.HW = H * W; p.B = B; p.groups = 32; p.L0 = C; p.nchunk = nchunk; p.partial = c->gn_partial;
-            prof_begin(RDM_PROF_GROUPNORM, (double)B * H * W * C * 2.0);
+            prof_begin(RDM_PROF_GROUPNORM, (double)B * H * W * C * 2.0, B * H * W, C, 2);
             check(launch_gn_stats(p, c->stream), "head groupnorm statistics");
             prof_end();
             check(launch_head_conv(hp, c->stream), "head conv");
@@ -753,7 +754,7 @@ struct Ops {
     }
     void layernorm(const void* x, int in_f32, size_t g, size_t b, void* out, int out_f32, int M, int C, int Clog = -1) {
         if (plan) return;
-        prof_begin(RDM_PROF_LAYERNORM, (double)M * C * ((in_f32 ? 4.0 : 2.0) + (out_f32 ? 4.0 : 2.0)));
+        prof_begin(RDM_PROF_LAYERNORM, (double)M * C * ((in_f32 ? 4.0 : 2.0) + (out_f32 ? 4.0 : 2.0)), M, C, 0);
         check(launch_layernorm(x, in_f32, w<float>(g), w<float>(b), out, out_f32, M, C, 1e-5f, c->stream, Clog < 0 ? C : Clog), "layernorm");
         prof_end();
     }
@@ -824,6 +825,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
     if (!o.plan) o.check(launch_timestep_embedding(t, temb, B, mcl, mc, o.c->stream), "timestep_embedding");
     bf16_t* e1 = o.abf((size_t)B * ted);
     o.single_row = true;                                  // one row per sample (see Ops::linear)
+    o.tag = "time_embed";
     o.linear(temb, nullptr, mc, 0, u.te0w, u.te0b, true, B, ted, ACT_SILU, nullptr, e1);
     bf16_t* semb = o.abf((size_t)B * ted);
     o.linear(e1, nullptr, ted, 0, u.te2w, u.te2b, true, B, ted, ACT_SILU, nullptr, semb);
@@ -861,18 +863,23 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         }
         const bf16_t* x1 = skip ? skip->p : nullptr;
         bf16_t* n1 = o.abf((size_t)M * r.cin);
+        o.tag = "res.gn1";
         o.groupnorm(a.p, x1, C0, C1, B, HW, r.gn1g, r.gn1b, 1e-5f, 1, n1, a.L, skip ? skip->L : 0, wrap_b);
         bf16_t* h1 = o.abf((size_t)M * r.cout);
+        o.tag = "res.conv1";
         o.conv3(n1, nullptr, r.cin, 0, r.w1, r.b1, B, a.H, a.W, r.cout, 1, 0, emb_all + r.emb_off, u.emb_total, nullptr, h1);
         bf16_t* n2 = o.abf((size_t)M * r.cout);
+        o.tag = "res.gn2";
         o.groupnorm(h1, nullptr, r.cout, 0, B, HW, r.gn2g, r.gn2b, 1e-5f, 1, n2, r.lout, 0);
         const bf16_t* res = a.p;
         if (r.skip) {
             bf16_t* s = o.abf((size_t)M * r.cout);
+            o.tag = "res.skip";
             o.linear(a.p, x1, C0, C1, r.wsk, r.bsk, true, M, r.cout, ACT_NONE, nullptr, s, nullptr, nullptr, wrap_b * HW);
             res = s;
         }
         bf16_t* out = o.abf((size_t)Bfull * HW * r.cout);           // Bfull: see expand()
+        o.tag = "res.conv2";
         o.conv3(n2, nullptr, r.cout, 0, r.w2, r.b2, B, a.H, a.W, r.cout, 1, 0, nullptr, 0, res, out);
         return Act{out, r.cout, a.H, a.W, r.lout};
     };
@@ -880,8 +887,10 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         const int C = s.c, n = a.H * a.W, M = B * n;
         o.rows_hint = n;
         bf16_t* xn = o.abf((size_t)M * C);
+        o.tag = "st.gn";
         o.groupnorm(a.p, nullptr, C, 0, B, n, s.gng, s.gnb, 1e-6f, 0, xn, s.lc, 0);
         bf16_t* t0 = o.abf((size_t)M * C);
+        o.tag = "st.proj_in";
         o.linear(xn, nullptr, C, 0, s.win, s.bin, true, M, C, ACT_NONE, nullptr, t0);
         // --- attn1 (self)
         bf16_t* l1 = o.abf((size_t)M * C);
@@ -892,17 +901,19 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         const bool vrow = (n % 64 == 0) && !no_vrow && s.v_follows;
         const int QW = vrow ? 3 * C : 2 * C;
         bf16_t* qk = o.abf((size_t)M * QW);
+        o.tag = "st.norm1+qkv";
         // norm1 folded into the q | k | v projection where lin4 takes it (only the fused form: the other paths read l1 again)
         if (!(vrow && o.linear_ln_big(t0, s.ln1g, s.ln1b, C, s.lc, s.wqk, 0, false, M, QW, ACT_NONE, qk))) {
             o.layernorm(t0, 0, s.ln1g, s.ln1b, l1, 0, M, C, s.lc);
             o.linear(l1, nullptr, C, 0, s.wqk, 0, false, M, QW, ACT_NONE, nullptr, qk);
         }
         bf16_t* ao = o.abf((size_t)M * C);
+        o.tag = "st.self_attention";
         if (vrow) {
             if (!o.plan) {
                 FlashParams f{}; f.q = qk; f.ldq = QW; f.k = qk + C; f.ldk = QW; f.v = qk + 2 * C; f.ldv = QW; f.out = ao; f.ldo = C;
                 f.n = n; f.C = C; f.scale_log2e = (1.0f / sqrtf(32.f)) * 1.4426950408889634f;
-                o.prof_begin(RDM_PROF_ATTENTION, 4.0 * B * s.heads * (double)n * n * 32);
+                o.prof_begin(RDM_PROF_ATTENTION, 4.0 * B * s.heads * (double)n * n * 32, B, n, C);
                 o.check(launch_flash_d32(f, s.heads, B, o.c->stream), "flash attention");
                 o.prof_end();
             }
@@ -915,7 +926,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                 o.check(launch_igemm(p, false, B, o.c->stream), "v^T gemm");
                 FlashParams f{}; f.q = qk; f.ldq = 2 * C; f.k = qk + C; f.ldk = 2 * C; f.vt = vt; f.out = ao; f.ldo = C;
                 f.n = n; f.C = C; f.scale_log2e = (1.0f / sqrtf(32.f)) * 1.4426950408889634f;
-                o.prof_begin(RDM_PROF_ATTENTION, 4.0 * B * s.heads * (double)n * n * 32);
+                o.prof_begin(RDM_PROF_ATTENTION, 4.0 * B * s.heads * (double)n * n * 32, B, n, C);
                 o.check(launch_flash_d32(f, s.heads, B, o.c->stream), "flash attention");
                 o.prof_end();
             }
@@ -929,9 +940,11 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
             }
         }
         bf16_t* t1 = o.abf((size_t)M * C);
+        o.tag = "st.attn1.to_out";
         o.linear(ao, nullptr, C, 0, s.wo1, s.bo1, true, M, C, ACT_NONE, t0, t1);
         // --- attn2 (cross over the k neighbours); samples >= Bx have all-zero neighbours: t2 = t1 + b_o exactly (see add_bias_rows_kernel)
         const int Mx = Bx * n;
+        o.tag = "st.norm2+attn2";
         bf16_t* l2 = o.abf((size_t)M * C);
         // norm2 + attn2 + residual in one kernel when the neighbours' operands are cached (xa) and no channel is padding
         static const int no_xfused = getenv("RDM_NO_XFUSED") ? atoi(getenv("RDM_NO_XFUSED")) : 0;       // 1: two GEMMs; 2: fused without the LayerNorm
@@ -955,7 +968,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                 xp.out = t2;
                 if (xln) { xp.x = t1; xp.res = nullptr; xp.ln_g = o.w<float>(s.ln2g); xp.ln_b = o.w<float>(s.ln2b); xp.ln_eps = 1e-5f; }
                 if (xfused) {       // both GEMMs, the softmax and the residual (and norm2) in one launch (attention.hip)
-                    o.prof_begin(RDM_PROF_LINEAR, 4.0 * Mx * XA_NP * (double)C);
+                    o.prof_begin(RDM_PROF_LINEAR, 4.0 * Mx * XA_NP * (double)C, Mx, XA_NP, C);
                     o.check(launch_xattn_fused(xp, o.c->stream), "fused cross attention");
                     o.prof_end();
                 } else {
@@ -986,6 +999,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         }
         // --- GEGLU feed-forward
         bf16_t* l3 = o.abf((size_t)M * C);
+        o.tag = "st.norm3+geglu";
         const int FI = 4 * s.lc;                     // GEGLU hidden width: 4 x the LOGICAL channels (a multiple of 128, never padded)
         bf16_t* ff = o.abf((size_t)M * FI);
         if (!o.linear_ln_big(t2, s.ln3g, s.ln3b, C, s.lc, s.wff1, s.bff1, true, M, 2 * FI, ACT_GEGLU, ff)) {       // norm3 folded into the GEGLU projection
@@ -993,6 +1007,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
             o.linear(l3, nullptr, C, 0, s.wff1, s.bff1, true, M, 2 * FI, ACT_GEGLU, nullptr, ff);
         }
         bf16_t* out = o.abf((size_t)M * C);
+        o.tag = "st.ff2*proj_out";
         static const int no_ffout = getenv("RDM_NO_FFOUT") ? atoi(getenv("RDM_NO_FFOUT")) : 0;
         if (!no_ffout) {
             // t3 = ff W_2^T + b_2 + t2 and out = t3 W_out^T + b_out + x are one GEMM over the K-concatenated operand [ff | t2]
@@ -1028,12 +1043,14 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                 case 3: {
                     const ConvW& d = u.down[L.idx];
                     bf16_t* out = o.abf((size_t)Bfull * (h.H / 2) * (h.W / 2) * d.c);
+                    o.tag = "downsample";
                     o.conv3(h.p, nullptr, d.c, 0, d.w, d.b, B, h.H, h.W, d.c, 2, 0, nullptr, 0, nullptr, out);
                     h = Act{out, d.c, h.H / 2, h.W / 2, d.lc};
                 } break;
                 case 4: {
                     const ConvW& d = u.up[L.idx];
                     bf16_t* out = o.abf((size_t)Bfull * (h.H * 2) * (h.W * 2) * d.c);
+                    o.tag = "upsample";
                     o.conv3(h.p, nullptr, d.c, 0, d.w, d.b, B, h.H, h.W, d.c, 1, 1, nullptr, 0, nullptr, out);
                     h = Act{out, d.c, h.H * 2, h.W * 2, d.lc};
                 } break;
@@ -1045,6 +1062,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
     if (B < Bfull) { expand(h); B = Bfull; }          // (a UNet without attention: the whole network was shared)
     bf16_t* no = o.abf((size_t)B * H * W * mc);
     bf16_t* hwp = o.abf(head_conv_wp_bytes(mc) / 2);
+    o.tag = "out_head";
     o.head(h.p, B, H, W, mc, mcl, u.outg, u.outb, 1e-5f, u.outw, u.outbias, c.out_channels, eps_out, no, hwp);
 }
 
@@ -1884,6 +1902,7 @@ static int knn_entry(rdm_ctx* c, const float* q, int b, int k, uint32_t* idx_out
     if (prof) {     // whole search (query prep + database scan + candidate merge); work = bytes of the database passes
         rdm_ctx::ProfRec r; r.a = c->prof_event(); r.b = c->prof_event(); r.kind = RDM_PROF_KNN;
         r.flops = (double)((b + 63) / 64) * (double)c->db.n * c->db.dim * 2.0;
+        r.tag = "knn"; r.d0 = b; r.d1 = k; r.d2 = c->db.dim;
         hipEventRecord(r.a, c->stream); c->prof_recs.push_back(r);
     }
     const char* msg = knn_search(c->db, q, b, k, idx_out, score_out, score64_out, c->stream);
@@ -1989,6 +2008,20 @@ int rdm_prof_collect(rdm_ctx* c, int kind, long long* launches, double* ms, doub
         n++; t += e; f += r.flops;
     }
     if (launches) *launches = n; if (ms) *ms = t; if (flops) *flops = f;
+    return 0;
+}
+int rdm_prof_dump(rdm_ctx* c, const char* path) {
+    RDM_ENTER(c);
+    if (!c || !path) return -1;
+    RDM_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    FILE* f = fopen(path, "w");
+    if (!f) return c->fail(-1, "rdm_prof_dump: cannot open %s", path);
+    fprintf(f, "kind,tag,d0,d1,d2,ms,work\n");
+    for (auto& r : c->prof_recs) {
+        float e = 0; hipEventElapsedTime(&e, r.a, r.b);
+        fprintf(f, "%d,%s,%d,%d,%d,%.6f,%.6e\n", r.kind, r.tag ? r.tag : "", r.d0, r.d1, r.d2, e, r.flops);
+    }
+    fclose(f);
     return 0;
 }
 int rdm_prof_reset(rdm_ctx* c) {

@@ -35,28 +35,33 @@ def _run_bench(n, tmp_path, tag, extra=(), port=29700):
 
 
 def test_bench_gpus_2_and_4_on_one_gpu_match_the_single_rank_run(tmp_path):
+    """Three runs of the default benchmark command on a shortened workload (global batch 8, 2 DDIM steps, 200 k database rows):
+    1 rank x 8 rows; 4 ranks x 2 rows with the fp32 all-gather -> bit-identical images; 2 ranks x 4 rows with `--gather uint8` (the
+    collective moves rdm_to_uint8's HWC bytes: 12.6 MB per rank at B = 64 instead of 50 MB) -> equal to the conversion of
+    the 1-rank images (scripts/rdm_sample.py:203-214: clamp, (x + 1) / 2 * 255, truncation)."""
     one, img1 = _run_bench(1, tmp_path, "w1")
     assert one["n_gpus"] == 1 and one["config"]["global_batch"] == GLOBAL_BATCH and one["config"]["deterministic_mode"] is True
+    assert one["config"]["collective"] is None
     assert img1.shape == (GLOBAL_BATCH, 3, 256, 256) and img1.dtype == np.float32 and np.isfinite(img1).all()
     assert not np.array_equal(img1[0], img1[GLOBAL_BATCH - 1])                      # different global rows are different samples
-    for n in (2, 4):
-        line, img = _run_bench(n, tmp_path, f"w{n}", port=29700 + n)
+    assert abs(one["roofline"]["conv_time_frac_of_step"]) < 1.0 and one["roofline"]["end_to_end_frac"] > 0
+
+    def check_line(line, n):
         assert line["n_gpus"] == n and line["steps"] == 1 and line["warmup"] == 1 and line["scaling"] == "weak"
         assert line["config"]["global_batch"] == GLOBAL_BATCH and line["config"]["batch_per_gpu"] == GLOBAL_BATCH // n
         assert line["config"]["parallelism"].startswith(f"dp{n}") and "gloo" in line["config"]["collective"]
         assert np.isfinite(line["value"]) and line["value"] > 0 and abs(line["value"] - GLOBAL_BATCH / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
         assert line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
-        assert img.shape == img1.shape and img.dtype == np.float32
-        assert np.array_equal(img, img1), f"{n} ranks: gathered images differ from the 1-rank run (max |d| {np.abs(img - img1).max():.3e})"
 
+    line4, img4 = _run_bench(4, tmp_path, "w4", port=29704)
+    check_line(line4, 4)
+    assert img4.shape == img1.shape and img4.dtype == np.float32
+    assert np.array_equal(img4, img1), f"4 ranks: gathered images differ from the 1-rank run (max |d| {np.abs(img4 - img1).max():.3e})"
 
-def test_bench_uint8_all_gather(tmp_path):
-    """--gather uint8: the collective moves rdm_to_uint8's HWC bytes (12.6 MB per rank at B = 64 instead of 50 MB); equal to
-    the conversion of the fp32 images of the same run configuration (scripts/rdm_sample.py:203-214: clamp, (x + 1) / 2 * 255, truncation)."""
-    _, img_f = _run_bench(2, tmp_path, "f32", port=29710)
-    line, img_u = _run_bench(2, tmp_path, "u8", extra=("--gather", "uint8"), port=29711)
-    assert "uint8" in line["config"]["gathered"] and str(256 * 256 * 3 * (GLOBAL_BATCH // 2)) in line["config"]["gathered"]
+    line2, img_u = _run_bench(2, tmp_path, "w2u8", extra=("--gather", "uint8"), port=29702)
+    check_line(line2, 2)
+    assert "uint8" in line2["config"]["gathered"] and str(256 * 256 * 3 * (GLOBAL_BATCH // 2)) in line2["config"]["gathered"]
     assert img_u.shape == (GLOBAL_BATCH, 256, 256, 3) and img_u.dtype == np.uint8
-    v = np.clip(img_f, np.float32(-1), np.float32(1))
+    v = np.clip(img1, np.float32(-1), np.float32(1))
     ref = (np.float32(255.0) * ((v + np.float32(1.0)) / np.float32(2.0))).astype(np.uint8).transpose(0, 2, 3, 1)
-    assert np.array_equal(img_u, ref)
+    assert np.array_equal(img_u, ref), "2 ranks, uint8 gather: bytes differ from the conversion of the 1-rank fp32 images"
