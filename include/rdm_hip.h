@@ -253,6 +253,12 @@ int rdm_prof_dump(rdm_ctx* ctx, const char* path);
 /* ---- operator-level entry points (used by the parity tests; thin wrappers over the kernels) ---- */
 int rdm_op_linear(rdm_ctx* ctx, const void* a_bf16, const void* w_bf16, const float* bias, const void* residual_bf16,
                   void* out_bf16, float* out_f32, int M, int N, int K, int act, float alpha);
+/* out[m] = a[m] W^T + bias + rowvec[m / rows_per_group] (+ residual[m]): nn.Linear with a per-row-group additive vector (rowvec f32
+ * [ceil(M / rows_per_group), N]).  The executor uses it for attn1.to_out over a guided batch [conditional | unconditional]
+ * (rdm/modules/attention.py:237-238 with ddim.py:229-234's batch): the unconditional rows' cross-attention is exactly attn2.to_out's
+ * bias, which rides in the projection's start values for those rows (two groups; any group count on the generic GEMM). */
+int rdm_op_linear_rowvec(rdm_ctx* ctx, const void* a_bf16, const void* w_bf16, const float* bias, const float* rowvec, int rows_per_group,
+                         const void* residual_bf16, void* out_bf16, int M, int N, int K);
 /* out = act(LayerNorm(x; gamma, beta, eps) W^T + bias) in ONE kernel: nn.LayerNorm followed by nn.Linear as in BasicTransformerBlock
  * (rdm/modules/attention.py:147-168: `self.attn1(self.norm1(x))`, `self.ff(self.norm3(x))`), the LayerNorm folded into the GEMM
  * (lin4.hip).  x bf16 [M, K] RAW rows, w bf16 [N, K] (GEGLU: rows in the packed [32 x | 32 gates] order), out bf16 [M, N] (GEGLU: [M, N/2]).
@@ -366,6 +372,12 @@ int rdm_op_self_attention_qkv(rdm_ctx* ctx, const void* qkv_bf16, int B, int n, 
 int rdm_op_xattn_fused(rdm_ctx* ctx, const void* x_bf16, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* G_bf16,
                        const void* U_bf16, const float* bias, const void* res_bf16, int B, int n, int C, int NP, int ncols, int group,
                        void* out_bf16);
+/* The LayerNorm-folded form IN PLACE with norm3 emitted as well (what the executor runs on a guided batch's conditional rows):
+ *   x[b] <- softmax_groups(LayerNorm(x[b]; ln) G[b]^T) U[b]^T + bias + x[b];   ln3_out[b] = LayerNorm(x[b] (the bf16 rows just stored); ln3)
+ * i.e. `x = attn2(norm2(x), context) + x` followed by `norm3(x)` of BasicTransformerBlock (attention.py:238-239) in one launch. */
+int rdm_op_xattn_fused_ln3(rdm_ctx* ctx, void* x_bf16_inout, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* G_bf16,
+                           const void* U_bf16, const float* bias, int B, int n, int C, int NP, int ncols, int group,
+                           const float* ln3_gamma, const float* ln3_beta, void* ln3_out_bf16);
 /* The UNet's `out` head (openaimodel.py:307-311: GroupNorm32 + SiLU + 3x3 conv to out_channels) and the VQ decoder's norm_out + swish +
  * conv_out as one statistics pass + one kernel: x bf16 NHWC [B, H, W, C] raw, 32 groups; gn_gamma / gn_beta null: no norm, x is convolved
  * as is.  w fp32 [Cout, C, 3, 3], bias fp32 [Cout] or null, out fp32 NCHW [B, Cout, H, W].  C % 32 == 0, C <= 240, W % 32 == 0, H even,

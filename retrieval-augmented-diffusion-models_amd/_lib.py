@@ -151,6 +151,8 @@ SIGNATURES = {
     "rdm_op_self_attention": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_op_self_attention_qkv": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_op_head_conv": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "rdm_op_linear_rowvec": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "rdm_op_xattn_fused_ln3": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "rdm_op_xattn_fused": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "rdm_op_small_attention": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_float, _P, C.c_int]),
@@ -656,6 +658,14 @@ class Context:
                                       act, float(alpha)))
         return of if out_f32 else ob
 
+    def op_linear_rowvec(self, a, w, bias, rowvec, rows_per_group, residual=None):
+        """a w^T + bias + rowvec[row // rows_per_group] (+ residual): rowvec f32 [groups, N]."""
+        M, K = a.shape; N = w.shape[0]
+        assert rowvec.dtype == torch.float32 and rowvec.shape == ((M + rows_per_group - 1) // rows_per_group, N) and rowvec.is_contiguous()
+        out = torch.empty((M, N), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_linear_rowvec(self._h, _ptr(a), _ptr(w), _ptr(bias), _ptr(rowvec), int(rows_per_group), _ptr(residual), _ptr(out), M, N, K))
+        return out
+
     def op_linear_ln(self, x, w, bias, gamma, beta, act=ACT_NONE, eps=1e-5):
         """act(LayerNorm(x) w^T + bias) with the LayerNorm folded into the GEMM (raises RdmError for shapes the folded kernel does not take)."""
         M, K = x.shape; N = w.shape[0]
@@ -932,6 +942,16 @@ class Context:
         self._check(lib.rdm_op_xattn_fused(self._h, _ptr(x), opt(g), opt(b_), float(eps), _ptr(G), _ptr(U), opt(bias), opt(res),
                                            B, n, Cc, NP, ncols, group, _ptr(out)))
         return out
+
+    def op_xattn_fused_ln3(self, x, G, U, bias, ncols, group, ln, ln3):
+        """IN PLACE x <- softmax_groups(LayerNorm(x; ln) G^T) U^T + bias + x, and -> LayerNorm(new x; ln3) (bf16).  ln / ln3 = (gamma, beta[, eps])."""
+        B, n, Cc = x.shape
+        assert x.is_contiguous() and x.dtype == torch.bfloat16
+        out3 = torch.empty_like(x)
+        opt = lambda t: _ptr(t) if t is not None else None
+        self._check(lib.rdm_op_xattn_fused_ln3(self._h, _ptr(x), _ptr(ln[0]), _ptr(ln[1]), float(ln[2] if len(ln) > 2 else 1e-5), _ptr(G), _ptr(U), opt(bias),
+                                               B, n, Cc, G.shape[1], ncols, group, _ptr(ln3[0]), _ptr(ln3[1]), _ptr(out3)))
+        return out3
 
     def op_small_attention_bwd(self, q, k, v, dout, heads, scale):
         """Gradient of op_small_attention at d_head 32 with 1..32 keys (the UNet's cross-attention): -> dq, dk, dv (bf16)."""

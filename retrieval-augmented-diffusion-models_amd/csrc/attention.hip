@@ -651,6 +651,52 @@ __global__ __launch_bounds__(256) void xattn_ln_fused_kernel(XattnParams p) {
         const uint4 v0 = *(const uint4*)(T + q0.l), v1 = *(const uint4*)(T + q1.l), v2 = *(const uint4*)(T + q2.l);
         *(uint4*)(p.out + q0.g) = v0; *(uint4*)(p.out + q1.g) = v1; *(uint4*)(p.out + q2.g) = v2;
     }
+    if (!p.ln3_out) return;
+    // ---- norm3 of the finished rows (the bf16 values just stored, as layernorm_bf16x8_kernel would read them back: mean, then the
+    // centred squares): statistics as above (lane = row, this wave's K quarter), then every thread normalises its pieces of the tile
+    {
+        float s3 = 0.f;
+        for (int st = 0; st < nsteps; st++) {
+            const bf16x8 x8 = *(const bf16x8*)(xl + st * 32);
+#pragma unroll
+            for (int e = 0; e < 8; e++) s3 += bf2f((bf16_t)x8[e]);
+        }
+        s3 += __shfl_xor(s3, 32);
+        if (hf == 0) stat[w * 32 + l31] = s3;
+        __syncthreads();
+        const float mean3 = (stat[l31] + stat[32 + l31] + stat[64 + l31] + stat[96 + l31]) / (float)C;
+        __syncthreads();
+        float q3 = 0.f;
+        for (int st = 0; st < nsteps; st++) {
+            const bf16x8 x8 = *(const bf16x8*)(xl + st * 32);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float d = bf2f((bf16_t)x8[e]) - mean3; q3 += d * d; }
+        }
+        q3 += __shfl_xor(q3, 32);
+        if (hf == 0) stat[w * 32 + l31] = q3;
+        __syncthreads();
+        const float rstd3 = rsqrtf((stat[l31] + stat[32 + l31] + stat[64 + l31] + stat[96 + l31]) / (float)C + p.ln_eps);
+        __syncthreads();
+        if (w == 0 && hf == 0) { stat[l31] = mean3; stat[32 + l31] = rstd3; }
+        __syncthreads();
+        for (int it = 0; it < npc; it++) {
+            const int id = it * 256 + tid, row = id / ppr, pc = id - row * ppr;
+            const uint4 v = *(const uint4*)(T + row * RS + pc * 16);
+            const float m = stat[row], r = stat[32 + row];
+            const f32x4 g0 = *(const f32x4*)(p.ln3_g + pc * 8), g1 = *(const f32x4*)(p.ln3_g + pc * 8 + 4);
+            const f32x4 b0 = *(const f32x4*)(p.ln3_b + pc * 8), b1 = *(const f32x4*)(p.ln3_b + pc * 8 + 4);
+            const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float x0 = __uint_as_float(u[i] << 16), x1 = __uint_as_float(u[i] & 0xffff0000u);
+                const float ga = i < 2 ? g0[2 * i] : g1[2 * i - 4], gb = i < 2 ? g0[2 * i + 1] : g1[2 * i - 3];
+                const float ba = i < 2 ? b0[2 * i] : b1[2 * i - 4], bb = i < 2 ? b0[2 * i + 1] : b1[2 * i - 3];
+                o[i] = cvt_pk_bf16((x0 - m) * r * ga + ba, (x1 - m) * r * gb + bb);
+            }
+            *(uint4*)(p.ln3_out + (row0 + row) * C + pc * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
 }
 
 bool xattn_fused_supported(const XattnParams& p) {

@@ -48,6 +48,9 @@ struct XattnParams {
     int rows, n, C, NP;              // rows = samples * n (n rows per sample, n % 32 == 0); NP = row count of G (128)
     int ncols, group;                // heads * k used score columns; softmax over groups of `group` (1, 2, 4) adjacent columns
     const float* ln_g; const float* ln_b; float ln_eps;   // given: x holds the RAW rows, the scores are taken on LayerNorm(x) and the residual is x itself (res unused)
+    // LN-fused form only: out may alias x (a block reads its 32 rows before it writes them); ln3_out given: LayerNorm(out rows; ln3_g,
+    // ln3_b, ln_eps) -- norm3 of BasicTransformerBlock (attention.py:239) -- leaves with the finished tile as the next GEMM's operand
+    const float* ln3_g; const float* ln3_b; bf16_t* ln3_out;
 };
 bool xattn_fused_supported(const XattnParams& p);
 hipError_t launch_xattn_fused(const XattnParams& p, hipStream_t st);        // G / U: FRAGMENT-ORDERED images, written by:

@@ -207,6 +207,13 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
     constexpr int L4_STG = 2 * L4_ABUF;                        // per-wave fp32 staging of one fragment row: 32 rows x 400 bytes
     constexpr int L4_BIAS = L4_STG + 4 * 32 * 400;
     const int L4_STAT = L4_BIAS + p.N * 8;                     // LN: (mean, rstd) of the tile's BM rows
+    // rowvec (IgemmParams: a per-sample per-column add) in the restricted form lin4_supported admits: at most TWO row groups of
+    // rows_per_sample rows (whole tiles each) -- the guided batch's conditional | unconditional halves, whose attn1.to_out bias differs
+    // by attn2's output bias (model.hip: the unconditional rows' cross-attention is exactly that bias).  Packed (hi | lo << 16) like the
+    // bias, [group][N] behind the bias table; it rides in k = 2, 3 of the start-value MFMA.
+    const int L4_RV = L4_BIAS + p.N * 4;
+    const bool has_rv = !LN && p.rowvec != nullptr;
+    const int rv_split = has_rv ? p.rows_per_sample : 0x7fffffff;          // tiles starting at or beyond this row use group 1
     if constexpr (LN) {                                        // (s, b') per column in FRAGMENT order; the accumulators start at zero
         for (int n = tid; n < p.N; n += 256)
             *(float2*)(smem + L4_BIAS + n * 8) = *(const float2*)(p.ln_sb + 2 * (GEGLU ? l4_geglu_row(n) : n));
@@ -217,24 +224,37 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
             const uint32_t lo = cvt_pk_bf16(bv - __uint_as_float(hi << 16), 0.f) & 0xffffu;
             *(uint32_t*)(smem + L4_BIAS + n * 4) = hi | (lo << 16);
         }
+        if (has_rv) {
+            for (int i = tid; i < 2 * p.N; i += 256) {
+                const int g = i >= p.N ? 1 : 0, n = i - g * p.N;
+                const float bv = ((long long)g * p.rows_per_sample < p.M) ? p.rowvec[(long long)g * p.rowvec_ld + (GEGLU ? l4_geglu_row(n) : n)] : 0.f;
+                const uint32_t hi = cvt_pk_bf16(bv, 0.f) & 0xffffu;
+                const uint32_t lo = cvt_pk_bf16(bv - __uint_as_float(hi << 16), 0.f) & 0xffffu;
+                *(uint32_t*)(smem + L4_RV + i * 4) = hi | (lo << 16);
+            }
+        }
     }
     __syncthreads();
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
     union FragU { u32x4_t u; bf16x8 f; };
-    auto bias_frags = [&](int bn, int row, int half, bf16x8 (&bf)[FN], bf16x8& ones) __attribute__((always_inline)) {
+    auto bias_frags = [&](int bn, int bm, int row, int half, bf16x8 (&bf)[FN], bf16x8& ones) __attribute__((always_inline)) {
+        const int rvoff = L4_RV + ((bm * BM >= rv_split) ? p.N * 4 : 0);          // uniform
 #pragma unroll
         for (int j = 0; j < FN; j++) {
-            uint32_t w = 0u;
-            if constexpr (!LN) w = *(const uint32_t*)(smem + L4_BIAS + (bn * BN + wn * WN + j * 32 + row) * 4);
-            FragU t; t.u = (u32x4_t){half ? 0u : w, 0u, 0u, 0u};
+            uint32_t w = 0u, w2 = 0u;
+            if constexpr (!LN) {
+                w = *(const uint32_t*)(smem + L4_BIAS + (bn * BN + wn * WN + j * 32 + row) * 4);
+                if (has_rv) w2 = *(const uint32_t*)(smem + rvoff + (bn * BN + wn * WN + j * 32 + row) * 4);
+            }
+            FragU t; t.u = (u32x4_t){half ? 0u : w, half ? 0u : w2, 0u, 0u};
             bf[j] = t.f;
         }
-        FragU o; o.u = (u32x4_t){half ? 0u : 0x3f803f80u, 0u, 0u, 0u};
+        FragU o; o.u = (u32x4_t){half ? 0u : 0x3f803f80u, half ? 0u : 0x3f803f80u, 0u, 0u};      // ones in k = 0..3 (the rowvec pair is zero without one)
         ones = o.f;
     };
-    auto acc_init = [&](int bn) __attribute__((always_inline)) {
+    auto acc_init = [&](int bn, int bm) __attribute__((always_inline)) {
         bf16x8 bf[FN], ones;
-        bias_frags(bn, frow, fhalf, bf, ones);
+        bias_frags(bn, bm, frow, fhalf, bf, ones);
         // the fragments were just written by the VALU: hipcc pads VALU -> MFMA operand hazards for its own MFMAs, not around asm
         asm volatile("s_nop 7" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(ones));
 #pragma unroll
@@ -267,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
 #pragma unroll
         for (int i = 0; i < FM; i++) { H4_LDSR(fa[0][i], vbase[i], 0); fa[1][i] = fa[0][i]; }
     }
-    acc_init(cc.bn);
+    acc_init(cc.bn, cc.bm);
 
     unsigned long long tprof[2] = {0, 0};
     unsigned long long tp0 = 0, tp1 = 0;
@@ -385,7 +405,18 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
         const unsigned stgw = (unsigned)(L4_STG + wave * (32 * 400) + erow * 400 + ehalf * 16);
         const char* const stgr = smem + L4_STG + wave * (32 * 400);
         bf16x8 nbf[FN], nones;                                 // the next tile's bias fragments
-        bias_frags(has_next ? nx.bn : cc.bn, erow, ehalf, nbf, nones);
+        if constexpr (LN) {                                     // start values are zero: one pinned zero fragment as both operands
+            FragU z; z.u = (u32x4_t){0u, 0u, 0u, 0u};
+            nones = z.f;
+        } else {
+            bias_frags(has_next ? nx.bn : cc.bn, has_next ? nx.bm : cc.bm, erow, ehalf, nbf, nones);
+        }
+        // pin them in registers HERE: left to itself hipcc (re)materialises a fragment's dwords -- v_mov / v_cndmask -- right in front of
+        // the asm MFMA that reads them, and a VALU write one or two instructions ahead of a matrix-pipe read is a hazard it does not pad
+        // around asm statements: the MFMA multiplies the STALE register (round 5: garbage columns as soon as a second dword of the
+        // ones-fragment became non-zero).  The first use is a dozen LDS writes and a wait away; check_mfma_hazard.py audits the assembly.
+        if constexpr (LN) { asm volatile("" : "+v"(nones)); nbf[0] = nones; nbf[1] = nones; nbf[2] = nones; }
+        else asm volatile("" : "+v"(nbf[0]), "+v"(nbf[1]), "+v"(nbf[2]), "+v"(nones));
         auto stage_row = [&](int i) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < FN; j++) {
@@ -541,14 +572,16 @@ static int lin4_wm(const IgemmParams& p) {        // wave arrangement: 1 x 4 wav
     return 0;
 }
 static int lin4_smem_bytes(const IgemmParams& p, int wm) {
-    return 2 * (128 * wm * 144) + 4 * 32 * 400 + (p.ln_sb ? p.N * 8 + 128 * wm * 8 : p.N * 4);
+    return 2 * (128 * wm * 144) + 4 * 32 * 400 + (p.ln_sb ? p.N * 8 + 128 * wm * 8 : p.N * 4 + (p.rowvec ? 2 * p.N * 4 : 0));
 }
 bool lin4_supported(const IgemmParams& p, int batch) {
     static const int off = getenv("RDM_NO_LIN4") ? atoi(getenv("RDM_NO_LIN4")) : 0;
     if ((off & 1) || !p.Wfrag || batch != 1) return false;
     const int wm = lin4_wm(p);
     if (!wm || p.K % 64 || p.C0 % 64 || p.C1 % 64 || p.K != p.C0 + p.C1) return false;
-    if (p.alpha != 1.0f || p.rowvec || p.res_f32 || p.out_f32 || !p.out_bf16) return false;
+    if (p.alpha != 1.0f || p.res_f32 || p.out_f32 || !p.out_bf16) return false;
+    // rowvec: at most two row groups of whole tiles (see the kernel), never with the folded LayerNorm
+    if (p.rowvec && (p.ln_sb || p.rows_per_sample <= 0 || p.rows_per_sample % (128 * wm) != 0 || 2LL * p.rows_per_sample < p.M || p.rowvec_ld < p.N)) return false;
     const bool geglu = p.act == ACT_GEGLU;
     if (p.act != ACT_NONE && !geglu) return false;
     if (geglu && (p.res_bf16 || (off & 2))) return false;

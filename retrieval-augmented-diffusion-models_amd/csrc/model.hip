@@ -537,6 +537,19 @@ struct rdm_ctx {
         wfrag[key] = FragVal{d, nullptr};
         return d;
     }
+    // [2][C] fp32 = {0, b}: the rowvec of attn1.to_out over a guided batch's [conditional | unconditional] halves (unet_body: the
+    // unconditional rows' cross-attention is exactly attn2.to_out's bias b, which then rides in attn1.to_out's start values)
+    const float* zero_bias_pair(const float* b, int C) {
+        const FragKey key{b, C, 2, 6, nullptr};
+        auto it = wfrag.find(key);
+        if (it != wfrag.end()) return it->second.sb;
+        float* t = nullptr;
+        if (hipMalloc((void**)&t, (size_t)2 * C * sizeof(float)) != hipSuccess) return nullptr;
+        if (hipMemsetAsync(t, 0, (size_t)C * sizeof(float), stream) != hipSuccess ||
+            hipMemcpyAsync(t + C, b, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) { (void)hipFree(t); return nullptr; }
+        wfrag[key] = FragVal{nullptr, t};
+        return t;
+    }
     // ... with LayerNorm(gamma, beta) folded in: the copy holds bf16(gamma[k] W[n][k]), *sb the (s, b') table (lin4.hip: lin_ln_sb_kernel)
     const bf16_t* frag_for_lin_ln(const bf16_t* W, int N, int K, int geglu, const float* gamma, const float* beta, const float* bias, const float** sb) {
         const FragKey key{W, N, K, geglu ? 4 : 3, gamma};
@@ -599,15 +612,17 @@ struct Ops {
         t.C0 = C0; t.C1 = C1; t.W = (const bf16_t*)blob; t.Wfrag = t.W; t.out_bf16 = (bf16_t*)blob; t.a1_wrap_rows = a1_wrap_rows;
         return lin4_supported(t, 1);
     }
+    // rowvec / rowvec_ld / rv_rows: a per-row-group per-column add (IgemmParams::rowvec with rows_per_sample = rv_rows)
     void linear(const bf16_t* A0, const bf16_t* A1, int C0, int C1, size_t woff, size_t boff, bool has_bias, int M, int N,
-                int act, const bf16_t* res, bf16_t* out, float* out_f32 = nullptr, const float* res_f32 = nullptr, int a1_wrap_rows = 0) {
+                int act, const bf16_t* res, bf16_t* out, float* out_f32 = nullptr, const float* res_f32 = nullptr, int a1_wrap_rows = 0,
+                const float* rowvec = nullptr, int rowvec_ld = 0, int rv_rows = 1) {
         if (plan) return;
         // skinny (weight-streaming) kernel for decode-sized operands.  Fast mode: whenever M <= 128.  Deterministic mode: exactly for
         // the ops with ONE row per sample (`single_row`: time embedding, RARM decode step, CLIP projection), at any batch
         // (one-row-per-sample operands of bigger batches -- RARM decode at 128+ sequences per GPU -- keep the skinny kernel: its row
         //  blocks scale with M, while the tiled kernels would run a dozen 256-row tiles)
         const bool skinny = c->deterministic ? single_row : (M <= 128 || (single_row && M <= 1024));
-        if (skinny && !A1 && C1 == 0) {         // N/32 x ceil(M/32) blocks (sgemm.hip)
+        if (skinny && !A1 && C1 == 0 && !rowvec) {         // N/32 x ceil(M/32) blocks (sgemm.hip)
             SgemmParams q{}; q.A = A0; q.lda = C0; q.W = w<bf16_t>(woff); q.M = M; q.N = N; q.K = C0; q.bias = has_bias ? w<float>(boff) : nullptr;
             q.act = act; q.res_f32 = res_f32; q.res_bf16 = res; q.out_f32 = out_f32; q.out_bf16 = out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
             if (sgemm_supported(q)) {
@@ -620,6 +635,7 @@ struct Ops {
         IgemmParams p = base(M, N, C0 + C1);
         p.A0 = A0; p.A1 = A1; p.C0 = C0; p.C1 = C1; p.W = w<bf16_t>(woff); p.bias = has_bias ? w<float>(boff) : nullptr;
         p.act = act; p.res_bf16 = res; p.res_f32 = res_f32; p.out_bf16 = out; p.out_f32 = out_f32; p.a1_wrap_rows = a1_wrap_rows;
+        if (rowvec) { p.rowvec = rowvec; p.rowvec_ld = rowvec_ld; p.rows_per_sample = rv_rows; }
         if (act == ACT_GEGLU) p.ldo = N / 2;
         // one-wave-per-SIMD kernel for the big-M projections (its tile choice follows M, so not in deterministic mode)
         // (deterministic mode: its use must not follow the batch -- exactly when the rows of ONE sample fill whole 128 / 256-row tiles,
@@ -940,10 +956,27 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
             }
         }
         bf16_t* t1 = o.abf((size_t)M * C);
-        o.tag = "st.attn1.to_out";
-        o.linear(ao, nullptr, C, 0, s.wo1, s.bo1, true, M, C, ACT_NONE, t0, t1);
         // --- attn2 (cross over the k neighbours); samples >= Bx have all-zero neighbours: t2 = t1 + b_o exactly (see add_bias_rows_kernel)
         const int Mx = Bx * n;
+        // Round 5: in a guided batch [conditional | unconditional] (Bx = B / 2) with the LayerNorm-fused cross-attention kernel,
+        //   * the unconditional rows' t2 = attn1.to_out(...) + t0 + b_o2 leaves attn1.to_out's GEMM directly (b_o2 rides in the start
+        //     values of those rows: Ops::linear's rowvec; one rounding less than t1 -> + b_o2), no add_bias_rows pass;
+        //   * the cross-attention kernel runs IN PLACE on the conditional rows (t2 aliases t1) and emits norm3 of its finished rows, so
+        //     the separate LayerNorm-3 pass only covers the unconditional rows.
+        // RDM_NO_XFOLD=1: the separate passes as before.
+        static const int no_xfold = getenv("RDM_NO_XFOLD") ? atoi(getenv("RDM_NO_XFOLD")) : 0;
+        static const int no_xfused_env = getenv("RDM_NO_XFUSED") ? atoi(getenv("RDM_NO_XFUSED")) : 0;
+        XattnParams xq{}; xq.rows = Mx; xq.n = n; xq.C = C; xq.NP = XA_NP; xq.ncols = s.heads * k; xq.group = k;
+        const bool xfold_shape = xa && Mx > 0 && !no_xfused_env && s.lc == C && C <= 2048 && xattn_fused_supported(xq) && !no_xfold && !o.c->deterministic;       // => xfused && xln below
+        const bool bias_fold = xfold_shape && Bx * 2 == B;             // the unconditional half exists and is exactly the second half
+        o.tag = "st.attn1.to_out";
+        if (bias_fold) {
+            const float* zb = o.plan ? nullptr : o.c->zero_bias_pair(o.w<float>(s.bo2), C);
+            if (!o.plan && !zb && o.rc == 0) o.rc = o.c->fail(-2, "out of memory for a bias table");
+            o.linear(ao, nullptr, C, 0, s.wo1, s.bo1, true, M, C, ACT_NONE, t0, t1, nullptr, nullptr, 0, zb, C, Mx);
+        } else {
+            o.linear(ao, nullptr, C, 0, s.wo1, s.bo1, true, M, C, ACT_NONE, t0, t1);
+        }
         o.tag = "st.norm2+attn2";
         bf16_t* l2 = o.abf((size_t)M * C);
         // norm2 + attn2 + residual in one kernel when the neighbours' operands are cached (xa) and no channel is padding
@@ -957,8 +990,9 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         const bool xfused = xa && Mx > 0 && no_xfused != 1 && xattn_fused_supported(xp);
         const bool xln = xfused && no_xfused != 2 && s.lc == C && C <= 2048;
         if (Mx > 0 && !xln) o.layernorm(t1, 0, s.ln2g, s.ln2b, l2, 0, Mx, C, s.lc);
-        bf16_t* t2 = o.abf((size_t)M * C);
-        if (Bx < B && !o.plan)
+        bf16_t* t2 = xfold_shape ? t1 : o.abf((size_t)M * C);
+        bf16_t* l3 = o.abf((size_t)M * C);
+        if (Bx < B && !bias_fold && !o.plan)
             o.check(launch_add_bias_rows(t1 + (size_t)Mx * C, o.w<float>(s.bo2), t2 + (size_t)Mx * C, (long long)(M - Mx), C, o.c->stream), "zero-context cross attention");
         if (Mx == 0) {
         } else if (xa) {       // two skinny per-sample GEMMs (see unet_compute_xattn)
@@ -967,6 +1001,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                 const bf16_t* G = xa + (size_t)B * s.xa_unit; const bf16_t* U = G + (size_t)B * XA_NP * C;
                 xp.out = t2;
                 if (xln) { xp.x = t1; xp.res = nullptr; xp.ln_g = o.w<float>(s.ln2g); xp.ln_b = o.w<float>(s.ln2b); xp.ln_eps = 1e-5f; }
+                if (xfold_shape && xln && xfused) { xp.ln3_g = o.w<float>(s.ln3g); xp.ln3_b = o.w<float>(s.ln3b); xp.ln3_out = l3; }
                 if (xfused) {       // both GEMMs, the softmax and the residual (and norm2) in one launch (attention.hip)
                     o.prof_begin(RDM_PROF_LINEAR, 4.0 * Mx * XA_NP * (double)C, Mx, XA_NP, C);
                     o.check(launch_xattn_fused(xp, o.c->stream), "fused cross attention");
@@ -998,11 +1033,13 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
             o.linear(ao2, nullptr, C, 0, s.wo2, s.bo2, true, Mx, C, ACT_NONE, t1, t2);
         }
         // --- GEGLU feed-forward
-        bf16_t* l3 = o.abf((size_t)M * C);
         o.tag = "st.norm3+geglu";
         const int FI = 4 * s.lc;                     // GEGLU hidden width: 4 x the LOGICAL channels (a multiple of 128, never padded)
         bf16_t* ff = o.abf((size_t)M * FI);
-        if (!o.linear_ln_big(t2, s.ln3g, s.ln3b, C, s.lc, s.wff1, s.bff1, true, M, 2 * FI, ACT_GEGLU, ff)) {       // norm3 folded into the GEGLU projection
+        if (xfold_shape) {       // norm3 of the conditional rows left the cross-attention kernel; the unconditional rows' here
+            if (M > Mx) o.layernorm(t2 + (size_t)Mx * C, 0, s.ln3g, s.ln3b, l3 + (size_t)Mx * C, 0, M - Mx, C, s.lc);
+            o.linear(l3, nullptr, C, 0, s.wff1, s.bff1, true, M, 2 * FI, ACT_GEGLU, nullptr, ff);
+        } else if (!o.linear_ln_big(t2, s.ln3g, s.ln3b, C, s.lc, s.wff1, s.bff1, true, M, 2 * FI, ACT_GEGLU, ff)) {       // norm3 folded into the GEGLU projection
             o.layernorm(t2, 0, s.ln3g, s.ln3b, l3, 0, M, C, s.lc);
             o.linear(l3, nullptr, C, 0, s.wff1, s.bff1, true, M, 2 * FI, ACT_GEGLU, nullptr, ff);
         }
@@ -2034,11 +2071,22 @@ int rdm_prof_reset(rdm_ctx* c) {
 }
 
 // ---- operator-level wrappers for the parity tests
+static int op_linear_impl(rdm_ctx* c, const void* a, const void* w, const float* bias, const void* res, void* out, float* out_f32,
+                          int M, int N, int K, int act, float alpha, const float* rowvec, int rows_per_group);
 int rdm_op_linear(rdm_ctx* c, const void* a, const void* w, const float* bias, const void* res, void* out, float* out_f32,
                   int M, int N, int K, int act, float alpha) {
+    return op_linear_impl(c, a, w, bias, res, out, out_f32, M, N, K, act, alpha, nullptr, 1);
+}
+int rdm_op_linear_rowvec(rdm_ctx* c, const void* a, const void* w, const float* bias, const float* rowvec, int rows_per_group, const void* res,
+                         void* out, int M, int N, int K) {
+    if (c && (!rowvec || rows_per_group < 1)) return c->fail(-1, "rdm_op_linear_rowvec: rowvec and rows_per_group >= 1 required");
+    return op_linear_impl(c, a, w, bias, res, out, nullptr, M, N, K, ACT_NONE, 1.0f, rowvec, rows_per_group);
+}
+static int op_linear_impl(rdm_ctx* c, const void* a, const void* w, const float* bias, const void* res, void* out, float* out_f32,
+                          int M, int N, int K, int act, float alpha, const float* rowvec, int rows_per_group) {
     RDM_ENTER(c);
     if (!c) return -1;
-    if (M <= 128 && alpha == 1.0f && !c->deterministic) {       // same dispatch as the executors (Ops::linear): decode-sized batches take the skinny kernel.  Deterministic mode: the
+    if (M <= 128 && alpha == 1.0f && !c->deterministic && !rowvec) {       // same dispatch as the executors (Ops::linear): decode-sized batches take the skinny kernel.  Deterministic mode: the
                                                                 // op has no notion of "one row per sample", so it never takes the batch-dependent shortcut (the tiled kernel for every M)
         SgemmParams q{}; q.A = (const bf16_t*)a; q.lda = K; q.W = (const bf16_t*)w; q.M = M; q.N = N; q.K = K; q.bias = bias; q.act = act;
         q.res_bf16 = (const bf16_t*)res; q.out_f32 = out_f32; q.out_bf16 = (bf16_t*)out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
@@ -2048,6 +2096,7 @@ int rdm_op_linear(rdm_ctx* c, const void* a, const void* w, const float* bias, c
     p.Hin = p.Win = p.Hout = p.Wout = 1; p.stride = 1; p.rows_per_sample = 1;
     p.A0 = (const bf16_t*)a; p.C0 = K; p.W = (const bf16_t*)w; p.bias = bias; p.res_bf16 = (const bf16_t*)res;
     p.out_bf16 = (bf16_t*)out; p.out_f32 = out_f32; p.act = act;
+    if (rowvec) { p.rowvec = rowvec; p.rowvec_ld = N; p.rows_per_sample = rows_per_group; }
     {
         IgemmParams t = p; t.Wfrag = p.W;
         if (!c->deterministic && lin4_supported(t, 1)) {
@@ -2399,6 +2448,23 @@ int rdm_op_xattn_fused(rdm_ctx* c, const void* x, const float* ln_gamma, const f
     if ((ln_gamma != nullptr) != (ln_beta != nullptr) || (ln_gamma && res)) return c->fail(-3, "rdm_op_xattn_fused: LayerNorm needs gamma and beta, and then the residual is x itself (res must be null)");
     if (!xattn_fused_supported(q)) return c->fail(-3, "rdm_op_xattn_fused: unsupported shape (n %% 32, C %% 64, NP %% 32, ncols <= min(NP, 128), group 1 / 2 / 4): n %d C %d NP %d ncols %d group %d", n, C, NP, ncols, group);
     const size_t img = (size_t)B * NP * C * 2;          // the kernel reads fragment-ordered images of G and U
+    RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, 2 * img));
+    bf16_t* Gp = (bf16_t*)c->bwd_tmp; bf16_t* Up = Gp + (size_t)B * NP * C;
+    RDM_CHECK_HIP(c, launch_xattn_pack(q.G, q.U, Gp, Up, B, NP, C, c->stream));
+    q.G = Gp; q.U = Up;
+    RDM_CHECK_HIP(c, launch_xattn_fused(q, c->stream));
+    return 0;
+}
+int rdm_op_xattn_fused_ln3(rdm_ctx* c, void* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* G, const void* U,
+                           const float* bias, int B, int n, int C, int NP, int ncols, int group, const float* ln3_gamma, const float* ln3_beta, void* ln3_out) {
+    RDM_ENTER(c);
+    if (!c) return -1;
+    if (!x || !ln_gamma || !ln_beta || !ln3_gamma || !ln3_beta || !ln3_out) return c->fail(-1, "rdm_op_xattn_fused_ln3: null argument");
+    XattnParams q{}; q.x = (const bf16_t*)x; q.G = (const bf16_t*)G; q.U = (const bf16_t*)U; q.bias = bias; q.res = nullptr;
+    q.out = (bf16_t*)x; q.rows = B * n; q.n = n; q.C = C; q.NP = NP; q.ncols = ncols; q.group = group;
+    q.ln_g = ln_gamma; q.ln_b = ln_beta; q.ln_eps = ln_eps; q.ln3_g = ln3_gamma; q.ln3_b = ln3_beta; q.ln3_out = (bf16_t*)ln3_out;
+    if (!xattn_fused_supported(q)) return c->fail(-3, "rdm_op_xattn_fused_ln3: unsupported shape: n %d C %d NP %d ncols %d group %d", n, C, NP, ncols, group);
+    const size_t img = (size_t)B * NP * C * 2;
     RDM_TRY(ensure_bytes(c, &c->bwd_tmp, &c->bwd_tmp_bytes, 2 * img));
     bf16_t* Gp = (bf16_t*)c->bwd_tmp; bf16_t* Up = Gp + (size_t)B * NP * C;
     RDM_CHECK_HIP(c, launch_xattn_pack(q.G, q.U, Gp, Up, B, NP, C, c->stream));

@@ -88,6 +88,26 @@ def test_linear_big_m(ctx, M, N, K, bias, res):
         _close(out, ref, what=f"big-M linear (run {rep})")
 
 
+# A per-row-group additive vector (Ops::linear's rowvec; the executor: attn1.to_out over a guided batch, the unconditional half's start
+# values carry attn2.to_out's bias): two groups through the one-wave-per-SIMD kernel (both wave arrangements, tiles on either side of
+# the split, a split that leaves the second group shorter), several groups / unaligned groups through the generic GEMM.
+@pytest.mark.parametrize("M,N,K,rows,res", [(65536, 384, 384, 32768, 1), (49152, 576, 576, 24576, 1), (49152, 384, 384, 32768, 0),
+                                            (8192, 960, 960, 4096, 1), (1000, 192, 128, 100, 0), (4096, 384, 384, 1024, 1)])
+def test_linear_rowvec(ctx, M, N, K, rows, res):
+    d = ctx.device
+    G = (M + rows - 1) // rows
+    a, w = bf16_round(_rand((M, K), 61)), bf16_round(_rand((N, K), 62, K ** -0.5))
+    b, rv = _rand((N,), 63, 0.5), _rand((G, N), 64, 0.7)
+    r = bf16_round(_rand((M, N), 65)) if res else None
+    ref = a @ w.t() + b + rv.repeat_interleave(rows, dim=0)[:M]
+    if res: ref = ref + r
+    for rep in range(2):
+        out = ctx.op_linear_rowvec(a.to(d, torch.bfloat16), w.to(d, torch.bfloat16), b.to(d), rv.to(d).contiguous(), rows,
+                                   residual=None if r is None else r.to(d, torch.bfloat16))
+        assert torch.isfinite(out).all()
+        _close(out, ref, what=f"linear with a row-group vector (run {rep})")
+
+
 @pytest.mark.parametrize("M,C", [(49152, 192), (32768, 384)])
 def test_linear_geglu_big_m(ctx, M, C):
     from rdm_amd import _lib
@@ -366,6 +386,39 @@ def test_xattn_fused(ctx, B, n, heads, k):
     ref_ln = torch.einsum("bnj,bcj->bnc", pr, U[:, :, :ncols]) + bias + raw
     out_ln = ctx.op_xattn_fused(dev(raw), dev(G), dev(U), bias.to(d), None, ncols, k, ln=(g.to(d), be.to(d), 1e-5))
     _close(out_ln, ref_ln, tol=2 ** -6, what="fused LayerNorm + cross attention + residual")
+
+
+@pytest.mark.parametrize("B,n,heads,k", [(3, 1024, 12, 4), (2, 256, 18, 4), (4, 64, 30, 4), (2, 32, 2, 1), (16, 256, 2, 2)])
+def test_xattn_fused_in_place_with_norm3(ctx, B, n, heads, k):
+    """norm2 + attn2 + residual IN PLACE and norm3 of the finished rows in the same launch (what the executor runs on the conditional rows
+    of a guided batch): x against fp32 torch on the bf16 operands, norm3 against F.layer_norm of the kernel's OWN bf16 rows (the
+    statistics are taken on the rounded values, like the separate LayerNorm pass that reads them back)."""
+    d = ctx.device
+    C, NP, ncols = heads * 32, 128, heads * k
+    G = torch.zeros(B, NP, C); U = torch.zeros(B, C, NP)
+    G[:, :ncols] = _rand((B, ncols, C), 52) * (4.0 / C ** 0.5)
+    U[:, :, :ncols] = _rand((B, C, ncols), 53)
+    G, U = bf16_round(G), bf16_round(U)
+    bias = _rand((C,), 54)
+    raw = bf16_round(_rand((B, n, C), 55) * 1.7 + 0.4)
+    g, be = 1 + 0.1 * _rand((C,), 56), 0.1 * _rand((C,), 57)
+    g3, be3 = 1 + 0.2 * _rand((C,), 58), 0.2 * _rand((C,), 59)
+    xn = bf16_round(F.layer_norm(raw, (C,), g, be, 1e-5))
+    sc = torch.einsum("bnc,bjc->bnj", xn, G[:, :ncols])
+    pr = bf16_round(sc.reshape(B, n, heads, k).softmax(-1).reshape(B, n, ncols))
+    ref = torch.einsum("bnj,bcj->bnc", pr, U[:, :, :ncols]) + bias + raw
+    dev = lambda t: t.to(d, torch.bfloat16).contiguous()
+    x = dev(raw)
+    l3 = ctx.op_xattn_fused_ln3(x, dev(G), dev(U), bias.to(d), ncols, k, ln=(g.to(d), be.to(d), 1e-5), ln3=(g3.to(d), be3.to(d)))
+    _close(x, ref, tol=2 ** -6, what="in-place LayerNorm + cross attention + residual")
+    # the separate-output form gives the same bits
+    sep = ctx.op_xattn_fused(dev(raw), dev(G), dev(U), bias.to(d), None, ncols, k, ln=(g.to(d), be.to(d), 1e-5))
+    assert torch.equal(sep, x)
+    ref3 = F.layer_norm(x.float().cpu(), (C,), g3, be3, 1e-5)
+    _close(l3, ref3, tol=2 ** -7, what="norm3 emitted by the cross-attention kernel")
+    # ... and agrees with the library's own LayerNorm pass over the same rows to the last rounding
+    own = ctx.op_layernorm(x.reshape(B * n, C), g3.to(d), be3.to(d), 1e-5).reshape(B, n, C)
+    assert (own.float() - l3.float()).abs().max().item() <= 2 ** -7 * ref3.abs().max().item()
 
 
 @pytest.mark.parametrize("B,nq,nkv,heads,D,causal", [(2, 64, 4, 4, 32, 0), (2, 77, 77, 2, 64, 1), (1, 50, 50, 3, 64, 0),

@@ -16,7 +16,7 @@ from rdm_amd.models.diffusion.ddpm import MinimalRETRODiffusion
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
-ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--steps", type=int, default=4, help="DDIM steps traced (must divide 1000)")
 ap.add_argument("--k", type=int, default=4)
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "op_trace.csv"))
 a = ap.parse_args()
