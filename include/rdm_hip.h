@@ -249,6 +249,14 @@ int rdm_prof_reset(rdm_ctx* ctx);
  * reference modules behind the roles: rdm/modules/attention.py:122-196, ldm ResBlock), its shape (M, N, K | rows, channels | B, n, C),
  * elapsed ms and algorithmic work -- the per-op table behind DESIGN.md's level-by-level costs (tools/op_trace.py). */
 int rdm_prof_dump(rdm_ctx* ctx, const char* path);
+/* test hook: the next UNet forwards copy ONE intermediate activation (bf16, row-major [rows, width] as the executor holds it: NHWC) into
+ * buf [dev] (at most nbytes).  block: index into the top-level block table (state-dict order: input_blocks.0 .., middle_block,
+ * output_blocks.0 ..; openaimodel.py:355-368's loop).  sub = 0: the block's output; sub = 16 * (layer inside the block) + stage:
+ *   ResBlock stages 1 in_layers norm+SiLU, 2 in_layers conv + emb, 3 out_layers norm+SiLU, 4 skip_connection, 5 output;
+ *   SpatialTransformer stages 1 norm, 2 proj_in, 3 norm1, 4 q|k|v, 5 attn1 heads, 6 x + attn1, 7 x + attn2, 8 norm3, 9 GEGLU, 10 output
+ *   (rdm/modules/attention.py:92-96, 170-196).  buf null: off.  tests/test_gpu_emul.py compares the library with the CPU restatement of its
+ * arithmetic stage by stage, TEACHER-FORCED, through this. */
+int rdm_debug_tap(rdm_ctx* ctx, void* buf /*[dev]*/, size_t nbytes, int block, int sub);
 
 /* ---- operator-level entry points (used by the parity tests; thin wrappers over the kernels) ---- */
 int rdm_op_linear(rdm_ctx* ctx, const void* a_bf16, const void* w_bf16, const float* bias, const void* residual_bf16,

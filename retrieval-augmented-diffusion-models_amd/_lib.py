@@ -106,6 +106,7 @@ SIGNATURES = {
     "rdm_prof_collect": (C.c_int, [_P, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rdm_prof_reset": (C.c_int, [_P]),
     "rdm_prof_dump": (C.c_int, [_P, C.c_char_p]),
+    "rdm_debug_tap": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int]),
     "rdm_comm_unique_id": (C.c_int, [_P, _P]),
     "rdm_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "rdm_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -638,6 +639,12 @@ class Context:
 
     def prof_reset(self):
         self._check(lib.rdm_prof_reset(self._h))
+
+    def debug_tap(self, buf, block, sub=0):
+        """The next UNet forwards copy one intermediate activation (block `block`, stage `sub`: include/rdm_hip.h) into `buf` (a bf16
+        device tensor); buf None: off."""
+        self._tap_keepalive = buf
+        self._check(lib.rdm_debug_tap(self._h, _ptr(buf) if buf is not None else None, 0 if buf is None else buf.numel() * buf.element_size(), int(block), int(sub)))
 
     def prof_dump(self, path):
         """One CSV row per recorded launch (kind, role tag, shape, ms, work): tools/op_trace.py."""

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(IgemmParams p) {
     }
 }
 
-// out = bf16(sum of the ksplit fp32 partial planes + bias + time-embedding row + residual), 8 columns per thread
+// out = bf16(sum of the ksplit fp32 partial planes + bias + time-embedding row + residual) -- one rounding --, 8 columns per thread
 __global__ __launch_bounds__(256) void splitk_finish_kernel(IgemmParams p) {
     const long long nvec = (long long)p.M * (p.N >> 3);
     const long long plane = (long long)p.M * p.N;
@@ -357,17 +357,16 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(IgemmParams p) {
 #pragma unroll
             for (int e = 0; e < 8; e++) a[e] += rv[e];
         }
-        uint32_t o[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) o[e] = cvt_pk_bf16(a[2 * e], a[2 * e + 1]);
-        if (p.res_bf16) {     // same double rounding as the fused epilogue: bf16(bf16(conv) + residual)
+        if (p.res_bf16) {     // the residual joins in fp32: ONE rounding, like conv_halo4's fused read-out (round 5: the finisher used to round
+                              // the conv first -- which of the two a layer got depended on the batch through the K-split decision)
             const uint4 r4 = *(const uint4*)(p.res_bf16 + m * p.ldo + n);
             const uint32_t rr[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
-            for (int e = 0; e < 4; e++)
-                o[e] = cvt_pk_bf16(__uint_as_float(o[e] << 16) + __uint_as_float(rr[e] << 16),
-                                   __uint_as_float(o[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u));
+            for (int e = 0; e < 4; e++) { a[2 * e] += __uint_as_float(rr[e] << 16); a[2 * e + 1] += __uint_as_float(rr[e] & 0xffff0000u); }
         }
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = cvt_pk_bf16(a[2 * e], a[2 * e + 1]);
         *(uint4*)(p.out_bf16 + m * p.ldo + n) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }

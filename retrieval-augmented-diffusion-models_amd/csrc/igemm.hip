@@ -376,7 +376,10 @@ __global__ __launch_bounds__(WAVES_M * 128, 2) void igemm_kernel(IgemmParams p) 
         if (p.dbg & 16) { tp1 = __builtin_readcyclecounter(); tprof[0] += tp1 - tp0; }
         constexpr int WNO = GEGLU ? WN / 2 : WN;                        // output columns per wave
         const int No = GEGLU ? p.N / 2 : p.N;
-        const bool lds_epi = ob && !of && !rf && (No % 8 == 0) && (p.ldo % 8 == 0) && !(p.dbg & 4);
+        // (a plain bf16 residual -- not the K-column form -- takes the direct epilogue, which adds it in fp32 BEFORE the one rounding: the LDS
+        //  transpose below packs to bf16 first, and the rest of the library (conv_halo4 / lin4 read-outs, the split-K finisher, the
+        //  residual-as-K-columns GEMMs) rounds once.  Reached by the generic-path convs of small batches / deterministic mode only.)
+        const bool lds_epi = ob && !of && !rf && !rb && (No % 8 == 0) && (p.ldo % 8 == 0) && !(p.dbg & 4);
         // PLAIN = no activation, alpha 1, no per-row time-embedding lookup: every UNet projection except the GEGLU one.  The flag is
         // a compile-time parameter of the body: as run-time tests inside the unrolled element loops hipcc kept a compare + branch
         // (+ hazard nops) per ELEMENT, and the epilogue took twice as long as the halo kernel's for the same tile.

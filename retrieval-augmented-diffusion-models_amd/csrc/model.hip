@@ -569,6 +569,8 @@ struct rdm_ctx {
     // halo vs generic conv, conv split-K, the zero-context shortcut) is a function of the PER-SAMPLE layer shape only, so a row's
     // result is bitwise independent of the batch it sits in and of the number of ranks the batch is sharded over
     bool deterministic = getenv("RDM_DETERMINISTIC") ? atoi(getenv("RDM_DETERMINISTIC")) != 0 : false;
+    // debug tap (rdm_debug_tap): the output activation of top-level UNet block `tap_block` (NHWC bf16) is copied into tap_buf by the next forward
+    void* tap_buf = nullptr; size_t tap_bytes = 0; int tap_block = -1, tap_sub = 0;      // tap_sub: 0 = the block's output, else 16 * layer-in-block + stage (unet_body)
     // RCCL communicator (rdm_comm_*): library handle from dlopen, function table, communicator
     void* rccl_lib = nullptr; void* comm = nullptr; int comm_world = 0;
     // optional per-launch HIP-event profiler for the GEMM-class kernels (bench.py roofline)
@@ -723,6 +725,12 @@ struct Ops {
         prof_begin(RDM_PROF_CONV3X3, 2.0 * p.M * N * (double)p.K, p.M, N, p.K);
         check(det_generic ? launch_igemm(p, true, 1, c->stream) : launch_conv3x3(p, c->stream), "conv3x3");
         prof_end();
+    }
+    int cur_block = -1, cur_layer = 0;           // position in the UNet's block table (debug tap)
+    void tap(int stage, const void* ptr, size_t nbytes) {      // rdm_debug_tap: stage `stage` of layer cur_layer of block cur_block
+        if (plan || !c->tap_buf || c->tap_block != cur_block || c->tap_sub != cur_layer * 16 + stage) return;
+        if (nbytes > c->tap_bytes) nbytes = c->tap_bytes;
+        check(hipMemcpyAsync(c->tap_buf, ptr, nbytes, hipMemcpyDeviceToDevice, c->stream), "debug tap");
     }
     bool single_row = false;     // set by callers around ops whose operand has one row per sample (see linear)
     int rows_hint = 0;           // rows per sample of the operand of the linear ops that follow (0 = unknown); set by the UNet block executors
@@ -881,22 +889,27 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         bf16_t* n1 = o.abf((size_t)M * r.cin);
         o.tag = "res.gn1";
         o.groupnorm(a.p, x1, C0, C1, B, HW, r.gn1g, r.gn1b, 1e-5f, 1, n1, a.L, skip ? skip->L : 0, wrap_b);
+        o.tap(1, n1, (size_t)M * r.cin * 2);
         bf16_t* h1 = o.abf((size_t)M * r.cout);
         o.tag = "res.conv1";
         o.conv3(n1, nullptr, r.cin, 0, r.w1, r.b1, B, a.H, a.W, r.cout, 1, 0, emb_all + r.emb_off, u.emb_total, nullptr, h1);
+        o.tap(2, h1, (size_t)M * r.cout * 2);
         bf16_t* n2 = o.abf((size_t)M * r.cout);
         o.tag = "res.gn2";
         o.groupnorm(h1, nullptr, r.cout, 0, B, HW, r.gn2g, r.gn2b, 1e-5f, 1, n2, r.lout, 0);
+        o.tap(3, n2, (size_t)M * r.cout * 2);
         const bf16_t* res = a.p;
         if (r.skip) {
             bf16_t* s = o.abf((size_t)M * r.cout);
             o.tag = "res.skip";
             o.linear(a.p, x1, C0, C1, r.wsk, r.bsk, true, M, r.cout, ACT_NONE, nullptr, s, nullptr, nullptr, wrap_b * HW);
+            o.tap(4, s, (size_t)M * r.cout * 2);
             res = s;
         }
         bf16_t* out = o.abf((size_t)Bfull * HW * r.cout);           // Bfull: see expand()
         o.tag = "res.conv2";
         o.conv3(n2, nullptr, r.cout, 0, r.w2, r.b2, B, a.H, a.W, r.cout, 1, 0, nullptr, 0, res, out);
+        o.tap(5, out, (size_t)M * r.cout * 2);
         return Act{out, r.cout, a.H, a.W, r.lout};
     };
     auto transformer = [&](const StW& s, const Act& a) -> Act {
@@ -905,9 +918,11 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         bf16_t* xn = o.abf((size_t)M * C);
         o.tag = "st.gn";
         o.groupnorm(a.p, nullptr, C, 0, B, n, s.gng, s.gnb, 1e-6f, 0, xn, s.lc, 0);
+        o.tap(1, xn, (size_t)M * C * 2);
         bf16_t* t0 = o.abf((size_t)M * C);
         o.tag = "st.proj_in";
         o.linear(xn, nullptr, C, 0, s.win, s.bin, true, M, C, ACT_NONE, nullptr, t0);
+        o.tap(2, t0, (size_t)M * C * 2);
         // --- attn1 (self)
         bf16_t* l1 = o.abf((size_t)M * C);
         // n % 64 == 0: q | k | v in ONE projection (to_v's rows follow to_q | to_k in the blob, asserted in build_unet); the flash kernel
@@ -921,8 +936,10 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         // norm1 folded into the q | k | v projection where lin4 takes it (only the fused form: the other paths read l1 again)
         if (!(vrow && o.linear_ln_big(t0, s.ln1g, s.ln1b, C, s.lc, s.wqk, 0, false, M, QW, ACT_NONE, qk))) {
             o.layernorm(t0, 0, s.ln1g, s.ln1b, l1, 0, M, C, s.lc);
+            o.tap(3, l1, (size_t)M * C * 2);
             o.linear(l1, nullptr, C, 0, s.wqk, 0, false, M, QW, ACT_NONE, nullptr, qk);
         }
+        o.tap(4, qk, (size_t)M * QW * 2);
         bf16_t* ao = o.abf((size_t)M * C);
         o.tag = "st.self_attention";
         if (vrow) {
@@ -955,6 +972,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                 o.check(launch_small_attention(p, 32, s.heads, B, o.c->stream), "small self attention");
             }
         }
+        o.tap(5, ao, (size_t)M * C * 2);
         bf16_t* t1 = o.abf((size_t)M * C);
         // --- attn2 (cross over the k neighbours); samples >= Bx have all-zero neighbours: t2 = t1 + b_o exactly (see add_bias_rows_kernel)
         const int Mx = Bx * n;
@@ -977,6 +995,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         } else {
             o.linear(ao, nullptr, C, 0, s.wo1, s.bo1, true, M, C, ACT_NONE, t0, t1);
         }
+        o.tap(6, t1, (size_t)M * C * 2);          // (with the bias fold: the unconditional rows already hold t2)
         o.tag = "st.norm2+attn2";
         bf16_t* l2 = o.abf((size_t)M * C);
         // norm2 + attn2 + residual in one kernel when the neighbours' operands are cached (xa) and no channel is padding
@@ -1032,6 +1051,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
             }
             o.linear(ao2, nullptr, C, 0, s.wo2, s.bo2, true, Mx, C, ACT_NONE, t1, t2);
         }
+        o.tap(7, t2, (size_t)M * C * 2);
         // --- GEGLU feed-forward
         o.tag = "st.norm3+geglu";
         const int FI = 4 * s.lc;                     // GEGLU hidden width: 4 x the LOGICAL channels (a multiple of 128, never padded)
@@ -1043,6 +1063,8 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
             o.layernorm(t2, 0, s.ln3g, s.ln3b, l3, 0, M, C, s.lc);
             o.linear(l3, nullptr, C, 0, s.wff1, s.bff1, true, M, 2 * FI, ACT_GEGLU, nullptr, ff);
         }
+        o.tap(8, l3, (size_t)M * C * 2);          // (only where a separate norm3 tensor exists: not with RDM_LNFOLD)
+        o.tap(9, ff, (size_t)M * FI * 2);
         bf16_t* out = o.abf((size_t)M * C);
         o.tag = "st.ff2*proj_out";
         static const int no_ffout = getenv("RDM_NO_FFOUT") ? atoi(getenv("RDM_NO_FFOUT")) : 0;
@@ -1055,6 +1077,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
             o.linear(ff, nullptr, FI, 0, s.wff2, s.bff2, true, M, C, ACT_NONE, t2, t3);
             o.linear(t3, nullptr, C, 0, s.wout, s.bout, true, M, C, ACT_NONE, a.p, out);
         }
+        o.tap(10, out, (size_t)M * C * 2);
         return Act{out, C, a.H, a.W, s.lc};
     };
 
@@ -1062,6 +1085,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         Act* skip = nullptr; Act sk{};
         if (blk.where == 2) { sk = hs.back(); hs.pop_back(); skip = &sk; }
         bool first = true;
+        o.cur_block = (int)(&blk - &u.blocks[0]); o.cur_layer = 0;
         for (const ULayer& L : blk.layers) {
             switch (L.kind) {
                 case 0: {
@@ -1093,8 +1117,13 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                 } break;
             }
             first = false;
+            o.cur_layer++;
         }
         if (blk.where == 0) hs.push_back(h);
+        if (!o.plan && o.c->tap_buf && o.c->tap_sub == 0 && o.c->tap_block == (int)(&blk - &u.blocks[0])) {       // (inside the shared guidance prefix: B < Bfull samples exist)
+            size_t nb = (size_t)B * h.H * h.W * h.C * 2; if (nb > o.c->tap_bytes) nb = o.c->tap_bytes;
+            o.check(hipMemcpyAsync(o.c->tap_buf, h.p, nb, hipMemcpyDeviceToDevice, o.c->stream), "debug tap");
+        }
     }
     if (B < Bfull) { expand(h); B = Bfull; }          // (a UNet without attention: the whole network was shared)
     bf16_t* no = o.abf((size_t)B * H * W * mc);
@@ -1190,19 +1219,30 @@ static void vq_trunk(Ops& o, VqModel& v, bf16_t* h, int B, int H, int W, float* 
         o.linear(ao, nullptr, C, 0, a.wo, a.bo, true, M, C, ACT_NONE, x, out);
         return out;
     };
-    h = res(v.mid1, h);
-    if (c.mid_attn) h = attn(v.attn, h);
-    h = res(v.mid2, h);
+    // debug tap (rdm_debug_tap): first-stage decoder layers are blocks 1000, 1001, ... in execution order (conv_in's output = 1000)
+    int tapi = 1000;
+    auto vtap = [&](const bf16_t* t, int ch) {
+        o.cur_block = tapi++; o.cur_layer = 0;
+        if (!o.plan && o.c->tap_buf && o.c->tap_sub == 0 && o.c->tap_block == o.cur_block) {
+            size_t nb = (size_t)B * H * W * ch * 2; if (nb > o.c->tap_bytes) nb = o.c->tap_bytes;
+            o.check(hipMemcpyAsync(o.c->tap_buf, t, nb, hipMemcpyDeviceToDevice, o.c->stream), "debug tap");
+        }
+    };
+    vtap(h, bin);
+    h = res(v.mid1, h); vtap(h, bin);
+    if (c.mid_attn) { h = attn(v.attn, h); vtap(h, bin); }
+    h = res(v.mid2, h); vtap(h, bin);
     for (int lvl = c.n_ch_mult - 1; lvl >= 0; lvl--) {
         for (size_t i = 0; i < v.up_blocks[lvl].size(); i++) {
-            h = res(v.up_blocks[lvl][i], h); bin = v.up_blocks[lvl][i].cout;
-            if (i < v.up_attn[lvl].size()) h = attn(v.up_attn[lvl][i], h);
+            h = res(v.up_blocks[lvl][i], h); bin = v.up_blocks[lvl][i].cout; vtap(h, bin);
+            if (i < v.up_attn[lvl].size()) { h = attn(v.up_attn[lvl][i], h); vtap(h, bin); }
         }
         if (lvl != 0) {
             const ConvW& u = v.upsample[lvl];
             bf16_t* out = o.abf((size_t)B * (H * 2) * (W * 2) * u.c);
             o.conv3(h, nullptr, u.c, 0, u.w, u.b, B, H, W, u.c, 1, 1, nullptr, 0, nullptr, out);
             h = out; H *= 2; W *= 2;
+            vtap(h, u.c);
         }
     }
     bf16_t* no = o.abf((size_t)B * H * W * bin);
@@ -2045,6 +2085,11 @@ int rdm_prof_collect(rdm_ctx* c, int kind, long long* launches, double* ms, doub
         n++; t += e; f += r.flops;
     }
     if (launches) *launches = n; if (ms) *ms = t; if (flops) *flops = f;
+    return 0;
+}
+int rdm_debug_tap(rdm_ctx* c, void* buf, size_t nbytes, int block, int sub) {
+    if (!c) return -1;
+    c->tap_buf = buf; c->tap_bytes = buf ? nbytes : 0; c->tap_block = buf ? block : -1; c->tap_sub = buf ? sub : 0;
     return 0;
 }
 int rdm_prof_dump(rdm_ctx* c, const char* path) {

@@ -198,3 +198,43 @@ def test_bulk_topk_oracle_equals_exact_topk():
     a = oret.exact_topk(dbn, qn, 20)
     b = oret.exact_topk_bulk(dbn, qn, 20, qblock=128, chunk=2048)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_emulated_unet_is_exact_algebra_without_rounding():
+    """oracle/unet_emul.py restates the LIBRARY's arithmetic (bf16 storage points + its algebraic re-associations: per-sample G / U
+    cross-attention, ff.net.2 x proj_out as one map, Upsample by output phase, SiLU folded into the time-embedding MLP, attn2's bias in
+    attn1.to_out's start values for zero-neighbour rows).  With the rounding switched off those re-associations must reproduce the fp32
+    oracle -- itself pinned bit for bit to the reference's classes -- to fp32 round-off: the emulator's algebra is verified without a GPU."""
+    from oracle import unet as ounet
+    from oracle.unet_emul import unet_forward_emulated
+    spec = ounet.tiny_spec()
+    sd = ounet.synth_state_dict(ounet.param_shapes(spec), seed=11)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 3, 16, 16, generator=g)
+    t = torch.tensor([981, 981, 501, 21])
+    ctx = torch.randn(4, 4, 512, generator=g) * 0.45
+    ctx[2:] = 0                                                     # the unconditional half of a guided batch
+    ref = ounet.unet_forward(sd, spec, x, t, ctx)
+    for rows in (None, 2):                                          # generic path for every row / the zero-neighbour shortcut for rows 2, 3
+        got = unet_forward_emulated(sd, spec, x, t, ctx, ctx_rows=rows, rounding=False)
+        e = float((got - ref).norm() / ref.norm())
+        assert e <= 2e-5, (rows, e)
+    # and with the rounding on it sits where the library sits: a bf16 distance away, not further
+    got = unet_forward_emulated(sd, spec, x, t, ctx, ctx_rows=2)
+    e = float((got - ref).norm() / ref.norm())
+    assert 1e-4 < e <= 2.5e-2, e
+
+
+def test_emulated_vq_decoder_is_exact_algebra_without_rounding():
+    from oracle import unet as ounet, vqdecoder as ovq
+    from oracle.vq_emul import vq_decode_emulated
+    spec = ovq.tiny_vq_spec()
+    sd = ounet.synth_state_dict(ovq.vq_param_shapes(spec), seed=5)
+    z = torch.randn(2, 3, spec.z_res, spec.z_res, generator=torch.Generator().manual_seed(2))
+    for fnq in (True, False):
+        ref = ovq.vq_decode(sd, spec, z, force_not_quantize=fnq)
+        got = vq_decode_emulated(sd, spec, z, force_not_quantize=fnq, rounding=False)
+        e = float((got - ref).norm() / ref.norm())
+        assert e <= 2e-5, (fnq, e)
+    e = float((vq_decode_emulated(sd, spec, z, force_not_quantize=True) - ovq.vq_decode(sd, spec, z, force_not_quantize=True)).norm() / ref.norm())
+    assert 1e-4 < e <= 2.5e-2, e
