@@ -13,7 +13,9 @@ A "step" is one pass of the whole hot path over one batch of synthetic inputs th
   --config 4: k=16 retrieval, 250 ancestral DDPM steps (ldm p_sample_loop(timesteps=250): no CFG on this path, as in the
       reference), B=64 per GPU (512 over 8 GPUs).
   --config 5: RARM (scripts/rarm_sample.py path): k=8 retrieval -> 256 autoregressive tokens (18-layer RetrievalPatchTransformer with a
-      K/V cache, top-k 256 multinomial, guidance scale 1.0 = the script's default) -> VQGAN-f16 decode, B=64 per GPU.
+      K/V cache, top-k 256 multinomial, guidance scale 1.0 = the script's default) -> VQGAN-f16 decode, B=512 sequences per GPU (BASELINE.json
+      does not fix this config's batch; one token step is ~110 dependent launches whatever the batch, so img/s per GPU grows 208 / 297 / 399 /
+      489 for 64 / 128 / 256 / 512 sequences and levels off there: the K/V-cache attention is then HBM-bound).
 Weights are seeded random tensors of the shipped architectures (no checkpoints are reachable), DB / queries / captions
 are synthetic.
 
@@ -48,7 +50,8 @@ def parse():
     p.add_argument("--steps", type=int, default=None, help="timed steps (default 3; 1 for --config 4)")
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5), help="BASELINE.json config number")
-    p.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    p.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 64; --config 5: 512 sequences, where the decode step's img/s per GPU "
+                                                            "levels off -- BASELINE.json does not fix config #5's batch)")
     p.add_argument("--ddim-steps", type=int, default=None, help="sampler steps (default 50; 250 for --config 4)")
     p.add_argument("--k", type=int, default=None, help="neighbours (default 4; 1 for --config 2; 16 for --config 4)")
     p.add_argument("--scale", type=float, default=2.0)
@@ -63,6 +66,7 @@ def parse():
     p.add_argument("--dump-images", default=None, help="rank 0 writes the last timed step's gathered images to this .npy (parity tests of the N > 1 path)")
     a = p.parse_args()
     a.k = a.k if a.k is not None else {2: 1, 3: 4, 4: 16, 5: 8}[a.config]
+    a.batch = a.batch if a.batch is not None else (512 if a.config == 5 else 64)
     a.ddim_steps_given = a.ddim_steps is not None
     a.ddim_steps = a.ddim_steps if a.ddim_steps is not None else (250 if a.config == 4 else 50)
     a.steps = a.steps if a.steps is not None else (1 if a.config == 4 else 3)
@@ -359,21 +363,33 @@ def main():
                                                      "frac": st_fl / (st_ms * 1e-3) / 1e12 / 2500.0, "time_ms_per_step": st_ms,
                                                      "classes": ["linear_gemm", "flash_attention", "layernorm"]}
         if a.config == 5 and "linear_gemm" in roof:
-            # RARM: the step is ~200 skinny GEMMs per token (M = B rows against 768..6144-row weight matrices: pure weight streaming),
-            # 70 % of the step; the 3x3 convs of the VQGAN decoder above are 3 %.  The dominant kernel's bound is HBM: a launch has to
-            # stream its N x K bf16 weights (= FLOPs / M bytes).  Measured on the extra UNTIMED step (one event pair per launch for
-            # ~28 k launches would sit in the timed region otherwise).
+            # RARM: a token step is ~110 dependent launches: the decode GEMMs (M = batch rows against 768..6144-row weight matrices: weight streaming;
+            # bound HBM: N K 2 bytes per launch) and the K/V-cache attention (bound HBM: the cache rows 0..pos of every sequence).  The top-level object
+            # describes whichever takes more of the step (at 64 sequences the GEMMs, latency-bound; at 512 the attention, bandwidth-bound); the
+            # other sits beside it.  Measured on the extra UNTIMED step (one event pair per launch for ~28 k launches would otherwise sit in the timed region).
             n_, ms_, w_ = classes["linear_gemm"]
             wbytes = w_ / B                                  # 2 M N K FLOP / M rows = 2 N K bytes of bf16 weights
+            step_s = dt / a.steps
             conv_roof = {k_: roof[k_] for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_ms", "conv_time_frac_of_step")}
-            roof.update({"kernel": "sgemm_kernel<MF,NF,U> (decode-step linear layers: M = batch rows, weights streamed once per launch)",
-                         "bound": "hbm", "achieved": wbytes / (ms_ * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                         "frac": wbytes / (ms_ * 1e-3) / 1e9 / 8000.0, "traffic": None, "launches": n_, "avg_launch_ms": ms_ / max(n_, 1),
-                         "algorithmic_bytes_per_launch": wbytes / max(n_, 1), "time_frac_of_step": ms_ * 1e-3 / (dt / a.steps),
-                         "note": "launch-latency bound (DESIGN.md section 3, RARM): ~14 us per launch for ~3 MB of weights; measured on the untimed profiled step",
-                         "vqgan_conv": conv_roof})
-            for k_ in ("traffic_note", "algorithmic_tflop_per_launch", "conv_time_frac_of_step"):
-                roof.pop(k_, None)
+            lin = {"kernel": "sgemm_kernel<MA,NB,U> (decode-step linear layers: M = batch rows, weights streamed once per launch)",
+                   "bound": "hbm", "achieved": wbytes / (ms_ * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                   "frac": wbytes / (ms_ * 1e-3) / 1e9 / 8000.0, "traffic": None, "launches": n_, "avg_launch_ms": ms_ / max(n_, 1),
+                   "algorithmic_bytes_per_launch": wbytes / max(n_, 1), "time_frac_of_step": ms_ * 1e-3 / step_s,
+                   "note": "weight bytes only: at big batches these launches are bound by latency and MFMA work per launch, not by the weight stream"}
+            att = None
+            if classes.get("flash_attention", (0, 0, 0))[0] > 0:
+                na_, msa_, wa_ = classes["flash_attention"]
+                att = {"kernel": "rarm_decode_attention_kernel (one query row per sequence against its K/V cache rows 0..pos, 18 layers x 256 steps)",
+                       "bound": "hbm", "achieved": wa_ / (msa_ * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": wa_ / (msa_ * 1e-3) / 1e9 / 8000.0,
+                       "traffic": None, "launches": na_, "avg_launch_ms": msa_ / max(na_, 1), "algorithmic_bytes_per_launch": wa_ / max(na_, 1),
+                       "time_frac_of_step": msa_ * 1e-3 / step_s}
+            for k_ in list(roof):
+                roof.pop(k_)
+            dom, other, oname = (att, lin, "decode_linear") if (att and att["time_frac_of_step"] > lin["time_frac_of_step"]) else (lin, att, "kv_cache_attention")
+            roof.update(dom)
+            if other:
+                roof[oname] = other
+            roof["vqgan_conv"] = conv_roof
         out = {
             "metric": "images/sec at 256x256, 50 DDIM steps, k=4 OpenImages retrieval",
             "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -657,6 +657,9 @@ struct Ops {
     // false = not available for this shape (the caller runs layernorm + linear)
     bool linear_ln(const float* x, size_t g, size_t b, int C, size_t woff, size_t boff, bool has_bias, int M, int N, int act, bf16_t* out) {
         static const int off = getenv("RDM_NO_LNFUSE") ? atoi(getenv("RDM_NO_LNFUSE")) : 0;
+        static const int ln_max_rows = getenv("RDM_SGEMM_LN_MAX_ROWS") ? atoi(getenv("RDM_SGEMM_LN_MAX_ROWS")) : 192;
+        // (from ~200 rows on a separate LayerNorm pass + the 64 x 64-tile GEMM beats the LayerNorm-fused 32-row tiles: sgemm.hip)
+        if (!c->deterministic && M > ln_max_rows) return false;
         const bool skinny = c->deterministic ? single_row : (M <= 128 || (single_row && M <= 1024));
         SgemmParams q{}; q.ln_x = x; q.ln_g = w<float>(g); q.ln_b = w<float>(b); q.ln_eps = 1e-5f; q.W = w<bf16_t>(woff); q.M = M; q.N = N; q.K = C;
         q.bias = has_bias ? w<float>(boff) : nullptr; q.act = act; q.out_bf16 = out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
@@ -1796,7 +1799,12 @@ static int rarm_prepare(rdm_ctx* c, int B2, int k, const float* context /*[B,k,c
     // (transformer.py:237-239), whose projections are zero (to_k / to_v have no bias)
     RDM_CHECK_HIP(c, hipMemsetAsync(m.ctxkv, 0, (size_t)B2 * k * m.kv_total * 2, c->stream));
     static const int no_xf = getenv("RDM_NO_RARM_XFUSED") ? atoi(getenv("RDM_NO_RARM_XFUSED")) : 0;
-    const bool fuse = !no_xf && g.n_heads * k <= 128 && C <= 1024 && C % 64 == 0;
+    // Round 5: the per-sequence re-association pays per-sequence operands (G and U^T: 2 x 128 x C bf16 = 393 KB per sequence and layer
+    // where the projections' weights are 2.4 MB per layer for ALL sequences): the one-launch form wins while launches are the cost
+    // (<= 128 sequences); from RDM_RARM_XGEMM_FROM sequences on (default 384) the decode step takes norm2 + to_q as a GEMM, the k-key attention
+    // and to_out + residual as a GEMM (same box, profiles/r05_rarm_sweep.log: 256 sequences 399 img/s fused vs 378 as GEMMs, 512 sequences 484 vs 489).
+    static const int xgemm_from = getenv("RDM_RARM_XGEMM_FROM") ? atoi(getenv("RDM_RARM_XGEMM_FROM")) : 384;
+    const bool fuse = !no_xf && g.n_heads * k <= 128 && C <= 1024 && C % 64 == 0 && (c->deterministic || B2 < xgemm_from);
     m.xa_B = 0; m.xa_k = 0;
     if (fuse) {
         RDM_TRY(ensure_bytes(c, &m.xa, &m.xa_bytes, (size_t)g.depth * 2 * B * 128 * C * 2));
@@ -1834,7 +1842,7 @@ static int rarm_prepare(rdm_ctx* c, int B2, int k, const float* context /*[B,k,c
     });
 }
 // one decode step for B2 sequences: token at position *pos -> logits of the next token
-static int rarm_step(rdm_ctx* c, int B2, int k) {
+static int rarm_step(rdm_ctx* c, int B2, int k, int pos_hint = -1 /* host's copy of the position processed (profiling only: the kernels read the device counter) */) {
     RarmModel& m = c->rarm; const rdm_rarm_cfg& g = m.cfg; const int C = m.C, L = g.sequence_length;
     RarmState st = rarm_state(m, B2);
     return run_with_arena(c, m.arena, m.blob, [&](Ops& o) {
@@ -1856,7 +1864,11 @@ static int rarm_step(rdm_ctx* c, int B2, int k) {
                 RarmAttnParams p{}; p.q = qkv; p.ldq = 3 * C; p.k_new = qkv + C; p.v_new = qkv + 2 * C;
                 p.Kc = (bf16_t*)m.cache + ((size_t)l * 2) * B2 * L * C; p.Vc = (bf16_t*)m.cache + ((size_t)l * 2 + 1) * B2 * L * C;
                 p.batch_stride = (long long)L * C; p.row_stride = C; p.nkv = L; p.pos = st.pos; p.scale = scale; p.out = ao; p.ldo = C;
+                // bytes of the K / V cache rows this step reads (positions 0 .. pos): what bounds the launch at big batches
+                o.tag = "rarm.cache_attention";
+                o.prof_begin(RDM_PROF_ATTENTION, pos_hint >= 0 ? (double)B2 * (pos_hint + 1) * C * 4.0 : 0.0, B2, pos_hint + 1, C);
                 o.check(launch_rarm_decode_attention(p, g.n_heads, B2, c->stream), "rarm self attention");
+                o.prof_end();
             }
             o.linear(ao, nullptr, C, 0, b.wo1, b.bo1, true, B2, C, ACT_NONE, nullptr, nullptr, x, x);
             if (m.xa_B > 0 && m.xa_k == k) {      // norm2 + to_q + attention over the neighbours + to_out + residual in one launch
@@ -1949,13 +1961,13 @@ int rdm_rarm_sample(rdm_ctx* c, const rdm_rarm_sample_args* a, const int64_t* co
     for (int i = 0; i < a->cond_len; i++) {                    // prefill the conditioning tokens (the sos token)
         RDM_TRY(rarm_set_tokens(c, st, cond_tokens, B, a->cond_len, i, cfg));
         RDM_CHECK_HIP(c, launch_set_int(st.pos, i, c->stream));
-        if (i + 1 < a->cond_len) RDM_TRY(rarm_step(c, B2, k));
+        if (i + 1 < a->cond_len) RDM_TRY(rarm_step(c, B2, k, i));
     }
     RarmSampleParams sp{}; sp.logits = st.logits; sp.vocab = m.cfg.vocab_out; sp.B = B; sp.cfg = cfg ? 1 : 0; sp.scale = a->guidance_scale;
     sp.temperature = a->temperature; sp.top_k = a->top_k > 0 ? a->top_k : m.cfg.vocab_out; sp.uniforms = uniforms; sp.pos = st.pos;
     sp.pos0 = a->cond_len - 1; sp.steps = a->steps; sp.tokens_out = (long long*)tokens_out; sp.next_tokens = st.tokens; sp.done = st.done;
     for (int s_ = 0; s_ < a->steps; s_++) {                    // every step: the same launches (the step counter lives on the device)
-        RDM_TRY(rarm_step(c, B2, k));
+        RDM_TRY(rarm_step(c, B2, k, a->cond_len - 1 + s_));
         RDM_CHECK_HIP(c, launch_rarm_sample(sp, c->stream));
     }
     return 0;

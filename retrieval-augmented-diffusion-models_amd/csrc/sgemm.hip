@@ -18,8 +18,11 @@
 // the RARM block, rdm/modules/attention.py:84-86, 199-272): a block needs its rows' whole K anyway (each wave one quarter), so the row
 // statistics cost one cross-wave exchange and the separate LayerNorm launch (~5 us of a ~8 us GEMM) disappears.  K / 4 = 32 U only
 // (one batch of loads holds a wave's whole K quarter in registers).
-// MA: 16-row fragments of M per block (1, 2, 4, 8); NB: 16-column fragments of the weight strip (plain: 1, 2; GEGLU: 2, 4 = x fragments
-// then their gate fragments); U: k-steps of 32 per batch of loads
+// MA: 16-row fragments of M per block (1, 2, 4); NB: 16-column fragments of the weight strip (plain: 1, 2, 4; GEGLU: 2, 4, 8 = per 64-row
+// strip its x fragments then their gate fragments; 8 = two strips); U: k-steps of 32 per batch of loads.
+// Round 5: the 64 x 64 tiles (MA = 4 with NB = 4, GEGLU NB = 8) are for M = 256 .. 1024 rows -- the RARM decode step at 256 / 512
+// sequences per GPU -- where the small tiles re-read the A rows once per 16 / 32 output columns (LN-fused q | k | v at M = 512: 1152
+// blocks x 147 KB = 169 MB through an L2 that holds neither operand: 40 us for a 1.8 GFLOP product).
 template <int MA, int NB, bool GEGLU, int U, bool LN = false>
 __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
     // 16x16x32 MFMAs, not 32x32x16: the operands come straight from global memory in fragment order, and what such a launch pays
@@ -55,6 +58,24 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
     for (int i = 0; i < MA; i++)
 #pragma unroll
         for (int j = 0; j < NB; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // The residual values this thread will add in the epilogue are requested FIRST, together with the operands (round 5): as the first
+    // thing after the partial-tile exchange they were one more dependent L2 round trip at the end of a launch that is three round trips
+    // long.  A thread reads and writes the same elements (the decode step accumulates in place: out == residual), and nothing else in
+    // the launch writes them, so the early read sees what the late one saw.
+    constexpr int NOUT = RB * OC, IT = (NOUT + 255) / 256;
+    float res_[IT];
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+        const int e = tid + it * 256;
+        const int row = e / OC, col = e - row * OC, m = mb0 + row;
+        float r = 0.f;
+        if (e < NOUT && m < p.M) {
+            const long long oi = (long long)m * p.ldo + ncol0 + col;
+            if (p.res_f32) r += p.res_f32[oi];
+            if (p.res_bf16) r += bf2f(p.res_bf16[oi]);
+        }
+        res_[it] = r;
+    }
     if constexpr (LN) {
         float* const lnv = part + 4 * RB * CB;                  // [gamma K][beta K][4 waves][RB rows][sum, sumsq]
         float* const stat = lnv + 2 * p.K;
@@ -147,24 +168,16 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
             for (int r = 0; r < 4; r++)
                 part[(wave * RB + i * 16 + q4 * 4 + r) * CB + j * 16 + r16] = acc[i][j][r];
     __syncthreads();
-    // Two phases: every residual / bias value this thread needs is requested first, THEN the results are formed and stored.  The
-    // decode step accumulates in place (out == residual: x += ...), so inside a single loop no load may move above the previous
-    // iteration's store and the iterations cost one L2 round trip each (~5 of the launch's ~14 us).  A thread reads and
-    // writes the same elements, so hoisting its own loads above its own stores is safe whatever aliases.
-    constexpr int NOUT = RB * OC, IT = (NOUT + 255) / 256;
-    float acc_[IT], res_[IT]; long long oi_[IT]; bool ok_[IT];
+    // Results are formed for ALL of this thread's outputs, THEN stored (the residual came in at the top of the kernel; bias values are
+    // L1 / L2 hits).  The decode step accumulates in place (out == residual: x += ...): with loads and stores interleaved in one loop no
+    // load may move above the previous iteration's store and the iterations cost one L2 round trip each (~5 of the launch's ~14 us).
+    float acc_[IT]; long long oi_[IT]; bool ok_[IT];
 #pragma unroll
     for (int it = 0; it < IT; it++) {
         const int e = tid + it * 256;
         const int row = e / OC, col = e - row * OC, m = mb0 + row;
         ok_[it] = e < NOUT && m < p.M;
         oi_[it] = (long long)m * p.ldo + ncol0 + col;
-        float r = 0.f;
-        if (ok_[it]) {
-            if (p.res_f32) r += p.res_f32[oi_[it]];
-            if (p.res_bf16) r += bf2f(p.res_bf16[oi_[it]]);
-        }
-        res_[it] = r;
     }
 #pragma unroll
     for (int it = 0; it < IT; it++) {
@@ -174,7 +187,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
         float v[GEGLU ? 2 : 1];
 #pragma unroll
         for (int j = 0; j < (GEGLU ? 2 : 1); j++) {
-            const int cc = col + j * OC;
+            // tile column of output `col` (x) and of its gate: half a strip [16 x | 16 g]; whole strips [32 x | 32 g] (NB = 8: two of them)
+            const int cc = !GEGLU ? col : (NB == 2 ? col + j * 16 : (col >> 5) * 64 + (col & 31) + j * 32);
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; w++) s += part[(w * RB + row) * CB + cc];
@@ -217,7 +231,7 @@ static hipError_t launch_one(const SgemmParams& p, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr = true;
     }
-    const int gx = GEGLU ? (NB == 4 ? p.N / 64 : p.N / 32) : p.N / CB;
+    const int gx = GEGLU ? (NB == 2 ? p.N / 32 : p.N / CB) : p.N / CB;
     sgemm_kernel<MA, NB, GEGLU, U, LN><<<dim3(gx, (p.M + RB - 1) / RB), 256, sm, st>>>(p);
     return hipGetLastError();
 }
@@ -227,11 +241,13 @@ static hipError_t launch_one(const SgemmParams& p, hipStream_t st) {
 template <bool GEGLU, bool LN>
 static void pick_tile(const SgemmParams& p, int& ma, int& nb) {
     static const int force_ma = getenv("RDM_SGEMM_MA") ? atoi(getenv("RDM_SGEMM_MA")) : 0, force_nb = getenv("RDM_SGEMM_NB") ? atoi(getenv("RDM_SGEMM_NB")) : 0;
-    const int mas[3] = {1, 2, 4}, nbs[2] = {GEGLU ? 2 : 1, GEGLU ? 4 : 2};
+    const int mas[3] = {1, 2, 4}, nbs[3] = {GEGLU ? 2 : 1, GEGLU ? 4 : 2, GEGLU ? 8 : 4};
     double best = 1e30; ma = 2; nb = nbs[1];
     for (int a : mas) for (int b : nbs) {
-        if (LN && a > 2) continue;                                    // the LayerNorm-fused variant holds fp32 rows in registers: <= 32 rows
-        const long long blocks = (long long)((p.M + 16 * a - 1) / (16 * a)) * (GEGLU ? (b == 4 ? p.N / 64 : p.N / 32) : p.N / (16 * b));
+        if (LN && (a > 2 || b == nbs[2])) continue;                   // the LayerNorm-fused variant holds fp32 rows in registers: <= 32 rows
+        if (b == nbs[2] && (GEGLU || a != 4 || p.N % (16 * b) != 0)) continue; // the 64-column tiles come with 64 rows only; GEGLU: two strips per
+                                                                               // block need three dependent load batches (31.8 vs 28.7 us at M = 512): not used
+        const long long blocks = (long long)((p.M + 16 * a - 1) / (16 * a)) * (GEGLU ? (b == 2 ? p.N / 32 : p.N / (16 * b)) : p.N / (16 * b));
         const double bytes = (double)p.K * (16.0 * a * (LN ? 4.0 : 2.0) + 16.0 * b * 2.0);
         const double rounds = (double)((blocks + 255) / 256);
         (void)rounds;
@@ -244,7 +260,7 @@ static void pick_tile(const SgemmParams& p, int& ma, int& nb) {
 template <bool GEGLU>
 static hipError_t launch_nf(const SgemmParams& p, hipStream_t st) {
     const bool deep = ((p.K >> 2) % 192) == 0;            // K quarter is a multiple of 6 k-steps of 32 (K = 768, 1536, 3072 ...)
-    constexpr int N1 = GEGLU ? 2 : 1, N2 = GEGLU ? 4 : 2;
+    constexpr int N1 = GEGLU ? 2 : 1, N2 = GEGLU ? 4 : 2, N3 = GEGLU ? 8 : 4;
     int ma, nb;
     if (p.ln_x) {
         pick_tile<GEGLU, true>(p, ma, nb);
@@ -252,6 +268,10 @@ static hipError_t launch_nf(const SgemmParams& p, hipStream_t st) {
         return nb == N1 ? launch_one<2, N1, GEGLU, 6, true>(p, st) : launch_one<2, N2, GEGLU, 6, true>(p, st);
     }
     pick_tile<GEGLU, false>(p, ma, nb);
+    if (nb == N3) {       // 64 x 64 outputs: two (GEGLU) / three k-steps per batch of loads keep the operand registers under the budget
+        if constexpr (GEGLU) return launch_one<4, N3, true, 2>(p, st);
+        else return ((p.K >> 2) % 96) == 0 ? launch_one<4, N3, false, 3>(p, st) : launch_one<4, N3, false, 2>(p, st);
+    }
     if (nb == N1) {
         switch (ma) {
             case 1: return deep ? launch_one<1, N1, GEGLU, 6>(p, st) : launch_one<1, N1, GEGLU, 2>(p, st);
