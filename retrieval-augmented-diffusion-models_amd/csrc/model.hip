@@ -754,7 +754,7 @@ struct Ops {
         int nchunk = HW / 64; if (nchunk < 1) nchunk = 1; if (nchunk > 32) nchunk = 32;
         p.nchunk = nchunk; p.partial = c->gn_partial; p.gamma = w<float>(g); p.beta = w<float>(b); p.eps = eps; p.silu = silu;
         p.out = out;
-        prof_begin(RDM_PROF_GROUPNORM, (double)B * HW * (C0 + C1) * 6.0, B * HW, C0 + C1, silu);       // two reads + one write of the bf16 tensor
+        prof_begin(RDM_PROF_GROUPNORM, (double)B * HW * (C0 + C1) * 4.0, B * HW, C0 + C1, silu);       // ALGORITHMIC bytes: one read + one write of the bf16 tensor (round 5: the one-pass kernel moves exactly these; the two-pass form of the 64 x 64 level reads twice)
         check(launch_groupnorm(p, c->stream), "groupnorm");
         prof_end();
     }

@@ -11,6 +11,8 @@
 // LDS.  Both passes read the decoder's skip-concat as two source tensors (never materialised).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 
@@ -145,6 +147,163 @@ __global__ void gn_apply_kernel(GnParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------ one-pass GroupNorm (round 5)
+// Groups are independent, so a block that owns WHOLE groups of one sample needs nobody else: it reads its [HW pixels] x [channels of gpb
+// consecutive groups] slice ONCE into registers (a thread keeps one 8-channel vector position of NV pixels: <= 32 x 16 bytes), forms the
+// group statistics (per-thread sums -> LDS per channel over the pixel lanes -> per group, all in a fixed order: results do not depend on
+// scheduling), normalises from the registers and writes once: 2 tensor passes instead of the 3 of gn_stats + gn_apply, one launch instead
+// of two.  Applies where a slice fits: every GroupNorm of the 32 x 32, 16 x 16 and 8 x 8 levels (the 64 x 64 level's groups are 6
+// channels = 12 bytes of a pixel row: slices would be read at a quarter of a cache line's efficiency; it keeps the two-pass form).
+// Slice bytes per pixel are gpb cg 2 (96 .. 480 B: whole cache lines or nearly); the blocks of one sample sit on ONE XCD (workgroups go
+// round-robin over the XCDs by id) so that lines shared by neighbouring slices cross the fabric once.
+// grid: B * nslice blocks of T threads; T / VS pixel lanes (VS = slice vectors per pixel).
+template <int NV, int T>
+__global__ __launch_bounds__(T) void gn_onepass_kernel(GnParams p, int gpb, int nslice) {
+    extern __shared__ float sm[];                          // [R][SC][2] per-lane channel partials, then [SC][2], then [gpb][2]
+    const int C = p.C0 + p.C1, cg = C / p.groups;
+    const int SC = gpb * cg, VS = SC >> 3;                 // slice channels / vectors per pixel
+    const int R = blockDim.x / VS;
+    int lin = blockIdx.x, b, slice;
+    if ((p.B & 7) == 0) { const int xcd = lin & 7, slot = lin >> 3; slice = slot % nslice; b = (slot / nslice) * 8 + xcd; }
+    else { slice = lin % nslice; b = lin / nslice; }
+    const int c0 = slice * SC;
+    const int v = threadIdx.x % VS, rr = threadIdx.x / VS;
+    const bool live = rr < R;
+    uint4 d[NV];
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { s[i] = 0.f; q[i] = 0.f; }
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int row = rr + i * R;
+            d[i] = row < p.HW ? *(const uint4*)gn_src(p, b, row, c0 + v * 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const uint32_t u[4] = {d[i].x, d[i].y, d[i].z, d[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float lo = __uint_as_float(u[e] << 16), hi = __uint_as_float(u[e] & 0xffff0000u);
+                s[2 * e] += lo; q[2 * e] += lo * lo; s[2 * e + 1] += hi; q[2 * e + 1] += hi * hi;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) *(float2*)(sm + ((i * R + rr) * VS + v) * 2) = make_float2(s[i], q[i]);      // conflict-free: consecutive threads, consecutive float2
+    }
+    __syncthreads();
+    float* ch = sm + R * SC * 2;
+    for (int idx = threadIdx.x; idx < SC; idx += blockDim.x) {
+        const int i = idx / VS, vv = idx - i * VS;
+        float a = 0.f, bq = 0.f;
+        for (int r = 0; r < R; r++) { const float2 t = *(const float2*)(sm + ((i * R + r) * VS + vv) * 2); a += t.x; bq += t.y; }
+        ch[(vv * 8 + i) * 2] = a; ch[(vv * 8 + i) * 2 + 1] = bq;
+    }
+    __syncthreads();
+    float* gst = ch + SC * 2;
+    if (threadIdx.x < gpb) {
+        double a = 0.0, bq = 0.0;
+        for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; c++) { a += ch[c * 2]; bq += ch[c * 2 + 1]; }
+        const double n = (double)cg * p.HW, mean = a / n;
+        double var = bq / n - mean * mean; if (var < 0) var = 0;
+        gst[threadIdx.x * 2] = (float)mean; gst[threadIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    __syncthreads();
+    if (!live) return;
+    float fa[8], fb[8];
+    {
+        int g = (v * 8) / cg, r = v * 8 - g * cg;
+        const float4 g0 = *(const float4*)(p.gamma + c0 + v * 8), g1 = *(const float4*)(p.gamma + c0 + v * 8 + 4);
+        const float4 b0 = *(const float4*)(p.beta + c0 + v * 8), b1 = *(const float4*)(p.beta + c0 + v * 8 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            fa[e] = gst[g * 2 + 1] * gg[e];
+            fb[e] = bb[e] - gst[g * 2] * fa[e];
+            if (++r == cg) { r = 0; g++; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int row = rr + i * R;
+        if (row >= p.HW) break;
+        const uint32_t u[4] = {d[i].x, d[i].y, d[i].z, d[i].w};
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            y[2 * e] = __uint_as_float(u[e] << 16) * fa[2 * e] + fb[2 * e];
+            y[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u) * fa[2 * e + 1] + fb[2 * e + 1];
+        }
+        if (p.silu) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) y[e] = silu_f(y[e]);
+        }
+        *(uint4*)(p.out + ((long long)(b * p.HW + row) * C + c0 + v * 8)) =
+            make_uint4(cvt_pk_bf16(y[0], y[1]), cvt_pk_bf16(y[2], y[3]), cvt_pk_bf16(y[4], y[5]), cvt_pk_bf16(y[6], y[7]));
+    }
+}
+
+// slice geometry of the one-pass form for this shape, or false (the two-pass kernels run)
+static bool gn_onepass_plan(const GnParams& p, int& gpb, int& T, int& nv) {
+    static const int off = getenv("RDM_NO_GN1PASS") ? atoi(getenv("RDM_NO_GN1PASS")) : 0;
+    static const int max_hw = getenv("RDM_GN1PASS_MAXHW") ? atoi(getenv("RDM_GN1PASS_MAXHW")) : 1024;
+    static const int min_seg = getenv("RDM_GN1PASS_MINSEG") ? atoi(getenv("RDM_GN1PASS_MINSEG")) : 96;      // bytes of a pixel row per slice
+    const int C = p.C0 + p.C1;
+    if (off || p.L0 != p.C0 || p.L1 != p.C1 || C % p.groups || p.HW > max_hw || p.HW < 1) return false;      // (padded widths: two-pass)
+    const int cg = C / p.groups;
+    // groups per block: slices of whole 16-byte vectors (C0 % 8 == 0, so no vector straddles the x0 | x1 boundary), at least min_seg bytes
+    // of every pixel row, and registers for it: T / VS pixel lanes x NV <= 32 (16 at 1024 threads) vectors each.  Among the feasible
+    // slicings the one closest to a quarter of a sample per block.  A function of the PER-SAMPLE shape only: the slicing -- hence the
+    // summation order -- must not follow the batch (deterministic mode).
+    const long long want = (long long)p.HW * C / 4;
+    long long best_d = -1;
+    for (int g = 1; g <= p.groups; g++) {
+        if (p.groups % g || (g * cg) % 8 || g * cg * 2 < min_seg) continue;
+        const int VS = g * cg / 8;
+        int t_ok = 0, n_ok = 0;
+        for (int t : {256, 512, 1024}) {
+            if (VS > t) continue;
+            const int R = t / VS, n = (p.HW + R - 1) / R;
+            if (n <= (t == 1024 ? 16 : 32)) { t_ok = t; n_ok = n; break; }      // (1024 threads: 128 registers each)
+        }
+        if (!t_ok) continue;
+        const long long el = (long long)g * cg * p.HW, dist = el > want ? el - want : want - el;
+        if (best_d < 0 || dist < best_d) { best_d = dist; gpb = g; T = t_ok; nv = n_ok <= 4 ? 4 : n_ok <= 8 ? 8 : n_ok <= 16 ? 16 : 32; }
+    }
+    return best_d >= 0;
+}
+static hipError_t launch_gn_onepass(const GnParams& p, int gpb, int T, int nv, hipStream_t st) {
+    const int C = p.C0 + p.C1, cg = C / p.groups, SC = gpb * cg, VS = SC / 8, R = T / VS, nslice = p.groups / gpb;
+    const size_t smb = ((size_t)(R + 1) * SC * 2 + (size_t)gpb * 2) * sizeof(float);
+    const dim3 grid((unsigned)(p.B * nslice));
+    auto go = [&](auto nvtag, auto ttag) -> hipError_t {
+        constexpr int NV = decltype(nvtag)::value, TT = decltype(ttag)::value;
+        static bool attr[RDM_MAX_DEVICES] = {};
+        const int dev = rdm_cur_device();
+        if (!attr[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void*)gn_onepass_kernel<NV, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) return e;
+            attr[dev] = true;
+        }
+        gn_onepass_kernel<NV, TT><<<grid, TT, smb, st>>>(p, gpb, nslice);
+        return hipGetLastError();
+    };
+    if (smb > 96 * 1024) return hipErrorInvalidValue;
+    auto by_t = [&](auto nvtag) -> hipError_t {
+        if (T == 256) return go(nvtag, std::integral_constant<int, 256>{});
+        if (T == 512) return go(nvtag, std::integral_constant<int, 512>{});
+        if constexpr (decltype(nvtag)::value <= 16) return go(nvtag, std::integral_constant<int, 1024>{});
+        return hipErrorInvalidValue;
+    };
+    switch (nv) {
+        case 4: return by_t(std::integral_constant<int, 4>{});
+        case 8: return by_t(std::integral_constant<int, 8>{});
+        case 16: return by_t(std::integral_constant<int, 16>{});
+        default: return by_t(std::integral_constant<int, 32>{});
+    }
+}
+
 static hipError_t gn_geometry(GnParams& p, int& R, int& threads) {
     const int C = p.C0 + p.C1;
     if (p.L0 <= 0) p.L0 = p.C0;
@@ -169,6 +328,10 @@ hipError_t launch_groupnorm(GnParams p, hipStream_t st) {
     int R, threads;
     hipError_t e = gn_geometry(p, R, threads);
     if (e != hipSuccess) return e;
+    {
+        int gpb, T, nv;
+        if (p.out && gn_onepass_plan(p, gpb, T, nv)) return launch_gn_onepass(p, gpb, T, nv, st);
+    }
     e = launch_gn_stats(p, st);
     if (e != hipSuccess) return e;
     // apply: ~64 rows per thread-row, at least ~2k blocks across the batch

@@ -293,7 +293,14 @@ def test_conv3x3_dual_source_rowvec_residual(ctx):
 
 
 @pytest.mark.parametrize("B,HW,C0,C1,silu,eps", [(2, 64, 192, 0, 1, 1e-5), (3, 256, 128, 64, 1, 1e-5), (2, 16, 960, 0, 0, 1e-6),
-                                                 (1, 1024, 576, 384, 1, 1e-5), (2, 4096, 64, 0, 1, 1e-6)])
+                                                 (1, 1024, 576, 384, 1, 1e-5), (2, 4096, 64, 0, 1, 1e-6),
+                                                 # the one-pass kernel's slices (round 5): every UNet shape of the 32 x 32 / 16 x 16 / 8 x 8 levels incl. the
+                                                 # dual-source decoder inputs whose slices straddle the h | skip boundary, batches that do / do not take the
+                                                 # XCD-grouped block order, 512- and 1024-thread blocks
+                                                 (8, 1024, 384, 0, 1, 1e-5), (3, 1024, 384, 0, 0, 1e-6), (8, 1024, 576, 384, 1, 1e-5), (2, 1024, 384, 384, 1, 1e-5),
+                                                 (8, 1024, 384, 192, 1, 1e-5), (16, 256, 576, 0, 1, 1e-5), (8, 256, 960, 576, 1, 1e-5), (5, 256, 576, 576, 1, 1e-5),
+                                                 (8, 256, 576, 384, 1, 1e-5), (16, 64, 960, 0, 0, 1e-6), (8, 64, 960, 960, 1, 1e-5), (9, 64, 960, 576, 1, 1e-5),
+                                                 (2, 4096, 192, 192, 1, 1e-5), (2, 4096, 384, 192, 1, 1e-5)])
 def test_groupnorm(ctx, B, HW, C0, C1, silu, eps):
     d = ctx.device
     C = C0 + C1
