@@ -30,6 +30,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned h4_u32x4;
 #define H4_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
 #define H4_GSTOREO(vaddr, data, off) asm volatile("global_store_dwordx4 %0, %1, off offset:%2\n\ts_nop 1" :: "v"(vaddr), "v"(data), "i"(off) : "memory")
 #define H4_GSTORES(voff, data, sbase) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(voff), "v"(data), "s"(sbase) : "memory")
+// non-temporal form: a write-once stream bigger than the L2 (the GEGLU hidden tensor: 400 MB per launch) should not evict the operands
+#define H4_GSTORES_NT(voff, data, sbase) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" :: "v"(voff), "v"(data), "s"(sbase) : "memory")
 #define H4_GSTORESO(voff, data, sbase, off) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" :: "v"(voff), "v"(data), "s"(sbase), "i"(off) : "memory")
 __device__ __forceinline__ unsigned long long h4_uni64(unsigned long long v) {    // uniform value -> SGPR pair
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));

@@ -470,7 +470,12 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
                     const f32x2_t r2 = (f32x2_t){x1.x, x1.y} * gelu_erf_f2((f32x2_t){g1.x, g1.y});
                     const f32x2_t r3 = (f32x2_t){x1.z, x1.w} * gelu_erf_f2((f32x2_t){g1.z, g1.w});
                     const h4_u32x4 dv = {cvt_pk_bf16(r0.x, r0.y), cvt_pk_bf16(r1.x, r1.y), cvt_pk_bf16(r2.x, r2.y), cvt_pk_bf16(r3.x, r3.y)};
-                    if constexpr (VAR == 2) { asm volatile("" :: "v"(dv), "v"(voffs[it])); } else H4_GSTORES(voffs[it], dv, op);
+                    // NON-TEMPORAL stores (round 5): the hidden tensor is a write-once 400 MB stream per launch at the 32 x 32 level -- as plain
+                    // stores it write-allocates through the L2 and evicts the A panels its eight column tiles share (FETCH_SIZE 4-9 x the
+                    // algorithmic bytes, verdict round 4 item 7).  Same box: GEGLU 415.6 -> 400.8 us, its consumer ff.net.2 x proj_out 210.4 -> 203.0,
+                    // headline + 0.45 .. 0.6 % (profiles/r05c_nt_stores_ab.log).  The same modifier on the other read-outs (plain lin4,
+                    // conv_halo4) and on the GroupNorm outputs measured neutral to slightly negative: their consumers re-read them at once.
+                    if constexpr (VAR == 2) { asm volatile("" :: "v"(dv), "v"(voffs[it])); } else H4_GSTORES_NT(voffs[it], dv, op);
                 }
             };
             stage_row(0); store_row(0);
