@@ -103,6 +103,7 @@ struct IgemmParams {
     int res_k;                  // set by launch_igemm: the bf16 residual enters as BN extra K columns against that identity
     int lda, ldw;               // linear only: row strides of A0 and W in elements when they are views into wider matrices (0 = K); backward.hip
     int l4_any_tiles;           // lin4: take the GEMM whatever its tile count (deterministic mode: the choice must not follow the batch)
+    int res_wrap_rows;          // lin4 only: > 0: the bf16 residual holds only that many rows and row m adds row m % res_wrap_rows (whole tiles, at most two copies)
     int a1_wrap_rows;           // lin4 only: > 0: A1 holds only that many rows and row m reads m % a1_wrap_rows (a multiple of the block tile's rows)
     const bf16_t* Wfrag;        // conv3x3: fragment-ordered copy of W (conv_halo4.hip, built by launch_conv_w_fragpack) or null
     // lin4 only: LayerNorm folded into the GEMM.  A0 holds the RAW rows, Wfrag the gamma-scaled fragment copy, ln_sb[n] = (s[n], b'[n]) per

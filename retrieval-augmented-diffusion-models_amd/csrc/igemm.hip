@@ -659,7 +659,7 @@ hipError_t launch_igemm(const IgemmParams& p_in, bool conv, int batch, hipStream
     if (force_bm == 128) tall = false;
     if (force_bm == 256) tall = true;
     if (!conv && p.Wfrag && lin4_supported(p, batch)) return launch_lin4(p, st);       // lin4.hip
-    if (p.a1_wrap_rows > 0) return hipErrorInvalidValue;                               // a wrapped second source is read by lin4 only
+    if (p.a1_wrap_rows > 0 || p.res_wrap_rows > 0) return hipErrorInvalidValue;                               // a wrapped second source is read by lin4 only
     if (p.act == ACT_GEGLU) {
         if (conv) return hipErrorInvalidValue;
         // 256-wide tile (x and gate interleaved: 128 outputs): the A tile is re-read once per column tile, and the

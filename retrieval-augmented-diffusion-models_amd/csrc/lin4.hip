@@ -493,7 +493,8 @@ __global__ __launch_bounds__(256, 1) void lin4_kernel(IgemmParams p) {
                 if (it < 3) { sbo[it] = (unsigned)(L4_BIAS + (en0 + wn * WN + ch * 8) * 8); srow[it] = (unsigned)(L4_STAT + (wm * 128 + row) * 8); }
             }
             const char* const obase = (const char*)(ob + (long long)(em0 + wm * 128) * ldo + eno);
-            const char* const rbase = (const char*)(rb + (long long)(em0 + wm * 128) * ldo + eno);
+            const int er0 = (p.res_wrap_rows > 0 && em0 >= p.res_wrap_rows) ? em0 - p.res_wrap_rows : em0;       // a residual that holds the first half of the rows only
+            const char* const rbase = (const char*)(rb + (long long)(er0 + wm * 128) * ldo + eno);
             const unsigned long long rowstep = (unsigned long long)(32 * ldo) * 2ull;
             // residual rows: asm loads (saddr form) with counted waits -- as compiler-visible loads they became flat_load + vmcnt(0).
             // Program order of the vector-memory requests: R0 R1 | S0 (6 stores) R2 | S1 R3 | S2 | S3; the wait in front of row i's
@@ -593,6 +594,7 @@ bool lin4_supported(const IgemmParams& p, int batch) {
     const int No = geglu ? p.N / 2 : p.N;
     if (p.N > 8192 || p.ldo % 8 || p.ldo < No || (p.ldw > 0 && p.ldw != p.K)) return false;
     if (p.C1 > 0 && p.lda > 0) return false;
+    if (p.res_wrap_rows > 0 && (!p.res_bf16 || p.res_wrap_rows % (128 * wm) != 0 || 2LL * p.res_wrap_rows < p.M)) return false;
     if (p.a1_wrap_rows > 0 && (p.C1 == 0 || p.a1_wrap_rows % (128 * wm) != 0 || 2LL * p.a1_wrap_rows < p.M)) return false;     // whole tiles, at most two copies
     // LayerNorm folded in: one source of >= 2 slices, no residual (the bias rides in ln_sb), everything in 160 KiB of LDS
     if (p.ln_sb && (p.C1 > 0 || p.K < 128 || p.res_bf16 || p.bias || lin4_smem_bytes(p, wm) > 160 * 1024 || !(p.ln_inv_c > 0.f))) return false;

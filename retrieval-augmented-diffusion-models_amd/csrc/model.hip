@@ -608,22 +608,28 @@ struct Ops {
     }
     // out[M,N] = act(A[M,K] W^T + bias) (+res)
     // a1_wrap_rows > 0: A1 holds that many rows only, row m reads m % a1_wrap_rows (lin4 only: callers check lin4_takes first)
-    bool lin4_takes(int M, int N, int C0, int C1, int a1_wrap_rows) {
+    bool lin4_takes(int M, int N, int C0, int C1, int a1_wrap_rows, int res_wrap_rows = 0) {
         if (c->deterministic) return false;
         IgemmParams t = base(M, N, C0 + C1);
         t.C0 = C0; t.C1 = C1; t.W = (const bf16_t*)blob; t.Wfrag = t.W; t.out_bf16 = (bf16_t*)blob; t.a1_wrap_rows = a1_wrap_rows;
+        if (res_wrap_rows > 0) { t.res_bf16 = (const bf16_t*)blob; t.res_wrap_rows = res_wrap_rows; }
         return lin4_supported(t, 1);
     }
     // rowvec / rowvec_ld / rv_rows: a per-row-group per-column add (IgemmParams::rowvec with rows_per_sample = rv_rows)
     void linear(const bf16_t* A0, const bf16_t* A1, int C0, int C1, size_t woff, size_t boff, bool has_bias, int M, int N,
                 int act, const bf16_t* res, bf16_t* out, float* out_f32 = nullptr, const float* res_f32 = nullptr, int a1_wrap_rows = 0,
-                const float* rowvec = nullptr, int rowvec_ld = 0, int rv_rows = 1) {
+                const float* rowvec = nullptr, int rowvec_ld = 0, int rv_rows = 1, int res_wrap_rows = 0) {
         if (plan) return;
         // skinny (weight-streaming) kernel for decode-sized operands.  Fast mode: whenever M <= 128.  Deterministic mode: exactly for
         // the ops with ONE row per sample (`single_row`: time embedding, RARM decode step, CLIP projection), at any batch
         // (one-row-per-sample operands of bigger batches -- RARM decode at 128+ sequences per GPU -- keep the skinny kernel: its row
         //  blocks scale with M, while the tiled kernels would run a dozen 256-row tiles)
-        const bool skinny = c->deterministic ? single_row : (M <= 128 || (single_row && M <= 1024));
+        // RDM_SGEMM_MAX_ROWS / RDM_SGEMM_GEGLU_MAX_ROWS (dev): one-row-per-sample operands beyond these row counts take the tiled kernels
+        static const int sg_max = getenv("RDM_SGEMM_MAX_ROWS") ? atoi(getenv("RDM_SGEMM_MAX_ROWS")) : 1024;
+        // (round 5, same box: the GEGLU projection of the RARM decode step through the tiled kernel from ~200 rows on: 397.8 -> 409.5 img/s at 256
+        //  sequences, 487.0 -> 514.8 at 512; the plain projections through it: 221 / 305 -- their N = 768 gives the tiled kernel 16-24 tiles)
+        static const int sg_geglu_max = getenv("RDM_SGEMM_GEGLU_MAX_ROWS") ? atoi(getenv("RDM_SGEMM_GEGLU_MAX_ROWS")) : 192;
+        const bool skinny = c->deterministic ? single_row : (M <= 128 || (single_row && M <= (act == ACT_GEGLU ? sg_geglu_max : sg_max)));
         if (skinny && !A1 && C1 == 0 && !rowvec) {         // N/32 x ceil(M/32) blocks (sgemm.hip)
             SgemmParams q{}; q.A = A0; q.lda = C0; q.W = w<bf16_t>(woff); q.M = M; q.N = N; q.K = C0; q.bias = has_bias ? w<float>(boff) : nullptr;
             q.act = act; q.res_f32 = res_f32; q.res_bf16 = res; q.out_f32 = out_f32; q.out_bf16 = out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
@@ -637,6 +643,7 @@ struct Ops {
         IgemmParams p = base(M, N, C0 + C1);
         p.A0 = A0; p.A1 = A1; p.C0 = C0; p.C1 = C1; p.W = w<bf16_t>(woff); p.bias = has_bias ? w<float>(boff) : nullptr;
         p.act = act; p.res_bf16 = res; p.res_f32 = res_f32; p.out_bf16 = out; p.out_f32 = out_f32; p.a1_wrap_rows = a1_wrap_rows;
+        p.res_wrap_rows = res_wrap_rows;
         if (rowvec) { p.rowvec = rowvec; p.rowvec_ld = rowvec_ld; p.rows_per_sample = rv_rows; }
         if (act == ACT_GEGLU) p.ldo = N / 2;
         // one-wave-per-SIMD kernel for the big-M projections (its tile choice follows M, so not in deterministic mode)
@@ -747,9 +754,9 @@ struct Ops {
     }
     void prof_end() { if (prof_open) hipEventRecord(c->prof_recs.back().b, c->stream); prof_open = false; }
     void groupnorm(const bf16_t* x0, const bf16_t* x1, int C0, int C1, int B, int HW, size_t g, size_t b, float eps, int silu,
-                   bf16_t* out, int L0 = -1, int L1 = -1, int x1_bmod = 0) {      // L0 / L1: logical channels of the (zero-padded) sources, default = all
+                   bf16_t* out, int L0 = -1, int L1 = -1, int x1_bmod = 0, int x0_bmod = 0) {      // L0 / L1: logical channels of the (zero-padded) sources, default = all
         if (plan) return;
-        GnParams p{}; p.x0 = x0; p.x1 = x1; p.C0 = C0; p.C1 = C1; p.HW = HW; p.B = B; p.groups = 32; p.x1_bmod = x1_bmod;
+        GnParams p{}; p.x0 = x0; p.x1 = x1; p.C0 = C0; p.C1 = C1; p.HW = HW; p.B = B; p.groups = 32; p.x1_bmod = x1_bmod; p.x0_bmod = x0_bmod;
         p.L0 = L0 < 0 ? C0 : L0; p.L1 = L1 < 0 ? C1 : L1;
         int nchunk = HW / 64; if (nchunk < 1) nchunk = 1; if (nchunk > 32) nchunk = 32;
         p.nchunk = nchunk; p.partial = c->gn_partial; p.gamma = w<float>(g); p.beta = w<float>(b); p.eps = eps; p.silu = silu;
@@ -918,9 +925,12 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
     auto transformer = [&](const StW& s, const Act& a) -> Act {
         const int C = s.c, n = a.H * a.W, M = B * n;
         o.rows_hint = n;
+        // a.half: the input left the shared guidance prefix and only its first Bfull / 2 samples exist: its two readers -- the entry GroupNorm and
+        // the residual of ff.net.2 x proj_out -- wrap the batch index (round 5: no 50 MB duplication pass per forward)
+        const int in_wrap = a.half ? Bfull / 2 : 0;
         bf16_t* xn = o.abf((size_t)M * C);
         o.tag = "st.gn";
-        o.groupnorm(a.p, nullptr, C, 0, B, n, s.gng, s.gnb, 1e-6f, 0, xn, s.lc, 0);
+        o.groupnorm(a.p, nullptr, C, 0, B, n, s.gng, s.gnb, 1e-6f, 0, xn, s.lc, 0, 0, in_wrap);
         o.tap(1, xn, (size_t)M * C * 2);
         bf16_t* t0 = o.abf((size_t)M * C);
         o.tag = "st.proj_in";
@@ -1074,7 +1084,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         if (!no_ffout) {
             // t3 = ff W_2^T + b_2 + t2 and out = t3 W_out^T + b_out + x are one GEMM over the K-concatenated operand [ff | t2]
             // (dual-source A) with the product weights built by the packer: t3 never exists (2 of 9 tensor passes, one launch)
-            o.linear(ff, t2, FI, C, s.wfo, s.bfo, true, M, C, ACT_NONE, a.p, out);
+            o.linear(ff, t2, FI, C, s.wfo, s.bfo, true, M, C, ACT_NONE, a.p, out, nullptr, nullptr, 0, nullptr, 0, 1, in_wrap * n);
         } else {
             bf16_t* t3 = o.abf((size_t)M * C);
             o.linear(ff, nullptr, FI, 0, s.wff2, s.bff2, true, M, C, ACT_NONE, t2, t3);
@@ -1099,7 +1109,15 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
                 case 1: h = resblock(u.res[L.idx], h, (first && skip) ? skip : nullptr); break;
                 case 2:
                     if (B < Bfull) {       // first context-dependent layer: leave the shared prefix
-                        expand(h);
+                        {   // the activation itself is duplicated only where its readers cannot wrap the batch index instead (transformer())
+                            const StW& s0 = u.st[L.idx];
+                            static const int no_inwrap = getenv("RDM_NO_INWRAP") ? atoi(getenv("RDM_NO_INWRAP")) : 0;
+                            static const int no_ffout_env = getenv("RDM_NO_FFOUT") ? atoi(getenv("RDM_NO_FFOUT")) : 0;
+                            const int n0 = h.H * h.W, Mfull = Bfull * n0;
+                            if (!no_inwrap && !no_wrap && !no_ffout_env && !o.c->deterministic &&
+                                o.lin4_takes(Mfull, s0.c, 4 * s0.lc, s0.c, 0, (Bfull / 2) * n0)) h.half = true;
+                            else expand(h);
+                        }
                         for (Act& a : hs) { if (no_wrap || o.c->deterministic) expand(a); else a.half = true; }
                         B = Bfull;
                     }

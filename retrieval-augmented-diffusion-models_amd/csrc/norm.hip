@@ -25,7 +25,7 @@ __device__ __forceinline__ int gn_logical(const GnParams& p, int c) {
 __device__ __forceinline__ int gn_physical(const GnParams& p, int l) { return l < p.L0 ? l : p.C0 + (l - p.L0); }
 
 __device__ __forceinline__ const bf16_t* gn_src(const GnParams& p, int b, int row, int c) {
-    if (c < p.C0) return p.x0 + ((long long)(b * p.HW + row) * p.C0 + c);
+    if (c < p.C0) return p.x0 + ((long long)((p.x0_bmod > 0 ? b % p.x0_bmod : b) * p.HW + row) * p.C0 + c);
     const int b1 = p.x1_bmod > 0 ? b % p.x1_bmod : b;
     return p.x1 + ((long long)(b1 * p.HW + row) * p.C1 + (c - p.C0));
 }
