@@ -23,15 +23,18 @@
 // Round 5: the 64 x 64 tiles (MA = 4 with NB = 4, GEGLU NB = 8) are for M = 256 .. 1024 rows -- the RARM decode step at 256 / 512
 // sequences per GPU -- where the small tiles re-read the A rows once per 16 / 32 output columns (LN-fused q | k | v at M = 512: 1152
 // blocks x 147 KB = 169 MB through an L2 that holds neither operand: 40 us for a 1.8 GFLOP product).
-template <int MA, int NB, bool GEGLU, int U, bool LN = false>
-__global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
+// NW: waves per block = K split (4; 8 for the 64 x 64 tiles: a wave's K share is then ONE batch of loads at K = 768 -- one dependent round trip
+// instead of two -- and half as many at K = 3072)
+template <int MA, int NB, bool GEGLU, int U, bool LN = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void sgemm_kernel(SgemmParams p) {
+    static_assert(!LN || NW == 4, "the LayerNorm-fused variant is written for four waves");
     // 16x16x32 MFMAs, not 32x32x16: the operands come straight from global memory in fragment order, and what such a launch pays
     // for is the number of cache LINES its load instructions touch (phase clocks at M = 64, K = 768: 9.1 of the launch's ~12 us are
     // the load phase).  A 32x32x16 fragment is 32 rows x 32 bytes per instruction -- 32 lines for 1 KB --, a 16x16x32 fragment is
     // 16 rows x 64 bytes: half the lines for the same bytes and the same FLOPs per cycle.
     constexpr int RB = 16 * MA, CB = 16 * NB;             // rows / weight rows of the block tile
     constexpr int OC = GEGLU ? CB / 2 : CB;               // output columns of the block
-    extern __shared__ float part[];                       // [4 waves][RB rows][CB cols]
+    extern __shared__ float part[];                       // [NW waves][RB rows][CB cols]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q4 = lane >> 4;
     const int mb0 = blockIdx.y * RB;                      // first of this block's rows
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
         for (int j = 0; j < NB; j++) wrow[j] = blockIdx.x * CB + j * 16;
         ncol0 = blockIdx.x * OC;
     }
-    const int kq = p.K >> 2, k0 = wave * kq;              // this wave's K quarter
+    const int kq = p.K / NW, k0 = wave * kq;              // this wave's share of K
     const bf16_t* wp[NB];
 #pragma unroll
     for (int j = 0; j < NB; j++) wp[j] = p.W + (long long)(wrow[j] + r16) * p.K + k0 + q4 * 8;
@@ -62,11 +65,11 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
     // thing after the partial-tile exchange they were one more dependent L2 round trip at the end of a launch that is three round trips
     // long.  A thread reads and writes the same elements (the decode step accumulates in place: out == residual), and nothing else in
     // the launch writes them, so the early read sees what the late one saw.
-    constexpr int NOUT = RB * OC, IT = (NOUT + 255) / 256;
+    constexpr int NT = 64 * NW, NOUT = RB * OC, IT = (NOUT + NT - 1) / NT;
     float res_[IT];
 #pragma unroll
     for (int it = 0; it < IT; it++) {
-        const int e = tid + it * 256;
+        const int e = tid + it * NT;
         const int row = e / OC, col = e - row * OC, m = mb0 + row;
         float r = 0.f;
         if (e < NOUT && m < p.M) {
@@ -174,14 +177,14 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
     float acc_[IT]; long long oi_[IT]; bool ok_[IT];
 #pragma unroll
     for (int it = 0; it < IT; it++) {
-        const int e = tid + it * 256;
+        const int e = tid + it * NT;
         const int row = e / OC, col = e - row * OC, m = mb0 + row;
         ok_[it] = e < NOUT && m < p.M;
         oi_[it] = (long long)m * p.ldo + ncol0 + col;
     }
 #pragma unroll
     for (int it = 0; it < IT; it++) {
-        const int e = tid + it * 256;
+        const int e = tid + it * NT;
         const int row = (e / OC) % RB, col = e % OC;
         // column `col` of the block's outputs = weight-tile column col (x) and, GEGLU, col + OC (its gate)
         float v[GEGLU ? 2 : 1];
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmParams p) {
             const int cc = !GEGLU ? col : (NB == 2 ? col + j * 16 : (col >> 5) * 64 + (col & 31) + j * 32);
             float s = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; w++) s += part[(w * RB + row) * CB + cc];
+            for (int w = 0; w < NW; w++) s += part[(w * RB + row) * CB + cc];
             // weight row behind tile column cc (= wrow[cc >> 4] + (cc & 15), spelled without a run-time array index)
             int wr;
             if constexpr (GEGLU && NB == 2) wr = wrow[0] + (cc < 16 ? cc : cc + 16);
@@ -220,19 +223,19 @@ bool sgemm_supported(const SgemmParams& p) {
     return p.N % 32 == 0 && (p.act == ACT_NONE || p.act == ACT_SILU || p.act == ACT_QUICKGELU);
 }
 
-template <int MA, int NB, bool GEGLU, int U, bool LN = false>
+template <int MA, int NB, bool GEGLU, int U, bool LN = false, int NW = 4>
 static hipError_t launch_one(const SgemmParams& p, hipStream_t st) {
     constexpr int RB = 16 * MA, CB = 16 * NB;
-    const size_t sm = (size_t)4 * RB * CB * sizeof(float) + (LN ? (size_t)(2 * p.K + 4 * RB * 2) * sizeof(float) : 0);
+    const size_t sm = (size_t)NW * RB * CB * sizeof(float) + (LN ? (size_t)(2 * p.K + 4 * RB * 2) * sizeof(float) : 0);
     static bool attr_dev[RDM_MAX_DEVICES] = {false};
     bool& attr = attr_dev[rdm_cur_device()];
     if (!attr && sm > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)sgemm_kernel<MA, NB, GEGLU, U, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipError_t e = hipFuncSetAttribute((const void*)sgemm_kernel<MA, NB, GEGLU, U, LN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) return e;
         attr = true;
     }
     const int gx = GEGLU ? (NB == 2 ? p.N / 32 : p.N / CB) : p.N / CB;
-    sgemm_kernel<MA, NB, GEGLU, U, LN><<<dim3(gx, (p.M + RB - 1) / RB), 256, sm, st>>>(p);
+    sgemm_kernel<MA, NB, GEGLU, U, LN, NW><<<dim3(gx, (p.M + RB - 1) / RB), 64 * NW, sm, st>>>(p);
     return hipGetLastError();
 }
 
@@ -270,7 +273,11 @@ static hipError_t launch_nf(const SgemmParams& p, hipStream_t st) {
     pick_tile<GEGLU, false>(p, ma, nb);
     if (nb == N3) {       // 64 x 64 outputs: two (GEGLU) / three k-steps per batch of loads keep the operand registers under the budget
         if constexpr (GEGLU) return launch_one<4, N3, true, 2>(p, st);
-        else return ((p.K >> 2) % 96) == 0 ? launch_one<4, N3, false, 3>(p, st) : launch_one<4, N3, false, 2>(p, st);
+        else {
+            static const int nw8_off = getenv("RDM_SGEMM_NW4") ? atoi(getenv("RDM_SGEMM_NW4")) : 0;
+            if (!nw8_off && p.M >= 384 && (p.K >> 3) % 96 == 0) return launch_one<4, N3, false, 3, false, 8>(p, st);      // eight waves: K / 8 in batches of three k-steps
+            return ((p.K >> 2) % 96) == 0 ? launch_one<4, N3, false, 3>(p, st) : launch_one<4, N3, false, 2>(p, st);
+        }
     }
     if (nb == N1) {
         switch (ma) {
@@ -282,7 +289,11 @@ static hipError_t launch_nf(const SgemmParams& p, hipStream_t st) {
     switch (ma) {
         case 1: return deep ? launch_one<1, N2, GEGLU, 6>(p, st) : launch_one<1, N2, GEGLU, 2>(p, st);
         case 2: return deep ? launch_one<2, N2, GEGLU, 6>(p, st) : launch_one<2, N2, GEGLU, 2>(p, st);
-        default: return deep ? launch_one<4, N2, GEGLU, 6>(p, st) : launch_one<4, N2, GEGLU, 2>(p, st);
+        default: {
+            static const int nw8_off = getenv("RDM_SGEMM_NW4") ? atoi(getenv("RDM_SGEMM_NW4")) : 0;
+            if constexpr (!GEGLU) { if (!nw8_off && p.M >= 384 && (p.K >> 3) % 96 == 0) return launch_one<4, N2, false, 3, false, 8>(p, st); }      // (same box: 512 rows 511.6 -> 519.5 img/s, 256 rows 407.8 -> 404.3: from 384 rows on)
+            return deep ? launch_one<4, N2, GEGLU, 6>(p, st) : launch_one<4, N2, GEGLU, 2>(p, st);
+        }
     }
 }
 
