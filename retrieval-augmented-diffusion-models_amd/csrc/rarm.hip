@@ -142,8 +142,48 @@ __global__ __launch_bounds__(256) void rarm_decode_attention_kernel(RarmAttnPara
         *(uint32_t*)(p.out + (long long)b * p.ldo + h * D + c) = pack2bf(o0, o1);
     }
 }
+// Cross-attention over <= 8 projected neighbours (the GEMM-form decode step of big batches, round 5): ONE block per sequence, a wave per
+// head in turn (heads w, w + 4, ..): a wave instruction reads the head's eight 128-byte key rows (eight lanes per row), the eight partial dot
+// products of a row meet by three lane exchanges, the softmax over the eight keys by three more, the values likewise -- the launch above
+// spends a 256-thread block with two LDS exchanges on each of heads x sequences eight-key problems (17 us at 512 sequences).
+__global__ __launch_bounds__(256) void rarm_fewkey_attention_kernel(RarmAttnParams p, int heads) {
+    constexpr int D = 64;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane >> 3, c8 = (lane & 7) * 8;
+    const bool live = j < p.nkv;
+    for (int h = w; h < heads; h += 4) {
+        const bf16_t* Kr = p.Kc + (long long)b * p.batch_stride + (long long)(live ? j : 0) * p.row_stride + h * D + c8;
+        const bf16_t* Vr = p.Vc + (long long)b * p.batch_stride + (long long)(live ? j : 0) * p.row_stride + h * D + c8;
+        const bf16x8 qq = *(const bf16x8*)(p.q + (long long)b * p.ldq + h * D + c8);
+        const bf16x8 kk = *(const bf16x8*)Kr, vv = *(const bf16x8*)Vr;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) s += bf2f((bf16_t)qq[e]) * p.scale * bf2f((bf16_t)kk[e]);
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        s = live ? s : -INFINITY;
+        float m = s;
+        m = fmaxf(m, __shfl_xor(m, 8)); m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+        const float e_ = live ? __expf(s - m) : 0.f;
+        float l = e_;
+        l += __shfl_xor(l, 8); l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+        const float pj = e_ / l;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            o[e] = pj * bf2f((bf16_t)vv[e]);
+            o[e] += __shfl_xor(o[e], 8); o[e] += __shfl_xor(o[e], 16); o[e] += __shfl_xor(o[e], 32);
+        }
+        if (j == 0)
+            *(uint4*)(p.out + (long long)b * p.ldo + h * D + c8) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+    }
+}
 hipError_t launch_rarm_decode_attention(const RarmAttnParams& p, int heads, int batch, hipStream_t st) {
     if (p.nkv > 1024) return hipErrorInvalidValue;
+    static const int no_fewkey = getenv("RDM_NO_RARM_FEWKEY") ? atoi(getenv("RDM_NO_RARM_FEWKEY")) : 0;
+    if (!no_fewkey && !p.k_new && !p.pos && p.nkv >= 1 && p.nkv <= 8 && batch >= 128) {       // cross-attention over few keys at big batches
+        rarm_fewkey_attention_kernel<<<batch, 256, 0, st>>>(p, heads);
+        return hipGetLastError();
+    }
     rarm_decode_attention_kernel<<<dim3(heads, batch), 256, 0, st>>>(p);
     return hipGetLastError();
 }

@@ -59,6 +59,30 @@ def test_rarm_forward_shipped_golden(ctx):
     assert e <= 2.5e-2
 
 
+@pytest.mark.parametrize("nseq", [256, 512])
+def test_rarm_forward_shipped_golden_big_batches(ctx, nseq):
+    """The decode geometries of the big batches (round 5: bench.py --config 5 defaults to 512 sequences per GPU): 256 sequences take the 64 x 64
+    skinny-GEMM tiles behind a separate LayerNorm, the tiled GEGLU projection and the fused one-block cross-attention; 512 sequences the
+    eight-wave GEMM tiles and the GEMM-form cross-attention (norm2 + to_q GEMM, the few-key attention kernel, to_out GEMM).  The golden's two
+    sequences (8-token prefix, reference logits of the last two positions) sit at rows 0 and nseq - 1 of the batch, random sequences between."""
+    g = golden("rarm_shipped.npz")
+    spec = orarm.shipped_rarm_spec()
+    _load(ctx, spec, int(g["seed"]))
+    tok, cx = torch.from_numpy(g["tokens"]), torch.from_numpy(g["ctx"])
+    gen = torch.Generator().manual_seed(17 + nseq)
+    T = tok.shape[1]
+    tokens = torch.cat([tok[:1], torch.randint(0, spec.vocab_out, (nseq - 2, T), generator=gen), tok[1:2]])
+    context = torch.cat([cx[:1], torch.randn((nseq - 2,) + tuple(cx.shape[1:]), generator=gen) * float(cx.std()), cx[1:2]])
+    logits = ctx.rarm_forward(tokens, context)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(logits).all())
+    ref = torch.from_numpy(g["logits_last"])
+    for row, r in ((0, 0), (nseq - 1, 1)):
+        e = rel_l2(logits[row, -2:], ref[r])
+        print(f"rarm shipped, batch {nseq}, row {row}: rel L2 vs reference golden {e:.3e}")
+        assert e <= 2.5e-2
+
+
 def test_rarm_forward_shipped_deep_golden(ctx):
     """The benchmarked size AT DEPTH (verdict round 2, weak 2): a full 256-token prefix through the K/V-cache decode path, a row with
     eight random neighbours and a row with ZERO neighbours (the unconditional half of a guided batch); logits at positions 0, 31,
