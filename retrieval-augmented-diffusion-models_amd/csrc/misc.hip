@@ -2,19 +2,37 @@
 #include "kernels.h"
 
 // ------------------------------------------------------------------ stem conv: few input channels
+typedef float f2_t __attribute__((ext_vector_type(2)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+// acc.xy += p[HI] * w.xy: the scalar factor is broadcast out of one half of a register pair through op_sel (hipcc materialises a
+// duplicated pair per factor instead: twice the registers for the 54 input taps a lane holds)
+template <int HI> __device__ __forceinline__ void pk_fma_bcast(f2_t& acc, const f2_t p, const f2_t w) {
+    if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(p), "v"(w));
+    else    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(p), "v"(w));
+}
 // 3x3 pad-1 conv, input NCHW f32 [B,Cin,H,W] (Cin <= 4), output NHWC bf16 [B,H,W,Cout].
 // Replaces input_blocks.0 conv (openaimodel.py:149) and the VQ decoder conv_in.  K = 9*Cin = 27 is
 // far too small for MFMA: VALU, weights in LDS as [tap*Cin][Cout].
+// OCT > 0 (Cout % (8 OCT) == 0): a lane's 16-byte result of one channel octet lands 2*Cout bytes from its neighbour's, so a direct store
+// touches 64 lines for 1 KB; instead every OCT octets go through a per-wave LDS tile [64 pixels][16 OCT + 16 B] and leave as contiguous
+// 16 OCT-byte runs (OCT lanes per pixel).  Same values, same rounding.  Measured (B = 64, 64 x 64, 3 -> 192): direct 123 us, OCT = 4 105 us,
+// OCT = 8 162 us (its 95 KB of LDS leave one block per CU): the stores were never the bound -- the tap loop was (a runtime trip count put a
+// branch between every tap's LDS reads and its FMAs, nothing could be hoisted): CIN is a template parameter now.
+template <int OCT, int CIN>
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* x, const float* w /*[Cout][Cin][3][3]*/,
                                                       const float* bias, bf16_t* out, int B, int Cin, int H, int W,
                                                       int Cout) {
     // thread = one output pixel: its 9*Cin input taps live in registers, every thread of the block reads the same
     // weight vector at the same time (LDS broadcast), 16-byte stores of 8 output channels.
-    extern __shared__ float ws[];   // [Cin*9][Cout] + bias[Cout]
-    const int K = Cin * 9;
+    extern __shared__ __attribute__((aligned(16))) float ws[];   // [CIN*9][Cout] (rows of channels >= Cin zero) + bias[Cout] (+ OCT: 2 x 4 waves x 64 x (16 OCT + 16) B)
+    constexpr int K = CIN * 9;
+    const int Kw = Cin * 9;
+    const int lane = threadIdx.x & 63;
+    constexpr int TS = 16 * OCT + 16, CM = 8 * OCT - 8;      // tile row stride (bytes); channel mask of an octet inside its group
+    char* tile = (char*)(ws + (K + 1) * Cout) + (threadIdx.x >> 6) * (64 * TS);
     for (int i = threadIdx.x; i < K * Cout; i += 256) {
-        const int co = i / K, k = i % K;              // w index = co*K + (ci*9 + tap)
-        ws[k * Cout + co] = w[i];
+        const int co = i / K, k = i % K;              // w index = co*Kw + (ci*9 + tap)
+        ws[k * Cout + co] = k < Kw ? w[co * Kw + k] : 0.f;
     }
     for (int i = threadIdx.x; i < Cout; i += 256) ws[K * Cout + i] = bias[i];
     __syncthreads();
@@ -22,45 +40,78 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* x, const floa
     // two pixels per thread: every broadcast weight read from LDS feeds 16 FMAs instead of 8 (the LDS reads, not the FMAs, bound
     // the one-pixel version)
     for (int lp0 = blockIdx.x * 512 + threadIdx.x; lp0 < npix; lp0 += gridDim.x * 512) {
-        float patch[2][36];                           // Cin <= 4
+        f2_t patch[2][(K + 1) / 2];                   // tap k of pixel q: half k & 1 of patch[q][k / 2]
+        const float* xb = x + (long long)b * Cin * npix;       // uniform base + 32-bit lane offsets: one address register per load
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int lp = lp0 + q * 256;
             const int xw = lp % W, yh = lp / W;
+            const bool inb = lp < npix;
+            const bool rv[3] = {inb && yh > 0, inb, inb && yh < H - 1}, cv[3] = {xw > 0, true, xw < W - 1};
 #pragma unroll
-            for (int ci = 0; ci < 4; ci++) {
+            for (int ci = 0; ci < CIN; ci++) {
 #pragma unroll
                 for (int t = 0; t < 9; t++) {
-                    const int iy = yh + t / 3 - 1, ix = xw + t % 3 - 1;
-                    float v = 0.f;
-                    if (lp < npix && ci < Cin && iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((long long)(b * Cin + ci) * H + iy) * W + ix];
-                    patch[q][ci * 9 + t] = v;
+                    const bool ok = rv[t / 3] && cv[t % 3] && ci < Cin;
+                    const int idx = ok ? lp + ci * npix + (t / 3 - 1) * W + (t % 3 - 1) : 0;
+                    const float v = xb[idx];
+                    if ((ci * 9 + t) & 1) patch[q][(ci * 9 + t) / 2].y = ok ? v : 0.f; else patch[q][(ci * 9 + t) / 2].x = ok ? v : 0.f;
                 }
             }
         }
 #pragma unroll 1
         for (int v8 = 0; v8 < Cout; v8 += 8) {
+            // packed fp32 FMAs (two channels per instruction), the next tap's weights in flight while this tap's FMAs issue
+            f2_t acc2[2][4];
+            {
+                const f4_t b0 = *(const f4_t*)(ws + K * Cout + v8), b1 = *(const f4_t*)(ws + K * Cout + v8 + 4);
+#pragma unroll
+                for (int q = 0; q < 2; q++) { acc2[q][0] = b0.xy; acc2[q][1] = b0.zw; acc2[q][2] = b1.xy; acc2[q][3] = b1.zw; }
+            }
+            f4_t w0 = *(const f4_t*)(ws + v8), w1 = *(const f4_t*)(ws + v8 + 4);
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int kn = k + 1 < K ? k + 1 : k;
+                const f4_t n0 = *(const f4_t*)(ws + kn * Cout + v8), n1 = *(const f4_t*)(ws + kn * Cout + v8 + 4);
+                __builtin_amdgcn_sched_barrier(0);       // keep ONE tap of weights in flight: left alone, the scheduler hoists all 27 taps' reads
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const f2_t pp = patch[q][k / 2];
+                    if (k & 1) { pk_fma_bcast<1>(acc2[q][0], pp, w0.xy); pk_fma_bcast<1>(acc2[q][1], pp, w0.zw); pk_fma_bcast<1>(acc2[q][2], pp, w1.xy); pk_fma_bcast<1>(acc2[q][3], pp, w1.zw); }
+                    else       { pk_fma_bcast<0>(acc2[q][0], pp, w0.xy); pk_fma_bcast<0>(acc2[q][1], pp, w0.zw); pk_fma_bcast<0>(acc2[q][2], pp, w1.xy); pk_fma_bcast<0>(acc2[q][3], pp, w1.zw); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                w0 = n0; w1 = n1;
+            }
             float acc[2][8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) { acc[0][e] = ws[K * Cout + v8 + e]; acc[1][e] = acc[0][e]; }
+            for (int q = 0; q < 2; q++)
 #pragma unroll
-            for (int k = 0; k < 36; k++) {
-                if (k < K) {
-                    const float4 w0 = *(const float4*)(ws + k * Cout + v8), w1 = *(const float4*)(ws + k * Cout + v8 + 4);
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const float pv = patch[q][k];
-                        acc[q][0] += pv * w0.x; acc[q][1] += pv * w0.y; acc[q][2] += pv * w0.z; acc[q][3] += pv * w0.w;
-                        acc[q][4] += pv * w1.x; acc[q][5] += pv * w1.y; acc[q][6] += pv * w1.z; acc[q][7] += pv * w1.w;
-                    }
-                }
-            }
+                for (int e = 0; e < 4; e++) { acc[q][2 * e] = acc2[q][e].x; acc[q][2 * e + 1] = acc2[q][e].y; }
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const int lp = lp0 + q * 256;
-                if (lp < npix)
-                    *(uint4*)(out + ((long long)b * npix + lp) * Cout + v8) =
-                        make_uint4(cvt_pk_bf16(acc[q][0], acc[q][1]), cvt_pk_bf16(acc[q][2], acc[q][3]), cvt_pk_bf16(acc[q][4], acc[q][5]), cvt_pk_bf16(acc[q][6], acc[q][7]));
+                const uint4 r = make_uint4(cvt_pk_bf16(acc[q][0], acc[q][1]), cvt_pk_bf16(acc[q][2], acc[q][3]), cvt_pk_bf16(acc[q][4], acc[q][5]), cvt_pk_bf16(acc[q][6], acc[q][7]));
+                if (OCT == 0) {
+                    if (lp < npix) *(uint4*)(out + ((long long)b * npix + lp) * Cout + v8) = r;
+                } else {
+                    *(uint4*)(tile + q * (64 * TS * 4) + lane * TS + (v8 & CM) * 2) = r;
+                }
+            }
+            if (OCT > 0 && (v8 & CM) == CM) {                 // OCT octets staged: 64 pixels x 16 OCT bytes per q
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int wave_lp0 = lp0 - lane + q * 256;
+#pragma unroll
+                    for (int j = 0; j < (OCT > 0 ? OCT : 1); j++) {
+                        constexpr int PPI = OCT > 0 ? 64 / OCT : 1;             // pixels per store instruction
+                        const int pl = j * PPI + lane / (OCT > 0 ? OCT : 1), oc = lane % (OCT > 0 ? OCT : 1);
+                        const uint4 r = *(const uint4*)(tile + q * (64 * TS * 4) + pl * TS + oc * 16);
+                        if (wave_lp0 + pl < npix) *(uint4*)(out + ((long long)b * npix + wave_lp0 + pl) * Cout + (v8 - CM) + oc * 8) = r;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
@@ -69,11 +120,27 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* x, const floa
 hipError_t launch_conv_in(const float* x, const float* w, const float* bias, bf16_t* out, int B, int Cin, int H, int W,
                           int Cout, hipStream_t st) {
     if (Cout % 8) return hipErrorInvalidValue;
-    const size_t sm = (size_t)(Cin * 9 + 1) * Cout * sizeof(float);
-    if (sm > 64 * 1024) return hipErrorInvalidValue;
-    if (Cin > 4 || Cout % 8) return hipErrorInvalidValue;
+    if (Cin > 4 || Cin < 1 || Cout % 8) return hipErrorInvalidValue;
+    const int cin_t = Cin <= 3 ? 3 : 4;
+    const size_t sm = (size_t)(cin_t * 9 + 1) * Cout * sizeof(float);
+    if (sm > 96 * 1024) return hipErrorInvalidValue;
     int grid = (H * W + 511) / 512; const int cap_in = (2048 + B - 1) / B; if (grid > cap_in) grid = cap_in; if (grid < 1) grid = 1;
-    conv_in_kernel<<<dim3(grid, B), 256, sm, st>>>(x, w, bias, out, B, Cin, H, W, Cout);
+    static const int oct_env = getenv("RDM_CONVIN_OCT") ? atoi(getenv("RDM_CONVIN_OCT")) : 4;     // 0: direct 16-byte stores
+    static bool attr_set = false;
+    if (!attr_set) {
+        const void* fns[] = {(const void*)conv_in_kernel<4, 3>, (const void*)conv_in_kernel<4, 4>, (const void*)conv_in_kernel<0, 3>, (const void*)conv_in_kernel<0, 4>};
+        for (const void* f : fns) { hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return e; }
+        attr_set = true;
+    }
+    const dim3 g(grid, B);
+    const size_t sm4 = sm + 2 * 4 * 64 * 80;
+    if (oct_env >= 4 && Cout % 32 == 0) {
+        if (cin_t == 3) conv_in_kernel<4, 3><<<g, 256, sm4, st>>>(x, w, bias, out, B, Cin, H, W, Cout);
+        else            conv_in_kernel<4, 4><<<g, 256, sm4, st>>>(x, w, bias, out, B, Cin, H, W, Cout);
+    } else {
+        if (cin_t == 3) conv_in_kernel<0, 3><<<g, 256, sm, st>>>(x, w, bias, out, B, Cin, H, W, Cout);
+        else            conv_in_kernel<0, 4><<<g, 256, sm, st>>>(x, w, bias, out, B, Cin, H, W, Cout);
+    }
     return hipGetLastError();
 }
 
