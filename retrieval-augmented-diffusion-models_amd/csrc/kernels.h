@@ -12,6 +12,7 @@ struct GnParams {
     float eps; int silu;
     bf16_t* out;                          // [B, HW, C0+C1]
     int x1_bmod;                          // > 0: x1 holds only x1_bmod samples and sample b reads b % x1_bmod (a shared-prefix skip tensor whose second half was never materialised)
+    int b0;                               // first sample of this launch (launch_groupnorm walks big tensors in sample ranges: blockIdx.y + b0)
     int x0_bmod;                          // the same for x0 (round 5: the activation leaving the shared guidance prefix is not duplicated either)
 };
 

@@ -1762,13 +1762,40 @@ int rdm_ddpm_sample(rdm_ctx* c, const rdm_ddpm_args* a, const float* x_T, const 
     return 0;
 }
 
+// Samples per decoder pass.  Decoding is per sample (GroupNorm statistics included), so a batch may be walked in ranges; a range is
+// sized so that the decoder's largest activation stays below 2^30 elements (2 GiB of bf16): the halo convs address an operand through
+// 32-bit offsets and leave bigger tensors to the generic implicit GEMM (RARM at 512 sequences per GPU: the seven 128-channel convs of
+// the 256 x 256 level on an 8.6 GB activation ran there at 0.30 of peak, 94 of the step's 933 ms).  RDM_VQ_RANGE overrides.
+static int vq_range(const VqModel& v, int b) {
+    static const int env = getenv("RDM_VQ_RANGE") ? atoi(getenv("RDM_VQ_RANGE")) : 0;
+    if (env > 0) return env < b ? env : b;
+    const rdm_vq_cfg& c = v.cfg;
+    long long per = 1;
+    for (int l = 0; l < c.n_ch_mult; l++) {
+        const long long r = c.resolution >> l, e = r * r * c.ch * c.ch_mult[l];
+        if (e > per) per = e;
+    }
+    long long n = (1LL << 30) / per;
+    if (n < 1) n = 1;
+    return n < b ? (int)n : b;
+}
+
 int rdm_vq_decode(rdm_ctx* c, const float* z, int b, int force_not_quantize, float* img_out, int32_t* indices_out) {
     RDM_ENTER(c);
     if (!c || !z || !img_out) return c ? c->fail(-1, "null argument") : -1;
     if (!c->vq.loaded) return c->fail(-1, "vq weights not loaded");
     if (c->vq.wide) return c->fail(-1, "this first stage has a wide latent (VQGAN-f16): decode from code indices with rdm_vq_decode_indices");
-    RDM_TRY(ensure_gn_partial(c, b));
-    return run_with_arena(c, c->vq.arena, c->vq.blob, [&](Ops& o) { vq_body(o, c->vq, z, b, force_not_quantize, img_out, indices_out); });
+    const rdm_vq_cfg& q = c->vq.cfg;
+    const int nb = vq_range(c->vq, b), zr = q.resolution >> (q.n_ch_mult - 1);
+    RDM_TRY(ensure_gn_partial(c, nb));
+    for (int b0 = 0; b0 < b; b0 += nb) {
+        const int n = b - b0 < nb ? b - b0 : nb;
+        RDM_TRY(run_with_arena(c, c->vq.arena, c->vq.blob, [&](Ops& o) {
+            vq_body(o, c->vq, z + (size_t)b0 * q.z_channels * zr * zr, n, force_not_quantize, img_out + (size_t)b0 * q.out_ch * q.resolution * q.resolution,
+                    indices_out ? indices_out + (size_t)b0 * zr * zr : nullptr);
+        }));
+    }
+    return 0;
 }
 int rdm_vq_quantize(rdm_ctx* c, const float* z, int b, float* zq_out, int32_t* indices_out) {
     RDM_ENTER(c);
@@ -1790,8 +1817,16 @@ int rdm_vq_decode_indices(rdm_ctx* c, const int64_t* indices, int b, float* img_
     if (!indices || !img_out || b < 1) return c->fail(-1, "bad argument");
     if (!c->vq.loaded) return c->fail(-1, "vq weights not loaded");
     if (!c->vq.wide || c->vq.cfg.kl) return c->fail(-1, "rdm_vq_decode_indices needs a VQGAN first stage with a wide latent (z_channels %% 64 == 0)");
-    RDM_TRY(ensure_gn_partial(c, b));
-    return run_with_arena(c, c->vq.arena, c->vq.blob, [&](Ops& o) { vq_wide_body(o, c->vq, (const long long*)indices, b, img_out); });
+    const rdm_vq_cfg& q = c->vq.cfg;
+    const int nb = vq_range(c->vq, b), zr = q.resolution >> (q.n_ch_mult - 1);
+    RDM_TRY(ensure_gn_partial(c, nb));
+    for (int b0 = 0; b0 < b; b0 += nb) {
+        const int n = b - b0 < nb ? b - b0 : nb;
+        RDM_TRY(run_with_arena(c, c->vq.arena, c->vq.blob, [&](Ops& o) {
+            vq_wide_body(o, c->vq, (const long long*)indices + (size_t)b0 * zr * zr, n, img_out + (size_t)b0 * q.out_ch * q.resolution * q.resolution);
+        }));
+    }
+    return 0;
 }
 
 int rdm_to_uint8(rdm_ctx* c, const float* img, int b, int ch, int h, int w, uint8_t* out) {

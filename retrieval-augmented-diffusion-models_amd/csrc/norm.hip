@@ -36,7 +36,7 @@ __global__ void gn_stats_kernel(GnParams p) {
     const int C = p.C0 + p.C1, VC = C >> 3;
     const int R = blockDim.x / VC;
     const int v = threadIdx.x % VC, rr = threadIdx.x / VC;
-    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int b = blockIdx.y + p.b0, chunk = blockIdx.x;
     const int rows_per = (p.HW + p.nchunk - 1) / p.nchunk;
     const int r0 = chunk * rows_per, r1 = min(p.HW, r0 + rows_per);
     float s[8], q[8];
@@ -91,7 +91,7 @@ __global__ void gn_apply_kernel(GnParams p) {
     const int C = p.C0 + p.C1, VC = C >> 3, cg = (p.L0 + p.L1) / p.groups;
     const int R = blockDim.x / VC;
     const int v = threadIdx.x % VC, rr = threadIdx.x / VC;
-    const int b = blockIdx.y;
+    const int b = blockIdx.y + p.b0;
     __shared__ float gstat[64][2];
     if (threadIdx.x < p.groups) {
         double a = 0.0, q = 0.0;
@@ -332,15 +332,27 @@ hipError_t launch_groupnorm(GnParams p, hipStream_t st) {
         int gpb, T, nv;
         if (p.out && gn_onepass_plan(p, gpb, T, nv)) return launch_gn_onepass(p, gpb, T, nv, st);
     }
-    e = launch_gn_stats(p, st);
-    if (e != hipSuccess) return e;
-    // apply: ~64 rows per thread-row, at least ~2k blocks across the batch
-    int nblk = (p.HW + 64 * R - 1) / (64 * R);
-    const int min_blocks = (2048 + p.B - 1) / p.B;
-    if (nblk < min_blocks) nblk = min_blocks;
-    if (nblk > p.HW) nblk = p.HW;
-    if (nblk < 1) nblk = 1;
-    gn_apply_kernel<<<dim3(nblk, p.B), threads, 0, st>>>(p);
+    // RDM_GN_RANGE_MB = n (default 0 = off): walk a tensor larger than 2n MB in sample ranges of n MB, statistics then apply per range, so
+    // that the apply pass could re-read from the 256 MB memory-side cache what the statistics pass of the SAME range pulled in (64 x 64
+    // level at B' = 128: 200 .. 600 MB per GroupNorm).  Measured round 5 (profiles/r05e_gn_sample_ranges_ab.log): 24 / 48 / 96 MB ranges
+    // = -7.6 % / -2.9 % / -1.0 % on the headline -- the under-filled launches and their tails cost more than any reuse returns.  Off.
+    static const long long range_mb = getenv("RDM_GN_RANGE_MB") ? atoll(getenv("RDM_GN_RANGE_MB")) : 0;
+    const long long per_sample = (long long)p.HW * (p.C0 + p.C1) * 2;
+    int nb = p.B;
+    if (range_mb > 0 && per_sample * p.B > 2 * range_mb * (1 << 20)) { nb = (int)(range_mb * (1 << 20) / per_sample); if (nb < 1) nb = 1; }
+    const size_t sm1 = (size_t)(R + 1) * (p.C0 + p.C1) * 2 * sizeof(float);
+    for (int b0 = 0; b0 < p.B; b0 += nb) {
+        GnParams q = p; q.b0 = p.b0 + b0;
+        const int n = p.B - b0 < nb ? p.B - b0 : nb;
+        gn_stats_kernel<<<dim3(q.nchunk, n), threads, sm1, st>>>(q);
+        // apply: ~64 rows per thread-row, at least ~2k blocks across the range
+        int nblk = (p.HW + 64 * R - 1) / (64 * R);
+        const int min_blocks = (2048 + n - 1) / n;
+        if (nblk < min_blocks) nblk = min_blocks;
+        if (nblk > p.HW) nblk = p.HW;
+        if (nblk < 1) nblk = 1;
+        gn_apply_kernel<<<dim3(nblk, n), threads, 0, st>>>(q);
+    }
     return hipGetLastError();
 }
 

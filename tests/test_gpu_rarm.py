@@ -286,6 +286,45 @@ def test_vqgan_decode_indices(ctx, which):
         ctx.vq_decode(torch.zeros(1, spec.z_channels, spec.z_res, spec.z_res))       # wide latents decode from indices only
 
 
+def test_vq_decode_walked_in_sample_ranges(ctx, tmp_path):
+    """A batch bigger than the decoder's range (model.hip vq_range: the largest activation below 2^30 elements, so that the halo convs'
+    32-bit operand offsets hold) is decoded range by range.  Forced here with RDM_VQ_RANGE=2 in a child process on 5 images of the tiny
+    VQGAN (ranges of 2, 2, 1) and on 3 latents of the tiny VQ-f4 decoder: every image must match the one-range decode of this process to 1e-6
+    (decoding is per sample; the tiny shapes take the same kernels at B = 1, 2 and 5, so equal bits are expected and reported)."""
+    import os
+    import subprocess
+    import sys
+    from rdm_amd import _lib, packing
+    spec = ovq.tiny_vqgan_spec()
+    sd = ounet.synth_state_dict(ovq.vq_param_shapes(spec), seed=888)
+    cfg = _lib.make_vq_cfg(embed_dim=spec.embed_dim, n_embed=spec.n_embed, z_channels=spec.z_channels, ch=spec.ch, ch_mult=spec.ch_mult,
+                           num_res_blocks=spec.num_res_blocks, resolution=spec.resolution, attn_resolutions=spec.attn_resolutions)
+    ctx.load_vq(cfg, packing.pack("vq", cfg, sd))
+    idx = torch.from_numpy(np.random.default_rng(3).integers(0, spec.n_embed, (5, spec.z_res ** 2)).astype(np.int64))
+    whole = ctx.vq_decode_indices(idx).cpu()
+    out = tmp_path / "ranges.npz"
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {os.path.dirname(here)!r}); sys.path.insert(0, {here!r})\n"
+        "import rdm_amd\nfrom rdm_amd import _lib, packing\nfrom oracle import vqdecoder as ovq, unet as ounet\n"
+        "torch.set_grad_enabled(False)\nctx = _lib.Context(0)\nspec = ovq.tiny_vqgan_spec()\n"
+        "sd = ounet.synth_state_dict(ovq.vq_param_shapes(spec), seed=888)\n"
+        "cfg = _lib.make_vq_cfg(embed_dim=spec.embed_dim, n_embed=spec.n_embed, z_channels=spec.z_channels, ch=spec.ch, ch_mult=spec.ch_mult,\n"
+        "                       num_res_blocks=spec.num_res_blocks, resolution=spec.resolution, attn_resolutions=spec.attn_resolutions)\n"
+        "ctx.load_vq(cfg, packing.pack('vq', cfg, sd))\n"
+        "idx = torch.from_numpy(np.random.default_rng(3).integers(0, spec.n_embed, (5, spec.z_res ** 2)).astype(np.int64))\n"
+        "img = ctx.vq_decode_indices(idx).cpu().numpy()\n"
+        f"np.savez({str(out)!r}, img=img)\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RDM_VQ_RANGE="2"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = torch.from_numpy(np.load(out)["img"])
+    assert got.shape == whole.shape
+    e = rel_l2(got, whole)
+    print(f"VQGAN decode in ranges of 2 vs one range of 5: rel L2 {e:.3e}, bitwise equal: {bool(torch.equal(got, whole))}")
+    assert e <= 1e-6
+
+
 def test_latent_image_retro_surface(ctx):
     """LatentImageRETRO.sample_from_rdata (transformer.py:314-404) through the mirror: pseudo-queries from nn_memory, exact
     retrieval, 64 sampled tokens (8x8 code grid of the tiny first stage), decode; seeded runs repeat."""
