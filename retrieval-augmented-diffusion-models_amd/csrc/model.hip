@@ -667,7 +667,10 @@ struct Ops {
         static const int off = getenv("RDM_NO_LNFUSE") ? atoi(getenv("RDM_NO_LNFUSE")) : 0;
         static const int ln_max_rows = getenv("RDM_SGEMM_LN_MAX_ROWS") ? atoi(getenv("RDM_SGEMM_LN_MAX_ROWS")) : 192;
         // (from ~200 rows on a separate LayerNorm pass + the 64 x 64-tile GEMM beats the LayerNorm-fused 32-row tiles: sgemm.hip)
-        if (!c->deterministic && M > ln_max_rows) return false;
+        // (RDM_SGEMM_LN8_FROM=m: the eight-wave 64-row tiles take the LayerNorm themselves from m rows on -- measured slower, off: sgemm.hip)
+        static const int ln8_from = getenv("RDM_SGEMM_LN8_FROM") ? atoi(getenv("RDM_SGEMM_LN8_FROM")) : 0;
+        const bool ln8 = ln8_from > 0 && M >= ln8_from && act != ACT_GEGLU && C == 768;
+        if (!c->deterministic && M > ln_max_rows && !ln8) return false;
         const bool skinny = c->deterministic ? single_row : (M <= 128 || (single_row && M <= 1024));
         SgemmParams q{}; q.ln_x = x; q.ln_g = w<float>(g); q.ln_b = w<float>(b); q.ln_eps = 1e-5f; q.W = w<bf16_t>(woff); q.M = M; q.N = N; q.K = C;
         q.bias = has_bias ? w<float>(boff) : nullptr; q.act = act; q.out_bf16 = out; q.ldo = act == ACT_GEGLU ? N / 2 : N;

@@ -27,7 +27,6 @@
 // instead of two -- and half as many at K = 3072)
 template <int MA, int NB, bool GEGLU, int U, bool LN = false, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void sgemm_kernel(SgemmParams p) {
-    static_assert(!LN || NW == 4, "the LayerNorm-fused variant is written for four waves");
     // 16x16x32 MFMAs, not 32x32x16: the operands come straight from global memory in fragment order, and what such a launch pays
     // for is the number of cache LINES its load instructions touch (phase clocks at M = 64, K = 768: 9.1 of the launch's ~12 us are
     // the load phase).  A 32x32x16 fragment is 32 rows x 32 bytes per instruction -- 32 lines for 1 KB --, a 16x16x32 fragment is
@@ -80,9 +79,9 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(SgemmParams p) {
         res_[it] = r;
     }
     if constexpr (LN) {
-        float* const lnv = part + 4 * RB * CB;                  // [gamma K][beta K][4 waves][RB rows][sum, sumsq]
+        float* const lnv = part + NW * RB * CB;                 // [gamma K][beta K][NW waves][RB rows][sum, sumsq]
         float* const stat = lnv + 2 * p.K;
-        for (int k = tid * 4; k < p.K; k += 1024) {
+        for (int k = tid * 4; k < p.K; k += 256 * NW) {
             *(float4*)(lnv + k) = *(const float4*)(p.ln_g + k);
             *(float4*)(lnv + p.K + k) = *(const float4*)(p.ln_b + k);
         }
@@ -100,7 +99,7 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(SgemmParams p) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // row statistics: this lane's 8 U elements -> the 4 lanes of a row (q4) -> the 4 waves (K quarters) through LDS
+        // row statistics: this lane's 8 U elements -> the 4 lanes of a row (q4) -> the NW waves (K shares) through LDS
 #pragma unroll
         for (int i = 0; i < MA; i++) {
             float sm = 0.f, sq = 0.f;
@@ -120,7 +119,7 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(SgemmParams p) {
         for (int i = 0; i < MA; i++) {
             float sm = 0.f, sq = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; w++) { sm += stat[((w * MA + i) * 16 + r16) * 2]; sq += stat[((w * MA + i) * 16 + r16) * 2 + 1]; }
+            for (int w = 0; w < NW; w++) { sm += stat[((w * MA + i) * 16 + r16) * 2]; sq += stat[((w * MA + i) * 16 + r16) * 2 + 1]; }
             const float mean = sm * invk;
             const float var = fmaxf(sq * invk - mean * mean, 0.f);
             const float rstd = rsqrtf(var + p.ln_eps);
@@ -226,7 +225,7 @@ bool sgemm_supported(const SgemmParams& p) {
 template <int MA, int NB, bool GEGLU, int U, bool LN = false, int NW = 4>
 static hipError_t launch_one(const SgemmParams& p, hipStream_t st) {
     constexpr int RB = 16 * MA, CB = 16 * NB;
-    const size_t sm = (size_t)NW * RB * CB * sizeof(float) + (LN ? (size_t)(2 * p.K + 4 * RB * 2) * sizeof(float) : 0);
+    const size_t sm = (size_t)NW * RB * CB * sizeof(float) + (LN ? (size_t)(2 * p.K + NW * RB * 2) * sizeof(float) : 0);
     static bool attr_dev[RDM_MAX_DEVICES] = {false};
     bool& attr = attr_dev[rdm_cur_device()];
     if (!attr && sm > 48 * 1024) {
@@ -266,6 +265,17 @@ static hipError_t launch_nf(const SgemmParams& p, hipStream_t st) {
     constexpr int N1 = GEGLU ? 2 : 1, N2 = GEGLU ? 4 : 2, N3 = GEGLU ? 8 : 4;
     int ma, nb;
     if (p.ln_x) {
+        // RDM_SGEMM_LN8_FROM = m (default 0 = off): from m rows on, plain projections take the LayerNorm inside the 64-row tiles on eight
+        // waves (a wave's K / 8 = 96 fp32 columns of 64 rows in registers) -- the separate LayerNorm launch is 5.4 us of a decode layer's
+        // 150 at 512 sequences, three times per layer.  Measured round 5 (profiles/r05e_rarm_ln8_sweep.log): 512 sequences 564 -> 524
+        // img/s, 256 sequences 419 -> 395: every column tile re-reads its 64 rows as fp32 (196 KB instead of 98 KB per block, 64 x 32
+        // outputs only: 64 x 64 is 41 registers over an eight-wave block's budget) and repeats the statistics; the two launches saved
+        // (10.8 us per layer) come back as + 26 us of GEMM.  Off.
+        static const int ln8_from = getenv("RDM_SGEMM_LN8_FROM") ? atoi(getenv("RDM_SGEMM_LN8_FROM")) : 0;
+        if constexpr (!GEGLU) {
+            if (ln8_from > 0 && p.M >= ln8_from && p.K == 768)
+                return launch_one<4, N2, false, 3, true, 8>(p, st);      // (64 x 64 outputs: 41 registers over the budget of an eight-wave block)
+        }
         pick_tile<GEGLU, true>(p, ma, nb);
         if (ma == 1) return nb == N1 ? launch_one<1, N1, GEGLU, 6, true>(p, st) : launch_one<1, N2, GEGLU, 6, true>(p, st);
         return nb == N1 ? launch_one<2, N1, GEGLU, 6, true>(p, st) : launch_one<2, N2, GEGLU, 6, true>(p, st);
