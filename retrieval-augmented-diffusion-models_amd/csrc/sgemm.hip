@@ -65,13 +65,14 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(SgemmParams p) {
     // long.  A thread reads and writes the same elements (the decode step accumulates in place: out == residual), and nothing else in
     // the launch writes them, so the early read sees what the late one saw.
     constexpr int NT = 64 * NW, NOUT = RB * OC, IT = (NOUT + NT - 1) / NT;
+    constexpr bool RES_EARLY = NB < 6;                   // (the 64 x 96 tile has no registers to park them in: read in the epilogue there)
     float res_[IT];
 #pragma unroll
     for (int it = 0; it < IT; it++) {
         const int e = tid + it * NT;
         const int row = e / OC, col = e - row * OC, m = mb0 + row;
         float r = 0.f;
-        if (e < NOUT && m < p.M) {
+        if (RES_EARLY && e < NOUT && m < p.M) {
             const long long oi = (long long)m * p.ldo + ncol0 + col;
             if (p.res_f32) r += p.res_f32[oi];
             if (p.res_bf16) r += bf2f(p.res_bf16[oi]);
@@ -162,13 +163,41 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(SgemmParams p) {
     }
     }
     // partial tiles -> LDS (D layout 16x16: column = lane & 15, rows (lane >> 4) * 4 + r)
+    // FOLD (eight waves, tiles whose eight partial copies would not fit the LDS): waves 4..7 park their tiles, waves 0..3 add them to their
+    // own registers, and four copies meet in the epilogue
+    constexpr bool FOLD = NW == 8 && (size_t)NW * RB * CB * 4 > 128 * 1024;
+    constexpr int NWP = FOLD ? 4 : NW;                     // partial copies the epilogue sums
+    if constexpr (FOLD) {
+        if (wave >= 4) {
 #pragma unroll
-    for (int i = 0; i < MA; i++)
+            for (int i = 0; i < MA; i++)
 #pragma unroll
-        for (int j = 0; j < NB; j++)
+                for (int j = 0; j < NB; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                part[(wave * RB + i * 16 + q4 * 4 + r) * CB + j * 16 + r16] = acc[i][j][r];
+                    for (int r = 0; r < 4; r++)
+                        part[((wave - 4) * RB + i * 16 + q4 * 4 + r) * CB + j * 16 + r16] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int i = 0; i < MA; i++)
+#pragma unroll
+                for (int j = 0; j < NB; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        acc[i][j][r] += part[(wave * RB + i * 16 + q4 * 4 + r) * CB + j * 16 + r16];
+        }
+        __syncthreads();
+    }
+    if (!FOLD || wave < 4) {
+#pragma unroll
+        for (int i = 0; i < MA; i++)
+#pragma unroll
+            for (int j = 0; j < NB; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    part[(wave * RB + i * 16 + q4 * 4 + r) * CB + j * 16 + r16] = acc[i][j][r];
+    }
     __syncthreads();
     // Results are formed for ALL of this thread's outputs, THEN stored (the residual came in at the top of the kernel; bias values are
     // L1 / L2 hits).  The decode step accumulates in place (out == residual: x += ...): with loads and stores interleaved in one loop no
@@ -193,7 +222,7 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(SgemmParams p) {
             const int cc = !GEGLU ? col : (NB == 2 ? col + j * 16 : (col >> 5) * 64 + (col & 31) + j * 32);
             float s = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; w++) s += part[(w * RB + row) * CB + cc];
+            for (int w = 0; w < NWP; w++) s += part[(w * RB + row) * CB + cc];
             // weight row behind tile column cc (= wrow[cc >> 4] + (cc & 15), spelled without a run-time array index)
             int wr;
             if constexpr (GEGLU && NB == 2) wr = wrow[0] + (cc < 16 ? cc : cc + 16);
@@ -204,7 +233,12 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(SgemmParams p) {
         if (GEGLU) o = v[0] * gelu_erf_f(v[GEGLU ? 1 : 0]);
         else if (p.act == ACT_SILU) o = silu_f(o);
         else if (p.act == ACT_QUICKGELU) o = quickgelu_f(o);
-        acc_[it] = o + res_[it];
+        if constexpr (RES_EARLY) acc_[it] = o + res_[it];
+        else {
+            float r = 0.f;
+            if (ok_[it]) { if (p.res_f32) r += p.res_f32[oi_[it]]; if (p.res_bf16) r += bf2f(p.res_bf16[oi_[it]]); }
+            acc_[it] = o + r;
+        }
     }
 #pragma unroll
     for (int it = 0; it < IT; it++) {
@@ -225,7 +259,8 @@ bool sgemm_supported(const SgemmParams& p) {
 template <int MA, int NB, bool GEGLU, int U, bool LN = false, int NW = 4>
 static hipError_t launch_one(const SgemmParams& p, hipStream_t st) {
     constexpr int RB = 16 * MA, CB = 16 * NB;
-    const size_t sm = (size_t)NW * RB * CB * sizeof(float) + (LN ? (size_t)(2 * p.K + NW * RB * 2) * sizeof(float) : 0);
+    const bool fold = NW == 8 && (size_t)NW * RB * CB * 4 > 128 * 1024;
+    const size_t sm = (size_t)(fold ? 4 : NW) * RB * CB * sizeof(float) + (LN ? (size_t)(2 * p.K + NW * RB * 2) * sizeof(float) : 0);
     static bool attr_dev[RDM_MAX_DEVICES] = {false};
     bool& attr = attr_dev[rdm_cur_device()];
     if (!attr && sm > 48 * 1024) {
@@ -280,6 +315,16 @@ static hipError_t launch_nf(const SgemmParams& p, hipStream_t st) {
         if (ma == 1) return nb == N1 ? launch_one<1, N1, GEGLU, 6, true>(p, st) : launch_one<1, N2, GEGLU, 6, true>(p, st);
         return nb == N1 ? launch_one<2, N1, GEGLU, 6, true>(p, st) : launch_one<2, N2, GEGLU, 6, true>(p, st);
     }
+    if constexpr (!GEGLU) {
+        // 64 x 96 outputs for wide projections at 384+ rows (q | k | v, N = 2304, at 512 rows: 8 x 24 = 192 blocks in ONE round of the 256 CUs;
+        // as 64 x 64 tiles it is 288 blocks of 128 KB LDS each, one per CU: two rounds).  RDM_SGEMM_N96=0: off
+        static const int n96 = getenv("RDM_SGEMM_N96") ? atoi(getenv("RDM_SGEMM_N96")) : 1;
+        static const int nw8_off2 = getenv("RDM_SGEMM_NW4") ? atoi(getenv("RDM_SGEMM_NW4")) : 0;
+        if (n96 && !nw8_off2 && p.M >= 384 && p.N % 96 == 0 && p.N >= 1536 && p.K == 768) {
+            const long long b64 = (long long)((p.M + 63) / 64) * (p.N / 64), b96 = (long long)((p.M + 63) / 64) * (p.N / 96);
+            if ((b64 + 255) / 256 > (b96 + 255) / 256) return launch_one<4, 6, false, 3, false, 8>(p, st);
+        }
+    }
     pick_tile<GEGLU, false>(p, ma, nb);
     if (nb == N3) {       // 64 x 64 outputs: two (GEGLU) / three k-steps per batch of loads keep the operand registers under the budget
         if constexpr (GEGLU) return launch_one<4, N3, true, 2>(p, st);
@@ -301,7 +346,12 @@ static hipError_t launch_nf(const SgemmParams& p, hipStream_t st) {
         case 2: return deep ? launch_one<2, N2, GEGLU, 6>(p, st) : launch_one<2, N2, GEGLU, 2>(p, st);
         default: {
             static const int nw8_off = getenv("RDM_SGEMM_NW4") ? atoi(getenv("RDM_SGEMM_NW4")) : 0;
-            if constexpr (!GEGLU) { if (!nw8_off && p.M >= 384 && (p.K >> 3) % 96 == 0) return launch_one<4, N2, false, 3, false, 8>(p, st); }      // (same box: 512 rows 511.6 -> 519.5 img/s, 256 rows 407.8 -> 404.3: from 384 rows on)
+            if constexpr (!GEGLU) {
+                // deep K (3072: a wave's share is 12 k-steps): six per batch of loads = two dependent round trips instead of four (RDM_SGEMM_U6=0: three)
+                static const int u6 = getenv("RDM_SGEMM_U6") ? atoi(getenv("RDM_SGEMM_U6")) : 1;
+                if (!nw8_off && u6 && p.M >= 384 && (p.K >> 3) % 192 == 0) return launch_one<4, N2, false, 6, false, 8>(p, st);
+                if (!nw8_off && p.M >= 384 && (p.K >> 3) % 96 == 0) return launch_one<4, N2, false, 3, false, 8>(p, st);
+            }      // (same box: 512 rows 511.6 -> 519.5 img/s, 256 rows 407.8 -> 404.3: from 384 rows on)
             return deep ? launch_one<4, N2, GEGLU, 6>(p, st) : launch_one<4, N2, GEGLU, 2>(p, st);
         }
     }
