@@ -59,11 +59,12 @@ def test_rarm_forward_shipped_golden(ctx):
     assert e <= 2.5e-2
 
 
-@pytest.mark.parametrize("nseq", [256, 512])
+@pytest.mark.parametrize("nseq", [256, 512, 1024])
 def test_rarm_forward_shipped_golden_big_batches(ctx, nseq):
-    """The decode geometries of the big batches (round 5: bench.py --config 5 defaults to 512 sequences per GPU): 256 sequences take the 64 x 64
-    skinny-GEMM tiles behind a separate LayerNorm, the tiled GEGLU projection and the fused one-block cross-attention; 512 sequences the
-    eight-wave GEMM tiles and the GEMM-form cross-attention (norm2 + to_q GEMM, the few-key attention kernel, to_out GEMM).  The golden's two
+    """The decode geometries of the big batches (round 5: bench.py --config 5 defaults to 1024 sequences per GPU): 256 sequences take the 64 x 64
+    skinny-GEMM tiles behind a separate LayerNorm, the tiled GEGLU projection and the fused one-block cross-attention; 512 and 1024 sequences the
+    eight-wave GEMM tiles (64 x 96 for q | k | v, six k-steps per load batch at K = 3072) and the GEMM-form cross-attention (norm2 + to_q GEMM,
+    the few-key attention kernel, to_out GEMM).  The golden's two
     sequences (8-token prefix, reference logits of the last two positions) sit at rows 0 and nseq - 1 of the batch, random sequences between."""
     g = golden("rarm_shipped.npz")
     spec = orarm.shipped_rarm_spec()
