@@ -123,6 +123,8 @@ def attach_library_comm(ctx, group=None) -> bool:
     the torch.distributed collective stays in use (and the caller can report which one ran)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1 or dist.get_backend(group) != "nccl":
         return False
+    if os.environ.get("RDM_NO_LIB_COMM", "0") not in ("", "0"):          # torch.distributed's collective only
+        return False
     if getattr(ctx, "comm_world", 0) == dist.get_world_size(group):
         return True
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -139,6 +141,14 @@ def attach_library_comm(ctx, group=None) -> bool:
         return False
     try:
         ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        # one known-answer gather before anything depends on it (this path cannot be exercised on the one-GPU build boxes): rank r
+        # contributes [r, r + 0.5, r, r + 0.5]; any other result -> the torch.distributed collective stays in use
+        probe = torch.tensor([rank, rank + 0.5, rank, rank + 0.5], dtype=torch.float32, device=ctx.device)
+        got = ctx.comm_all_gather(probe, world)
+        torch.cuda.synchronize(ctx.device)
+        want = torch.arange(world, dtype=torch.float32, device=ctx.device)[:, None] + torch.tensor([0.0, 0.5, 0.0, 0.5], device=ctx.device)
+        if got.shape != want.shape or not torch.equal(got, want):
+            ok.zero_()
     except Exception:
         ok.zero_()
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)          # all ranks agree on which collective they will call

@@ -762,8 +762,8 @@ def _det_rank_worker(rank, world, port, q):
 @pytest.mark.parametrize("world", [2])
 def test_deterministic_mode_sharded_equals_single_rank_bitwise(world):
     """The sharded run of test_ranks_sharing_one_gpu_match_single_rank in deterministic mode (RDM_DETERMINISTIC=1 in every process):
-    images AND latents of the rank-gathered batch are bitwise those of the single-rank run.  (Four ranks -- the ragged split -- in
-    deterministic mode: tests/test_gpu_bench.py on the shipped model, bit-identical too; four processes time-slicing one GPU cost
+    images AND latents of the rank-gathered batch are bitwise those of the single-rank run.  (Four ranks in
+    deterministic mode: tests/test_gpu_bench.py on the shipped model, bit-identical too; the ragged four-way split: the test above; four processes time-slicing one GPU cost
     over a minute per test, the suite has a 20-minute budget.)"""
     import os
     import torch.multiprocessing as mp
