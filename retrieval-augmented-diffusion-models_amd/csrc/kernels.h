@@ -86,6 +86,7 @@ struct RarmAttnParams {
     const bf16_t* k_new; const bf16_t* v_new; // self-attention: the new token's rows (appended to the cache at *pos); null for cross-attention
     bf16_t* Kc; bf16_t* Vc;                   // cache [B][rows][row_stride]
     long long batch_stride; int row_stride;
+    long long head_stride;                    // elements between the heads of a cache row set: 0 / 64 = heads side by side inside a row (row_stride = C); rows * 64 = head-major [B][head][rows][64] (row_stride = 64)
     int nkv;                                  // cross-attention: rows to attend; self-attention: capacity (<= 1024)
     const int* pos;                           // device step counter (self-attention attends rows 0..*pos)
     float scale; bf16_t* out; int ldo;

@@ -1949,6 +1949,10 @@ static int rarm_step(rdm_ctx* c, int B2, int k, int pos_hint = -1 /* host's copy
                 RarmAttnParams p{}; p.q = qkv; p.ldq = 3 * C; p.k_new = qkv + C; p.v_new = qkv + 2 * C;
                 p.Kc = (bf16_t*)m.cache + ((size_t)l * 2) * B2 * L * C; p.Vc = (bf16_t*)m.cache + ((size_t)l * 2 + 1) * B2 * L * C;
                 p.batch_stride = (long long)L * C; p.row_stride = C; p.nkv = L; p.pos = st.pos; p.scale = scale; p.out = ao; p.ldo = C;
+                // Head-major cache [B][head][L][64] (round 5): a (head, sequence) block reads ONE contiguous run of (pos + 1) x 128 bytes
+                // instead of 128-byte pieces 2 C bytes apart.  The cache is private to this kernel (it appends the new row itself).
+                static const int rowmajor = getenv("RDM_RARM_CACHE_ROWMAJOR") ? atoi(getenv("RDM_RARM_CACHE_ROWMAJOR")) : 0;
+                if (!rowmajor) { p.row_stride = g.d_head; p.head_stride = (long long)L * g.d_head; }
                 // bytes of the K / V cache rows this step reads (positions 0 .. pos): what bounds the launch at big batches
                 o.tag = "rarm.cache_attention";
                 o.prof_begin(RDM_PROF_ATTENTION, pos_hint >= 0 ? (double)B2 * (pos_hint + 1) * C * 4.0 : 0.0, B2, pos_hint + 1, C);

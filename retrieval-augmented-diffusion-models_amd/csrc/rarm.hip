@@ -34,21 +34,27 @@ hipError_t launch_rarm_embed(const long long* tokens, const float* emb, const fl
 // neighbours and all nkv rows are attended.  Phase 1: scores of the wave's chunks into LDS; block-wide maximum and sum; phase 2: the
 // wave's chunks of sum_j p_j V[j][:], the four partial rows meet in LDS and are added in wave order.  CrossAttention.forward,
 // attention.py:42-74.
-__global__ __launch_bounds__(256) void rarm_decode_attention_kernel(RarmAttnParams p) {
+// NW: waves per block = 32-row chunks in flight at once.  Eight waves (all 256 cached rows of a (head, sequence) requested in ONE round
+// trip; RDM_RARM_ATTN_NW8_FROM=<sequences>) measured SLOWER, round 5: 419 / 578 / 683 -> 406 / 552 / 644 img/s at 256 / 512 / 1024 sequences
+// (profiles/r05e_rarm_attn_8wave_sweep.log) -- averaged over the 256 positions the launch is a fixed ~6.5 us + the cache bytes at ~5.5 TB/s
+// already; the bigger blocks raise the fixed part (idle waves at short prefixes, wider barriers).  Four waves stay the default.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void rarm_decode_attention_kernel(RarmAttnParams p) {
     // Eight lanes per cache row (16 bytes each), eight rows per load instruction: an instruction touches 8 cache lines.  (One lane
     // per key row -- 64 rows, 64 lines per instruction -- in the score phase and one 128-byte row per instruction in the value
     // phase made this launch 11.5 us of mostly address traffic.)
     constexpr int D = 64;
     __shared__ float sc[1024];
-    __shared__ float red[8];
-    __shared__ float part[4][D];
+    __shared__ float red[2 * NW];
+    __shared__ float part[NW][D];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int jr = lane >> 3, c8 = (lane & 7) * 8;
     const int t = p.pos ? *p.pos : 0;
     const int n = p.k_new ? t + 1 : p.nkv;
     const int nc = p.k_new ? t : n;                     // rows read from the cache by the value phase
-    bf16_t* Kc = p.Kc + (long long)b * p.batch_stride + h * D;
-    bf16_t* Vc = p.Vc + (long long)b * p.batch_stride + h * D;
+    const long long hs = p.head_stride > 0 ? p.head_stride : D;
+    bf16_t* Kc = p.Kc + (long long)b * p.batch_stride + h * hs;
+    bf16_t* Vc = p.Vc + (long long)b * p.batch_stride + h * hs;
     const bf16_t* knew = p.k_new ? p.k_new + (long long)b * p.ldq + h * D : nullptr;
     const bf16_t* vnew = p.k_new ? p.v_new + (long long)b * p.ldq + h * D : nullptr;
     float qv[8];
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256) void rarm_decode_attention_kernel(RarmAttnPara
     }
     // ---- scores: rows j0 + 8 u + jr of chunks w, w + 4, ...
     float m = -INFINITY;
-    for (int j0 = w * 32; j0 < n; j0 += 128) {
+    for (int j0 = w * 32; j0 < n; j0 += 32 * NW) {
         if (j0 != w * 32) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -95,17 +101,20 @@ __global__ __launch_bounds__(256) void rarm_decode_attention_kernel(RarmAttnPara
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if (lane == 0) red[w] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    m = red[0];
+#pragma unroll
+    for (int u = 1; u < NW; u++) m = fmaxf(m, red[u]);
     float l = 0.f;
-    for (int j = tid; j < n; j += 256) { const float e = __expf(sc[j] - m); sc[j] = e; l += e; }
+    for (int j = tid; j < n; j += 64 * NW) { const float e = __expf(sc[j] - m); sc[j] = e; l += e; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
-    if (lane == 0) red[4 + w] = l;
+    if (lane == 0) red[NW + w] = l;
     __syncthreads();
-    l = (red[4] + red[5]) + (red[6] + red[7]);
+    l = (red[NW] + red[NW + 1]) + (red[NW + 2] + red[NW + 3]);
+    if constexpr (NW == 8) l += (red[NW + 4] + red[NW + 5]) + (red[NW + 6] + red[NW + 7]);
     // ---- values: the wave's chunks of the cached rows
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int j0 = w * 32; j0 < nc; j0 += 128) {
+    for (int j0 = w * 32; j0 < nc; j0 += 32 * NW) {
         if (j0 != w * 32) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -137,8 +146,13 @@ __global__ __launch_bounds__(256) void rarm_decode_attention_kernel(RarmAttnPara
     if (tid < D / 2) {                                    // fixed order over the waves: deterministic
         const int c = tid * 2;
         const float inv = 1.f / l;
-        const float o0 = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) * inv;
-        const float o1 = ((part[0][c + 1] + part[1][c + 1]) + (part[2][c + 1] + part[3][c + 1])) * inv;
+        float o0 = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+        float o1 = (part[0][c + 1] + part[1][c + 1]) + (part[2][c + 1] + part[3][c + 1]);
+        if constexpr (NW == 8) {
+            o0 += (part[4][c] + part[5][c]) + (part[6][c] + part[7][c]);
+            o1 += (part[4][c + 1] + part[5][c + 1]) + (part[6][c + 1] + part[7][c + 1]);
+        }
+        o0 *= inv; o1 *= inv;
         *(uint32_t*)(p.out + (long long)b * p.ldo + h * D + c) = pack2bf(o0, o1);
     }
 }
@@ -184,7 +198,9 @@ hipError_t launch_rarm_decode_attention(const RarmAttnParams& p, int heads, int 
         rarm_fewkey_attention_kernel<<<batch, 256, 0, st>>>(p, heads);
         return hipGetLastError();
     }
-    rarm_decode_attention_kernel<<<dim3(heads, batch), 256, 0, st>>>(p);
+    static const int nw8_from = getenv("RDM_RARM_ATTN_NW8_FROM") ? atoi(getenv("RDM_RARM_ATTN_NW8_FROM")) : 0;
+    if (p.k_new && nw8_from > 0 && batch >= nw8_from) rarm_decode_attention_kernel<8><<<dim3(heads, batch), 512, 0, st>>>(p);
+    else rarm_decode_attention_kernel<4><<<dim3(heads, batch), 256, 0, st>>>(p);
     return hipGetLastError();
 }
 
