@@ -13,10 +13,11 @@ A "step" is one pass of the whole hot path over one batch of synthetic inputs th
   --config 4: k=16 retrieval, 250 ancestral DDPM steps (ldm p_sample_loop(timesteps=250): no CFG on this path, as in the
       reference), B=64 per GPU (512 over 8 GPUs).
   --config 5: RARM (scripts/rarm_sample.py path): k=8 retrieval -> 256 autoregressive tokens (18-layer RetrievalPatchTransformer with a
-      K/V cache, top-k 256 multinomial, guidance scale 1.0 = the script's default) -> VQGAN-f16 decode, B=1024 sequences per GPU (BASELINE.json
-      does not fix this config's batch; one token step is ~110 dependent launches whatever the batch, so img/s per GPU grows 200 / 300 / 418 /
-      575 / 677 / 707 for 64 / 128 / 256 / 512 / 1024 / 2048 sequences (round 5) and levels off around 1024: the K/V-cache attention is then
-      HBM-bound and the first-stage decode, walked in 128-image ranges, costs the same per image at any batch).
+      K/V cache, top-k 256 multinomial, guidance scale 1.0 = the script's default) -> VQGAN-f16 decode, B=2048 sequences per GPU (BASELINE.json
+      does not fix this config's batch; one token step is ~110 dependent launches whatever the batch, so img/s per GPU grows 200 / 300 / 420 /
+      580 / 685 / 780 / 845 for 64 / 128 / 256 / 512 / 1024 / 2048 / 4096 sequences (round 5) and flattens from 2048 on (+ 8 % for the next
+      doubling, at 4.8 s per step): the K/V-cache attention is then HBM-bound and the first-stage decode, walked in 128-image ranges, costs the
+      same per image at any batch).
 Weights are seeded random tensors of the shipped architectures (no checkpoints are reachable), DB / queries / captions
 are synthetic.
 
@@ -51,7 +52,7 @@ def parse():
     p.add_argument("--steps", type=int, default=None, help="timed steps (default 3; 1 for --config 4)")
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5), help="BASELINE.json config number")
-    p.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 64; --config 5: 1024 sequences, where the decode step's img/s per GPU "
+    p.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 64; --config 5: 2048 sequences, where the decode step's img/s per GPU "
                                                             "levels off -- BASELINE.json does not fix config #5's batch)")
     p.add_argument("--ddim-steps", type=int, default=None, help="sampler steps (default 50; 250 for --config 4)")
     p.add_argument("--k", type=int, default=None, help="neighbours (default 4; 1 for --config 2; 16 for --config 4)")
@@ -67,7 +68,7 @@ def parse():
     p.add_argument("--dump-images", default=None, help="rank 0 writes the last timed step's gathered images to this .npy (parity tests of the N > 1 path)")
     a = p.parse_args()
     a.k = a.k if a.k is not None else {2: 1, 3: 4, 4: 16, 5: 8}[a.config]
-    a.batch = a.batch if a.batch is not None else (1024 if a.config == 5 else 64)
+    a.batch = a.batch if a.batch is not None else (2048 if a.config == 5 else 64)
     a.ddim_steps_given = a.ddim_steps is not None
     a.ddim_steps = a.ddim_steps if a.ddim_steps is not None else (250 if a.config == 4 else 50)
     a.steps = a.steps if a.steps is not None else (1 if a.config == 4 else 3)

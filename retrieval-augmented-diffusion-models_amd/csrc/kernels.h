@@ -125,6 +125,9 @@ struct SgemmParams {
 };
 bool sgemm_supported(const SgemmParams& p);
 hipError_t launch_sgemm(const SgemmParams& p, hipStream_t st);
+// mid-size GEMM (mgemm.hip): one-row-per-sequence operands at 1024+ rows, LDS-staged BM x 64 tiles, fp32 / bf16 residual and output
+bool mgemm_supported(const SgemmParams& p);
+hipError_t launch_mgemm(const SgemmParams& p, hipStream_t st);
 hipError_t launch_igemm(const IgemmParams& p, bool conv, int batch, hipStream_t st);
 bool conv_halo_supported(const IgemmParams& p);
 int conv_halo_ksplit(const IgemmParams& p);                // K-split factor worth using for this conv (1 = none); needs p.ws of ksplit*M*N floats

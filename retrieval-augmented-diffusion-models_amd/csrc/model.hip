@@ -626,7 +626,7 @@ struct Ops {
         // (one-row-per-sample operands of bigger batches -- RARM decode at 128+ sequences per GPU -- keep the skinny kernel: its row
         //  blocks scale with M, while the tiled kernels would run a dozen 256-row tiles)
         // RDM_SGEMM_MAX_ROWS / RDM_SGEMM_GEGLU_MAX_ROWS (dev): one-row-per-sample operands beyond these row counts take the tiled kernels
-        static const int sg_max = getenv("RDM_SGEMM_MAX_ROWS") ? atoi(getenv("RDM_SGEMM_MAX_ROWS")) : 1024;
+        static const int sg_max = getenv("RDM_SGEMM_MAX_ROWS") ? atoi(getenv("RDM_SGEMM_MAX_ROWS")) : 4096;      // (2048 sequences: 716 -> 780 img/s against the tiled kernels, round 5)
         // (round 5, same box: the GEGLU projection of the RARM decode step through the tiled kernel from ~200 rows on: 397.8 -> 409.5 img/s at 256
         //  sequences, 487.0 -> 514.8 at 512; the plain projections through it: 221 / 305 -- their N = 768 gives the tiled kernel 16-24 tiles)
         static const int sg_geglu_max = getenv("RDM_SGEMM_GEGLU_MAX_ROWS") ? atoi(getenv("RDM_SGEMM_GEGLU_MAX_ROWS")) : 192;
@@ -634,6 +634,15 @@ struct Ops {
         if (skinny && !A1 && C1 == 0 && !rowvec) {         // N/32 x ceil(M/32) blocks (sgemm.hip)
             SgemmParams q{}; q.A = A0; q.lda = C0; q.W = w<bf16_t>(woff); q.M = M; q.N = N; q.K = C0; q.bias = has_bias ? w<float>(boff) : nullptr;
             q.act = act; q.res_f32 = res_f32; q.res_bf16 = res; q.out_f32 = out_f32; q.out_bf16 = out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
+            // 1536+ rows: LDS-staged 64 x 64 tiles (mgemm.hip) -- the skinny kernel's per-wave operand fetch is 75 MB through the L2 -> CU
+            // fabric for a [2048 x 768] x [768 x 768] product (33.6 us; 15.5 there).  Not in deterministic mode (the kernel choice would follow the batch).
+            static const int mg_from = getenv("RDM_MGEMM_FROM") ? atoi(getenv("RDM_MGEMM_FROM")) : 1536;
+            if (!c->deterministic && single_row && mg_from > 0 && M >= mg_from && act != ACT_GEGLU && mgemm_supported(q)) {
+                prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)C0, M, N, C0);
+                check(launch_mgemm(q, c->stream), "mid-size linear");
+                prof_end();
+                return;
+            }
             if (sgemm_supported(q)) {
                 prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)C0, M, N, C0);
                 check(launch_sgemm(q, c->stream), "skinny linear");
@@ -2237,6 +2246,12 @@ static int op_linear_impl(rdm_ctx* c, const void* a, const void* w, const float*
         SgemmParams q{}; q.A = (const bf16_t*)a; q.lda = K; q.W = (const bf16_t*)w; q.M = M; q.N = N; q.K = K; q.bias = bias; q.act = act;
         q.res_bf16 = (const bf16_t*)res; q.out_f32 = out_f32; q.out_bf16 = (bf16_t*)out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
         if (sgemm_supported(q)) { RDM_CHECK_HIP(c, launch_sgemm(q, c->stream)); return 0; }
+    }
+    static const int mg_any = getenv("RDM_MGEMM_ANY") ? atoi(getenv("RDM_MGEMM_ANY")) : 0;      // dev / tests: plain ops of >= mg_any rows on the mid-size GEMM (mgemm.hip)
+    if (mg_any > 0 && M >= mg_any && alpha == 1.0f && !rowvec && act != ACT_GEGLU) {
+        SgemmParams q{}; q.A = (const bf16_t*)a; q.lda = K; q.W = (const bf16_t*)w; q.M = M; q.N = N; q.K = K; q.bias = bias; q.act = act;
+        q.res_bf16 = (const bf16_t*)res; q.out_f32 = out_f32; q.out_bf16 = (bf16_t*)out; q.ldo = N;
+        if (mgemm_supported(q)) { RDM_CHECK_HIP(c, launch_mgemm(q, c->stream)); return 0; }
     }
     IgemmParams p{}; p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.ldo = (act == ACT_GEGLU) ? N / 2 : N; p.zero_page = c->zero_page;
     p.Hin = p.Win = p.Hout = p.Wout = 1; p.stride = 1; p.rows_per_sample = 1;

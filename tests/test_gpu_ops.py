@@ -108,6 +108,43 @@ def test_linear_rowvec(ctx, M, N, K, rows, res):
         _close(out, ref, what=f"linear with a row-group vector (run {rep})")
 
 
+def test_linear_mid_size_gemm(tmp_path):
+    """mgemm.hip (LDS-staged 64 x 64 / 128 x 64 tiles: the RARM decode step's plain projections from 1536 sequences on) on its own, through
+    rdm_op_linear in a child process with RDM_MGEMM_ANY=64 (dev switch: plain ops of >= 64 rows take it): ragged row counts, fp32 and bf16
+    outputs, bias, bf16 residual, SiLU / QuickGELU, both tile heights and two ring depths -- against fp32 products of the same bf16 operands
+    (bound: the fp32-accumulation level for fp32 outputs, one bf16 rounding for bf16 outputs)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {os.path.dirname(here)!r}); sys.path.insert(0, {here!r})\n"
+        "import rdm_amd\nfrom rdm_amd import _lib\nfrom _util import bf16_round\n"
+        "torch.set_grad_enabled(False)\nctx = _lib.Context(0); d = ctx.device\n"
+        "def rnd(shape, seed, scale=1.0):\n"
+        "    return torch.from_numpy((np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32))\n"
+        "worst = 0.0\n"
+        "for (M, N, K, act, res, f32) in [(1064, 768, 768, 0, 1, 1), (2048, 2304, 768, 0, 0, 0), (1000, 192, 3072, 3, 1, 0), (130, 64, 128, 2, 0, 1), (4096, 768, 256, 0, 1, 0)]:\n"
+        "    a, w, b = bf16_round(rnd((M, K), 1)), bf16_round(rnd((N, K), 2, K ** -0.5)), rnd((N,), 3, 0.3)\n"
+        "    r = bf16_round(rnd((M, N), 4)) if res else None\n"
+        "    y = a.double() @ w.double().t() + b.double()\n"
+        "    if act == 3: y = y * torch.sigmoid(y)\n"
+        "    if act == 2: y = y * torch.sigmoid(1.702 * y)\n"
+        "    if res: y = y + r.double()\n"
+        "    out = ctx.op_linear(a.to(d, torch.bfloat16), w.to(d, torch.bfloat16), b.to(d), residual=None if r is None else r.to(d, torch.bfloat16), act=act, out_f32=bool(f32))\n"
+        "    assert out.shape == (M, N) and bool(torch.isfinite(out).all())\n"
+        "    e = ((out.double().cpu() - y).abs().max() / y.abs().max()).item()\n"
+        "    print('mgemm', M, N, K, 'act', act, 'res', res, 'f32' if f32 else 'bf16', 'max err / max |ref|: %.3e' % e)\n"
+        "    assert e <= (2e-5 if f32 else 6e-3), (M, N, K, e)\n"
+        "    worst = max(worst, e)\n"
+        "print('OK', worst)\n")
+    for extra in ({}, {"RDM_MGEMM_BM": "128", "RDM_MGEMM_NS": "3"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RDM_MGEMM_ANY="64", **extra), capture_output=True, text=True, timeout=600)
+        print(r.stdout[-1500:])
+        assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
 @pytest.mark.parametrize("M,C", [(49152, 192), (32768, 384)])
 def test_linear_geglu_big_m(ctx, M, C):
     from rdm_amd import _lib

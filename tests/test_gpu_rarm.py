@@ -59,10 +59,10 @@ def test_rarm_forward_shipped_golden(ctx):
     assert e <= 2.5e-2
 
 
-@pytest.mark.parametrize("nseq", [256, 512, 1024])
+@pytest.mark.parametrize("nseq", [256, 512, 1024, 2048])
 def test_rarm_forward_shipped_golden_big_batches(ctx, nseq):
-    """The decode geometries of the big batches (round 5: bench.py --config 5 defaults to 1024 sequences per GPU): 256 sequences take the 64 x 64
-    skinny-GEMM tiles behind a separate LayerNorm, the tiled GEGLU projection and the fused one-block cross-attention; 512 and 1024 sequences the
+    """The decode geometries of the big batches (round 5: bench.py --config 5 defaults to 2048 sequences per GPU): 256 sequences take the 64 x 64
+    skinny-GEMM tiles behind a separate LayerNorm, the tiled GEGLU projection and the fused one-block cross-attention; 512, 1024 and 2048 sequences the
     eight-wave GEMM tiles (64 x 96 for q | k | v, six k-steps per load batch at K = 3072) and the GEMM-form cross-attention (norm2 + to_q GEMM,
     the few-key attention kernel, to_out GEMM).  The golden's two
     sequences (8-token prefix, reference logits of the last two positions) sit at rows 0 and nseq - 1 of the batch, random sequences between."""
@@ -82,6 +82,43 @@ def test_rarm_forward_shipped_golden_big_batches(ctx, nseq):
         e = rel_l2(logits[row, -2:], ref[r])
         print(f"rarm shipped, batch {nseq}, row {row}: rel L2 vs reference golden {e:.3e}")
         assert e <= 2.5e-2
+
+
+def test_rarm_mid_size_gemm_against_skinny_kernel(ctx, tmp_path):
+    """From 1536 sequences on the decode step's plain projections run on the LDS-staged mid-size GEMM (mgemm.hip: fp32 residual stream
+    updated in place, 64 x 64 tiles); here RDM_MGEMM_FROM=1024 in a CHILD process puts a 1064-sequence, 12-token decode on it (ragged last
+    row tile), and this process (default threshold: not reached) runs
+    them on the skinny kernel (another summation order over K, the same bf16 operands): the logits of all sequences must agree to the
+    rounding of the bf16 activations of 18 layers in between (measured 5.4e-3, the same distance as any two summation orders of this
+    step; bound 1.5e-2, the parity bound against the reference being 2.5e-2; a wrong fragment, swizzle or tile edge gives O(1))."""
+    import os
+    import subprocess
+    import sys
+    spec = orarm.shipped_rarm_spec()
+    _load(ctx, spec, 91)
+    gen = torch.Generator().manual_seed(23)
+    tokens = torch.randint(0, spec.vocab_out, (1024 + 40, 12), generator=gen)          # 1064 rows: a ragged last 128-row tile
+    context = torch.randn((1024 + 40, 8, spec.context_dim), generator=gen) * 0.45
+    ref = ctx.rarm_forward(tokens, context)[:, -3:].float().cpu()
+    assert bool(torch.isfinite(ref).all())
+    out = tmp_path / "skinny.npy"
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {os.path.dirname(here)!r}); sys.path.insert(0, {here!r})\n"
+        "import rdm_amd\nfrom rdm_amd import _lib\nfrom oracle import rarm as orarm\nimport test_gpu_rarm as T\n"
+        "torch.set_grad_enabled(False)\nctx = _lib.Context(0)\nspec = orarm.shipped_rarm_spec()\nT._load(ctx, spec, 91)\n"
+        "gen = torch.Generator().manual_seed(23)\ntokens = torch.randint(0, spec.vocab_out, (1064, 12), generator=gen)\n"
+        "context = torch.randn((1064, 8, spec.context_dim), generator=gen) * 0.45\n"
+        f"np.save({str(out)!r}, ctx.rarm_forward(tokens, context)[:, -3:].float().cpu().numpy())\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RDM_MGEMM_FROM="1024"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    mine = torch.from_numpy(np.load(out))
+    e = rel_l2(mine, ref)
+    worst = max(rel_l2(mine[i], ref[i]) for i in range(mine.shape[0]))
+    print(f"mid-size GEMM vs skinny kernel, 1064 sequences x 12 tokens: rel L2 {e:.3e}, worst sequence {worst:.3e}, identical: {bool(torch.equal(mine, ref))}")
+    assert not torch.equal(mine, ref), "RDM_MGEMM_FROM=1024 did not change the kernel: the comparison is void"
+    assert e <= 1.5e-2 and worst <= 5e-2
 
 
 def test_rarm_forward_shipped_deep_golden(ctx):

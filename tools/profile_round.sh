@@ -34,15 +34,15 @@ with open("$OUT/sq_durations.csv", "w") as f:
 PY
 python3 $REPO/tools/pmc_sum.py json $OUT/pmc.json $OUT/sq.csv $OUT/fetch.csv $OUT/write.csv "FETCH_SIZE x 2 (gfx950 wide-read correction) + WRITE_SIZE, KB -> bytes; separate rocprofv3 --pmc passes of bench.py --ddim-steps 4 on this tree (tools/profile_round.sh $TAG); means over the launches of the passes"
 rm -rf $OUT/stats $OUT/sq1 $OUT/sq2 $OUT/fetch $OUT/write
-# RARM decode (config #5): bench line + kernel stats at 64 / 256 / 512 / 1024 sequences, one SQ pass at the default batch (1024) on a short run (32 tokens)
-for b in 64 256 512 1024; do
+# RARM decode (config #5): bench line + kernel stats at 64 / 256 / 512 / 1024 / 2048 sequences, one SQ pass at the default batch (2048) on a short run (32 tokens)
+for b in 64 256 512 1024 2048; do
   python3 $REPO/bench.py --config 5 --batch $b --db-rows 2000000 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/rarm_bench_b$b.json 2> $OUT/rarm_bench_b$b.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rstats_b$b -- python3 $REPO/bench.py --config 5 --batch $b --db-rows 2000000 --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $OUT/rstats_b$b.log 2>&1
   python3 $REPO/tools/pmc_sum.py stats $OUT/rarm_b${b}_kernel_stats.csv $OUT/rstats_b$b
   rm -rf $OUT/rstats_b$b
 done
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM GRBM_GUI_ACTIVE -d $OUT/rsq -- python3 $REPO/bench.py --config 5 --db-rows 2000000 --ddim-steps 32 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/rsq.log 2>&1
-python3 $REPO/tools/pmc_sum.py counters $OUT/rarm_b1024_sq.csv $OUT/rsq
+python3 $REPO/tools/pmc_sum.py counters $OUT/rarm_b2048_sq.csv $OUT/rsq
 rm -rf $OUT/rsq
 # per-op table of one guided UNet forward (tools/op_trace.py)
 python3 $REPO/tools/op_trace.py --out $OUT/op_trace.csv > $OUT/op_trace.log 2>&1
