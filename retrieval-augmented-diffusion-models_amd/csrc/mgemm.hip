@@ -7,14 +7,16 @@
 // 384 such blocks in two rounds, 75 MB through the L2 -> CU fabric for a 2.4 GFLOP product: 33.6 us per launch, four launches per layer
 // = 24 % of the decode step at 2048 sequences (profiles/r05_rarm_b2048_kernel_stats.csv).  The big-M kernels (lin4 / igemm) have 128- to
 // 256-row tiles of bf16 output: 16 x 4 tiles for [2048 x 768], 64 of 256 CUs (21 us).  Here: 64 x 64 output tiles, operands staged ONCE
-// per block in LDS by the asynchronous global -> LDS path (two stages of 64 x 64 + 64 x 64 bf16 = 32 KB: five blocks per CU), four waves
+// per block in LDS by the asynchronous global -> LDS path (a ring of three stages of 64 x 64 + 64 x 64 bf16 = 48 KB: three blocks per CU;
+// ONE barrier per K step: the request for stage k + 2 goes out, stage k is multiplied, stage k + 1 is waited for), four waves
 // of 16x16x32 MFMAs over 16 rows x 64 columns each, the residual requested before the K loop, the epilogue straight from the accumulators
 // (bias, SiLU / QuickGELU, fp32 / bf16 residual, fp32 / bf16 output: 64-byte row segments per 16 lanes).
 // Measured (rocprofv3, tools/lin_bench.py with RDM_MGEMM_ANY): [2048 x 768] x [768 x 768] 15.5 us (skinny 33.6, tiled 21.1), q | k | v
 // [2048 x 2304] 23.8, K = 3072 39.6; at 4096 rows 17.8 / 37.5 / 45.7 us.  RARM decode: 2048 sequences 776 -> 850 img/s, 4096: 844 -> 960;
-// at 1024 sequences the skinny kernel is still ahead (675 vs 660): used from 1536 rows on.  128-row tiles (fewer, bigger blocks) and
-// three / four ring stages (fewer blocks per CU) measured the same or slower: what paces a block is its LDS traffic (a wave re-reads the
-// whole weight tile: 40 KB of fragment reads per K step of 64) and the two barriers per step, hidden by the other blocks of the CU.
+// at 1024 sequences the skinny kernel is still ahead (675 vs 660): used from 1536 rows on.  (Those figures: two stages, two barriers per
+// step; the three-stage ring with one barrier: 2048 sequences 840 -> 865 img/s, 4096: 960 -> 978.)  128-row tiles, 128-column tiles with
+// the waves 2 x 2 (fewer, bigger blocks) and a fourth stage (fewer blocks per CU) measured slower: what paces a block is its chain of
+// barrier -> fragment reads -> MFMAs per K step (77 % of the wave cycles wait, MFMA busy 6.5 %), hidden only by the other blocks of the CU.
 // LDS rows are 128 bytes (64 k); the 16-byte piece p of row r sits at piece p ^ ((r >> 1) & 7): the 16 lanes of a fragment read
 // (consecutive rows, one piece index) land on 16 different 16-byte bank groups.
 #include <stdlib.h>
@@ -90,6 +92,37 @@ __global__ __launch_bounds__(256) void mgemm_kernel(SgemmParams p) {
         }
     const int nk = p.K / BK;
     constexpr int PER = A_INSTR + W_INSTR;                 // requests of one stage per wave
+    auto compute = [&](const char* const st) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 fa[MA], fb[4];
+#pragma unroll
+            for (int i = 0; i < MA; i++) fa[i] = *(const bf16x8*)(st + arow[i] * 128 + (((ks * 4 + q4) ^ ((arow[i] >> 1) & 7)) << 4));
+#pragma unroll
+            for (int j = 0; j < 4; j++) fb[j] = *(const bf16x8*)(st + A_BYTES + wrow[j] * 128 + (((ks * 4 + q4) ^ ((wrow[j] >> 1) & 7)) << 4));
+#pragma unroll
+            for (int i = 0; i < MA; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if constexpr (NS == 3) {
+        // ONE barrier per K step: stage kt is known to have landed when the step begins (waited for at the end of the step before), the
+        // request for stage kt + 2 goes into the buffer of stage kt - 1, which every wave finished reading before that same barrier
+        request(0, 0);
+        if (nk > 1) { request(1, 1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt++) {
+            if (kt + 2 < nk) request(kt + 2, (kt + 2) % 3);
+            compute(smem + (kt % 3) * STAGE);
+            if (kt + 1 < nk) {
+                if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");      // stage kt + 1 landed (this wave's share)
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+    } else {
 #pragma unroll
     for (int c = 0; c < NS - 1; c++) if (c < nk) request(c, c);
     for (int kt = 0; kt < nk; kt++) {
@@ -103,19 +136,8 @@ __global__ __launch_bounds__(256) void mgemm_kernel(SgemmParams p) {
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // ... and everybody else's
-        const char* const s = smem + buf * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            bf16x8 fa[MA], fb[4];
-#pragma unroll
-            for (int i = 0; i < MA; i++) fa[i] = *(const bf16x8*)(s + arow[i] * 128 + (((ks * 4 + q4) ^ ((arow[i] >> 1) & 7)) << 4));
-#pragma unroll
-            for (int j = 0; j < 4; j++) fb[j] = *(const bf16x8*)(s + A_BYTES + wrow[j] * 128 + (((ks * 4 + q4) ^ ((wrow[j] >> 1) & 7)) << 4));
-#pragma unroll
-            for (int i = 0; i < MA; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
+        compute(smem + buf * STAGE);
+    }
     }
     // epilogue from the accumulators: D layout 16x16 = column lane & 15, rows (lane >> 4) * 4 + r
     float bv[4];
@@ -168,7 +190,7 @@ static hipError_t mgemm_launch_one(const SgemmParams& p, hipStream_t st) {
 hipError_t launch_mgemm(const SgemmParams& p, hipStream_t st) {
     if (!mgemm_supported(p)) return hipErrorInvalidValue;
     static const int bm = getenv("RDM_MGEMM_BM") ? atoi(getenv("RDM_MGEMM_BM")) : 64;
-    static const int ns = getenv("RDM_MGEMM_NS") ? atoi(getenv("RDM_MGEMM_NS")) : 2;          // (dev switches: tile rows 64 / 128, ring stages 2 .. 4, tile columns 64 / 128)
+    static const int ns = getenv("RDM_MGEMM_NS") ? atoi(getenv("RDM_MGEMM_NS")) : 3;          // (dev switches: tile rows 64 / 128, ring stages 2 .. 4, tile columns 64 / 128)
     static const int bn = getenv("RDM_MGEMM_BN") ? atoi(getenv("RDM_MGEMM_BN")) : 64;
     if (bn == 128 && p.N % 128 == 0) return bm == 128 ? mgemm_launch_one<128, 2, 128>(p, st) : mgemm_launch_one<64, 2, 128>(p, st);
     if (bm == 128) return ns >= 3 ? mgemm_launch_one<128, 3>(p, st) : mgemm_launch_one<128, 2>(p, st);

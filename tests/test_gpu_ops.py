@@ -139,7 +139,7 @@ def test_linear_mid_size_gemm(tmp_path):
         "    assert e <= (2e-5 if f32 else 6e-3), (M, N, K, e)\n"
         "    worst = max(worst, e)\n"
         "print('OK', worst)\n")
-    for extra in ({}, {"RDM_MGEMM_BM": "128", "RDM_MGEMM_NS": "3"}, {"RDM_MGEMM_BN": "128"}, {"RDM_MGEMM_BN": "128", "RDM_MGEMM_BM": "128"}):
+    for extra in ({}, {"RDM_MGEMM_NS": "3"}, {"RDM_MGEMM_NS": "2"}, {"RDM_MGEMM_BM": "128", "RDM_MGEMM_NS": "3"}, {"RDM_MGEMM_BN": "128"}, {"RDM_MGEMM_BN": "128", "RDM_MGEMM_BM": "128"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RDM_MGEMM_ANY="64", **extra), capture_output=True, text=True, timeout=600)
         print(r.stdout[-1500:])
         assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
