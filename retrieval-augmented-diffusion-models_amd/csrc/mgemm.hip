@@ -17,6 +17,8 @@
 // step; the three-stage ring with one barrier: 2048 sequences 840 -> 865 img/s, 4096: 960 -> 978.)  128-row tiles, 128-column tiles with
 // the waves 2 x 2 (fewer, bigger blocks) and a fourth stage (fewer blocks per CU) measured slower: what paces a block is its chain of
 // barrier -> fragment reads -> MFMAs per K step (77 % of the wave cycles wait, MFMA busy 6.5 %), hidden only by the other blocks of the CU.
+// Reading the fragments of stage k + 1 under the MFMAs of stage k (current stage in registers, three buffers, lgkmcnt(0) before the one
+// barrier): built and measured, 876 -> 868 img/s at 2048 sequences (profiles/r05e_rarm_mgemm_fragment_prefetch_sweep.log) -- removed.
 // LDS rows are 128 bytes (64 k); the 16-byte piece p of row r sits at piece p ^ ((r >> 1) & 7): the 16 lanes of a fragment read
 // (consecutive rows, one piece index) land on 16 different 16-byte bank groups.
 #include <stdlib.h>
