@@ -14,8 +14,8 @@ A "step" is one pass of the whole hot path over one batch of synthetic inputs th
       reference), B=64 per GPU (512 over 8 GPUs).
   --config 5: RARM (scripts/rarm_sample.py path): k=8 retrieval -> 256 autoregressive tokens (18-layer RetrievalPatchTransformer with a
       K/V cache, top-k 256 multinomial, guidance scale 1.0 = the script's default) -> VQGAN-f16 decode, B=2048 sequences per GPU (BASELINE.json
-      does not fix this config's batch; one token step is ~110 dependent launches whatever the batch, so img/s per GPU grows 200 / 300 / 422 /
-      584 / 688 / 855 / 988 for 64 / 128 / 256 / 512 / 1024 / 2048 / 4096 sequences (round 5) and flattens from 2048 on (+ 15 % for the next
+      does not fix this config's batch; one token step is ~110 dependent launches whatever the batch, so img/s per GPU grows 200 / 300 / 424 /
+      585 / 692 / 878 / 994 for 64 / 128 / 256 / 512 / 1024 / 2048 / 4096 sequences (round 5) and flattens from 2048 on (+ 13 % for the next
       doubling, at 4.1 s per step): the K/V-cache attention is then HBM-bound and the first-stage decode, walked in 128-image ranges, costs the
       same per image at any batch).
 Weights are seeded random tensors of the shipped architectures (no checkpoints are reachable), DB / queries / captions
