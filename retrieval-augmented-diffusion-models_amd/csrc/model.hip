@@ -1761,8 +1761,22 @@ int rdm_ddpm_sample(rdm_ctx* c, const rdm_ddpm_args* a, const float* x_T, const 
         RDM_CHECK_HIP(c, hipStreamSynchronize(c->stream));
     }
     RDM_CHECK_HIP(c, hipMemcpyAsync(x, x_T, n1 * 4, hipMemcpyDeviceToDevice, c->stream));
+    // the T timesteps' time-embedding rows once per call (as rdm_ddim_sample: every sample of a step shares the step's timestep)
+    static const int no_emb_table = getenv("RDM_NO_EMB_TABLE") ? atoi(getenv("RDM_NO_EMB_TABLE")) : 0;
+    const float* emb_table = nullptr;
+    if (!no_emb_table && !c->deterministic) {
+        RDM_TRY(ensure_bytes(c, (char**)&u.emb_table, &u.emb_table_bytes, (size_t)T * u.emb_total * 4 + (size_t)T * 8 + 256));
+        long long* tuniq = (long long*)((char*)u.emb_table + (((size_t)T * u.emb_total * 4 + 255) & ~(size_t)255));
+        std::vector<long long> th((size_t)T);
+        for (int i = 0; i < T; i++) th[i] = i;
+        RDM_CHECK_HIP(c, hipMemcpyAsync(tuniq, th.data(), (size_t)T * 8, hipMemcpyHostToDevice, c->stream));
+        RDM_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+        RDM_TRY(run_with_arena(c, u.arena, u.blob, [&](Ops& o) { unet_time_rows(o, u, tuniq, T, u.emb_table); }));
+        emb_table = u.emb_table;
+    }
     for (int n = 0, i = T - 1; i >= 0; i--, n++) {
-        RDM_TRY(unet_forward_impl(c, x, (const int64_t*)(tdev + (size_t)i * B), nullptr, u.kv_cache, B, k, a->height, a->width, eps, B));
+        RDM_TRY(unet_forward_impl(c, x, (const int64_t*)(tdev + (size_t)i * B), nullptr, u.kv_cache, B, k, a->height, a->width, eps, B, 0,
+                                  emb_table ? emb_table + (size_t)i * u.emb_total : nullptr));
         DdpmStepParams p{};
         p.x = x; p.eps = eps; p.noise = noise + (size_t)n * n1; p.x_prev = x; p.n = n1;
         p.sqrt_recip = a->sqrt_recip_alphas_cumprod[i]; p.sqrt_recipm1 = a->sqrt_recipm1_alphas_cumprod[i];
