@@ -125,7 +125,7 @@ def attach_library_comm(ctx, group=None) -> bool:
         return False
     if os.environ.get("RDM_NO_LIB_COMM", "0") not in ("", "0"):          # torch.distributed's collective only
         return False
-    if getattr(ctx, "comm_world", 0) == dist.get_world_size(group):
+    if getattr(ctx, "lib_comm_agreed", 0) == dist.get_world_size(group):
         return True
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     ok = torch.ones(1, dtype=torch.int32, device=ctx.device)
@@ -139,25 +139,40 @@ def attach_library_comm(ctx, group=None) -> bool:
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
     if int(ok.item()) == 0:
         return False
-    try:
-        ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
-        # one known-answer gather before anything depends on it (this path cannot be exercised on the one-GPU build boxes): rank r
-        # contributes [r, r + 0.5, r, r + 0.5]; any other result -> the torch.distributed collective stays in use
-        probe = torch.tensor([rank, rank + 0.5, rank, rank + 0.5], dtype=torch.float32, device=ctx.device)
-        got = ctx.comm_all_gather(probe, world)
-        torch.cuda.synchronize(ctx.device)
-        want = torch.arange(world, dtype=torch.float32, device=ctx.device)[:, None] + torch.tensor([0.0, 0.5, 0.0, 0.5], device=ctx.device)
-        if got.shape != want.shape or not torch.equal(got, want):
-            ok.zero_()
-    except Exception:
+    uid_bytes = bytes(uid.cpu().numpy().tobytes())
+    result = {"ok": False}
+
+    def _init_and_probe():
+        try:
+            ctx.comm_init(uid_bytes, rank, world)
+            # one known-answer gather before anything depends on it (this path cannot be exercised on the one-GPU build boxes): rank r
+            # contributes [r, r + 0.5, r, r + 0.5]; any other result -> the torch.distributed collective stays in use
+            probe = torch.tensor([rank, rank + 0.5, rank, rank + 0.5], dtype=torch.float32, device=ctx.device)
+            got = ctx.comm_all_gather(probe, world)
+            torch.cuda.synchronize(ctx.device)
+            want = torch.arange(world, dtype=torch.float32, device=ctx.device)[:, None] + torch.tensor([0.0, 0.5, 0.0, 0.5], device=ctx.device)
+            result["ok"] = got.shape == want.shape and bool(torch.equal(got, want))
+        except Exception:
+            result["ok"] = False
+
+    # in a helper thread with a deadline: a rendezvous that never completes (a rank that failed before it, a fabric problem) must cost
+    # this path, not the run -- a rank whose helper is still blocked votes "no" below and everybody keeps the torch.distributed collective
+    import threading
+    th = threading.Thread(target=_init_and_probe, daemon=True)
+    th.start()
+    th.join(timeout=float(os.environ.get("RDM_LIB_COMM_TIMEOUT", "120")))
+    if th.is_alive() or not result["ok"]:
         ok.zero_()
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)          # all ranks agree on which collective they will call
     if int(ok.item()) == 0:
-        try:
-            ctx.comm_destroy()
-        except Exception:
-            pass
+        if not th.is_alive():
+            try:
+                ctx.comm_destroy()
+            except Exception:
+                pass
+        ctx.lib_comm_agreed = 0
         return False
+    ctx.lib_comm_agreed = world                                     # (not comm_world: a late helper thread must not switch one rank over)
     return True
 
 
@@ -174,7 +189,7 @@ def all_gather_images(local: torch.Tensor, n_total: int = None, group=None, ctx=
         n_total = local.shape[0] * world
     counts = [shard_range(n_total, world, r)[1] - shard_range(n_total, world, r)[0] for r in range(world)]
     bmax = max(counts)
-    if ctx is not None and local.is_cuda and getattr(ctx, "comm_world", 0) == world and all(c == bmax for c in counts):
+    if ctx is not None and local.is_cuda and getattr(ctx, "lib_comm_agreed", 0) == world and all(c == bmax for c in counts):
         out = ctx.comm_all_gather(local, world)                                  # [world, b, ...]
         return out.reshape((world * bmax,) + tuple(local.shape[1:]))
     if all(c == bmax for c in counts):
