@@ -149,7 +149,8 @@ def attach_library_comm(ctx, group=None) -> bool:
             # contributes [r, r + 0.5, r, r + 0.5]; any other result -> the torch.distributed collective stays in use
             probe = torch.tensor([rank, rank + 0.5, rank, rank + 0.5], dtype=torch.float32, device=ctx.device)
             got = ctx.comm_all_gather(probe, world)
-            torch.cuda.synchronize(ctx.device)
+            if torch.device(ctx.device).type == "cuda":
+                torch.cuda.synchronize(ctx.device)
             want = torch.arange(world, dtype=torch.float32, device=ctx.device)[:, None] + torch.tensor([0.0, 0.5, 0.0, 0.5], device=ctx.device)
             result["ok"] = got.shape == want.shape and bool(torch.equal(got, want))
         except Exception:

@@ -304,6 +304,83 @@ def test_batch_sharding_world2_gloo(n_total):
         assert np.array_equal(a, b)                               # sharding is bit-invariant
 
 
+class _MockCommCtx:
+    """Stands in for a library context in the hand-shake of parallel.attach_library_comm: the 'communicator' is the gloo group itself."""
+    device = "cpu"
+
+    def __init__(self, mode, rank, grp):
+        self.mode, self.rank, self.comm_world, self.destroyed, self.grp = mode, rank, 0, False, grp     # grp: the mock communicator's OWN group
+
+    def comm_unique_id(self):
+        return bytes(range(128))
+
+    def comm_init(self, uid, rank, world):
+        assert uid == bytes(range(128)) and rank == self.rank
+        if self.mode == "hang" and rank == 1:
+            import time
+            time.sleep(8)                                    # a rendezvous that does not come back within the deadline (3 s here)
+        if self.mode == "raise" and rank == 0:
+            raise RuntimeError("no communicator")
+        self.comm_world = world
+
+    def comm_all_gather(self, local, world):
+        import torch.distributed as dist
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local, group=self.grp)
+        out = torch.stack(parts)
+        if self.mode == "wrong" and self.rank == 1:
+            out = out + 1.0                                  # a gather that answers, wrongly, on one rank only
+        return out
+
+    def comm_destroy(self):
+        self.destroyed = True; self.comm_world = 0
+
+
+def _worker_lib_comm(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      RDM_LIB_COMM_TIMEOUT="3")
+    from rdm_amd import parallel
+    import torch.distributed as dist
+    parallel.init_distributed("gloo")
+    real = dist.get_backend
+    res = {}
+    for mode in ("ok", "raise", "wrong", "hang"):
+        # (a real library communicator is independent of the torch group; so is the mock's: one fresh gloo group per case, so that a helper
+        #  thread still blocked in its probe cannot interleave with the hand-shake's own collectives)
+        ctx = _MockCommCtx(mode, rank, dist.new_group(backend="gloo"))
+        dist.get_backend = lambda g=None: "nccl"             # the hand-shake is for RCCL groups; its own traffic here is CPU tensors over gloo
+        try:
+            got = parallel.attach_library_comm(ctx)
+            again = parallel.attach_library_comm(ctx) if got else None
+        finally:
+            dist.get_backend = real
+        res[mode] = (got, again, getattr(ctx, "lib_comm_agreed", None))
+        if mode == "ok":                                    # ... and the gather then goes through the context
+            res["gather"] = ctx.comm_all_gather(torch.full((2, 3), float(rank)), world).reshape(4, 3)[:, 0].tolist()
+    import time
+    time.sleep(7)                                            # let the "hang" case's helper threads run out before the group goes away
+    q.put((rank, res))
+    parallel.shutdown()
+
+
+def test_library_comm_handshake_agreement_world2_gloo():
+    """parallel.attach_library_comm on a mock context over a gloo world of 2 (the real thing needs two GPUs): all ranks must come out with
+    the SAME answer -- True when every rank's rendezvous + known-answer gather succeeded; False on every rank when one rank raises, when
+    one rank's probe gather answers wrongly, and when one rank's rendezvous does not return within the deadline (RDM_LIB_COMM_TIMEOUT)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_lib_comm, args=(r, 2, 29631, q)) for r in range(2)]
+    for p in procs: p.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs: p.join(timeout=60)
+    for rank in (0, 1):
+        r = got[rank]
+        assert r["ok"] == (True, True, 2), r
+        assert r["gather"] == [0.0, 0.0, 1.0, 1.0]
+        for mode in ("raise", "wrong", "hang"):
+            assert r[mode][0] is False and r[mode][2] == 0, (rank, mode, r[mode])
+
+
 def _worker_unseeded(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from rdm_amd import parallel
