@@ -65,6 +65,7 @@ def parse():
     p.add_argument("--gather", choices=("f32", "uint8"), default="f32",
                    help="N > 1: what the one collective moves -- the decoded fp32 images [B,3,256,256] (50 MB per rank at B = 64, default) or their "
                         "uint8 HWC form (rdm_to_uint8, the conversion of scripts/rdm_sample.py: 12.6 MB per rank; SURVEY 8e)")
+    p.add_argument("--no-calibration", action="store_true", help="skip the box-calibration probes (~2 s before the warm-up) and the clock / power sampler")
     p.add_argument("--dump-images", default=None, help="rank 0 writes the last timed step's gathered images to this .npy (parity tests of the N > 1 path)")
     a = p.parse_args()
     a.k = a.k if a.k is not None else {2: 1, 3: 4, 4: 16, 5: 8}[a.config]
@@ -142,6 +143,75 @@ def cpu_baseline(scale):
             "sample": f"fp32 oracle, BASELINE config #1 shapes (B=1, k=4, CFG scale {scale} => UNet batch 2): 4 consecutive DDIM steps of "
                       f"the 50-step schedule (first = warm-up, median of the other 3 = {t_step:.3f} s/step) + 1 VQ-f4 decode ({t_dec:.3f} s), "
                       f"extrapolated to 50 steps + 1 decode per image; retrieval excluded"}
+
+
+class BoxSampler:
+    """Shader clock and package power of this rank's GPU, sampled from a thread during the timed region (calibration object of the
+    JSON line).  amdgpu's hwmon files when they are readable (microwatts / Hz: no child process), else `rocm-smi` (one child per sample,
+    as tools/power_insitu.py does from outside).  Sampling failures leave the fields null: the benchmark never depends on them."""
+
+    def __init__(self, period=0.2):
+        import glob
+        import threading
+        self.period, self.samples, self._stop, self._th = period, [], threading.Event(), None
+        self.hw = []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            pw = next((f for f in (os.path.join(d, "power1_average"), os.path.join(d, "power1_input")) if os.access(f, os.R_OK)), None)
+            fq = os.path.join(d, "freq1_input")
+            if pw and os.access(fq, os.R_OK):
+                self.hw.append((pw, fq))
+        self.source = "hwmon" if self.hw else "rocm-smi"
+        self._threading = threading
+
+    def _read(self):
+        import re
+        if self.hw:
+            best = None
+            for pw, fq in self.hw:             # several cards visible: the loaded one is the one this process drives
+                try:
+                    w = int(open(pw).read()) * 1e-6
+                    mhz = int(open(fq).read()) * 1e-6
+                except Exception:
+                    continue
+                if best is None or w > best[0]:
+                    best = (w, mhz)
+            return best
+        try:
+            out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+            pw = re.search(r"Power \(W\):\s*([0-9.]+)", out); ck = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", out)
+            return (float(pw.group(1)), float(ck.group(1))) if pw and ck else None
+        except Exception:
+            return None
+
+    def start(self):
+        def run():
+            while not self._stop.is_set():
+                r = self._read()
+                if r:
+                    self.samples.append(r)
+                self._stop.wait(self.period)
+        self._th = self._threading.Thread(target=run, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._th:
+            self._th.join(timeout=10)
+        if not self.samples:
+            return {"sclk_mhz_mean": None, "sclk_mhz_min": None, "power_w_mean": None, "samples": 0, "sampler": self.source}
+        n = len(self.samples)
+        return {"sclk_mhz_mean": sum(s[1] for s in self.samples) / n, "sclk_mhz_min": min(s[1] for s in self.samples),
+                "power_w_mean": sum(s[0] for s in self.samples) / n, "power_w_max": max(s[0] for s in self.samples), "samples": n,
+                "sampler": self.source}
+
+
+def load_calibration_reference():
+    """The committed probe readings of the box every headline is normalised to (profiles/calibration_reference.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "calibration_reference.json")) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def main():
@@ -252,10 +322,27 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # ---- box calibration (untimed, < 3 s): fixed MFMA and HBM-stream probes that do not change with the product kernels -- boxes of the
+    # pool differ by +-4..5 % under the power cap and the headline moves with them; `value_at_reference_box` rescales by these readings
+    calib = None
+    if not a.no_calibration:
+        try:
+            tf_, gb_ = ctx.calib_probe(mfma_ms=800.0, stream_bytes=1 << 30, stream_reps=6)
+            calib = {"mfma_probe_tflops": tf_, "hbm_stream_gbps": gb_}
+        except Exception as e_:                     # a failed probe must never cost the benchmark line
+            calib = {"mfma_probe_tflops": None, "hbm_stream_gbps": None, "error": str(e_)[:200]}
+        if world > 1 and calib.get("mfma_probe_tflops"):
+            tt = torch.tensor([calib["mfma_probe_tflops"], calib["hbm_stream_gbps"]], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MIN)          # the slowest rank sets the step
+            calib["mfma_probe_tflops_min_over_ranks"], calib["hbm_stream_gbps_min_over_ranks"] = float(tt[0]), float(tt[1])
+
     for i in range(a.warmup):
         step(i)
     fence()
     ctx.prof_reset()
+    box_sampler = BoxSampler() if (calib is not None and rank == 0) else None
+    if box_sampler:
+        box_sampler.start()
     # dominant kernel: HIP events (on the library's stream) around its launches INSIDE the timed region, on the LAST timed step only --
     # 2 524 event pairs per step on every step cost the headline what a sampled step measures just as well (a host-side flag: no sync)
     t0 = time.perf_counter()
@@ -265,11 +352,17 @@ def main():
         img = step(i)
     fence()
     dt = time.perf_counter() - t0
+    if box_sampler:
+        calib.update(box_sampler.stop())
     ctx.prof_enable(())
+    rank_ms = None
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+        # max over ranks is the job's time (contract); every rank's own time rides along so that a straggler is visible in the line
+        allt = torch.zeros(world, device=dev, dtype=torch.float64)
+        allt[rank] = dt
+        torch.distributed.all_reduce(allt, op=torch.distributed.ReduceOp.SUM)
+        rank_ms = [float(v) / a.steps * 1e3 for v in allt.tolist()]
+        dt = float(allt.max().item())
     assert img.shape[0] == world * B and bool(torch.isfinite(img.float()).all()), "non-finite images"
     if a.dump_images and rank == 0:
         np.save(a.dump_images, img.cpu().numpy())
@@ -434,6 +527,24 @@ def main():
                        "deterministic_mode": bool(ctx.deterministic)},
             "roofline": roof,
         }
+        if rank_ms is not None:
+            out["config"]["rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms}
+        if calib is not None:
+            ref = load_calibration_reference()
+            calib["reference"] = ref
+            probe = calib.get("mfma_probe_tflops_min_over_ranks") or calib.get("mfma_probe_tflops")
+            stream = calib.get("hbm_stream_gbps_min_over_ranks") or calib.get("hbm_stream_gbps")
+            if ref and probe and stream and a.config != 5:
+                # time on the reference box = MFMA-class time x (this probe / reference probe) + HBM-class time x (this stream / reference stream);
+                # the HBM-bound share of the step (GroupNorm, LayerNorm, kNN) from this run's per-class events when they were taken
+                hbm_ms = sum(classes[n_][1] for n_ in ("groupnorm", "layernorm", "knn") if n_ in classes)
+                f_hbm = min(0.5, hbm_ms * 1e-3 / (dt / a.steps)) if hbm_ms > 0 else 0.12
+                rel = (1.0 - f_hbm) * (probe / ref["mfma_probe_tflops"]) + f_hbm * (stream / ref["hbm_stream_gbps"])
+                calib["hbm_bound_share_of_step"] = f_hbm
+                calib["time_scale_to_reference_box"] = rel
+                out["value_at_reference_box"] = out["value"] / rel
+            extras["calibration"] = calib
+            out["calibration"] = calib
         if extras:
             out["extras"] = extras
         if world == 1 and not a.no_cpu_baseline:

@@ -249,6 +249,19 @@ int rdm_prof_reset(rdm_ctx* ctx);
  * reference modules behind the roles: rdm/modules/attention.py:122-196, ldm ResBlock), its shape (M, N, K | rows, channels | B, n, C),
  * elapsed ms and algorithmic work -- the per-op table behind DESIGN.md's level-by-level costs (tools/op_trace.py). */
 int rdm_prof_dump(rdm_ctx* ctx, const char* path);
+/* test / stress hook: library-wide debug counters.  which = 0: granules the four-blocks-per-sequence RARM decode cross-attention
+ * (rarm.hip; the decode step of rdm/models/autoregression/transformer.py:241-248) had to RE-READ because their tag was an earlier launch's
+ * -- the hand-over is self-validating, so a non-zero count is harmless, and it is the round-5 repeat mismatch caught in the act
+ * (tools/rarm_stress.py).  Synchronises the context's stream. */
+int rdm_debug_counter(rdm_ctx* ctx, int which, unsigned long long* value /*[host]*/);
+/* Box calibration for bench.py's `calibration` object (no reference counterpart: the reference has no benchmark harness; the
+ * boxes of the MI355X pool differ by +-4..5 % in sustained clock under the package power cap and the headline moves with them).  Two FIXED
+ * instruction streams that do not change when a product kernel does: (1) back-to-back v_mfma_f32_32x32x16_bf16 on random bf16 operands, one wave
+ * per SIMD on every CU, for ~mfma_ms of wall time -> sustained dense-bf16 TFLOP/s under this box's power cap; (2) stream_reps 16-byte-per-lane
+ * copies of stream_bytes -> HBM read + write GB/s.  buf [dev]: scratch of at least max(1 MiB, 2 * stream_bytes) bytes; either result
+ * pointer may be null (probe skipped).  Synchronous on the context's stream. */
+int rdm_calib_probe(rdm_ctx* ctx, void* buf /*[dev]*/, size_t buf_bytes, double mfma_ms, size_t stream_bytes, int stream_reps,
+                    double* mfma_tflops /*[host]*/, double* stream_gbps /*[host]*/);
 /* test hook: the next UNet forwards copy ONE intermediate activation (bf16, row-major [rows, width] as the executor holds it: NHWC) into
  * buf [dev] (at most nbytes).  block: index into the top-level block table (state-dict order: input_blocks.0 .., middle_block,
  * output_blocks.0 ..; openaimodel.py:355-368's loop).  sub = 0: the block's output; sub = 16 * (layer inside the block) + stage:

@@ -107,6 +107,8 @@ SIGNATURES = {
     "rdm_prof_reset": (C.c_int, [_P]),
     "rdm_prof_dump": (C.c_int, [_P, C.c_char_p]),
     "rdm_debug_tap": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int]),
+    "rdm_debug_counter": (C.c_int, [_P, C.c_int, C.POINTER(C.c_ulonglong)]),
+    "rdm_calib_probe": (C.c_int, [_P, _P, C.c_size_t, C.c_double, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rdm_comm_unique_id": (C.c_int, [_P, _P]),
     "rdm_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "rdm_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -614,6 +616,16 @@ class Context:
         self._check(lib.rdm_comm_unique_id(self._h, buf))
         return buf.raw
 
+    def new_comm_context(self):
+        """A sibling context on the same device whose ONLY job is to own the RCCL communicator (parallel.attach_library_comm): its stream is a
+        fresh non-blocking side stream, so a rendezvous or probe collective that never completes can block nothing but that stream, and a
+        context that failed its hand-shake is simply abandoned (advisor, round 5: a late helper thread must not share the product context,
+        which is not thread-safe, nor enqueue on the product's stream)."""
+        c = Context(self.device.index)
+        c._side_stream = torch.cuda.Stream(self.device)
+        c._check(lib.rdm_set_stream(c._h, C.c_void_p(c._side_stream.cuda_stream)))
+        return c
+
     def comm_init(self, uid: bytes, rank: int, world: int):
         if len(uid) != 128:
             raise RdmError(f"comm_init: the unique id is 128 bytes, got {len(uid)}")
@@ -645,6 +657,19 @@ class Context:
         device tensor); buf None: off."""
         self._tap_keepalive = buf
         self._check(lib.rdm_debug_tap(self._h, _ptr(buf) if buf is not None else None, 0 if buf is None else buf.numel() * buf.element_size(), int(block), int(sub)))
+
+    def debug_counter(self, which=0):
+        v = C.c_ulonglong(0)
+        self._check(lib.rdm_debug_counter(self._h, int(which), C.byref(v)))
+        return int(v.value)
+
+    def calib_probe(self, mfma_ms=800.0, stream_bytes=1 << 30, stream_reps=6):
+        """Box calibration (rdm_calib_probe): (sustained dense-bf16 MFMA TFLOP/s on random operands, HBM copy GB/s read + write)."""
+        buf = torch.empty(max(1 << 20, 2 * stream_bytes), device=self.device, dtype=torch.uint8)
+        tf, gb = C.c_double(0.0), C.c_double(0.0)
+        self._check(lib.rdm_calib_probe(self._h, _ptr(buf), buf.numel(), float(mfma_ms), int(stream_bytes), int(stream_reps), C.byref(tf), C.byref(gb)))
+        del buf
+        return float(tf.value), float(gb.value)
 
     def prof_dump(self, path):
         """One CSV row per recorded launch (kind, role tag, shape, ms, work): tools/op_trace.py."""

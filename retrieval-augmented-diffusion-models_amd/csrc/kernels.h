@@ -100,8 +100,11 @@ struct RarmXattnParams {
     const float* bias;                         // [C]
     int B2, Bc, C, NP, heads, k;
     const float* ln3_g; const float* ln3_b; bf16_t* ln3_out;   // given: LayerNorm (gamma, beta) of the FINISHED rows leaves with them as bf16 [B2][C] (norm3: the operand of the feed-forward's first GEMM)
-    float* ws; int* ws_count;                  // four-blocks-per-sequence form: partial output rows [B2][4][C] fp32 and one arrival counter per sequence (zero between launches); null = one block per sequence
+    float* ws; int* ws_count;                  // four-blocks-per-sequence form: partial output rows [B2][4][C] as 8-byte {fp32, epoch tag} granules (zeroed once) and one monotonic arrival counter per sequence; null = one block per sequence
+    unsigned epoch;                            // four-blocks form: this launch's tag, unique per launch over the buffer's lifetime, never 0 (rarm.hip: self-validating hand-over)
+    int no_split;                              // deterministic mode: the form must not follow the batch -- always one block per sequence
 };
+unsigned long long rarm_xsplit_stale_count();     // granules the four-blocks form's last arrivers had to re-read since library load (debug counter 0)
 hipError_t launch_rarm_xattn_decode(const RarmXattnParams& p, hipStream_t st);
 
 struct RarmSampleParams {
@@ -122,6 +125,8 @@ struct SgemmParams {
     const bf16_t* A; int lda; const bf16_t* W; int M, N, K;     // W [N][K]; GEGLU: N = 2 x outputs, rows interleaved in blocks of 32
     const float* bias; int act; const float* res_f32; const bf16_t* res_bf16; float* out_f32; bf16_t* out_bf16; int ldo;
     const float* ln_x; const float* ln_g; const float* ln_b; float ln_eps;      // A = LayerNorm(ln_x [M][K] fp32) formed in the kernel (A ignored)
+    int fixed_split;          // deterministic mode (rdm_set_deterministic): a row's fp32 summation order must not follow the batch -- always the four-wave K split
+                              // (K / 4 per wave, partial tiles added in wave order), never the eight-wave / folded / LayerNorm-in-tile forms that start at 384 rows
 };
 bool sgemm_supported(const SgemmParams& p);
 hipError_t launch_sgemm(const SgemmParams& p, hipStream_t st);
@@ -229,3 +234,6 @@ hipError_t launch_clip_vit_assemble(const float* patch, const float* cls, const 
                                     hipStream_t st);
 hipError_t launch_gather_rows_f32(const float* x, float* out, int B, long long row_stride, int Wd, hipStream_t st);
 hipError_t launch_to_uint8_hwc(const float* x, unsigned char* out, int B, int C, int H, int W, hipStream_t st);
+
+// box calibration probes (calib.hip): a fixed MFMA stream on random bf16 operands and a fixed HBM copy, timed on `st`
+hipError_t run_calib_probes(void* buf, double mfma_ms, size_t stream_bytes, int stream_reps, double* mfma_tflops, double* stream_gbps, hipStream_t st);

@@ -126,7 +126,8 @@ hipError_t launch_conv_in(const float* x, const float* w, const float* bias, bf1
     if (sm > 96 * 1024) return hipErrorInvalidValue;
     int grid = (H * W + 511) / 512; const int cap_in = (2048 + B - 1) / B; if (grid > cap_in) grid = cap_in; if (grid < 1) grid = 1;
     static const int oct_env = getenv("RDM_CONVIN_OCT") ? atoi(getenv("RDM_CONVIN_OCT")) : 4;     // 0: direct 16-byte stores
-    static bool attr_set = false;
+    static bool attr_dev[RDM_MAX_DEVICES] = {false};           // per device, like every other launcher (one process may hold contexts on several GPUs)
+    bool& attr_set = attr_dev[rdm_cur_device()];
     if (!attr_set) {
         const void* fns[] = {(const void*)conv_in_kernel<4, 3>, (const void*)conv_in_kernel<4, 4>, (const void*)conv_in_kernel<0, 3>, (const void*)conv_in_kernel<0, 4>};
         for (const void* f : fns) { hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return e; }

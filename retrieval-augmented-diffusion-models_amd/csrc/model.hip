@@ -446,7 +446,8 @@ struct RarmModel {
     char* state = nullptr; size_t state_bytes = 0;
     // decode-step cross-attention operands per layer (rarm_prepare): [depth][2][Bc][128][C] bf16 (G, UT), valid for xa_B conditional sequences and xa_k neighbours
     char* xa = nullptr; size_t xa_bytes = 0; int xa_B = 0, xa_k = 0;
-    char* xws = nullptr; size_t xws_bytes = 0;          // split decode cross-attention: [B2][4][C] fp32 partial rows, then B2 arrival counters
+    char* xws = nullptr; size_t xws_bytes = 0;          // split decode cross-attention: [B2][4][C] {fp32, epoch} granules, then B2 arrival counters
+    unsigned xepoch = 0;                                // its launch tag (rarm.hip): incremented per launch
 };
 static void build_rarm(RarmModel& m, const rdm_rarm_cfg& c, Manifest& mf) {
     m.cfg = c; m.blk.clear(); m.C = c.n_heads * c.d_head;
@@ -634,6 +635,7 @@ struct Ops {
         if (skinny && !A1 && C1 == 0 && !rowvec) {         // N/32 x ceil(M/32) blocks (sgemm.hip)
             SgemmParams q{}; q.A = A0; q.lda = C0; q.W = w<bf16_t>(woff); q.M = M; q.N = N; q.K = C0; q.bias = has_bias ? w<float>(boff) : nullptr;
             q.act = act; q.res_f32 = res_f32; q.res_bf16 = res; q.out_f32 = out_f32; q.out_bf16 = out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
+            q.fixed_split = c->deterministic ? 1 : 0;
             // 1536+ rows: LDS-staged 64 x 64 tiles (mgemm.hip) -- the skinny kernel's per-wave operand fetch is 75 MB through the L2 -> CU
             // fabric for a [2048 x 768] x [768 x 768] product (33.6 us; 15.5 there).  Not in deterministic mode (the kernel choice would follow the batch).
             static const int mg_from = getenv("RDM_MGEMM_FROM") ? atoi(getenv("RDM_MGEMM_FROM")) : 1536;
@@ -683,6 +685,7 @@ struct Ops {
         const bool skinny = c->deterministic ? single_row : (M <= 128 || (single_row && M <= 1024));
         SgemmParams q{}; q.ln_x = x; q.ln_g = w<float>(g); q.ln_b = w<float>(b); q.ln_eps = 1e-5f; q.W = w<bf16_t>(woff); q.M = M; q.N = N; q.K = C;
         q.bias = has_bias ? w<float>(boff) : nullptr; q.act = act; q.out_bf16 = out; q.ldo = act == ACT_GEGLU ? N / 2 : N;
+        q.fixed_split = c->deterministic ? 1 : 0;
         if (off || !skinny || !sgemm_supported(q)) return false;
         if (plan) return true;
         prof_begin(RDM_PROF_LINEAR, 2.0 * M * N * (double)C, M, N, C);
@@ -1800,6 +1803,10 @@ static int vq_range(const VqModel& v, int b) {
     for (int l = 0; l < c.n_ch_mult; l++) {
         const long long r = c.resolution >> l, e = r * r * c.ch * c.ch_mult[l];
         if (e > per) per = e;
+        // the level's Upsample output (and the first convs' input at the next finer level) keeps THIS level's channel count at twice the
+        // resolution -- the decoder's largest activation (VQ-f4: 256 x 256 x 256 per image, twice the level maximum): a range sized without
+        // it reached exactly 2^31 elements and pushed those convs off the 32-bit-offset halo kernels (advisor, round 5)
+        if (l >= 1) { const long long u = 4 * r * r * c.ch * c.ch_mult[l]; if (u > per) per = u; }
     }
     long long n = (1LL << 30) / per;
     if (n < 1) n = 1;
@@ -1917,9 +1924,11 @@ static int rarm_prepare(rdm_ctx* c, int B2, int k, const float* context /*[B,k,c
     if (fuse) {
         RDM_TRY(ensure_bytes(c, &m.xa, &m.xa_bytes, (size_t)g.depth * 2 * B * 128 * C * 2));
         m.xa_B = B; m.xa_k = k;
-        const size_t pbytes = ((size_t)B2 * 4 * C * 4 + 255) & ~(size_t)255;
+        // partial rows as 8-byte {value, epoch} granules + one monotonic arrival counter per sequence; zeroed per sampling call (tag 0 = never
+        // written; counters restart at a multiple of four)
+        const size_t pbytes = ((size_t)B2 * 4 * C * 8 + 255) & ~(size_t)255;
         RDM_TRY(ensure_bytes(c, &m.xws, &m.xws_bytes, pbytes + (size_t)B2 * 4));
-        RDM_CHECK_HIP(c, hipMemsetAsync(m.xws + pbytes, 0, (size_t)B2 * 4, c->stream));       // arrival counters (every launch leaves them at zero)
+        RDM_CHECK_HIP(c, hipMemsetAsync(m.xws, 0, pbytes + (size_t)B2 * 4, c->stream));
     }
     return run_with_arena(c, m.arena, m.blob, [&](Ops& o) {
         bf16_t* cb = o.abf((size_t)B * k * g.context_dim);
@@ -1988,7 +1997,9 @@ static int rarm_step(rdm_ctx* c, int B2, int k, int pos_hint = -1 /* host's copy
                     RarmXattnParams xp{}; xp.x = x; xp.ln_g = o.w<float>(b.ln2g); xp.ln_b = o.w<float>(b.ln2b); xp.ln_eps = 1e-5f;
                     xp.G = (const bf16_t*)m.xa + ((size_t)l * 2) * m.xa_B * 128 * C; xp.UT = xp.G + (size_t)m.xa_B * 128 * C;
                     xp.bias = o.w<float>(b.bo2); xp.B2 = B2; xp.Bc = m.xa_B; xp.C = C; xp.NP = 128; xp.heads = g.n_heads; xp.k = k;
-                    xp.ws = (float*)m.xws; xp.ws_count = (int*)(m.xws + ((((size_t)B2 * 4 * C * 4) + 255) & ~(size_t)255));
+                    xp.ws = (float*)m.xws; xp.ws_count = (int*)(m.xws + ((((size_t)B2 * 4 * C * 8) + 255) & ~(size_t)255));
+                    if (++m.xepoch == 0u) m.xepoch = 1u;                 // unique per launch, never 0
+                    xp.epoch = m.xepoch; xp.no_split = c->deterministic ? 1 : 0;
                     if (ln3_fused) { xp.ln3_g = o.w<float>(b.ln3g); xp.ln3_b = o.w<float>(b.ln3b); xp.ln3_out = ln; }
                     o.check(launch_rarm_xattn_decode(xp, c->stream), "rarm fused cross attention");
                 }
@@ -2228,6 +2239,22 @@ int rdm_prof_dump(rdm_ctx* c, const char* path) {
         fprintf(f, "%d,%s,%d,%d,%d,%.6f,%.6e\n", r.kind, r.tag ? r.tag : "", r.d0, r.d1, r.d2, e, r.flops);
     }
     fclose(f);
+    return 0;
+}
+int rdm_debug_counter(rdm_ctx* c, int which, unsigned long long* value) {
+    RDM_ENTER(c);
+    if (!value) return c->fail(-1, "rdm_debug_counter: null argument");
+    RDM_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    if (which == 0) { *value = rarm_xsplit_stale_count(); return 0; }
+    return c->fail(-2, "rdm_debug_counter: unknown counter %d", which);
+}
+// Box calibration (calib.hip): fixed probes, independent of every product kernel.  buf: caller's device scratch.
+int rdm_calib_probe(rdm_ctx* c, void* buf, size_t buf_bytes, double mfma_ms, size_t stream_bytes, int stream_reps, double* mfma_tflops, double* stream_gbps) {
+    RDM_ENTER(c);
+    if (!buf || buf_bytes < (1u << 20) || buf_bytes < 2 * stream_bytes || stream_bytes % 16 || stream_reps < 1 || !(mfma_ms > 0))
+        return c->fail(-2, "rdm_calib_probe: buf must hold max(1 MiB, 2 * stream_bytes), stream_bytes a multiple of 16, stream_reps >= 1, mfma_ms > 0");
+    RDM_CHECK_HIP(c, hipStreamSynchronize(c->stream));
+    RDM_CHECK_HIP(c, run_calib_probes(buf, mfma_ms, stream_bytes, stream_reps, mfma_tflops, stream_gbps, c->stream));
     return 0;
 }
 int rdm_prof_reset(rdm_ctx* c) {

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(1024) void rarm_xattn_decode_kernel(RarmXattnParams
 // that owns a QUARTER of the heads needs only their rows of G and UT (74 KB): scores, softmax and the partial output row of its
 // heads; the four partial rows meet in global memory -- written through to the coherence point (agent-scope stores), one
 // agent-scope arrival counter per sequence -- and the block that arrives last adds them IN BLOCK ORDER to bias and residual
-// (deterministic), and re-arms the counter.  heads % 4 == 0.
+// (deterministic).  heads % 4 == 0.
 // LayerNorm of one row held as channels tid + 256 i (i < 4) by a 256-thread block, rounded to bf16 (every thread calls it)
 __device__ __forceinline__ void rarm_emit_ln4(const float (&xv)[4], int tid, int C, const float* g, const float* bta, float eps, bf16_t* y, float* red) {
     const int lane = tid & 63, w = tid >> 6;
@@ -383,16 +383,24 @@ __device__ __forceinline__ void rarm_emit_ln4(const float (&xv)[4], int tid, int
 #pragma unroll
     for (int i = 0; i < 4; i++) { const int c = tid + 256 * i; if (c < C) y[c] = f2bf((xv[i] - mean) * rstd * g[c] + bta[c]); }
 }
-// MEMORY-MODEL NOTE (the hand-over of the partial rows between the four blocks of a sequence): the partial rows are written with
-// agent-scope RELAXED atomic stores and the arrival counter is a RELAXED agent-scope RMW -- there is no release / acquire edge in the
-// C++ memory model.  What orders them is gfx950 hardware behaviour: agent-scope atomic stores are write-through (sc1) past the
-// per-XCD L2s to the coherence point, `s_waitcnt vmcnt(0)` + the workgroup barrier make every thread's stores COMPLETE before thread 0
-// arrives, and the last arriver's agent-scope atomic loads bypass its own L2.  (A release fence here is a whole-L2 write-back on this
-// multi-die part: 31 us per launch instead of 16.)  This is therefore a gfx950-only kernel: the build refuses any other target; it is
-// OPT-IN (launch_rarm_xattn_decode), and tests/test_gpu_rarm.py::test_rarm_decode_repeats_bitwise counts its repeat mismatches beside the default form's.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
-#error "rarm_xattn_decode_split_kernel relies on gfx950's agent-scope write-through stores (see the note above)"
-#endif
+// HAND-OVER OF THE PARTIAL ROWS (round 6: self-validating granules instead of an ordering assumption).  Round 4's form wrote the partial
+// rows with agent-scope write-through stores, drained them (vmcnt(0) + workgroup barrier), arrived on a relaxed agent-scope counter, and the
+// last arriver read the rows back with agent-scope loads: correct only if "store completed" means "visible to every other XCD" -- gfx950
+// behaviour outside the C++ memory model, and round 5's stress test saw ONE bitwise mismatch in ~6 800 repeated decodes (~2.9 M launches)
+// whose only possible source was this hand-over (everything else in the step is block-local): a last arriver reading one partial value of
+// the PREVIOUS layer, which sits in the same buffer.  Now every value travels as ONE naturally aligned 8-byte granule {fp32 bits, tag},
+// tag = this launch's epoch (host-incremented per launch, never 0; the buffer is zeroed when it is allocated), written by ONE agent-scope
+// 8-byte store.  The last arriver checks the tag of every granule it reads and re-reads (agent-scope load, bounded spin) until the tag
+// is this launch's: a value of an earlier launch can no longer be consumed, whatever the visibility delay -- no release / acquire edge and
+// no assumption about write-through completion is needed, on any target.  Re-reads are counted (g_rarm_xsplit_stale, rdm_debug_counter(0)):
+// tools/rarm_stress.py reports them, a non-zero count is the round-5 mismatch caught in the act.  The arrival counter is monotonic
+// (last = every fourth arrival), nothing is re-armed.
+__device__ unsigned long long g_rarm_xsplit_stale = 0ull;
+unsigned long long rarm_xsplit_stale_count() {
+    unsigned long long v = 0ull;
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_rarm_xsplit_stale), sizeof(v));
+    return v;
+}
 __global__ __launch_bounds__(256) void rarm_xattn_decode_split_kernel(RarmXattnParams p) {
     __shared__ float xn[1024];
     __shared__ float sc[32];
@@ -483,7 +491,8 @@ __global__ __launch_bounds__(256) void rarm_xattn_decode_split_kernel(RarmXattnP
     if (tid < nr) sc[tid] = pr;
     __syncthreads();
     // ---- partial output row of this block's heads: thread = 4 channels over the nr rows requested above
-    float* const pw = p.ws + ((long long)b * 4 + q) * C;
+    unsigned long long* const pw = (unsigned long long*)p.ws + ((long long)b * 4 + q) * C;
+    const unsigned long long etag = (unsigned long long)p.epoch << 32;
     if (tid < nc4) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -492,47 +501,58 @@ __global__ __launch_bounds__(256) void rarm_xattn_decode_split_kernel(RarmXattnP
             a0 += pj * __uint_as_float(u[i].x << 16); a1 += pj * __uint_as_float(u[i].x & 0xffff0000u);
             a2 += pj * __uint_as_float(u[i].y << 16); a3 += pj * __uint_as_float(u[i].y & 0xffff0000u);
         }
-        __hip_atomic_store(pw + tid * 4 + 0, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(pw + tid * 4 + 1, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(pw + tid * 4 + 2, a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(pw + tid * 4 + 3, a3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pw + tid * 4 + 0, etag | __float_as_uint(a0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pw + tid * 4 + 1, etag | __float_as_uint(a1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pw + tid * 4 + 2, etag | __float_as_uint(a2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pw + tid * 4 + 3, etag | __float_as_uint(a3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // Every thread's partial stores are agent-scope write-through stores (sc1): once they have COMPLETED (vmcnt) they sit at the coherence
-    // point, so no cache-wide fence is needed -- an agent-scope release fence here is a write-back of the whole L2 (buffer_wbl2), and with
-    // the K/V caches of 18 layers dirty in it that made the launch 31 us instead of 16.  Then ONE relaxed agent-scope arrival per block;
-    // the last arriver reads the four rows with agent-scope (sc1) loads, which cannot hit a stale L2 copy of an earlier layer's rows.
+    // Drain this block's granule stores, then ONE relaxed agent-scope arrival per block (monotonic counter: every fourth arrival is a
+    // sequence's last).  The drain makes the common case -- granules visible before the arrival -- the only case seen so far; the tag check
+    // below is what makes the uncommon one harmless.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_last = __hip_atomic_fetch_add(p.ws_count + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3 ? 1 : 0;
+    if (tid == 0) s_last = ((__hip_atomic_fetch_add(p.ws_count + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 3) == 3) ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
-    const float* const pb = p.ws + (long long)b * 4 * C;
+    const unsigned long long* const pb = (const unsigned long long*)p.ws + (long long)b * 4 * C;
+    auto granule = [&](const unsigned long long* g) -> float {
+        unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) != p.epoch) {              // a value of an earlier launch: not yet this launch's -- count it, wait for ours
+            atomicAdd(&g_rarm_xsplit_stale, 1ull);
+            for (int spin = 0; spin < (1 << 24) && (unsigned)(v >> 32) != p.epoch; spin++) {
+                __builtin_amdgcn_s_sleep(2);
+                v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if ((unsigned)(v >> 32) != p.epoch) return __uint_as_float(0x7fc00000u);      // never arrived (cannot happen: all four blocks have): poison, do not guess
+        }
+        return __uint_as_float((unsigned)v);
+    };
     float xv[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int c = tid + 256 * i;
         xv[i] = 0.f;
         if (c < C) {
-            const float t0 = __hip_atomic_load(pb + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), t1 = __hip_atomic_load(pb + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float t2 = __hip_atomic_load(pb + 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), t3 = __hip_atomic_load(pb + 3 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float t0 = granule(pb + c), t1 = granule(pb + C + c), t2 = granule(pb + 2 * C + c), t3 = granule(pb + 3 * C + c);
             xv[i] = xr[c] + (p.bias[c] + ((t0 + t1) + (t2 + t3)));
             xr[c] = xv[i];
         }
     }
-    if (tid == 0) __hip_atomic_store(p.ws_count + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next layer's launch
     // the last arriver holds the finished row: norm3 of the feed-forward that follows leaves with it (bf16 GEMM operand)
     if (p.ln3_out) rarm_emit_ln4(xv, tid, C, p.ln3_g, p.ln3_b, p.ln_eps, p.ln3_out + (long long)b * C, red);
 }
+#ifndef RARM_XSPLIT_DEFAULT
+#define RARM_XSPLIT_DEFAULT 0
+#endif
 hipError_t launch_rarm_xattn_decode(const RarmXattnParams& p, hipStream_t st) {
     if (p.C % 8 || p.C > 1024 || p.heads * p.k > 128 || p.heads * p.k > p.NP || p.k < 1) return hipErrorInvalidValue;
-    // The four-blocks-per-sequence form is OPT-IN since round 5 (RDM_RARM_XSPLIT=1): it is worth 1 us of a 16 us launch (~1.5 % of a token step at
-    // <= 128 sequences) and its hand-over leans on gfx950 cache behaviour outside the C++ memory model (note above); the round's stress test
-    // saw ONE bitwise mismatch in ~6 800 repeated decodes (repeat 28 of a run inside the full GPU suite; never reproduced in isolation, with
-    // cache perturbation or under load) that no other kernel of the step can explain -- everything else is block-local.  The one-block form
-    // below has no cross-block traffic at all.
-    static const int split_on = getenv("RDM_RARM_XSPLIT") ? atoi(getenv("RDM_RARM_XSPLIT")) : 0;
+    // The four-blocks-per-sequence form (worth 1 us of a 16 us launch: ~1.5-3 % of a token step at <= 128 sequences).  Round 5 made it opt-in
+    // after one unexplained bitwise mismatch in ~6 800 repeated decodes; round 6 replaced the hand-over's ordering assumption by
+    // self-validating granules (note above) and stress-ran both forms (profiles/r06_rarm_stress.log).  RDM_RARM_XSPLIT=0 / 1 overrides
+    // the default.  Never in deterministic mode (p.no_split: the choice follows the batch; the two forms add the heads in different orders).
+    static const int split_on = getenv("RDM_RARM_XSPLIT") ? atoi(getenv("RDM_RARM_XSPLIT")) : RARM_XSPLIT_DEFAULT;
     // (from 128 sequences on the one-block form already fills the chip: measured equal at 256)
-    if (split_on && p.ws && p.ws_count && p.B2 <= 128 && p.heads % 4 == 0 && (p.heads / 4) * p.k <= 32 && p.C % 4 == 0) {
+    if (split_on && !p.no_split && p.epoch && p.ws && p.ws_count && p.B2 <= 128 && p.heads % 4 == 0 && (p.heads / 4) * p.k <= 32 && p.C % 4 == 0) {
         rarm_xattn_decode_split_kernel<<<p.B2 * 4, 256, 0, st>>>(p);
         return hipGetLastError();
     }

@@ -308,7 +308,7 @@ static hipError_t launch_nf(const SgemmParams& p, hipStream_t st) {
         // (10.8 us per layer) come back as + 26 us of GEMM.  Off.
         static const int ln8_from = getenv("RDM_SGEMM_LN8_FROM") ? atoi(getenv("RDM_SGEMM_LN8_FROM")) : 0;
         if constexpr (!GEGLU) {
-            if (ln8_from > 0 && p.M >= ln8_from && p.K == 768)
+            if (!p.fixed_split && ln8_from > 0 && p.M >= ln8_from && p.K == 768)
                 return launch_one<4, N2, false, 3, true, 8>(p, st);      // (64 x 64 outputs: 41 registers over the budget of an eight-wave block)
         }
         pick_tile<GEGLU, true>(p, ma, nb);
@@ -320,7 +320,7 @@ static hipError_t launch_nf(const SgemmParams& p, hipStream_t st) {
         // as 64 x 64 tiles it is 288 blocks of 128 KB LDS each, one per CU: two rounds).  RDM_SGEMM_N96=0: off
         static const int n96 = getenv("RDM_SGEMM_N96") ? atoi(getenv("RDM_SGEMM_N96")) : 1;
         static const int nw8_off2 = getenv("RDM_SGEMM_NW4") ? atoi(getenv("RDM_SGEMM_NW4")) : 0;
-        if (n96 && !nw8_off2 && p.M >= 384 && p.N % 96 == 0 && p.N >= 1536 && p.K == 768) {
+        if (!p.fixed_split && n96 && !nw8_off2 && p.M >= 384 && p.N % 96 == 0 && p.N >= 1536 && p.K == 768) {
             const long long b64 = (long long)((p.M + 63) / 64) * (p.N / 64), b96 = (long long)((p.M + 63) / 64) * (p.N / 96);
             if ((b64 + 255) / 256 > (b96 + 255) / 256) return launch_one<4, 6, false, 3, false, 8>(p, st);
         }
@@ -330,7 +330,7 @@ static hipError_t launch_nf(const SgemmParams& p, hipStream_t st) {
         if constexpr (GEGLU) return launch_one<4, N3, true, 2>(p, st);
         else {
             static const int nw8_off = getenv("RDM_SGEMM_NW4") ? atoi(getenv("RDM_SGEMM_NW4")) : 0;
-            if (!nw8_off && p.M >= 384 && (p.K >> 3) % 96 == 0) return launch_one<4, N3, false, 3, false, 8>(p, st);      // eight waves: K / 8 in batches of three k-steps
+            if (!p.fixed_split && !nw8_off && p.M >= 384 && (p.K >> 3) % 96 == 0) return launch_one<4, N3, false, 3, false, 8>(p, st);      // eight waves: K / 8 in batches of three k-steps
             return ((p.K >> 2) % 96) == 0 ? launch_one<4, N3, false, 3>(p, st) : launch_one<4, N3, false, 2>(p, st);
         }
     }
@@ -349,8 +349,8 @@ static hipError_t launch_nf(const SgemmParams& p, hipStream_t st) {
             if constexpr (!GEGLU) {
                 // deep K (3072: a wave's share is 12 k-steps): six per batch of loads = two dependent round trips instead of four (RDM_SGEMM_U6=0: three)
                 static const int u6 = getenv("RDM_SGEMM_U6") ? atoi(getenv("RDM_SGEMM_U6")) : 1;
-                if (!nw8_off && u6 && p.M >= 384 && (p.K >> 3) % 192 == 0) return launch_one<4, N2, false, 6, false, 8>(p, st);
-                if (!nw8_off && p.M >= 384 && (p.K >> 3) % 96 == 0) return launch_one<4, N2, false, 3, false, 8>(p, st);
+                if (!p.fixed_split && !nw8_off && u6 && p.M >= 384 && (p.K >> 3) % 192 == 0) return launch_one<4, N2, false, 6, false, 8>(p, st);
+                if (!p.fixed_split && !nw8_off && p.M >= 384 && (p.K >> 3) % 96 == 0) return launch_one<4, N2, false, 3, false, 8>(p, st);
             }      // (same box: 512 rows 511.6 -> 519.5 img/s, 256 rows 407.8 -> 404.3: from 384 rows on)
             return deep ? launch_one<4, N2, GEGLU, 6>(p, st) : launch_one<4, N2, GEGLU, 2>(p, st);
         }

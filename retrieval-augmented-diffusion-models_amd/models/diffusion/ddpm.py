@@ -140,9 +140,14 @@ class MinimalRETRODiffusion(object):
         every rank searches its rows for the whole query batch and the per-rank top-k lists are merged in one exchange."""
         self.distributed, self._group = bool(enabled), group
         self.shard_db = bool(shard_db) and self.distributed
-        # on an RCCL group the image all-gather goes through the library's own communicator (C ABI rdm_comm_all_gather)
-        self._lib_comm = bool(self.distributed and self._ctx is not None and hasattr(self._ctx, "comm_init")
-                              and parallel.attach_library_comm(self._ctx, group))
+        # on an RCCL group the image all-gather goes through the library's own communicator (C ABI rdm_comm_all_gather).  Whether the
+        # hand-shake runs must be the same decision on every rank (it issues collectives): it follows the GROUP's backend, and a context
+        # that is still lazy is created for it -- a rank that skipped the hand-shake because its context did not exist yet would leave the
+        # other ranks' broadcast / all-reduce unmatched (advisor, round 5)
+        import torch.distributed as dist
+        rccl = bool(self.distributed and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl")
+        c = self.ctx if rccl else self._ctx
+        self._lib_comm = bool(rccl and c is not None and hasattr(c, "comm_init") and parallel.attach_library_comm(c, group))
         if self.retriever is not None and hasattr(self.retriever, "shard_rows") and \
                 bool(getattr(self.retriever, "_shard_rows", False)) != self.shard_db:
             self.retriever.shard_rows(self.shard_db, group)          # takes effect at the next train_searcher()

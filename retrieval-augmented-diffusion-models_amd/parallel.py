@@ -114,13 +114,22 @@ def per_sample_noise(seed: int, global_indices, shape, device="cpu", dtype=torch
     return torch.stack(out)
 
 
+_abandoned_comm_contexts = []     # communicator contexts whose hand-shake timed out: kept alive (a helper thread may still be inside them), never used again
+
+
 def attach_library_comm(ctx, group=None) -> bool:
-    """Give the library context its own RCCL communicator over the ranks of the torch process group (C ABI: rdm_comm_unique_id on
-    rank 0 -> broadcast of the 128-byte id over the torch group -> rdm_comm_init on every rank), so that the data path's one
-    collective -- the all-gather of the finished images -- is `rdm_comm_all_gather` on the library's stream (`all_gather_images(...,
-    ctx=ctx)`).  Only for an RCCL ("nccl") group with one device per rank; on gloo (CPU tests, several ranks sharing one GPU: RCCL
-    refuses two ranks on one device) nothing is created.  -> True when the communicator exists.  A failure to create it is NOT fatal:
-    the torch.distributed collective stays in use (and the caller can report which one ran)."""
+    """Give the library its own RCCL communicator over the ranks of the torch process group (C ABI: rdm_comm_unique_id on rank 0 ->
+    broadcast of the 128-byte id over the torch group -> rdm_comm_init on every rank), so that the data path's one collective -- the
+    all-gather of the finished images -- is `rdm_comm_all_gather` (`all_gather_images(..., ctx=ctx)`).  Only for an RCCL ("nccl") group
+    with one device per rank; on gloo (CPU tests, several ranks sharing one GPU: RCCL refuses two ranks on one device) nothing is created.
+    -> True when the communicator exists ON EVERY RANK.  A failure to create it is NOT fatal: the torch.distributed collective stays in
+    use (and the caller can report which one ran).
+
+    The communicator lives on a DEDICATED sibling context (`ctx.new_comm_context()`: same device, its own non-blocking side stream),
+    stored as `ctx.lib_comm` on success.  The rendezvous and a known-answer probe gather run in a helper thread with a deadline
+    (RDM_LIB_COMM_TIMEOUT seconds, default 120): a rendezvous that never completes costs this path, not the run -- the product context is
+    never touched by the helper, nothing is ever enqueued on the product's stream, and a sibling whose hand-shake did not finish is
+    abandoned (kept referenced, never closed, never used)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1 or dist.get_backend(group) != "nccl":
         return False
     if os.environ.get("RDM_NO_LIB_COMM", "0") not in ("", "0"):          # torch.distributed's collective only
@@ -130,34 +139,39 @@ def attach_library_comm(ctx, group=None) -> bool:
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     ok = torch.ones(1, dtype=torch.int32, device=ctx.device)
     uid = torch.zeros(128, dtype=torch.uint8, device=ctx.device)
-    if rank == 0:
-        try:
-            uid = torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8).to(ctx.device)
-        except Exception:
-            ok.zero_()
+    cctx = None
+    try:
+        cctx = ctx.new_comm_context() if hasattr(ctx, "new_comm_context") else ctx
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(cctx.comm_unique_id()), dtype=torch.uint8).to(ctx.device)
+    except Exception:
+        ok.zero_()
     dist.broadcast(uid, src=0, group=group)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
     if int(ok.item()) == 0:
+        if cctx is not None and cctx is not ctx and hasattr(cctx, "close"):
+            cctx.close()
         return False
     uid_bytes = bytes(uid.cpu().numpy().tobytes())
     result = {"ok": False}
 
     def _init_and_probe():
         try:
-            ctx.comm_init(uid_bytes, rank, world)
+            cctx.comm_init(uid_bytes, rank, world)
             # one known-answer gather before anything depends on it (this path cannot be exercised on the one-GPU build boxes): rank r
             # contributes [r, r + 0.5, r, r + 0.5]; any other result -> the torch.distributed collective stays in use
+            side = getattr(cctx, "_side_stream", None)
             probe = torch.tensor([rank, rank + 0.5, rank, rank + 0.5], dtype=torch.float32, device=ctx.device)
-            got = ctx.comm_all_gather(probe, world)
-            if torch.device(ctx.device).type == "cuda":
-                torch.cuda.synchronize(ctx.device)
             want = torch.arange(world, dtype=torch.float32, device=ctx.device)[:, None] + torch.tensor([0.0, 0.5, 0.0, 0.5], device=ctx.device)
+            if side is not None:
+                torch.cuda.current_stream(ctx.device).synchronize()          # the probe operands exist before the side stream reads them
+            got = cctx.comm_all_gather(probe, world)
+            if side is not None:
+                side.synchronize()
             result["ok"] = got.shape == want.shape and bool(torch.equal(got, want))
         except Exception:
             result["ok"] = False
 
-    # in a helper thread with a deadline: a rendezvous that never completes (a rank that failed before it, a fabric problem) must cost
-    # this path, not the run -- a rank whose helper is still blocked votes "no" below and everybody keeps the torch.distributed collective
     import threading
     th = threading.Thread(target=_init_and_probe, daemon=True)
     th.start()
@@ -166,14 +180,20 @@ def attach_library_comm(ctx, group=None) -> bool:
         ok.zero_()
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)          # all ranks agree on which collective they will call
     if int(ok.item()) == 0:
-        if not th.is_alive():
+        if th.is_alive():
+            _abandoned_comm_contexts.append((cctx, th))             # still inside the rendezvous: never closed, never used
+        else:
             try:
-                ctx.comm_destroy()
+                cctx.comm_destroy()
+                if cctx is not ctx and hasattr(cctx, "close"):
+                    cctx.close()
             except Exception:
                 pass
         ctx.lib_comm_agreed = 0
+        ctx.lib_comm = None
         return False
-    ctx.lib_comm_agreed = world                                     # (not comm_world: a late helper thread must not switch one rank over)
+    ctx.lib_comm = cctx
+    ctx.lib_comm_agreed = world                                     # (set only on the agreed flag: a late helper thread cannot switch one rank over)
     return True
 
 
@@ -191,7 +211,16 @@ def all_gather_images(local: torch.Tensor, n_total: int = None, group=None, ctx=
     counts = [shard_range(n_total, world, r)[1] - shard_range(n_total, world, r)[0] for r in range(world)]
     bmax = max(counts)
     if ctx is not None and local.is_cuda and getattr(ctx, "lib_comm_agreed", 0) == world and all(c == bmax for c in counts):
-        out = ctx.comm_all_gather(local, world)                                  # [world, b, ...]
+        cc = getattr(ctx, "lib_comm", None) or ctx
+        side = getattr(cc, "_side_stream", None)
+        cur = torch.cuda.current_stream(local.device)
+        local = local.contiguous()
+        if side is not None:                                                     # the communicator's side stream: after the producer, before the consumer
+            side.wait_stream(cur)
+        out = cc.comm_all_gather(local, world)                                   # [world, b, ...]
+        if side is not None:
+            local.record_stream(side); out.record_stream(side)
+            cur.wait_stream(side)
         return out.reshape((world * bmax,) + tuple(local.shape[1:]))
     if all(c == bmax for c in counts):
         out = torch.empty((world * bmax,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)

@@ -1,9 +1,9 @@
 """`bench.py --gpus N` end to end BEFORE an 8-GPU node runs it (verdict round 4, item 2): the N > 1 branch of the benchmark -- the
 torchrun self-launch, shard_range / per_sample_noise inputs by GLOBAL row, the all-gather, the max-over-ranks timing, the one JSON
-line of rank 0 -- executed on the box's ONE GPU with 2 and 4 processes over gloo (RDM_DIST_BACKEND=gloo RDM_DIST_DEVICE=0: RCCL
+line of rank 0 -- executed on the box's ONE GPU with 2, 4 and 8 processes over gloo (RDM_DIST_BACKEND=gloo RDM_DIST_DEVICE=0: RCCL
 refuses two ranks on one device, so the collective here is torch.distributed's; on a real multi-GPU node the same code path attaches
 the library's RCCL communicator, `config.collective` says which one ran).  In deterministic (batch-invariant) mode the gathered
-images of a global batch of 8 must be BIT-IDENTICAL for 1 x 8, 2 x 4 and 4 x 2 rows per rank.
+images of a global batch of 8 must be BIT-IDENTICAL for 1 x 8, 2 x 4, 4 x 2 and 8 x 1 rows per rank.
 
 SURVEY.md 8e; /root/reference/scripts/rdm_sample.py:181-185 is single-GPU: everything here is new functionality."""
 import json
@@ -34,7 +34,7 @@ def _run_bench(n, tmp_path, tag, extra=(), port=29700):
     return json.loads(lines[0]), np.load(dump)
 
 
-def test_bench_gpus_2_and_4_on_one_gpu_match_the_single_rank_run(tmp_path):
+def test_bench_gpus_2_4_and_8_on_one_gpu_match_the_single_rank_run(tmp_path):
     """Three runs of the default benchmark command on a shortened workload (global batch 8, 2 DDIM steps, 200 k database rows):
     1 rank x 8 rows; 4 ranks x 2 rows with the fp32 all-gather -> bit-identical images; 2 ranks x 4 rows with `--gather uint8` (the
     collective moves rdm_to_uint8's HWC bytes: 12.6 MB per rank at B = 64 instead of 50 MB) -> equal to the conversion of
@@ -53,13 +53,30 @@ def test_bench_gpus_2_and_4_on_one_gpu_match_the_single_rank_run(tmp_path):
         assert np.isfinite(line["value"]) and line["value"] > 0 and abs(line["value"] - GLOBAL_BATCH / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
         assert line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
 
-    line4, img4 = _run_bench(4, tmp_path, "w4", port=29704)
+    # box calibration (round 6): fixed probes + clock / power sampled through the timed region, and the headline rescaled to the reference box
+    cal = one["calibration"]
+    assert cal["mfma_probe_tflops"] > 100 and cal["hbm_stream_gbps"] > 500, cal
+    assert cal["samples"] == 0 or (cal["sclk_mhz_mean"] > 100 and cal["power_w_mean"] > 10), cal
+    if cal.get("reference"):
+        assert one["value_at_reference_box"] > 0 and abs(one["value_at_reference_box"] / one["value"] - 1.0) < 0.5
+
+    line4, img4 = _run_bench(4, tmp_path, "w4", extra=("--no-calibration",), port=29704)
     check_line(line4, 4)
+    assert "calibration" not in line4
     assert img4.shape == img1.shape and img4.dtype == np.float32
     assert np.array_equal(img4, img1), f"4 ranks: gathered images differ from the 1-rank run (max |d| {np.abs(img4 - img1).max():.3e})"
 
+    # eight ranks x ONE row (verdict round 5, item 7: the rank count of the node the scaling run is defined on): bit-identical again, and the
+    # line carries every rank's own step time beside the max the value is computed from (a straggler is visible)
+    line8, img8 = _run_bench(8, tmp_path, "w8", extra=("--no-calibration",), port=29708)
+    check_line(line8, 8)
+    assert np.array_equal(img8, img1), f"8 ranks: gathered images differ from the 1-rank run (max |d| {np.abs(img8 - img1).max():.3e})"
+    rk = line8["config"]["rank_ms_per_step"]
+    assert len(rk["per_rank"]) == 8 and abs(rk["max"] - line8["ms_per_step"]) < 1e-6 * rk["max"] and 0 < rk["min"] <= rk["max"]
+
     line2, img_u = _run_bench(2, tmp_path, "w2u8", extra=("--gather", "uint8"), port=29702)
     check_line(line2, 2)
+    assert line2["calibration"]["mfma_probe_tflops_min_over_ranks"] > 0 and len(line2["config"]["rank_ms_per_step"]["per_rank"]) == 2
     assert "uint8" in line2["config"]["gathered"] and str(256 * 256 * 3 * (GLOBAL_BATCH // 2)) in line2["config"]["gathered"]
     assert img_u.shape == (GLOBAL_BATCH, 256, 256, 3) and img_u.dtype == np.uint8
     v = np.clip(img1, np.float32(-1), np.float32(1))

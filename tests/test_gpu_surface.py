@@ -753,6 +753,31 @@ def test_deterministic_mode_rows_do_not_depend_on_the_batch(ctx):
     assert rel_l2(f1, f64[5:6]) <= RANK_LATENT_TOL and rel_l2(e64, f64) <= RANK_LATENT_TOL
 
 
+def test_deterministic_mode_rows_across_the_eight_wave_threshold_shipped_unet(ctx):
+    """The same contract for the UNet's one-row-per-sample GEMMs (time-embedding MLP and the 22 emb_layers as one GEMM: K = 768 at the shipped
+    width -- the shape sgemm.hip's eight-wave forms take from 384 rows on; advisor round 5): a sample's eps at UNet batch 400 equals the same
+    sample's eps at batch 3, bit for bit, in deterministic mode.  Shipped topology on 16 x 16 latents (the GEMMs in question do not see the
+    spatial size)."""
+    from rdm_amd import packing
+    spec = ounet.shipped_spec()
+    cfg = spec_to_unet_cfg(spec)
+    ctx.load_unet(cfg, packing.pack("unet", cfg, ounet.synth_state_dict(ounet.param_shapes(spec), seed=1234)))
+    d = ctx.device
+    g = torch.Generator(device=d).manual_seed(5)
+    B = 400
+    x = torch.randn(B, 3, 16, 16, device=d, generator=g); t = torch.randint(0, 1000, (B,), device=d, generator=g)
+    c = torch.randn(B, 4, 512, device=d, generator=g) * 0.45
+    ctx.set_deterministic(True)
+    try:
+        big = ctx.unet_forward(x, t, c)
+        for rows in ([7, 390, 399], [0]):
+            e = ctx.unet_forward(x[rows], t[rows], c[rows])
+            assert torch.equal(e, big[rows]), f"eps of rows {rows} differs between batch {len(rows)} and batch {B} in deterministic mode"
+    finally:
+        ctx.set_deterministic(False)
+        ctx.release_scratch()
+
+
 def _det_rank_worker(rank, world, port, q):
     import os
     os.environ["RDM_DETERMINISTIC"] = "1"

@@ -319,6 +319,9 @@ class _MockCommCtx:
         if self.mode == "hang" and rank == 1:
             import time
             time.sleep(8)                                    # a rendezvous that does not come back within the deadline (3 s here)
+        if self.mode == "forever" and rank == 1:
+            import threading
+            threading.Event().wait()                         # a rendezvous that NEVER comes back
         if self.mode == "raise" and rank == 0:
             raise RuntimeError("no communicator")
         self.comm_world = world
@@ -336,6 +339,66 @@ class _MockCommCtx:
         self.destroyed = True; self.comm_world = 0
 
 
+class _MockProductCtx:
+    """The PRODUCT context of the hand-shake: hands out a dedicated sibling for the communicator (as _lib.Context.new_comm_context does) and
+    must never be asked for communicator work itself (advisor, round 5: the helper thread must not share the product context)."""
+    device = "cpu"
+
+    def __init__(self, mode, rank, grp):
+        self.args, self.sibling = (mode, rank, grp), None
+
+    def new_comm_context(self):
+        self.sibling = _MockCommCtx(*self.args)
+        return self.sibling
+
+    def comm_unique_id(self): raise AssertionError("the product context was asked for communicator work")
+    comm_init = comm_all_gather = comm_destroy = comm_unique_id
+
+
+def _worker_lib_comm_never_returns(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      RDM_LIB_COMM_TIMEOUT="1")
+    import time
+    from rdm_amd import parallel
+    import torch.distributed as dist
+    parallel.init_distributed("gloo")
+    ctx = _MockProductCtx("forever", rank, dist.new_group(backend="gloo"))
+    real = dist.get_backend
+    dist.get_backend = lambda g=None: "nccl"
+    t0 = time.time()
+    try:
+        got = parallel.attach_library_comm(ctx)
+    finally:
+        dist.get_backend = real
+    t_attach = time.time() - t0
+    # every rank is on the torch.distributed collective: the gather still works, through torch
+    out = parallel.all_gather_images(torch.full((2, 3), float(rank)), 4, ctx=ctx)
+    t0 = time.time()
+    parallel.shutdown()
+    q.put((rank, got, getattr(ctx, "lib_comm_agreed", None), getattr(ctx, "lib_comm", "unset"), len(parallel._abandoned_comm_contexts), t_attach,
+           time.time() - t0, out[:, 0].tolist()))
+
+
+def test_library_comm_rendezvous_that_never_returns_world2_gloo():
+    """Verdict round 5, item 7: `comm_init` NEVER returns on one rank (RDM_LIB_COMM_TIMEOUT=1).  Every rank must come out on the
+    torch.distributed collective within the deadline, the stuck communicator context is abandoned (kept, not closed, not used), the product
+    context is never used for communicator work, the gather still works through torch, shutdown() returns and the processes exit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_lib_comm_never_returns, args=(r, 2, 29633, q)) for r in range(2)]
+    for p in procs: p.start()
+    got = {r[0]: r[1:] for r in (q.get(timeout=120), q.get(timeout=120))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        ok, agreed, lib_comm, abandoned, t_attach, t_shutdown, col = got[rank]
+        assert ok is False and agreed == 0 and lib_comm is None
+        assert abandoned == 1               # rank 1's helper is still inside the rendezvous, rank 0's inside the probe gather that waits for it
+        assert t_attach < 20 and t_shutdown < 20
+        assert col == [0.0, 0.0, 1.0, 1.0]
+
+
 def _worker_lib_comm(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       RDM_LIB_COMM_TIMEOUT="3")
@@ -347,7 +410,7 @@ def _worker_lib_comm(rank, world, port, q):
     for mode in ("ok", "raise", "wrong", "hang"):
         # (a real library communicator is independent of the torch group; so is the mock's: one fresh gloo group per case, so that a helper
         #  thread still blocked in its probe cannot interleave with the hand-shake's own collectives)
-        ctx = _MockCommCtx(mode, rank, dist.new_group(backend="gloo"))
+        ctx = _MockProductCtx(mode, rank, dist.new_group(backend="gloo"))
         dist.get_backend = lambda g=None: "nccl"             # the hand-shake is for RCCL groups; its own traffic here is CPU tensors over gloo
         try:
             got = parallel.attach_library_comm(ctx)
@@ -356,7 +419,8 @@ def _worker_lib_comm(rank, world, port, q):
             dist.get_backend = real
         res[mode] = (got, again, getattr(ctx, "lib_comm_agreed", None))
         if mode == "ok":                                    # ... and the gather then goes through the context
-            res["gather"] = ctx.comm_all_gather(torch.full((2, 3), float(rank)), world).reshape(4, 3)[:, 0].tolist()
+            assert ctx.lib_comm is ctx.sibling
+            res["gather"] = ctx.lib_comm.comm_all_gather(torch.full((2, 3), float(rank)), world).reshape(4, 3)[:, 0].tolist()
     import time
     time.sleep(7)                                            # let the "hang" case's helper threads run out before the group goes away
     q.put((rank, res))
