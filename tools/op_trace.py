@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=4, help="DDIM steps traced (must divide 1000)")
 ap.add_argument("--k", type=int, default=4)
+ap.add_argument("--scale", type=float, default=2.0, help="guidance scale; 1.0 = no CFG (config #4's geometry: UNet batch = --batch)")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "op_trace.csv"))
 a = ap.parse_args()
 torch.set_grad_enabled(False)
@@ -27,12 +28,12 @@ model.load_unet_state_dict(synthetic.unet_state_dict(model.unet_cfg))
 g = torch.Generator(device=ctx.device).manual_seed(0)
 x = torch.randn((a.batch, 3, 64, 64), device=ctx.device, generator=g)
 cond = torch.randn((a.batch, a.k, 512), device=ctx.device, generator=g) * 0.45
-uncond = torch.zeros_like(cond)
-ctx.ddim_sample(a.steps, x, cond, uncond, model.alphas_cumprod, eta=0.0, scale=2.0)          # warm-up (derived weights, arena)
+uncond = torch.zeros_like(cond) if a.scale > 1 else None
+ctx.ddim_sample(a.steps, x, cond, uncond, model.alphas_cumprod, eta=0.0, scale=a.scale)          # warm-up (derived weights, arena)
 torch.cuda.synchronize()
 ctx.prof_reset()
 ctx.prof_enable(tuple(range(7)))
-ctx.ddim_sample(a.steps, x, cond, uncond, model.alphas_cumprod, eta=0.0, scale=2.0)
+ctx.ddim_sample(a.steps, x, cond, uncond, model.alphas_cumprod, eta=0.0, scale=a.scale)
 torch.cuda.synchronize()
 ctx.prof_enable(())
 os.makedirs(os.path.dirname(a.out), exist_ok=True)
