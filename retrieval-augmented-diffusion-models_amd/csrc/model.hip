@@ -482,6 +482,8 @@ static void build_rarm(RarmModel& m, const rdm_rarm_cfg& c, Manifest& mf) {
 // ------------------------------------------------------------------------------------ context
 struct rdm_ctx {
     int device = 0; hipStream_t stream = nullptr; char err[512] = {0};
+    // side stream for work that is independent of the main chain (the ResBlocks' skip_connection GEMM, round 6): forked / joined by events
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; hipStream_t side_saved = nullptr;
     void* zero_page = nullptr; float* eye3 = nullptr;
     UNet unet; VqModel vq; VqEncModel vqenc; ClipModel clip; RarmModel rarm; KnnDb db;
     float* gn_partial = nullptr; size_t gn_partial_bytes = 0;
@@ -604,6 +606,30 @@ struct Ops {
     void check(hipError_t e, const char* what) {
         if (e != hipSuccess && rc == 0) rc = c->fail(-3, "%s: %s", what, hipGetErrorString(e));
     }
+    // ---- side stream (round 6).  A ResBlock's skip_connection 1x1 conv depends on the block's INPUT only, while the main chain runs
+    // GroupNorm -> conv1 -> GroupNorm before conv2 consumes it as the residual.  Issued on a second (non-blocking) stream at the top of the
+    // block it fills the CUs the persistent conv kernels leave idle in their last, partial round of tiles (16 x 16 level: 384 tiles on
+    // 256 CUs) instead of taking its own slot in the serial chain.  Same kernels, same arithmetic: only the issue order changes.
+    // RDM_SKIP_OVERLAP=0: off.  side_begin(): launches that follow go to the side stream (ordered after everything issued so far).
+    bool side_begin() {
+        static const int on = getenv("RDM_SKIP_OVERLAP") ? atoi(getenv("RDM_SKIP_OVERLAP")) : 1;
+        if (plan || !on) return false;
+        if (!c->side) {
+            if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = nullptr; return false; }
+            if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+                (void)hipStreamDestroy(c->side); c->side = nullptr; return false;
+            }
+        }
+        check(hipEventRecord(c->ev_fork, c->stream), "side stream fork");
+        check(hipStreamWaitEvent(c->side, c->ev_fork, 0), "side stream fork");
+        c->side_saved = c->stream; c->stream = c->side;
+        return true;
+    }
+    void side_end() {                                           // back to the main stream; the side work is still in flight
+        check(hipEventRecord(c->ev_join, c->stream), "side stream join");
+        c->stream = c->side_saved;
+    }
+    void side_join() { check(hipStreamWaitEvent(c->stream, c->ev_join, 0), "side stream join"); }     // main stream: wait for the side work
     IgemmParams base(int M, int N, int K) {
         IgemmParams p{}; p.M = M; p.N = N; p.K = K; p.alpha = 1.f; p.ldo = N; p.zero_page = c->zero_page;
         p.Hin = p.Win = p.Hout = p.Wout = 1; p.stride = 1; p.rows_per_sample = 1; return p;
@@ -926,6 +952,17 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
             else expand(*skip);
         }
         const bf16_t* x1 = skip ? skip->p : nullptr;
+        // skip_connection first, on the side stream (Ops::side_begin): it needs the block's input only
+        const bf16_t* res = a.p;
+        bf16_t* sk = nullptr; bool forked = false;
+        if (r.skip) {
+            sk = o.abf((size_t)M * r.cout);
+            o.tag = "res.skip";
+            forked = o.side_begin();
+            o.linear(a.p, x1, C0, C1, r.wsk, r.bsk, true, M, r.cout, ACT_NONE, nullptr, sk, nullptr, nullptr, wrap_b * HW);
+            if (forked) o.side_end();
+            res = sk;
+        }
         bf16_t* n1 = o.abf((size_t)M * r.cin);
         o.tag = "res.gn1";
         o.groupnorm(a.p, x1, C0, C1, B, HW, r.gn1g, r.gn1b, 1e-5f, 1, n1, a.L, skip ? skip->L : 0, wrap_b);
@@ -938,14 +975,8 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         o.tag = "res.gn2";
         o.groupnorm(h1, nullptr, r.cout, 0, B, HW, r.gn2g, r.gn2b, 1e-5f, 1, n2, r.lout, 0);
         o.tap(3, n2, (size_t)M * r.cout * 2);
-        const bf16_t* res = a.p;
-        if (r.skip) {
-            bf16_t* s = o.abf((size_t)M * r.cout);
-            o.tag = "res.skip";
-            o.linear(a.p, x1, C0, C1, r.wsk, r.bsk, true, M, r.cout, ACT_NONE, nullptr, s, nullptr, nullptr, wrap_b * HW);
-            o.tap(4, s, (size_t)M * r.cout * 2);
-            res = s;
-        }
+        if (forked) o.side_join();
+        if (r.skip) o.tap(4, sk, (size_t)M * r.cout * 2);
         bf16_t* out = o.abf((size_t)Bfull * HW * r.cout);           // Bfull: see expand()
         o.tag = "res.conv2";
         o.conv3(n2, nullptr, r.cout, 0, r.w2, r.b2, B, a.H, a.W, r.cout, 1, 0, nullptr, 0, res, out);
@@ -1485,6 +1516,7 @@ void rdm_ctx_destroy(rdm_ctx* c) {
     if (c->comm) rdm_comm_destroy(c);
     DevGuard guard(c->device);
     hipDeviceSynchronize();
+    if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); }
     void* ptrs[] = {c->zero_page, c->unet.blob, c->unet.arena.base, c->unet.kv_cache, c->vq.blob, c->vq.arena.base,
                     c->clip.blob, c->clip.arena.base, c->gn_partial, c->samp, c->splitk_ws, c->unet.xa_cache,
                     c->rarm.blob, c->rarm.arena.base, c->rarm.cache, c->rarm.ctxkv, c->rarm.state, c->rarm.xa, c->rarm.xws, c->wfrag_tmp, c->bwd_tmp,

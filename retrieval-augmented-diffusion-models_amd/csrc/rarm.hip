@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void rarm_xattn_decode_split_kernel(RarmXattnP
     if (p.ln3_out) rarm_emit_ln4(xv, tid, C, p.ln3_g, p.ln3_b, p.ln_eps, p.ln3_out + (long long)b * C, red);
 }
 #ifndef RARM_XSPLIT_DEFAULT
-#define RARM_XSPLIT_DEFAULT 0
+#define RARM_XSPLIT_DEFAULT 1
 #endif
 hipError_t launch_rarm_xattn_decode(const RarmXattnParams& p, hipStream_t st) {
     if (p.C % 8 || p.C > 1024 || p.heads * p.k > 128 || p.heads * p.k > p.NP || p.k < 1) return hipErrorInvalidValue;

@@ -57,7 +57,7 @@ def test_bench_gpus_2_4_and_8_on_one_gpu_match_the_single_rank_run(tmp_path):
     cal = one["calibration"]
     assert cal["mfma_probe_tflops"] > 100 and cal["hbm_stream_gbps"] > 500, cal
     assert cal["samples"] == 0 or (cal["sclk_mhz_mean"] > 100 and cal["power_w_mean"] > 10), cal
-    if cal.get("reference"):
+    if cal.get("reference") and cal.get("sclk_mhz_mean"):
         assert one["value_at_reference_box"] > 0 and abs(one["value_at_reference_box"] / one["value"] - 1.0) < 0.5
 
     line4, img4 = _run_bench(4, tmp_path, "w4", extra=("--no-calibration",), port=29704)
