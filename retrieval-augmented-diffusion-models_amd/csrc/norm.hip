@@ -265,14 +265,14 @@ static bool gn_onepass_plan(const GnParams& p, int& gpb, int& T, int& nv) {
         for (int t : {256, 512, 1024}) {
             if (VS > t) continue;
             const int R = t / VS, n = (p.HW + R - 1) / R;
-            // (1024 threads: 128 registers each; 512 threads: 256 each -- RDM_GN1PASS_NV512=48 admits 48 vectors per thread there: the 64 x 64
+            // (1024 threads: 128 registers each; 512 threads: 256 each -- RDM_GN1PASS_NV512=52 admits 52 vectors per thread there: the 64 x 64
             //  level's 8-group slices of 192 / 384-channel tensors, 96-byte row segments, with RDM_GN1PASS_MAXHW=4096; round 6 experiment)
             static const int nv512 = getenv("RDM_GN1PASS_NV512") ? atoi(getenv("RDM_GN1PASS_NV512")) : 32;
             if (n <= (t == 1024 ? 16 : t == 512 ? nv512 : 32)) { t_ok = t; n_ok = n; break; }
         }
         if (!t_ok) continue;
         const long long el = (long long)g * cg * p.HW, dist = el > want ? el - want : want - el;
-        if (best_d < 0 || dist < best_d) { best_d = dist; gpb = g; T = t_ok; nv = n_ok <= 4 ? 4 : n_ok <= 8 ? 8 : n_ok <= 16 ? 16 : n_ok <= 32 ? 32 : 48; }
+        if (best_d < 0 || dist < best_d) { best_d = dist; gpb = g; T = t_ok; nv = n_ok <= 4 ? 4 : n_ok <= 8 ? 8 : n_ok <= 16 ? 16 : n_ok <= 32 ? 32 : 52; }
     }
     return best_d >= 0;
 }
@@ -304,7 +304,7 @@ static hipError_t launch_gn_onepass(const GnParams& p, int gpb, int T, int nv, h
         case 8: return by_t(std::integral_constant<int, 8>{});
         case 16: return by_t(std::integral_constant<int, 16>{});
         case 32: return by_t(std::integral_constant<int, 32>{});
-        default: return T == 512 ? go(std::integral_constant<int, 48>{}, std::integral_constant<int, 512>{}) : hipErrorInvalidValue;
+        default: return T == 512 ? go(std::integral_constant<int, 52>{}, std::integral_constant<int, 512>{}) : hipErrorInvalidValue;
     }
 }
 
