@@ -620,7 +620,7 @@ static hipError_t launch_halo4_cfg(const IgemmParams& p, hipStream_t st) {
     const int ncu = ncu_dev[dev];
     const long long ntiles = (long long)(p.M / 256) * (p.N / BN) * (p.ksplit > 1 ? p.ksplit : 1);
     long long g = (ncu + 7) & ~7;
-    if (g > ntiles) g = ntiles;
+    if (g > ntiles || p.one_item_per_block) g = ntiles;
     static const int prof = getenv("RDM_HALO_PROF") ? atoi(getenv("RDM_HALO_PROF")) : 0;
     if (prof) {
         IgemmParams q = p; q.dbg |= 16;

@@ -610,12 +610,13 @@ struct Ops {
     // GroupNorm -> conv1 -> GroupNorm before conv2 consumes it as the residual.  Issued on a second (non-blocking) stream at the top of the
     // block it fills the CUs the persistent conv kernels leave idle in their last, partial round of tiles (16 x 16 level: 384 tiles on
     // 256 CUs) instead of taking its own slot in the serial chain.  Same kernels, same arithmetic: only the issue order changes.
-    // RDM_SKIP_OVERLAP=0: off.  side_begin(): launches that follow go to the side stream (ordered after everything issued so far).
+    // RDM_SKIP_OVERLAP=0: off (resblock).  side_begin(): launches that follow go to the side stream (ordered after everything issued so far).
     bool side_begin() {
-        static const int on = getenv("RDM_SKIP_OVERLAP") ? atoi(getenv("RDM_SKIP_OVERLAP")) : 1;
-        if (plan || !on) return false;
+        if (plan) return false;
         if (!c->side) {
-            if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = nullptr; return false; }
+            int pr_lo = 0, pr_hi = 0;                          // lowest priority: side work fills what the main chain leaves idle, it never goes first
+            (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
+            if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, pr_lo) != hipSuccess) { c->side = nullptr; return false; }
             if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
                 (void)hipStreamDestroy(c->side); c->side = nullptr; return false;
             }
@@ -625,6 +626,14 @@ struct Ops {
         c->side_saved = c->stream; c->stream = c->side;
         return true;
     }
+    // the same in two steps: side_fork() marks the point on the main stream the side work depends on (more main-stream launches may follow
+    // BEFORE the side work is issued: they are then ahead of it in the hardware queues), side_enter() switches to the side stream
+    bool side_fork() {
+        if (!side_begin()) return false;
+        c->stream = c->side_saved;
+        return true;
+    }
+    void side_enter() { c->side_saved = c->stream; c->stream = c->side; }
     void side_end() {                                           // back to the main stream; the side work is still in flight
         check(hipEventRecord(c->ev_join, c->stream), "side stream join");
         c->stream = c->side_saved;
@@ -775,8 +784,56 @@ struct Ops {
         if (ks > 1 && ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)ks * p.M * N * 4) == 0) { p.ksplit = ks; p.ws = (float*)c->splitk_ws; }
         if (!det_generic && (conv_halo_supported(p) || conv_halo4_strip_supported(p))) p.Wfrag = c->frag_for(p.W, N, C0 + C1);
         prof_begin(RDM_PROF_CONV3X3, 2.0 * p.M * N * (double)p.K, p.M, N, p.K);
+        if (!det_generic && conv_tail_split(p)) { prof_end(); return; }
         check(det_generic ? launch_igemm(p, true, 1, c->stream) : launch_conv3x3(p, c->stream), "conv3x3");
         prof_end();
+    }
+    // ---- wave quantisation of the persistent halo kernel (round 6).  A conv whose tile count is q full rounds of the CUs plus a partial
+    // round of r tiles runs q + 1 rounds: the 16 x 16 level of a guided batch of 64 (M = 32768, N = 576: 384 tiles on 256 CUs) spends a
+    // whole second round on 128 tiles.  Here the rows are cut at a sample boundary: the HEAD (whole row tiles filling at most q rounds) runs
+    // as before on the main stream; the TAIL's tiles run as 2-part K-splits -- one part per block, so that the hardware places them on
+    // CUs as they come free -- on the low-priority side stream, CONCURRENTLY: when the head's blocks finish, the remaining half-length
+    // parts fill every CU once.  q + 1 rounds become q + 0.5 (+ the tail's fp32 planes and finisher: a third of the rows).  Same kernels,
+    // existing K-split arithmetic (fp32 partial planes summed in a fixed order, one rounding): the tail rows are computed like every
+    // K-split conv.  Not in deterministic mode (the cut follows the batch).  RDM_CONV_TAIL=0: off.
+    bool conv_tail_split(IgemmParams& p) {
+        static const int on = getenv("RDM_CONV_TAIL") ? atoi(getenv("RDM_CONV_TAIL")) : 1;
+        if (!on || c->deterministic || p.ksplit > 1 || !p.Wfrag || p.stride != 1 || p.ups || p.Wout > 64 || !conv_halo4_supported(p)) return false;
+        static int ncu_dev[RDM_MAX_DEVICES] = {0};
+        const int dev = rdm_cur_device();
+        if (!ncu_dev[dev]) hipDeviceGetAttribute(&ncu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev);
+        const int ncu = ncu_dev[dev], bn = (p.N % 192 == 0) ? 192 : 128, nbn = p.N / bn, mt = p.M / 256;
+        const long long T = (long long)mt * nbn;
+        const int q = (int)(T / ncu), r = (int)(T % ncu);
+        if (q < 1 || r == 0 || 2 * r > ncu) return false;                  // only where the partial round is at most half full
+        // tail = whole row tiles covering the partial round, cut at a sample boundary (the time-embedding row is indexed per sample)
+        int mt_tail = (r + nbn - 1) / nbn;
+        const int tiles_per_sample = p.rows_per_sample >= 256 ? p.rows_per_sample / 256 : 1;
+        if (p.rows_per_sample % 256 != 0 && 256 % p.rows_per_sample != 0) return false;
+        mt_tail = ((mt_tail + tiles_per_sample - 1) / tiles_per_sample) * tiles_per_sample;
+        const int mt_head = mt - mt_tail;
+        if (mt_head < 1 || (long long)mt_head * nbn > (long long)q * ncu + nbn || 2LL * mt_tail * nbn > ncu + 2 * nbn) return false;
+        const int nslice = (p.C0 + p.C1) / 64;
+        if (nslice < 4) return false;
+        const long long m0 = (long long)mt_head * 256, mtail = (long long)mt_tail * 256;
+        if (ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)2 * mtail * p.N * 4) != 0) return false;
+        IgemmParams pa = p, pb = p;
+        pa.M = (int)m0;
+        pb.M = (int)mtail;
+        pb.A0 = p.A0 + m0 * p.C0; if (p.A1) pb.A1 = p.A1 + m0 * p.C1;
+        pb.out_bf16 = p.out_bf16 + m0 * p.ldo;
+        if (p.res_bf16) pb.res_bf16 = p.res_bf16 + m0 * p.ldo;
+        if (p.rowvec) pb.rowvec = p.rowvec + (m0 / p.rows_per_sample) * p.rowvec_ld;
+        pb.ksplit = 2; pb.ws = (float*)c->splitk_ws; pb.one_item_per_block = 1;
+        if (!conv_halo4_supported(pa)) return false;
+        { IgemmParams t = pb; t.ksplit = 0; if (!conv_halo4_supported(t)) return false; }
+        if (!side_fork()) return false;
+        check(launch_conv3x3(pa, c->stream), "conv3x3 (head rows)");
+        side_enter();
+        check(launch_conv3x3(pb, c->stream), "conv3x3 (tail rows, K-split parts)");
+        side_end();
+        side_join();
+        return true;
     }
     int cur_block = -1, cur_layer = 0;           // position in the UNet's block table (debug tap)
     void tap(int stage, const void* ptr, size_t nbytes) {      // rdm_debug_tap: stage `stage` of layer cur_layer of block cur_block
@@ -958,7 +1015,8 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         if (r.skip) {
             sk = o.abf((size_t)M * r.cout);
             o.tag = "res.skip";
-            forked = o.side_begin();
+            static const int skip_on = getenv("RDM_SKIP_OVERLAP") ? atoi(getenv("RDM_SKIP_OVERLAP")) : 1;
+            forked = skip_on && o.side_begin();
             o.linear(a.p, x1, C0, C1, r.wsk, r.bsk, true, M, r.cout, ACT_NONE, nullptr, sk, nullptr, nullptr, wrap_b * HW);
             if (forked) o.side_end();
             res = sk;
