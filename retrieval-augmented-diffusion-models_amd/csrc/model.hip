@@ -616,7 +616,8 @@ struct Ops {
         if (!c->side) {
             int pr_lo = 0, pr_hi = 0;                          // lowest priority: side work fills what the main chain leaves idle, it never goes first
             (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
-            if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, pr_lo) != hipSuccess) { c->side = nullptr; return false; }
+            static const int lowprio = getenv("RDM_SIDE_LOWPRIO") ? atoi(getenv("RDM_SIDE_LOWPRIO")) : 1;
+            if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lowprio ? pr_lo : pr_hi) != hipSuccess) { c->side = nullptr; return false; }
             if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
                 (void)hipStreamDestroy(c->side); c->side = nullptr; return false;
             }
@@ -797,7 +798,7 @@ struct Ops {
     // existing K-split arithmetic (fp32 partial planes summed in a fixed order, one rounding): the tail rows are computed like every
     // K-split conv.  Not in deterministic mode (the cut follows the batch).  RDM_CONV_TAIL=0: off.
     bool conv_tail_split(IgemmParams& p) {
-        static const int on = getenv("RDM_CONV_TAIL") ? atoi(getenv("RDM_CONV_TAIL")) : 1;
+        static const int on = getenv("RDM_CONV_TAIL") ? atoi(getenv("RDM_CONV_TAIL")) : 0;
         if (!on || c->deterministic || p.ksplit > 1 || !p.Wfrag || p.stride != 1 || p.ups || p.Wout > 64 || !conv_halo4_supported(p)) return false;
         static int ncu_dev[RDM_MAX_DEVICES] = {0};
         const int dev = rdm_cur_device();
