@@ -784,8 +784,16 @@ struct Ops {
         const int ks = c->deterministic ? 1 : conv_halo_ksplit(p);
         if (ks > 1 && ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)ks * p.M * N * 4) == 0) { p.ksplit = ks; p.ws = (float*)c->splitk_ws; }
         if (!det_generic && (conv_halo_supported(p) || conv_halo4_strip_supported(p))) p.Wfrag = c->frag_for(p.W, N, C0 + C1);
+        // wave quantisation, in-kernel form (round 6): the remainder tiles of the persistent walk as two K halves each (conv_halo4.hip)
+        static const int tailk = getenv("RDM_CONV_TAILK") ? atoi(getenv("RDM_CONV_TAILK")) : 1;
+        if (tailk && !c->deterministic && !det_generic && p.ksplit <= 1 && p.Wfrag && Wout <= 64 && conv_halo4_supported(p)) {
+            const int bn = (N % 192 == 0) ? 192 : 128, G = conv_halo4_grid(p);
+            const long long T = (long long)(p.M / 256) * (N / bn);
+            if (T > G && conv_halo4_tail_tiles(p, bn, G) > 0 &&
+                ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)2 * p.M * N * 4) == 0) { p.tail_split = 1; p.ws = (float*)c->splitk_ws; }
+        }
         prof_begin(RDM_PROF_CONV3X3, 2.0 * p.M * N * (double)p.K, p.M, N, p.K);
-        if (!det_generic && conv_tail_split(p)) { prof_end(); return; }
+        if (!det_generic && !p.tail_split && conv_tail_split(p)) { prof_end(); return; }
         check(det_generic ? launch_igemm(p, true, 1, c->stream) : launch_conv3x3(p, c->stream), "conv3x3");
         prof_end();
     }
