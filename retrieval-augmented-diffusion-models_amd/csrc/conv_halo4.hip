@@ -81,7 +81,7 @@ constexpr int H4_HALO_MAX = 66560;                 // largest HBYTES admitted (W
 // strips' real pixels (zero only at the image border), rows of a tile are WI pixels apart in memory, and tile index -> (sample, row
 // group, strip).  Costs three VALU per halo piece (column = strip origin + halo column, its validity, the source column), so it is a
 // template variant: the UNet's kernels (W <= 64) are unchanged.
-template <int FN, int VAR, bool STRIP = false, bool TAIL = false>      // TAIL: the tail-split walk (below; single source, no fused upsample: what the 16 x 16 ResBlock convs need); VAR: dev-only ablations (RDM_H4_VAR): 1 = no halo-piece address work (wrong results)
+template <int FN, int VAR, bool STRIP = false, bool RANGE = false>      // RANGE: tile sub-range launches (below); VAR: dev-only ablations (RDM_H4_VAR): 1 = no halo-piece address work (wrong results)
 __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     constexpr int BM = 256, BK = 64, FM = 4, WN = FN * 32, BN = 2 * WN;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [halo0][halo1][dump: 1 KB per wave]
@@ -102,7 +102,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     const int npw = (NPT - wave + 3) >> 2;                  // halo pieces this wave stages: wave, wave + 4, ...
 
     const int nbn = p.N / BN, nbm = p.M / BM;
-    const int ntiles_mn = nbm * nbn;
+    // tile sub-range (round 6, IgemmParams::tile_cnt > 0): this launch covers tiles [tile_lo, tile_lo + tile_cnt) of the (m-major, n-minor) tile
+    // order only -- Ops::conv3 runs the full rounds of a conv as whole tiles and the remainder tiles as a second, K-split launch.  ntiles_mn
+    // is then the RANGE's tile count; tile_lo is re-read from the kernel arguments where a tile is decoded (the scalar file is full).
+    // (a template variant: the classic kernel has not one register to spare -- the audits in the Makefile fail on a single extra live scalar;
+    //  the RANGE variant pays for tile_lo with the dev-only phase clocks it leaves out)
+    const int ntiles_mn = RANGE ? p.tile_cnt : nbm * nbn;
+    auto tile_lo = [&]() { return RANGE ? p.tile_lo : 0; };
     const int S = p.ksplit > 1 ? p.ksplit : 1;
     const int ntiles = ntiles_mn * S;
     const int G = gridDim.x, xcd = blockIdx.x & 7;
@@ -110,28 +116,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     const int tq = ntiles >> 3, tr = ntiles & 7;
     const int t_begin = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
     const int t_end = t_begin + tq + (xcd < tr ? 1 : 0);
-    // Work items of this block.  Classic walk: items t_begin + jx, + gx, ... (an item = a tile, or one K part of a tile under the uniform
-    // K-split).  TAIL SPLIT (round 6, p.tail_split; whole-tile mode only): an XCD's range of nx tiles is qx full rounds of its gx blocks plus
-    // rx remainder tiles; when 2 rx <= gx the remainder tiles are cut in two K halves -- item code TB + 2 tile + half -- and handed one half per
-    // block to blocks 0 .. 2 rx - 1 (the two halves of a tile to neighbouring blocks of the same XCD): the last, partial round costs half a
-    // tile instead of a whole one (the 16 x 16 level of a guided batch of 64: 384 tiles = 48 per XCD on 32 blocks: 1 + 0.5 instead of 2
-    // rounds).  Halves leave as fp32 planes like every K-split part; splitk_tail_finish_kernel adds them (bias, time-embedding row, residual,
-    // one rounding).  The decision is a function of (tile count, grid) only: the host and the finisher recompute it with the same formulas.
-    // (item codes < 0: tail halves, -1 - (2 tile + half).  ONE more live scalar than the classic walk -- tail_item -- and t_lim in t_end's
-    //  place: the scalar file of this kernel is full, and every value hipcc parks in a VGPR instead brings the accumulator-register audit down.)
-    int t_lim = t_end, tail_item = 0;
-    if constexpr (TAIL) {
-        const int jx = blockIdx.x >> 3, nx = t_end - t_begin;
-        const int qx = nx / gx, rx = nx - qx * gx;
-        const bool split_x = S == 1 && qx >= 1 && rx > 0 && 2 * rx <= gx && nslice >= 4;
-        t_lim = split_x ? t_begin + qx * gx : t_end;       // whole items of this block: t0, t0 + gx, ... < t_lim
-        tail_item = (split_x && jx < 2 * rx) ? -1 - (2 * (t_begin + qx * gx + (jx >> 1)) + (jx & 1)) : 0;
-    }
     int tile = t_begin + (blockIdx.x >> 3);
-    if (tile >= t_end) return;                              // (split ranges have qx >= 1: every block owns a whole tile)
-    auto it_tmn = [&](int t) { return (TAIL && t < 0) ? (-1 - t) >> 1 : t % ntiles_mn; };       // tile (m, n) index of an item
-    auto it_part = [&](int t) { return (TAIL && t < 0) ? (-1 - t) & 1 : t / ntiles_mn; };       // its K part ...
-    auto it_np = [&](int t) { return (TAIL && t < 0) ? 2 : S; };                                // ... of how many
+    if (tile >= t_end) return;
 
     const char* const zero = (const char*)p.zero_page;
     const char* const Wf = (const char*)p.Wfrag;
@@ -155,15 +141,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     // a tap further on is tap_stride bytes away, a slice 4 KiB
     const long long tap_stride = (long long)KQ * 1024;
     auto w_base = [&](int t) -> const char* {
-        const int bn = it_tmn(t) % nbn;
+        const int bn = (tile_lo() + t % ntiles_mn) % nbn;
         const int nb0 = bn * (BN / 32) + wn * FN;
         const long long off = (long long)nb0 * 9 * tap_stride;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(off & 0xffffffffLL));
         const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(off >> 32));
         return Wf + (((unsigned long long)hi << 32) | lo);
     };
-    auto slice_begin = [&](int t) { return (it_part(t) * nslice) / it_np(t); };
-    auto slice_end = [&](int t) { return ((it_part(t) + 1) * nslice) / it_np(t); };
+    auto slice_begin = [&](int t) { return ((t / ntiles_mn) * nslice) / S; };
+    auto slice_end = [&](int t) { return ((t / ntiles_mn + 1) * nslice) / S; };
 
     // ---- halo staging.  Piece g (8 consecutive positions of one halo row, 64 channels: one KiB, 16 bytes per lane) belongs to wave
     // g % 4.  Everything about a piece but the lane's column is wave-uniform (scalar unit): halo row R, first column, source row,
@@ -176,9 +162,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     auto ht_y0 = [](const HaloTile& h) { return STRIP ? (h.y0 & 0xffff) : h.y0; };
     auto ht_x0 = [](const HaloTile& h) { return STRIP ? (int)((unsigned)h.y0 >> 16) : 0; };
     struct HaloSrc { const char* src; unsigned ldb; };                   // src: channel slice of pixel 0 in the slice's source tensor
-    const int ups = (!TAIL && p.ups) ? 1 : 0;
+    const int ups = p.ups ? 1 : 0;
     auto halo_tile = [&](int t) {
-        const int tm0 = (it_tmn(t) / nbn) * BM;
+        const int tm0 = ((tile_lo() + t % ntiles_mn) / nbn) * BM;
         HaloTile h;
         if constexpr (STRIP) {              // tiles of an image: row groups of RS = 4 rows x strips of 64 columns, strips fastest
             const int spr = WI >> 6, tpi = (H >> 2) * spr, tmi = tm0 >> 8;
@@ -190,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     };
     auto halo_src = [&](int sl) {
         const int kc = sl * BK;
-        const bool second = !TAIL && kc >= p.C0;
+        const bool second = kc >= p.C0;
         HaloSrc h;
         h.src = (const char*)(second ? p.A1 : p.A0) + (second ? kc - p.C0 : kc) * 2;
         h.ldb = (unsigned)(second ? p.C1 : p.C0) * 2u;
@@ -251,28 +237,27 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     const char* wb_tile = Wf; const char* wb_next = Wf;
     HaloTile ht_tile{0, 0}, ht_next{0, 0};
     auto tile_setup = [&]() {
-        // (TAIL: tile origins and the K part are recomputed from the item codes where they are used -- prologue and epilogue -- instead of
-        //  living across the main loop: that variant has no register to spare)
-        if constexpr (!TAIL) {
-            const int tmn = it_tmn(tile);
+        // (RANGE: tile origins and the K part are recomputed from the item index where they are used -- prologue and epilogue -- instead of
+        //  living across the main loop)
+        if constexpr (!RANGE) {
+            const int tmn = tile % ntiles_mn;
             em0 = (tmn / nbn) * BM; en0 = (tmn % nbn) * BN;
-            part = it_part(tile);
+            part = tile / ntiles_mn;
         }
-        if constexpr (TAIL) {
-            has_next = tile >= 0 && (tile + gx < t_lim || tail_item < 0);
-            next = has_next ? (tile + gx < t_lim ? tile + gx : tail_item) : tile;
-        } else { next = tile + gx; has_next = next < t_end; }
+        next = tile + gx;
+        has_next = next < t_end;
         s_begin = slice_begin(tile); s_end = slice_end(tile);
         ns_begin = has_next ? slice_begin(next) : 0;
         wb_tile = w_base(tile);
         wb_next = has_next ? w_base(next) + (long long)ns_begin * 4096 : wb_tile;       // first step of the next work item
         ht_next = has_next ? halo_tile(next) : HaloTile{0, 0};
-        if constexpr (!TAIL) { const int nmn = it_tmn(has_next ? next : tile); nem0 = (nmn / nbn) * BM; nen0 = (nmn % nbn) * BN; }
+        if constexpr (!RANGE) { const int nmn = (has_next ? next : tile) % ntiles_mn; nem0 = (nmn / nbn) * BM; nen0 = (nmn % nbn) * BN; }
         ht_tile = halo_tile(tile);
     };
-    auto origins = [&]() {                                  // TAIL: (em0, en0, part) of the current item, (nem0, nen0) of the next
-        const int tmn = it_tmn(tile), nmn = it_tmn(has_next ? next : tile);
-        em0 = (tmn / nbn) * BM; en0 = (tmn % nbn) * BN; part = it_part(tile);
+    auto origins = [&]() {                                  // RANGE: (em0, en0, part) of the current item, (nem0, nen0) of the next
+        const int lo = tile_lo();
+        const int tmn = lo + tile % ntiles_mn, nmn = lo + (has_next ? next : tile) % ntiles_mn;
+        em0 = (tmn / nbn) * BM; en0 = (tmn % nbn) * BN; part = tile / ntiles_mn;
         nem0 = (nmn / nbn) * BM; nen0 = (nmn % nbn) * BN;
     };
     int sl = 0, tap = 0;
@@ -325,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     // finisher adds the bias).  The epilogue of a tile writes the next tile's start values as it empties the accumulators.
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
     union FragU { u32x4_t u; bf16x8 f; };
-    auto start_values = [&](int tm0, int tn0, int row, float (&pb)[FM][FN], bool whole) {      // whole: the item is a whole tile (K parts start at zero: their finisher adds the bias)      // fp32 start value of channel `row` of fragment (i, j), tile at (tm0, tn0)
+    auto start_values = [&](int tm0, int tn0, int row, float (&pb)[FM][FN]) {      // fp32 start value of channel `row` of fragment (i, j), tile at (tm0, tn0)
 #pragma unroll
         for (int i = 0; i < FM; i++) {
             const int mf = tm0 + wm * 128 + i * 32;
@@ -333,8 +318,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
 #pragma unroll
             for (int j = 0; j < FN; j++) {
                 const int ncol = tn0 + wn * WN + j * 32 + row;
-                float bv = (whole && p.bias) ? p.bias[ncol] : 0.f;
-                if (whole && rv) bv += rv[ncol];
+                float bv = (S == 1 && p.bias) ? p.bias[ncol] : 0.f;
+                if (S == 1 && rv) bv += rv[ncol];
                 pb[i][j] = bv;
             }
         }
@@ -347,8 +332,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     };
     {
         float pb[FM][FN];
-        if constexpr (TAIL) origins();
-        start_values(em0, en0, frow, pb, it_np(tile) == 1);
+        if constexpr (RANGE) origins();
+        start_values(em0, en0, frow, pb);
         FragU o; o.u = (u32x4_t){fhalf ? 0u : 0x3f803f80u, 0u, 0u, 0u};
         bf16x8 ones = o.f;
 #pragma unroll
@@ -373,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     // weight stream (vmcnt retires in order: with per-k-step weight requests a piece that was late stalled every wait behind it).
     unsigned long long tprof[2] = {0, 0};
     unsigned long long tp0 = 0, tp1 = 0;
-    if (!TAIL && (p.dbg & 16)) tp0 = __builtin_readcyclecounter();
+    if (!RANGE && (p.dbg & 16)) tp0 = __builtin_readcyclecounter();
     // descriptors of the NEXT tap-step (uniform), refreshed before every step
     bool slice_last_tap = false;
     int epi_stores = 0;                                     // stores of the epilogue just finished that may still be in flight
@@ -381,8 +366,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     auto describe = [&]() {
         slice_last_tap = tap == 8;
         const int n_tap = slice_last_tap ? 0 : tap + 1;
-        if constexpr (TAIL) sbn = (const char*)h4_uni64((unsigned long long)(slice_last_tap ? sb_after : sb_run + tap_stride));     // (SGPR pair for the saddr-form loads: with per-item K parts hipcc keeps this chain on the VALU)
-        else sbn = slice_last_tap ? sb_after : sb_run + tap_stride;
+        sbn = slice_last_tap ? sb_after : sb_run + tap_stride;
         sb_run = sbn;
         const int ndy = (n_tap * 11) >> 5, ndx = n_tap - ndy * 3;
         noff = (slice_last_tap ? hbase_nxt : hbase_cur) + (unsigned)(ndy * RSTR + ndx * 144);
@@ -478,13 +462,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
         if (!has_next) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
-        if (!TAIL && (p.dbg & 16)) { tp1 = __builtin_readcyclecounter(); tprof[0] += tp1 - tp0; }
+        if (!RANGE && (p.dbg & 16)) { tp1 = __builtin_readcyclecounter(); tprof[0] += tp1 - tp0; }
         // ---- epilogue.  The halo buffer of the slice just finished (hb ^ 1 after the toggle) is free for every wave: all of them
         // passed the slice-end barrier after their last read of it.  Staging is wave-private.
         char* const stg_base = smem + (hb ^ 1) * HBYTES;
         // lane-derived epilogue addressing is recomputed per tile from an opaque copy of the lane id: hoisted out of the tile loop
         // it would sit in registers across the main loop, which has none to spare
-        if constexpr (TAIL) origins();
+        if constexpr (RANGE) origins();
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int erow = lane_e & 31, ehalf = lane_e >> 5;
@@ -507,7 +491,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
         const int eno = en0 + wn * WN;
         // the next work item's start values (bias + time-embedding row; zero for K-split parts): requested before the read-out
         float pb[FM][FN];
-        start_values(nem0, nen0, erow, pb, !has_next || it_np(next) == 1);
+        start_values(nem0, nen0, erow, pb);
         FragU o1; o1.u = (u32x4_t){ehalf ? 0u : 0x3f803f80u, 0u, 0u, 0u};
         bf16x8 ones = o1.f;
         auto stage_row = [&](int i) {
@@ -525,7 +509,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
 #pragma unroll
             for (int j = 0; j < FN; j++) H4_MFMA0(i * FN + j, sf[j], ones);
         };
-        if (it_np(tile) > 1) {
+        if (S > 1) {
             // K-split part: fp32 planes [part][M][N]; 16-byte units (4 channels), WN / 4 lanes per row segment
             constexpr int CPR4 = WN / 4, NIT4 = (32 * CPR4) / 64;
             unsigned voffs[NIT4], lrd4[NIT4];
@@ -617,8 +601,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
             }
         }
         // (the epilogue's own loads -- bias, residual -- were consumed above, i.e. waited for; its stores are asm)
-        epi_stores = (it_np(tile) > 1) ? 2 * FM * ((32 * (WN / 8)) / 64) : FM * ((32 * (WN / 8)) / 64);
-        if (!TAIL && (p.dbg & 16)) tprof[1] += __builtin_readcyclecounter() - tp1;
+        epi_stores = (S > 1) ? 2 * FM * ((32 * (WN / 8)) / 64) : FM * ((32 * (WN / 8)) / 64);
+        if (!RANGE && (p.dbg & 16)) tprof[1] += __builtin_readcyclecounter() - tp1;
         if (!has_next) return true;
         // the staging area is the buffer the next tile's SECOND slice is staged into during its first steps: every wave must have
         // left its epilogue first
@@ -627,7 +611,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
         tile_setup();
         sl = s_begin;
         slice_setup();
-        if (!TAIL && (p.dbg & 16)) tp0 = __builtin_readcyclecounter();
+        if (!RANGE && (p.dbg & 16)) tp0 = __builtin_readcyclecounter();
         return false;
     };
     // straight-line pairs of steps (parity 0, parity 1): no control-flow merge ever sits between the request of a fragment and its use
@@ -635,112 +619,40 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
         describe(); step(std::integral_constant<int, 0>{}); if (advance()) break;
         describe(); step(std::integral_constant<int, 1>{}); if (advance()) break;
     }
-    if (!TAIL && (p.dbg & 16) && tid == 0) {
+    if (!RANGE && (p.dbg & 16) && tid == 0) {
         atomicAdd(&g_halo4_prof[0], tprof[0]); atomicAdd(&g_halo4_prof[1], tprof[1]); atomicAdd(&g_halo4_prof[3], 1ull);
     }
 }
 
-// ---- tail split: the walk's per-XCD ranges, recomputed with the kernel's formulas (host: is anything split?  finisher: which tiles?)
-struct H4Walk { int t_begin, nx, gx, qx, rx; bool split; };
-__host__ __device__ inline H4Walk h4_walk(int ntiles, int G, int xcd, int nslice) {
-    H4Walk w;
-    w.gx = (G - xcd + 7) >> 3;
-    const int tq = ntiles >> 3, tr = ntiles & 7;
-    w.t_begin = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
-    w.nx = tq + (xcd < tr ? 1 : 0);
-    w.qx = w.gx > 0 ? w.nx / w.gx : 0; w.rx = w.gx > 0 ? w.nx - w.qx * w.gx : 0;
-    w.split = w.gx > 0 && w.qx >= 1 && w.rx > 0 && 2 * w.rx <= w.gx && nslice >= 4;
-    return w;
-}
-// number of tiles the kernel will split for (ntiles whole tiles, grid G); 0 = the flag changes nothing
-int conv_halo4_tail_tiles(const IgemmParams& p, int bn_tile, int G) {
-    const int ntiles = (p.M / 256) * (p.N / bn_tile), nslice = (p.C0 + p.C1) / 64;
-    int n = 0;
-    for (int x = 0; x < 8; x++) { const H4Walk w = h4_walk(ntiles, G, x, nslice); if (w.split) n += w.rx; }
-    return n;
-}
-// out = bf16(plane 0 + plane 1 + bias + time-embedding row + residual) for the split tiles: one block per tile, 8 columns per thread
-__global__ __launch_bounds__(256) void splitk_tail_finish_kernel(IgemmParams p, int BN, int G) {
-    const int nbn = p.N / BN, ntiles = (p.M / 256) * nbn, nslice = (p.C0 + p.C1) / 64;
-    int b = blockIdx.x, tile = -1;
-    for (int x = 0; x < 8; x++) {
-        const H4Walk w = h4_walk(ntiles, G, x, nslice);
-        if (!w.split) continue;
-        if (b < w.rx) { tile = w.t_begin + w.qx * w.gx + b; break; }
-        b -= w.rx;
-    }
-    if (tile < 0) return;
-    const int m0 = (tile / nbn) * 256, n0 = (tile % nbn) * BN, vpr = BN >> 3;
-    const long long plane = (long long)p.M * p.N;
-    for (int v = threadIdx.x; v < 256 * vpr; v += 256) {
-        const int r = v / vpr, n = n0 + (v - r * vpr) * 8;
-        const long long m = m0 + r;
-        const float* w0p = p.ws + m * p.N + n;
-        const float4 a0 = *(const float4*)w0p, a1 = *(const float4*)(w0p + 4), c0 = *(const float4*)(w0p + plane), c1 = *(const float4*)(w0p + plane + 4);
-        float a[8] = {a0.x + c0.x, a0.y + c0.y, a0.z + c0.z, a0.w + c0.w, a1.x + c1.x, a1.y + c1.y, a1.z + c1.z, a1.w + c1.w};    // part 0 + part 1: fixed order
-        if (p.bias) {
-            const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
-            a[0] += b0.x; a[1] += b0.y; a[2] += b0.z; a[3] += b0.w; a[4] += b1.x; a[5] += b1.y; a[6] += b1.z; a[7] += b1.w;
-        }
-        if (p.rowvec) {
-            const float* rv = p.rowvec + (m / p.rows_per_sample) * p.rowvec_ld + n;
-#pragma unroll
-            for (int e = 0; e < 8; e++) a[e] += rv[e];
-        }
-        if (p.res_bf16) {
-            const uint4 r4 = *(const uint4*)(p.res_bf16 + m * p.ldo + n);
-            const uint32_t rr[4] = {r4.x, r4.y, r4.z, r4.w};
-#pragma unroll
-            for (int e = 0; e < 4; e++) { a[2 * e] += __uint_as_float(rr[e] << 16); a[2 * e + 1] += __uint_as_float(rr[e] & 0xffff0000u); }
-        }
-        *(uint4*)(p.out_bf16 + m * p.ldo + n) = make_uint4(cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3]), cvt_pk_bf16(a[4], a[5]), cvt_pk_bf16(a[6], a[7]));
-    }
-}
-
-template <int FN, int VAR, bool STRIP = false, bool TAIL = false>
+template <int FN, int VAR, bool STRIP = false, bool RANGE = false>
 static hipError_t launch_halo4_cfg(const IgemmParams& p, hipStream_t st) {
     constexpr int smem = 2 * H4_HALO_MAX + 4096 + 4 * 21 * 256;       // halo x 2, dump, piece tables
     constexpr int BN = FN * 64;
     static int ncu_dev[RDM_MAX_DEVICES] = {0};
     const int dev = rdm_cur_device();
     if (!ncu_dev[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo4_kernel<FN, VAR, STRIP, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo4_kernel<FN, VAR, STRIP, RANGE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         hipDeviceGetAttribute(&ncu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev);
     }
     const int ncu = ncu_dev[dev];
-    const long long ntiles = (long long)(p.M / 256) * (p.N / BN) * (p.ksplit > 1 ? p.ksplit : 1);
+    const long long ntiles = (RANGE ? (long long)p.tile_cnt : (long long)(p.M / 256) * (p.N / BN)) * (p.ksplit > 1 ? p.ksplit : 1);
     long long g = (ncu + 7) & ~7;
-    if (g > ntiles || p.one_item_per_block) g = ntiles;
+    if (g > ntiles) g = ntiles;
     static const int prof = getenv("RDM_HALO_PROF") ? atoi(getenv("RDM_HALO_PROF")) : 0;
     if (prof) {
         IgemmParams q = p; q.dbg |= 16;
         unsigned long long z[4] = {0, 0, 0, 0}, r[4];
         hipMemcpyToSymbol(HIP_SYMBOL(g_halo4_prof), z, sizeof(z));
-        conv3x3_halo4_kernel<FN, VAR, STRIP, TAIL><<<dim3((unsigned)g), 256, smem, st>>>(q);
+        conv3x3_halo4_kernel<FN, VAR, STRIP, RANGE><<<dim3((unsigned)g), 256, smem, st>>>(q);
         hipStreamSynchronize(st);
         hipMemcpyFromSymbol(r, HIP_SYMBOL(g_halo4_prof), sizeof(r));
         fprintf(stderr, "[halo4<%d> M=%d N=%d K=%d] blocks=%llu per-block cycles: main %.0f epilogue %.0f (tiles/block %.2f)\n", BN, p.M, p.N, p.K,
                 r[3], (double)r[0] / r[3], (double)r[1] / r[3], (double)ntiles / g);
         return hipGetLastError();
     }
-    conv3x3_halo4_kernel<FN, VAR, STRIP, TAIL><<<dim3((unsigned)g), 256, smem, st>>>(p);
-    if (TAIL) {
-        const int nt = conv_halo4_tail_tiles(p, BN, (int)g);
-        if (nt > 0) splitk_tail_finish_kernel<<<dim3((unsigned)nt), 256, 0, st>>>(p, BN, (int)g);
-    }
+    conv3x3_halo4_kernel<FN, VAR, STRIP, RANGE><<<dim3((unsigned)g), 256, smem, st>>>(p);
     return hipGetLastError();
-}
-// grid launch_halo4_cfg will use for whole-tile mode (the tail-split policy needs it)
-int conv_halo4_grid(const IgemmParams& p) {
-    int dev = rdm_cur_device(), ncu = 256;
-    static int ncu_dev[RDM_MAX_DEVICES] = {0};
-    if (!ncu_dev[dev]) hipDeviceGetAttribute(&ncu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev);
-    ncu = ncu_dev[dev];
-    const int bn = (p.N % 192 == 0) ? 192 : 128;
-    const long long ntiles = (long long)(p.M / 256) * (p.N / bn);
-    long long g = (ncu + 7) & ~7;
-    return (int)(g > ntiles ? ntiles : g);
 }
 
 // images wider than 64 pixels as 64-column strips (conv3x3_halo4_kernel<.., STRIP>): the first-stage decoder's 128- / 256-pixel levels
@@ -784,9 +696,9 @@ hipError_t launch_conv_halo4(const IgemmParams& p, hipStream_t st) {
         if (var == 1) return launch_halo4_cfg<3, 1>(p, st);
         if (var == 3) return launch_halo4_cfg<3, 3>(p, st);
         if (var == 2) return launch_halo4_cfg<3, 2>(p, st);
-        if (p.tail_split && p.ksplit <= 1 && p.C1 == 0 && !p.ups) return launch_halo4_cfg<3, 0, false, true>(p, st);
+        if (p.tile_cnt > 0) return launch_halo4_cfg<3, 0, false, true>(p, st);
         return launch_halo4_cfg<3, 0>(p, st);
     }
-    if (p.tail_split && p.ksplit <= 1 && p.C1 == 0 && !p.ups) return launch_halo4_cfg<2, 0, false, true>(p, st);
+    if (p.tile_cnt > 0) return launch_halo4_cfg<2, 0, false, true>(p, st);
     return launch_halo4_cfg<2, 0>(p, st);
 }

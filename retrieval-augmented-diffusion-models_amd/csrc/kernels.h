@@ -141,8 +141,6 @@ hipError_t launch_conv_halo(const IgemmParams& p, hipStream_t st);
 bool conv_halo4_supported(const IgemmParams& p);
 bool conv_halo4_strip_supported(const IgemmParams& p);     // output wider than 64 pixels: 64-column strips (N % 128 == 0, no K-split); needs p.Wfrag
 hipError_t launch_conv_halo4(const IgemmParams& p, hipStream_t st);
-int conv_halo4_grid(const IgemmParams& p);                 // blocks the whole-tile launch will use
-int conv_halo4_tail_tiles(const IgemmParams& p, int bn_tile, int G);     // tiles IgemmParams::tail_split would cut in two K halves for that grid (0 = none)
 // one-wave-per-SIMD linear GEMM (lin4.hip): needs p.Wfrag = the fragment-ordered copy of W built by launch_lin_w_fragpack
 bool lin4_supported(const IgemmParams& p, int batch);
 hipError_t launch_lin4(const IgemmParams& p, hipStream_t st);

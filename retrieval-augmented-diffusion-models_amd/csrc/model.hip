@@ -784,64 +784,38 @@ struct Ops {
         const int ks = c->deterministic ? 1 : conv_halo_ksplit(p);
         if (ks > 1 && ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)ks * p.M * N * 4) == 0) { p.ksplit = ks; p.ws = (float*)c->splitk_ws; }
         if (!det_generic && (conv_halo_supported(p) || conv_halo4_strip_supported(p))) p.Wfrag = c->frag_for(p.W, N, C0 + C1);
-        // wave quantisation, in-kernel form (round 6): the remainder tiles of the persistent walk as two K halves each (conv_halo4.hip)
-        static const int tailk = getenv("RDM_CONV_TAILK") ? atoi(getenv("RDM_CONV_TAILK")) : 1;
-        if (tailk && !c->deterministic && !det_generic && p.ksplit <= 1 && p.Wfrag && Wout <= 64 && conv_halo4_supported(p)) {
-            const int bn = (N % 192 == 0) ? 192 : 128, G = conv_halo4_grid(p);
-            const long long T = (long long)(p.M / 256) * (N / bn);
-            if (T > G && conv_halo4_tail_tiles(p, bn, G) > 0 &&
-                ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)2 * p.M * N * 4) == 0) { p.tail_split = 1; p.ws = (float*)c->splitk_ws; }
-        }
         prof_begin(RDM_PROF_CONV3X3, 2.0 * p.M * N * (double)p.K, p.M, N, p.K);
-        if (!det_generic && !p.tail_split && conv_tail_split(p)) { prof_end(); return; }
+        if (!det_generic && conv_remainder_split(p)) { prof_end(); return; }
         check(det_generic ? launch_igemm(p, true, 1, c->stream) : launch_conv3x3(p, c->stream), "conv3x3");
         prof_end();
     }
     // ---- wave quantisation of the persistent halo kernel (round 6).  A conv whose tile count is q full rounds of the CUs plus a partial
     // round of r tiles runs q + 1 rounds: the 16 x 16 level of a guided batch of 64 (M = 32768, N = 576: 384 tiles on 256 CUs) spends a
-    // whole second round on 128 tiles.  Here the rows are cut at a sample boundary: the HEAD (whole row tiles filling at most q rounds) runs
-    // as before on the main stream; the TAIL's tiles run as 2-part K-splits -- one part per block, so that the hardware places them on
-    // CUs as they come free -- on the low-priority side stream, CONCURRENTLY: when the head's blocks finish, the remaining half-length
-    // parts fill every CU once.  q + 1 rounds become q + 0.5 (+ the tail's fp32 planes and finisher: a third of the rows).  Same kernels,
-    // existing K-split arithmetic (fp32 partial planes summed in a fixed order, one rounding): the tail rows are computed like every
-    // K-split conv.  Not in deterministic mode (the cut follows the batch).  RDM_CONV_TAIL=0: off.
-    bool conv_tail_split(IgemmParams& p) {
-        static const int on = getenv("RDM_CONV_TAIL") ? atoi(getenv("RDM_CONV_TAIL")) : 0;
+    // whole second round on 128 tiles.  When 2 r <= CUs the conv runs as TWO launches of the same kernel on tile sub-ranges
+    // (IgemmParams::tile_lo / tile_cnt): tiles [0, q CUs) whole, then the r remainder tiles as 2-part K-splits (2 r <= CUs items: one
+    // half-length round) + the finisher over those tiles -- q + 1 rounds become q + ~0.6.  The remainder tiles are computed like every
+    // K-split conv (fp32 partial planes summed in a fixed order, bias / time-embedding row / residual added in fp32, one rounding).  Not in
+    // deterministic mode (the cut follows the batch).  RDM_CONV_REM=0: off.
+    // (Measured first, and dropped: the same cut at a sample boundary with the tail on a second stream -- the tail did not start before the
+    //  head had finished, and 258 parts need two half rounds: -1.2 %; the halves handed out INSIDE one launch by a TAIL variant of the kernel
+    //  -- that variant has no register to spare and its main loop lost more than the half round it saved: -1.0 %.  profiles/r06_conv_tail_*.)
+    bool conv_remainder_split(IgemmParams& p) {
+        static const int on = getenv("RDM_CONV_REM") ? atoi(getenv("RDM_CONV_REM")) : 1;
         if (!on || c->deterministic || p.ksplit > 1 || !p.Wfrag || p.stride != 1 || p.ups || p.Wout > 64 || !conv_halo4_supported(p)) return false;
         static int ncu_dev[RDM_MAX_DEVICES] = {0};
         const int dev = rdm_cur_device();
         if (!ncu_dev[dev]) hipDeviceGetAttribute(&ncu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev);
-        const int ncu = ncu_dev[dev], bn = (p.N % 192 == 0) ? 192 : 128, nbn = p.N / bn, mt = p.M / 256;
-        const long long T = (long long)mt * nbn;
+        const int ncu = ncu_dev[dev] & ~7, bn = (p.N % 192 == 0) ? 192 : 128;
+        const long long T = (long long)(p.M / 256) * (p.N / bn);
+        if (ncu < 8 || T > 0x3fffffff) return false;
         const int q = (int)(T / ncu), r = (int)(T % ncu);
-        if (q < 1 || r == 0 || 2 * r > ncu) return false;                  // only where the partial round is at most half full
-        // tail = whole row tiles covering the partial round, cut at a sample boundary (the time-embedding row is indexed per sample)
-        int mt_tail = (r + nbn - 1) / nbn;
-        const int tiles_per_sample = p.rows_per_sample >= 256 ? p.rows_per_sample / 256 : 1;
-        if (p.rows_per_sample % 256 != 0 && 256 % p.rows_per_sample != 0) return false;
-        mt_tail = ((mt_tail + tiles_per_sample - 1) / tiles_per_sample) * tiles_per_sample;
-        const int mt_head = mt - mt_tail;
-        if (mt_head < 1 || (long long)mt_head * nbn > (long long)q * ncu + nbn || 2LL * mt_tail * nbn > ncu + 2 * nbn) return false;
-        const int nslice = (p.C0 + p.C1) / 64;
-        if (nslice < 4) return false;
-        const long long m0 = (long long)mt_head * 256, mtail = (long long)mt_tail * 256;
-        if (ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)2 * mtail * p.N * 4) != 0) return false;
+        if (q < 1 || r == 0 || 2 * r > ncu || (p.C0 + p.C1) / 64 < 4) return false;
+        if (ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)2 * p.M * p.N * 4) != 0) return false;
         IgemmParams pa = p, pb = p;
-        pa.M = (int)m0;
-        pb.M = (int)mtail;
-        pb.A0 = p.A0 + m0 * p.C0; if (p.A1) pb.A1 = p.A1 + m0 * p.C1;
-        pb.out_bf16 = p.out_bf16 + m0 * p.ldo;
-        if (p.res_bf16) pb.res_bf16 = p.res_bf16 + m0 * p.ldo;
-        if (p.rowvec) pb.rowvec = p.rowvec + (m0 / p.rows_per_sample) * p.rowvec_ld;
-        pb.ksplit = 2; pb.ws = (float*)c->splitk_ws; pb.one_item_per_block = 1;
-        if (!conv_halo4_supported(pa)) return false;
-        { IgemmParams t = pb; t.ksplit = 0; if (!conv_halo4_supported(t)) return false; }
-        if (!side_fork()) return false;
-        check(launch_conv3x3(pa, c->stream), "conv3x3 (head rows)");
-        side_enter();
-        check(launch_conv3x3(pb, c->stream), "conv3x3 (tail rows, K-split parts)");
-        side_end();
-        side_join();
+        pa.tile_lo = 0; pa.tile_cnt = q * ncu;
+        pb.tile_lo = q * ncu; pb.tile_cnt = r; pb.ksplit = 2; pb.ws = (float*)c->splitk_ws;
+        check(launch_conv3x3(pa, c->stream), "conv3x3 (full rounds)");
+        check(launch_conv3x3(pb, c->stream), "conv3x3 (remainder tiles, K-split)");
         return true;
     }
     int cur_block = -1, cur_layer = 0;           // position in the UNet's block table (debug tap)
