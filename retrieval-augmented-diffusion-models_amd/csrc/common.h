@@ -109,7 +109,5 @@ struct IgemmParams {
     // lin4 only: LayerNorm folded into the GEMM.  A0 holds the RAW rows, Wfrag the gamma-scaled fragment copy, ln_sb[n] = (s[n], b'[n]) per
     // stored weight row (launch_lin_ln_sb); the kernel takes the row statistics itself: out = rstd (A Wg^T - mean s) + b'
     const float* ln_sb; float ln_inv_c, ln_eps;      // ln_inv_c = 1 / (logical row width): zero padding beyond it adds nothing to the sums
-    int tile_lo, tile_cnt;      // conv_halo4 only: tile_cnt > 0: the launch (and its K-split finisher) covers tiles [tile_lo, tile_lo + tile_cnt) of the (m-major, n-minor)
-                                // order of 256-pixel x BN-channel tiles only (model.hip: Ops::conv3 splits a conv into full rounds + a K-split remainder launch)
     int dbg;                    // debug ablation bits (env RDM_IGEMM_DBG): 1 no MFMA, 2 no in-loop staging, 4 no stores
 };

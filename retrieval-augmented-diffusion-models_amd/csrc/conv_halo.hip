@@ -423,37 +423,6 @@ bool conv_halo_supported(const IgemmParams& p) {
     return true;
 }
 
-// the same for the tiles [tile_lo, tile_lo + tile_cnt) of a sub-range launch (256 pixels x BN channels each): one block per tile
-__global__ __launch_bounds__(256) void splitk_finish_tiles_kernel(IgemmParams p, int BN) {
-    const int nbn = p.N / BN, tile = p.tile_lo + blockIdx.x;
-    const int m0 = (tile / nbn) * 256, n0 = (tile % nbn) * BN, vpr = BN >> 3;
-    const long long plane = (long long)p.M * p.N;
-    for (int v = threadIdx.x; v < 256 * vpr; v += 256) {
-        const int r = v / vpr, n = n0 + (v - r * vpr) * 8;
-        const long long m = m0 + r;
-        float a[8];
-        { const float4 b0 = p.bias ? *(const float4*)(p.bias + n) : make_float4(0, 0, 0, 0), b1 = p.bias ? *(const float4*)(p.bias + n + 4) : make_float4(0, 0, 0, 0);
-          a[0] = b0.x; a[1] = b0.y; a[2] = b0.z; a[3] = b0.w; a[4] = b1.x; a[5] = b1.y; a[6] = b1.z; a[7] = b1.w; }
-        for (int s = 0; s < p.ksplit; s++) {                  // fixed order: deterministic (the order of splitk_finish_kernel)
-            const float* w = p.ws + s * plane + m * p.N + n;
-            const float4 w0 = *(const float4*)w, w1 = *(const float4*)(w + 4);
-            a[0] += w0.x; a[1] += w0.y; a[2] += w0.z; a[3] += w0.w; a[4] += w1.x; a[5] += w1.y; a[6] += w1.z; a[7] += w1.w;
-        }
-        if (p.rowvec) {
-            const float* rv = p.rowvec + (m / p.rows_per_sample) * p.rowvec_ld + n;
-#pragma unroll
-            for (int e = 0; e < 8; e++) a[e] += rv[e];
-        }
-        if (p.res_bf16) {
-            const uint4 r4 = *(const uint4*)(p.res_bf16 + m * p.ldo + n);
-            const uint32_t rr[4] = {r4.x, r4.y, r4.z, r4.w};
-#pragma unroll
-            for (int e = 0; e < 4; e++) { a[2 * e] += __uint_as_float(rr[e] << 16); a[2 * e + 1] += __uint_as_float(rr[e] & 0xffff0000u); }
-        }
-        *(uint4*)(p.out_bf16 + m * p.ldo + n) = make_uint4(cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3]), cvt_pk_bf16(a[4], a[5]), cvt_pk_bf16(a[6], a[7]));
-    }
-}
-
 // K-split only pays when the MxN tiles leave most of the chip idle (the 8x8 level: 160 tiles on 256 CUs): S parts per tile
 // turn one 62 %-occupied round into ceil(160 S / 256) rounds of 1/S the length
 int conv_halo_ksplit(const IgemmParams& p) {
@@ -478,10 +447,6 @@ hipError_t launch_conv_halo(const IgemmParams& p, hipStream_t st) {
     if (conv_halo4_supported(p)) e = launch_conv_halo4(p, st);            // one wave per SIMD (conv_halo4.hip)
     else e = (p.N % 192 == 0) ? launch_halo<192>(p, st) : launch_halo<128>(p, st);
     if (e != hipSuccess || p.ksplit <= 1) return e;
-    if (p.tile_cnt > 0) {                                      // a tile sub-range: the finisher walks those tiles only
-        splitk_finish_tiles_kernel<<<dim3((unsigned)p.tile_cnt), 256, 0, st>>>(p, (p.N % 192 == 0) ? 192 : 128);
-        return hipGetLastError();
-    }
     const long long nvec = (long long)p.M * (p.N >> 3);
     long long g = (nvec + 255) / 256; if (g > 4096) g = 4096;
     splitk_finish_kernel<<<dim3((unsigned)g), 256, 0, st>>>(p);

@@ -81,7 +81,7 @@ constexpr int H4_HALO_MAX = 66560;                 // largest HBYTES admitted (W
 // strips' real pixels (zero only at the image border), rows of a tile are WI pixels apart in memory, and tile index -> (sample, row
 // group, strip).  Costs three VALU per halo piece (column = strip origin + halo column, its validity, the source column), so it is a
 // template variant: the UNet's kernels (W <= 64) are unchanged.
-template <int FN, int VAR, bool STRIP = false, bool RANGE = false>      // RANGE: tile sub-range launches (below); VAR: dev-only ablations (RDM_H4_VAR): 1 = no halo-piece address work (wrong results)
+template <int FN, int VAR, bool STRIP = false>      // VAR: dev-only ablations (RDM_H4_VAR): 1 = no halo-piece address work (wrong results)
 __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     constexpr int BM = 256, BK = 64, FM = 4, WN = FN * 32, BN = 2 * WN;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [halo0][halo1][dump: 1 KB per wave]
@@ -102,13 +102,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     const int npw = (NPT - wave + 3) >> 2;                  // halo pieces this wave stages: wave, wave + 4, ...
 
     const int nbn = p.N / BN, nbm = p.M / BM;
-    // tile sub-range (round 6, IgemmParams::tile_cnt > 0): this launch covers tiles [tile_lo, tile_lo + tile_cnt) of the (m-major, n-minor) tile
-    // order only -- Ops::conv3 runs the full rounds of a conv as whole tiles and the remainder tiles as a second, K-split launch.  ntiles_mn
-    // is then the RANGE's tile count; tile_lo is re-read from the kernel arguments where a tile is decoded (the scalar file is full).
-    // (a template variant: the classic kernel has not one register to spare -- the audits in the Makefile fail on a single extra live scalar;
-    //  the RANGE variant pays for tile_lo with the dev-only phase clocks it leaves out)
-    const int ntiles_mn = RANGE ? p.tile_cnt : nbm * nbn;
-    auto tile_lo = [&]() { return RANGE ? p.tile_lo : 0; };
+    const int ntiles_mn = nbm * nbn;
     const int S = p.ksplit > 1 ? p.ksplit : 1;
     const int ntiles = ntiles_mn * S;
     const int G = gridDim.x, xcd = blockIdx.x & 7;
@@ -141,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     // a tap further on is tap_stride bytes away, a slice 4 KiB
     const long long tap_stride = (long long)KQ * 1024;
     auto w_base = [&](int t) -> const char* {
-        const int bn = (tile_lo() + t % ntiles_mn) % nbn;
+        const int bn = (t % ntiles_mn) % nbn;
         const int nb0 = bn * (BN / 32) + wn * FN;
         const long long off = (long long)nb0 * 9 * tap_stride;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(off & 0xffffffffLL));
@@ -164,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     struct HaloSrc { const char* src; unsigned ldb; };                   // src: channel slice of pixel 0 in the slice's source tensor
     const int ups = p.ups ? 1 : 0;
     auto halo_tile = [&](int t) {
-        const int tm0 = ((tile_lo() + t % ntiles_mn) / nbn) * BM;
+        const int tm0 = ((t % ntiles_mn) / nbn) * BM;
         HaloTile h;
         if constexpr (STRIP) {              // tiles of an image: row groups of RS = 4 rows x strips of 64 columns, strips fastest
             const int spr = WI >> 6, tpi = (H >> 2) * spr, tmi = tm0 >> 8;
@@ -237,13 +231,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     const char* wb_tile = Wf; const char* wb_next = Wf;
     HaloTile ht_tile{0, 0}, ht_next{0, 0};
     auto tile_setup = [&]() {
-        // (RANGE: tile origins and the K part are recomputed from the item index where they are used -- prologue and epilogue -- instead of
-        //  living across the main loop)
-        if constexpr (!RANGE) {
-            const int tmn = tile % ntiles_mn;
-            em0 = (tmn / nbn) * BM; en0 = (tmn % nbn) * BN;
-            part = tile / ntiles_mn;
-        }
+        const int tmn = tile % ntiles_mn;
+        em0 = (tmn / nbn) * BM; en0 = (tmn % nbn) * BN;
+        part = tile / ntiles_mn;
         next = tile + gx;
         has_next = next < t_end;
         s_begin = slice_begin(tile); s_end = slice_end(tile);
@@ -251,14 +241,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
         wb_tile = w_base(tile);
         wb_next = has_next ? w_base(next) + (long long)ns_begin * 4096 : wb_tile;       // first step of the next work item
         ht_next = has_next ? halo_tile(next) : HaloTile{0, 0};
-        if constexpr (!RANGE) { const int nmn = (has_next ? next : tile) % ntiles_mn; nem0 = (nmn / nbn) * BM; nen0 = (nmn % nbn) * BN; }
+        { const int nmn = (has_next ? next : tile) % ntiles_mn; nem0 = (nmn / nbn) * BM; nen0 = (nmn % nbn) * BN; }
         ht_tile = halo_tile(tile);
-    };
-    auto origins = [&]() {                                  // RANGE: (em0, en0, part) of the current item, (nem0, nen0) of the next
-        const int lo = tile_lo();
-        const int tmn = lo + tile % ntiles_mn, nmn = lo + (has_next ? next : tile) % ntiles_mn;
-        em0 = (tmn / nbn) * BM; en0 = (tmn % nbn) * BN; part = tile / ntiles_mn;
-        nem0 = (nmn / nbn) * BM; nen0 = (nmn % nbn) * BN;
     };
     int sl = 0, tap = 0;
     bool last_slice = false;
@@ -332,7 +316,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     };
     {
         float pb[FM][FN];
-        if constexpr (RANGE) origins();
         start_values(em0, en0, frow, pb);
         FragU o; o.u = (u32x4_t){fhalf ? 0u : 0x3f803f80u, 0u, 0u, 0u};
         bf16x8 ones = o.f;
@@ -358,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
     // weight stream (vmcnt retires in order: with per-k-step weight requests a piece that was late stalled every wait behind it).
     unsigned long long tprof[2] = {0, 0};
     unsigned long long tp0 = 0, tp1 = 0;
-    if (!RANGE && (p.dbg & 16)) tp0 = __builtin_readcyclecounter();
+    if (p.dbg & 16) tp0 = __builtin_readcyclecounter();
     // descriptors of the NEXT tap-step (uniform), refreshed before every step
     bool slice_last_tap = false;
     int epi_stores = 0;                                     // stores of the epilogue just finished that may still be in flight
@@ -462,13 +445,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
         if (!has_next) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
-        if (!RANGE && (p.dbg & 16)) { tp1 = __builtin_readcyclecounter(); tprof[0] += tp1 - tp0; }
+        if (p.dbg & 16) { tp1 = __builtin_readcyclecounter(); tprof[0] += tp1 - tp0; }
         // ---- epilogue.  The halo buffer of the slice just finished (hb ^ 1 after the toggle) is free for every wave: all of them
         // passed the slice-end barrier after their last read of it.  Staging is wave-private.
         char* const stg_base = smem + (hb ^ 1) * HBYTES;
         // lane-derived epilogue addressing is recomputed per tile from an opaque copy of the lane id: hoisted out of the tile loop
         // it would sit in registers across the main loop, which has none to spare
-        if constexpr (RANGE) origins();
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int erow = lane_e & 31, ehalf = lane_e >> 5;
@@ -602,7 +584,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
         }
         // (the epilogue's own loads -- bias, residual -- were consumed above, i.e. waited for; its stores are asm)
         epi_stores = (S > 1) ? 2 * FM * ((32 * (WN / 8)) / 64) : FM * ((32 * (WN / 8)) / 64);
-        if (!RANGE && (p.dbg & 16)) tprof[1] += __builtin_readcyclecounter() - tp1;
+        if (p.dbg & 16) tprof[1] += __builtin_readcyclecounter() - tp1;
         if (!has_next) return true;
         // the staging area is the buffer the next tile's SECOND slice is staged into during its first steps: every wave must have
         // left its epilogue first
@@ -611,7 +593,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
         tile_setup();
         sl = s_begin;
         slice_setup();
-        if (!RANGE && (p.dbg & 16)) tp0 = __builtin_readcyclecounter();
+        if (p.dbg & 16) tp0 = __builtin_readcyclecounter();
         return false;
     };
     // straight-line pairs of steps (parity 0, parity 1): no control-flow merge ever sits between the request of a fragment and its use
@@ -619,24 +601,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4_kernel(IgemmParams p) {
         describe(); step(std::integral_constant<int, 0>{}); if (advance()) break;
         describe(); step(std::integral_constant<int, 1>{}); if (advance()) break;
     }
-    if (!RANGE && (p.dbg & 16) && tid == 0) {
+    if ((p.dbg & 16) && tid == 0) {
         atomicAdd(&g_halo4_prof[0], tprof[0]); atomicAdd(&g_halo4_prof[1], tprof[1]); atomicAdd(&g_halo4_prof[3], 1ull);
     }
 }
 
-template <int FN, int VAR, bool STRIP = false, bool RANGE = false>
+template <int FN, int VAR, bool STRIP = false>
 static hipError_t launch_halo4_cfg(const IgemmParams& p, hipStream_t st) {
     constexpr int smem = 2 * H4_HALO_MAX + 4096 + 4 * 21 * 256;       // halo x 2, dump, piece tables
     constexpr int BN = FN * 64;
     static int ncu_dev[RDM_MAX_DEVICES] = {0};
     const int dev = rdm_cur_device();
     if (!ncu_dev[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo4_kernel<FN, VAR, STRIP, RANGE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo4_kernel<FN, VAR, STRIP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         hipDeviceGetAttribute(&ncu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev);
     }
     const int ncu = ncu_dev[dev];
-    const long long ntiles = (RANGE ? (long long)p.tile_cnt : (long long)(p.M / 256) * (p.N / BN)) * (p.ksplit > 1 ? p.ksplit : 1);
+    const long long ntiles = (long long)(p.M / 256) * (p.N / BN) * (p.ksplit > 1 ? p.ksplit : 1);
     long long g = (ncu + 7) & ~7;
     if (g > ntiles) g = ntiles;
     static const int prof = getenv("RDM_HALO_PROF") ? atoi(getenv("RDM_HALO_PROF")) : 0;
@@ -644,14 +626,14 @@ static hipError_t launch_halo4_cfg(const IgemmParams& p, hipStream_t st) {
         IgemmParams q = p; q.dbg |= 16;
         unsigned long long z[4] = {0, 0, 0, 0}, r[4];
         hipMemcpyToSymbol(HIP_SYMBOL(g_halo4_prof), z, sizeof(z));
-        conv3x3_halo4_kernel<FN, VAR, STRIP, RANGE><<<dim3((unsigned)g), 256, smem, st>>>(q);
+        conv3x3_halo4_kernel<FN, VAR, STRIP><<<dim3((unsigned)g), 256, smem, st>>>(q);
         hipStreamSynchronize(st);
         hipMemcpyFromSymbol(r, HIP_SYMBOL(g_halo4_prof), sizeof(r));
         fprintf(stderr, "[halo4<%d> M=%d N=%d K=%d] blocks=%llu per-block cycles: main %.0f epilogue %.0f (tiles/block %.2f)\n", BN, p.M, p.N, p.K,
                 r[3], (double)r[0] / r[3], (double)r[1] / r[3], (double)ntiles / g);
         return hipGetLastError();
     }
-    conv3x3_halo4_kernel<FN, VAR, STRIP, RANGE><<<dim3((unsigned)g), 256, smem, st>>>(p);
+    conv3x3_halo4_kernel<FN, VAR, STRIP><<<dim3((unsigned)g), 256, smem, st>>>(p);
     return hipGetLastError();
 }
 
@@ -696,9 +678,7 @@ hipError_t launch_conv_halo4(const IgemmParams& p, hipStream_t st) {
         if (var == 1) return launch_halo4_cfg<3, 1>(p, st);
         if (var == 3) return launch_halo4_cfg<3, 3>(p, st);
         if (var == 2) return launch_halo4_cfg<3, 2>(p, st);
-        if (p.tile_cnt > 0) return launch_halo4_cfg<3, 0, false, true>(p, st);
         return launch_halo4_cfg<3, 0>(p, st);
     }
-    if (p.tile_cnt > 0) return launch_halo4_cfg<2, 0, false, true>(p, st);
     return launch_halo4_cfg<2, 0>(p, st);
 }

@@ -627,14 +627,6 @@ struct Ops {
         c->side_saved = c->stream; c->stream = c->side;
         return true;
     }
-    // the same in two steps: side_fork() marks the point on the main stream the side work depends on (more main-stream launches may follow
-    // BEFORE the side work is issued: they are then ahead of it in the hardware queues), side_enter() switches to the side stream
-    bool side_fork() {
-        if (!side_begin()) return false;
-        c->stream = c->side_saved;
-        return true;
-    }
-    void side_enter() { c->side_saved = c->stream; c->stream = c->side; }
     void side_end() {                                           // back to the main stream; the side work is still in flight
         check(hipEventRecord(c->ev_join, c->stream), "side stream join");
         c->stream = c->side_saved;
@@ -785,39 +777,16 @@ struct Ops {
         if (ks > 1 && ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)ks * p.M * N * 4) == 0) { p.ksplit = ks; p.ws = (float*)c->splitk_ws; }
         if (!det_generic && (conv_halo_supported(p) || conv_halo4_strip_supported(p))) p.Wfrag = c->frag_for(p.W, N, C0 + C1);
         prof_begin(RDM_PROF_CONV3X3, 2.0 * p.M * N * (double)p.K, p.M, N, p.K);
-        if (!det_generic && conv_remainder_split(p)) { prof_end(); return; }
         check(det_generic ? launch_igemm(p, true, 1, c->stream) : launch_conv3x3(p, c->stream), "conv3x3");
         prof_end();
     }
-    // ---- wave quantisation of the persistent halo kernel (round 6).  A conv whose tile count is q full rounds of the CUs plus a partial
-    // round of r tiles runs q + 1 rounds: the 16 x 16 level of a guided batch of 64 (M = 32768, N = 576: 384 tiles on 256 CUs) spends a
-    // whole second round on 128 tiles.  When 2 r <= CUs the conv runs as TWO launches of the same kernel on tile sub-ranges
-    // (IgemmParams::tile_lo / tile_cnt): tiles [0, q CUs) whole, then the r remainder tiles as 2-part K-splits (2 r <= CUs items: one
-    // half-length round) + the finisher over those tiles -- q + 1 rounds become q + ~0.6.  The remainder tiles are computed like every
-    // K-split conv (fp32 partial planes summed in a fixed order, bias / time-embedding row / residual added in fp32, one rounding).  Not in
-    // deterministic mode (the cut follows the batch).  RDM_CONV_REM=0: off.
-    // (Measured first, and dropped: the same cut at a sample boundary with the tail on a second stream -- the tail did not start before the
-    //  head had finished, and 258 parts need two half rounds: -1.2 %; the halves handed out INSIDE one launch by a TAIL variant of the kernel
-    //  -- that variant has no register to spare and its main loop lost more than the half round it saved: -1.0 %.  profiles/r06_conv_tail_*.)
-    bool conv_remainder_split(IgemmParams& p) {
-        static const int on = getenv("RDM_CONV_REM") ? atoi(getenv("RDM_CONV_REM")) : 1;
-        if (!on || c->deterministic || p.ksplit > 1 || !p.Wfrag || p.stride != 1 || p.ups || p.Wout > 64 || !conv_halo4_supported(p)) return false;
-        static int ncu_dev[RDM_MAX_DEVICES] = {0};
-        const int dev = rdm_cur_device();
-        if (!ncu_dev[dev]) hipDeviceGetAttribute(&ncu_dev[dev], hipDeviceAttributeMultiprocessorCount, dev);
-        const int ncu = ncu_dev[dev] & ~7, bn = (p.N % 192 == 0) ? 192 : 128;
-        const long long T = (long long)(p.M / 256) * (p.N / bn);
-        if (ncu < 8 || T > 0x3fffffff) return false;
-        const int q = (int)(T / ncu), r = (int)(T % ncu);
-        if (q < 1 || r == 0 || 2 * r > ncu || (p.C0 + p.C1) / 64 < 4) return false;
-        if (ensure_bytes(c, &c->splitk_ws, &c->splitk_ws_bytes, (size_t)2 * p.M * p.N * 4) != 0) return false;
-        IgemmParams pa = p, pb = p;
-        pa.tile_lo = 0; pa.tile_cnt = q * ncu;
-        pb.tile_lo = q * ncu; pb.tile_cnt = r; pb.ksplit = 2; pb.ws = (float*)c->splitk_ws;
-        check(launch_conv3x3(pa, c->stream), "conv3x3 (full rounds)");
-        check(launch_conv3x3(pb, c->stream), "conv3x3 (remainder tiles, K-split)");
-        return true;
-    }
+    // (Round 6, wave quantisation: a conv of q full rounds of the CUs plus a partial round -- the 16 x 16 level of a guided batch of 64 is 384
+    //  tiles on 256 CUs -- was run as full rounds + a K-split remainder in three forms: tail rows on a second stream, halves handed out inside
+    //  one launch, two launches on tile sub-ranges.  All parity-exact, all SLOWER (-1.0 .. -1.4 % on the headline), and the launch trace says
+    //  why: under the package power cap a half-empty round is nearly half price -- 256 tiles take 140 us, 384 tiles 213 us: the 128
+    //  remainder tiles cost 73 us on a chip that clocks up when half its CUs idle -- while 256 K halves + their fp32 planes and finisher cost
+    //  118 us.  The code is in the history (commits "conv tail split", "conv_halo4 TAIL variant", "conv remainder split"), the numbers in
+    //  profiles/r06_conv_tail_split_*.log, r06_conv_remainder_split_*.)
     int cur_block = -1, cur_layer = 0;           // position in the UNet's block table (debug tap)
     void tap(int stage, const void* ptr, size_t nbytes) {      // rdm_debug_tap: stage `stage` of layer cur_layer of block cur_block
         if (plan || !c->tap_buf || c->tap_block != cur_block || c->tap_sub != cur_layer * 16 + stage) return;

@@ -260,39 +260,3 @@ def test_knn_full_database_bit_exact(ctx):
     assert np.array_equal(got, ref_i), f"top-k indices differ in {(got != ref_i).sum()} places"
     assert np.abs(sc.cpu().numpy() - ref_s).max() <= 1e-6
     assert got[5, 0] == 777                                          # the duplicate pair: lower index first
-
-
-def test_conv_remainder_split_rows_match_the_unsplit_run(shipped, tmp_path):
-    """Round 6, wave quantisation: at the 16 x 16 level of a 128-sample UNet batch a 3x3 conv is 384 tiles on 256 CUs = two rounds of the persistent
-    kernel for 1.5 rounds of work.  Ops::conv3 runs it as two launches on tile sub-ranges: tiles [0, 256) whole, tiles [256, 384) as 2-part
-    K-splits (256 half-length items) + the tile-wise finisher (model.hip: conv_remainder_split).  Samples are independent and every other op is per
-    sample, so against a run with RDM_CONV_REM=0 (a child process: the switch is read once) the samples whose tiles were not split must agree
-    BIT FOR BIT -- 85 of 128 -- and the others, whose 16 x 16 convs add their K halves in the K-split order (fp32 planes, one rounding, like every
-    K-split conv), to rounding."""
-    import os
-    import subprocess
-    import sys
-    ctx = shipped
-    gen = torch.Generator().manual_seed(123)
-    B = 128
-    x = torch.randn(B, 3, 64, 64, generator=gen); t = torch.randint(0, 1000, (B,), generator=gen); c = torch.randn(B, 4, 512, generator=gen) * 0.45
-    torch.save({"x": x, "t": t, "c": c}, tmp_path / "in.pt")
-    eps = ctx.unet_forward(x, t, c).cpu()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, torch\n"
-        f"sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})\n"
-        "import rdm_amd\nfrom rdm_amd import _lib, packing\nfrom oracle import unet as ounet\nfrom _util import spec_to_unet_cfg\n"
-        "torch.set_grad_enabled(False)\nctx = _lib.Context(0)\nspec = ounet.shipped_spec()\ncfg = spec_to_unet_cfg(spec)\n"
-        "ctx.load_unet(cfg, packing.pack('unet', cfg, ounet.synth_state_dict(ounet.param_shapes(spec), seed=1234)))\n"
-        f"d = torch.load({str(tmp_path / 'in.pt')!r})\n"
-        f"torch.save(ctx.unet_forward(d['x'], d['t'], d['c']).cpu(), {str(tmp_path / 'plain.pt')!r})\n")
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RDM_CONV_REM="0"), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    plain = torch.load(tmp_path / "plain.pt")
-    same = [bool(torch.equal(eps[i], plain[i])) for i in range(B)]
-    worst = max(rel_l2(eps[i:i + 1], plain[i:i + 1]) for i in range(B))
-    print(f"conv remainder split: {sum(same)} of {B} samples bit-identical to the unsplit run, the others differ by <= {worst:.3e} rel L2")
-    if os.environ.get("RDM_CONV_REM", "1") != "0":
-        assert 64 <= sum(same) < B, "samples outside the split tiles must be bitwise those of the unsplit run (and split tiles must exist at this shape)"
-    assert worst <= 1.5e-2
