@@ -404,7 +404,7 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process -- taken from the committed
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (gfx950 corrections applied; profiles/README.md)
     traffic, traffic_src, pmc = None, None, {}
-    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_v4.json"):
+    for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_v4.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc = json.load(f)

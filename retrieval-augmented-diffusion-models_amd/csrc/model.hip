@@ -612,7 +612,8 @@ struct Ops {
     // 256 CUs) instead of taking its own slot in the serial chain.  Same kernels, same arithmetic: only the issue order changes.
     // RDM_SKIP_OVERLAP=0: off (resblock).  side_begin(): launches that follow go to the side stream (ordered after everything issued so far).
     bool side_begin() {
-        if (plan) return false;
+        // (not while kernel classes other than the conv are bracketed with events: concurrent side work would be billed to whatever runs beside it)
+        if (plan || (c->prof & ~(1u << RDM_PROF_CONV3X3))) return false;
         if (!c->side) {
             int pr_lo = 0, pr_hi = 0;                          // lowest priority: side work fills what the main chain leaves idle, it never goes first
             (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
