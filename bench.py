@@ -539,7 +539,7 @@ def main():
             #     time here = time on the reference box x [ s x (sclk reference / sclk here) + (1 - s) ]
             sclk = calib.get("sclk_mhz_mean")
             if ref and sclk and ref.get("sclk_mhz_mean") and a.config != 5:
-                s_ = float(ref.get("clock_bound_share", 0.55))
+                s_ = float(ref.get("clock_bound_share", 0.6))
                 rel = s_ * (ref["sclk_mhz_mean"] / sclk) + (1.0 - s_)
                 calib["clock_bound_share"] = s_
                 calib["value_scale_to_reference_box"] = rel
