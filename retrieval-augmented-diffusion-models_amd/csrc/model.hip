@@ -615,10 +615,7 @@ struct Ops {
         // (not while kernel classes other than the conv are bracketed with events: concurrent side work would be billed to whatever runs beside it)
         if (plan || (c->prof & ~(1u << RDM_PROF_CONV3X3))) return false;
         if (!c->side) {
-            int pr_lo = 0, pr_hi = 0;                          // lowest priority: side work fills what the main chain leaves idle, it never goes first
-            (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
-            static const int lowprio = getenv("RDM_SIDE_LOWPRIO") ? atoi(getenv("RDM_SIDE_LOWPRIO")) : 1;
-            if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lowprio ? pr_lo : pr_hi) != hipSuccess) { c->side = nullptr; return false; }
+            if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = nullptr; return false; }     // (a low-priority stream measured the same: profiles/r06_conv_tail_split_normal_priority_ab.log)
             if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
                 (void)hipStreamDestroy(c->side); c->side = nullptr; return false;
             }
@@ -1527,7 +1524,8 @@ void rdm_ctx_destroy(rdm_ctx* c) {
     if (c->comm) rdm_comm_destroy(c);
     DevGuard guard(c->device);
     hipDeviceSynchronize();
-    if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); }
+    // (the side stream and its two events are left to the runtime: a context may be destroyed from a finaliser at interpreter shutdown, and tearing
+    //  streams down there is not worth one lost handle per context)
     void* ptrs[] = {c->zero_page, c->unet.blob, c->unet.arena.base, c->unet.kv_cache, c->vq.blob, c->vq.arena.base,
                     c->clip.blob, c->clip.arena.base, c->gn_partial, c->samp, c->splitk_ws, c->unet.xa_cache,
                     c->rarm.blob, c->rarm.arena.base, c->rarm.cache, c->rarm.ctxkv, c->rarm.state, c->rarm.xa, c->rarm.xws, c->wfrag_tmp, c->bwd_tmp,

@@ -542,14 +542,15 @@ __global__ __launch_bounds__(256) void rarm_xattn_decode_split_kernel(RarmXattnP
     if (p.ln3_out) rarm_emit_ln4(xv, tid, C, p.ln3_g, p.ln3_b, p.ln_eps, p.ln3_out + (long long)b * C, red);
 }
 #ifndef RARM_XSPLIT_DEFAULT
-#define RARM_XSPLIT_DEFAULT 1
+#define RARM_XSPLIT_DEFAULT 0
 #endif
 hipError_t launch_rarm_xattn_decode(const RarmXattnParams& p, hipStream_t st) {
     if (p.C % 8 || p.C > 1024 || p.heads * p.k > 128 || p.heads * p.k > p.NP || p.k < 1) return hipErrorInvalidValue;
-    // The four-blocks-per-sequence form (worth 1 us of a 16 us launch: ~1.5-3 % of a token step at <= 128 sequences).  Round 5 made it opt-in
-    // after one unexplained bitwise mismatch in ~6 800 repeated decodes; round 6 replaced the hand-over's ordering assumption by
-    // self-validating granules (note above) and stress-ran both forms (profiles/r06_rarm_stress.log).  RDM_RARM_XSPLIT=0 / 1 overrides
-    // the default.  Never in deterministic mode (p.no_split: the choice follows the batch; the two forms add the heads in different orders).
+    // The four-blocks-per-sequence form: OPT-IN (RDM_RARM_XSPLIT=1).  Round 5 made it opt-in after one unexplained bitwise mismatch in ~6 800
+    // repeated decodes; round 6 replaced the hand-over's ordering assumption by self-validating granules (note above), stress-ran both forms clean
+    // (profiles/r06_rarm_stress.log) -- and then measured the granule form SLOWER than one block per sequence (64 sequences 199.4 vs 198.0 img/s,
+    // 128: 290.6 vs 284.5; profiles/r06_rarm_split_ab.log): the 8-byte granules and the tag checks cost more than the 1 us the split bought.
+    // Never in deterministic mode (p.no_split: the choice follows the batch; the two forms add the heads in different orders).
     static const int split_on = getenv("RDM_RARM_XSPLIT") ? atoi(getenv("RDM_RARM_XSPLIT")) : RARM_XSPLIT_DEFAULT;
     // (from 128 sequences on the one-block form already fills the chip: measured equal at 256)
     if (split_on && !p.no_split && p.epoch && p.ws && p.ws_count && p.B2 <= 128 && p.heads % 4 == 0 && (p.heads / 4) * p.k <= 32 && p.C % 4 == 0) {
