@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 6, call 14: the GPU suite twice on the final tree (whole logs kept), smoke, final bench line
+mkdir -p gpurun_out; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r06_14; mkdir -p $O
+for i in 1 2; do
+  timeout 1500 python3 -m pytest tests -x -q -m gpu > $O/tests_run$i.log 2>&1 </dev/null
+  echo "run $i exit code $?" >> $O/tests_run$i.log
+  grep -v amdgpu.ids $O/tests_run$i.log | tail -6 > $O/tests_run${i}_tail.log
+done
+timeout 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 </dev/null
+timeout 600 python3 bench.py > $O/bench.json 2> $O/bench.err </dev/null
+echo done

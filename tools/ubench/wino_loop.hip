@@ -9,6 +9,7 @@
 // transform, 16 ds_read_b128 of U fragments (G g G^T, fragment-ordered), 16 v_mfma_f32_32x32x16_bf16.
 //   mode 0: the whole loop;  mode 1: no transform (raw pixels as A fragments: LDS reads + MFMA only);  mode 2: transform, no MFMA;
 //   mode 3: MFMA only (operands loaded once).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/wino_loop.hip -o tools/ubench/wino_loop (the binary travels to the GPU box with the snapshot).
 // Prints cycles per k-step and the DIRECT-CONV-EQUIVALENT rate: 2.25 x (MFMA FLOPs executed) / time, the number to put beside
 // conv3x3_halo4_kernel's 1.25 PFLOP/s in isolation (0.50 of peak) / 1.05-1.10 in situ.
 #include <hip/hip_runtime.h>
