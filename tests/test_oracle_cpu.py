@@ -238,3 +238,22 @@ def test_emulated_vq_decoder_is_exact_algebra_without_rounding():
         assert e <= 2e-5, (fnq, e)
     e = float((vq_decode_emulated(sd, spec, z, force_not_quantize=True) - ovq.vq_decode(sd, spec, z, force_not_quantize=True)).norm() / ref.norm())
     assert 1e-4 < e <= 2.5e-2, e
+
+
+def test_winograd_restatement_is_exact_algebra_and_its_bf16_error_is_the_measured_one():
+    """Round 6 (verdict item 1a): oracle/unet_emul.py's Winograd F(2x2, 3x3) conv -- the accuracy half of the Winograd decision, run on the CPU by
+    tools/wino_accuracy.py -- equals F.conv2d with the rounding switched off, and with a fused bf16-MFMA kernel's roundings (bf16 U and V, fp32 sums and
+    output transform) sits at ~4e-3 per conv on unit-scale data (the direct conv's single output rounding: 1.7e-3): profiles/r06_wino_accuracy.log."""
+    import torch.nn.functional as F
+    from oracle.unet_emul import wino_conv3x3, _R
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 64, 16, 16, generator=g); w = torch.randn(32, 64, 3, 3, generator=g) * (9 * 64) ** -0.5
+    ref = F.conv2d(x, w, padding=1)
+    assert float((wino_conv3x3(x, w, _R(False)) - ref).norm() / ref.norm()) <= 2e-6
+    bf = lambda t: t.to(torch.bfloat16).float()
+    xb, wb = bf(x), bf(w)
+    refb = F.conv2d(xb, wb, padding=1)
+    e1 = float((wino_conv3x3(xb, wb, _R(True)) - refb).norm() / refb.norm())
+    e2 = float((wino_conv3x3(xb, wb, _R(True), two_stage=True) - refb).norm() / refb.norm())
+    assert 2e-3 <= e1 <= 6e-3 and e1 <= e2 <= 7e-3
+
