@@ -197,6 +197,23 @@ def attach_library_comm(ctx, group=None) -> bool:
     return True
 
 
+def library_comm_gather(ctx, local: torch.Tensor, world: int) -> torch.Tensor:
+    """[b, ...] -> [world, b, ...] through the library's communicator (`ctx.lib_comm`, the sibling context attach_library_comm created, or the
+    context itself): rdm_comm_all_gather on the communicator's own non-blocking side stream, ordered after the producer of `local` on the
+    current stream and before its consumers (stream waits, no host synchronisation)."""
+    cc = getattr(ctx, "lib_comm", None) or ctx
+    side = getattr(cc, "_side_stream", None)
+    cur = torch.cuda.current_stream(local.device)
+    local = local.contiguous()
+    if side is not None:
+        side.wait_stream(cur)
+    out = cc.comm_all_gather(local, world)
+    if side is not None:
+        local.record_stream(side); out.record_stream(side)
+        cur.wait_stream(side)
+    return out
+
+
 def all_gather_images(local: torch.Tensor, n_total: int = None, group=None, ctx=None) -> torch.Tensor:
     """Gather [b_rank, ...] shards into [n_total, ...] on every rank (shards may differ by one sample).
     ctx: a library context with a communicator (attach_library_comm) -> the gather is rdm_comm_all_gather (RCCL through the C ABI, on
@@ -211,17 +228,7 @@ def all_gather_images(local: torch.Tensor, n_total: int = None, group=None, ctx=
     counts = [shard_range(n_total, world, r)[1] - shard_range(n_total, world, r)[0] for r in range(world)]
     bmax = max(counts)
     if ctx is not None and local.is_cuda and getattr(ctx, "lib_comm_agreed", 0) == world and all(c == bmax for c in counts):
-        cc = getattr(ctx, "lib_comm", None) or ctx
-        side = getattr(cc, "_side_stream", None)
-        cur = torch.cuda.current_stream(local.device)
-        local = local.contiguous()
-        if side is not None:                                                     # the communicator's side stream: after the producer, before the consumer
-            side.wait_stream(cur)
-        out = cc.comm_all_gather(local, world)                                   # [world, b, ...]
-        if side is not None:
-            local.record_stream(side); out.record_stream(side)
-            cur.wait_stream(side)
-        return out.reshape((world * bmax,) + tuple(local.shape[1:]))
+        return library_comm_gather(ctx, local, world).reshape((world * bmax,) + tuple(local.shape[1:]))
     if all(c == bmax for c in counts):
         out = torch.empty((world * bmax,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)

@@ -710,6 +710,31 @@ def test_c_abi_rccl_wrappers_single_rank():
     ctx.close()
 
 
+def test_library_communicator_on_its_sibling_context_single_rank(ctx):
+    """Round 6: the RCCL communicator of the image all-gather lives on a DEDICATED sibling context with its own non-blocking side stream
+    (`Context.new_comm_context`, parallel.attach_library_comm), and the gather is ordered against the producer / consumer by stream waits
+    (`parallel.library_comm_gather`).  A one-GPU box can only form a world of one, but that exercises everything except the wire: sibling
+    creation, rdm_set_stream on a torch stream, rdm_comm_init / rdm_comm_all_gather on that stream, the stream ordering (40 gathers of
+    tensors produced on the current stream right before, each compared after), teardown."""
+    from rdm_amd import parallel
+    sib = ctx.new_comm_context()
+    assert sib is not ctx and sib._side_stream is not None
+    sib.comm_init(sib.comm_unique_id(), 0, 1)
+    ctx.lib_comm, ctx.lib_comm_agreed = sib, 1
+    try:
+        d = ctx.device
+        for i in range(40):
+            x = torch.randn(8, 3, 64, 64, device=d) * (i + 1)            # producer on the current stream
+            y = parallel.library_comm_gather(ctx, x, 1)
+            z = y[0] * 2.0                                               # consumer on the current stream
+            torch.cuda.synchronize()
+            assert y.shape == (1, 8, 3, 64, 64) and torch.equal(y[0], x) and torch.equal(z, x * 2.0)
+    finally:
+        ctx.lib_comm, ctx.lib_comm_agreed = None, 0
+        sib.comm_destroy()
+        sib.close()
+
+
 # ---- batch-invariant ("deterministic") mode: include/rdm_hip.h rdm_set_deterministic
 def _det_models(ctx):
     from rdm_amd import packing

@@ -794,3 +794,20 @@ def test_configure_optimizers_resumes_litema_from_checkpoint():
     m.load_state_dict({"model.diffusion_model." + k: v for k, v in live.items()})
     st = m.configure_optimizers()
     assert st.ema.num_updates == 0 and st.ema.decay == 0.9999 and torch.equal(st.ema.shadow[k0], st.P[k0])
+
+
+def test_bench_box_sampler_without_sensors_and_calibration_reference():
+    """bench.py's calibration helpers must never cost the benchmark line: on a host without amdgpu hwmon files and without rocm-smi (this
+    container) the sampler comes back with nulls, and the committed reference box has the fields the normalisation reads."""
+    import importlib.util
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    s = b.BoxSampler(period=0.05)
+    s.start(); time.sleep(0.2)
+    out = s.stop()
+    assert out["samples"] == 0 or (out["sclk_mhz_mean"] > 0 and out["power_w_mean"] > 0)
+    assert set(out) >= {"sclk_mhz_mean", "sclk_mhz_min", "power_w_mean", "samples", "sampler"}
+    ref = b.load_calibration_reference()
+    assert ref and ref["sclk_mhz_mean"] > 1000 and 0 < ref["clock_bound_share"] <= 1 and ref["mfma_probe_tflops"] > 1000 and ref["hbm_stream_gbps"] > 1000
