@@ -249,6 +249,13 @@ int rdm_prof_reset(rdm_ctx* ctx);
  * reference modules behind the roles: rdm/modules/attention.py:122-196, ldm ResBlock), its shape (M, N, K | rows, channels | B, n, C),
  * elapsed ms and algorithmic work -- the per-op table behind DESIGN.md's level-by-level costs (tools/op_trace.py). */
 int rdm_prof_dump(rdm_ctx* ctx, const char* path);
+/* out = [ x gelu(g) | t2 ] wf^T + bf + xin with [x | g] = l3 w1^T + b1: the GEGLU feed-forward of BasicTransformerBlock and proj_out's residual
+ * (rdm/modules/attention.py:77-96 `self.ff(self.norm3(x)) + x`, :194 `self.proj_out(x) + x_in`; ldm FeedForward / GEGLU) in ONE kernel, the hidden tensor never
+ * in HBM -- round 6's measurement vehicle for that fusion (compiler-scheduled; csrc/ffn.hip), NOT used by the executors: it measured slower than the two
+ * kernels it would replace.  bf16 [M, C] activations; w1 bf16 [8C, C] and b1 f32 [8C] in the packed GEGLU row order of rdm_op_linear
+ * ([32 x | 32 gates] blocks); wf bf16 [C, 5C] = [W_out W_2 | W_out]; bf f32 [C].  C = 384 and M % 128 == 0 only (-5 otherwise). */
+int rdm_op_ffn_fused(rdm_ctx* ctx, const void* l3_bf16, const void* t2_bf16, const void* xin_bf16, const void* w1_bf16, const float* b1,
+                     const void* wf_bf16, const float* bf, void* out_bf16, int M, int C);
 /* test / stress hook: library-wide debug counters.  which = 0: granules the four-blocks-per-sequence RARM decode cross-attention
  * (rarm.hip; the decode step of rdm/models/autoregression/transformer.py:241-248) had to RE-READ because their tag was an earlier launch's
  * -- the hand-over is self-validating, so a non-zero count is harmless, and it is the round-5 repeat mismatch caught in the act

@@ -107,6 +107,7 @@ SIGNATURES = {
     "rdm_prof_reset": (C.c_int, [_P]),
     "rdm_prof_dump": (C.c_int, [_P, C.c_char_p]),
     "rdm_debug_tap": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int]),
+    "rdm_op_ffn_fused": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int]),
     "rdm_debug_counter": (C.c_int, [_P, C.c_int, C.POINTER(C.c_ulonglong)]),
     "rdm_calib_probe": (C.c_int, [_P, _P, C.c_size_t, C.c_double, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rdm_comm_unique_id": (C.c_int, [_P, _P]),
@@ -657,6 +658,13 @@ class Context:
         device tensor); buf None: off."""
         self._tap_keepalive = buf
         self._check(lib.rdm_debug_tap(self._h, _ptr(buf) if buf is not None else None, 0 if buf is None else buf.numel() * buf.element_size(), int(block), int(sub)))
+
+    def op_ffn_fused(self, l3, t2, xin, w1, b1, wf, bf):
+        """[x gelu(g) | t2] wf^T + bf + xin with [x | g] = l3 w1^T + b1 in one kernel (rdm_op_ffn_fused; C = 384, M % 128 == 0)."""
+        M, Cc = l3.shape
+        out = torch.empty((M, Cc), device=self.device, dtype=torch.bfloat16)
+        self._check(lib.rdm_op_ffn_fused(self._h, _ptr(l3), _ptr(t2), _ptr(xin), _ptr(w1), _ptr(b1), _ptr(wf), _ptr(bf), _ptr(out), M, Cc))
+        return out
 
     def debug_counter(self, which=0):
         v = C.c_ulonglong(0)

@@ -237,3 +237,9 @@ hipError_t launch_to_uint8_hwc(const float* x, unsigned char* out, int B, int C,
 
 // box calibration probes (calib.hip): a fixed MFMA stream on random bf16 operands and a fixed HBM copy, timed on `st`
 hipError_t run_calib_probes(void* buf, double mfma_ms, size_t stream_bytes, int stream_reps, double* mfma_tflops, double* stream_gbps, hipStream_t st);
+
+// fused feed-forward (ffn.hip, round 6: a measurement vehicle, C = 384 only): out = [x gelu(g) | t2] Wf^T + bf + xin, [x | g] = l3 W1^T + b1
+size_t ffn_fused_scratch_bytes(int C);
+bool ffn_fused_supported(int M, int C);
+hipError_t launch_ffn_fused(const bf16_t* l3, const bf16_t* t2, const bf16_t* xin, const bf16_t* w1, const float* b1, const bf16_t* wf, const float* bf,
+                            bf16_t* out, int M, int C, char* scratch, bool repack, hipStream_t st);

