@@ -14,6 +14,9 @@
 //     0 1 2 3 8 9 10 11 4 5 6 7 12 13 14 15: the packer does it); 12 output accumulators stay resident; the t2 part of K follows at the end;
 //   * every weight fragment is needed by all four waves: fragments travel L2 -> LDS once per block (global_load_lds, 1 KiB per wave
 //     instruction) through two double-buffered rings (W1: 16 fragments per stage, Wf: 48), one barrier per stage.
+#include <stdlib.h>
+#include <type_traits>
+
 #include "kernels.h"
 
 struct FfnParams {
@@ -26,10 +29,11 @@ struct FfnParams {
 };
 
 constexpr int FFN_C = 384, FFN_KQ1 = FFN_C / 16, FFN_KQ2 = 5 * FFN_C / 16, FFN_NO = FFN_C / 32, FFN_CHUNKS = 4 * FFN_C / 64;
-constexpr int FFN_RING1 = 16 * 1024, FFN_RING2 = 48 * 1024;            // bytes per stage
-constexpr int FFN_SMEM = 2 * FFN_RING1 + 2 * FFN_RING2;
+constexpr int FFN_RING2 = 48 * 1024;                                    // bytes per Wf stage (4 k-steps x 12 fragments); W1 stage: SKS k-steps x 4 fragments
 
+template <int SKS>      // k-steps of GEMM 1 per LDS stage (4, 6 or 8: one barrier per stage)
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
+    constexpr int FFN_RING1 = SKS * 4 * 1024, NSUB = FFN_KQ1 / SKS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ring1 = smem; char* const ring2 = smem + 2 * FFN_RING1;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -38,13 +42,13 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     const long long row = (long long)blockIdx.x * 128 + wave * 32 + r;
 
     // ---- stage loaders: 1 KiB fragments, one global_load_lds per wave and fragment
-    auto issue_w1 = [&](int t) {            // stage t = (chunk, sub-step): fragments (nb = 4 chunk + f, kq = 4 sub + ks), slot order [f][ks]
-        const int chunk = t / 6, sub = t - chunk * 6;
+    auto issue_w1 = [&](int t) {            // stage t = (chunk, sub-step): fragments (nb = 4 chunk + f, kq = SKS sub + ks), slot order [f][ks]
+        const int chunk = t / NSUB, sub = t - chunk * NSUB;
         char* dst = ring1 + (t & 1) * FFN_RING1;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int idx = wave * 4 + q, f = idx >> 2, ks = idx & 3;
-            const char* src = (const char*)p.W1f + ((long long)((chunk * 4 + f) * FFN_KQ1 + sub * 4 + ks) * 1024) + lane * 16;
+        for (int q = 0; q < SKS; q++) {
+            const int idx = wave * SKS + q, f = idx / SKS, ks = idx - f * SKS;
+            const char* src = (const char*)p.W1f + ((long long)((chunk * 4 + f) * FFN_KQ1 + sub * SKS + ks) * 1024) + lane * 16;
             glds16(src, dst + idx * 1024);
         }
     };
@@ -80,19 +84,19 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
         for (int f = 0; f < 4; f++)
 #pragma unroll
             for (int e = 0; e < 16; e++) cacc[f][e] = 0.f;
-        // ---- GEMM 1: 6 stages of 4 k-steps
+        // ---- GEMM 1: NSUB stages of SKS k-steps
 #pragma unroll
-        for (int sub = 0; sub < 6; sub++) {
-            const int t = chunk * 6 + sub;
-            if (t + 1 < FFN_CHUNKS * 6) issue_w1(t + 1);
+        for (int sub = 0; sub < NSUB; sub++) {
+            const int t = chunk * NSUB + sub;
+            if (t + 1 < FFN_CHUNKS * NSUB) issue_w1(t + 1);
             if (sub == 1 && chunk + 1 < FFN_CHUNKS) issue_wf((chunk + 1) * 4, (chunk + 1) & 1);      // (all waves are past GEMM 2 of chunk - 1: its slot is free)
             const char* st = ring1 + (t & 1) * FFN_RING1 + lane * 16;
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++)
+            for (int ks = 0; ks < SKS; ks++)
 #pragma unroll
                 for (int f = 0; f < 4; f++) {
-                    const bf16x8 a = *(const bf16x8*)(st + (f * 4 + ks) * 1024);
-                    cacc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[sub * 4 + ks], cacc[f], 0, 0, 0);
+                    const bf16x8 a = *(const bf16x8*)(st + (f * SKS + ks) * 1024);
+                    cacc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[sub * SKS + ks], cacc[f], 0, 0, 0);
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -189,13 +193,19 @@ hipError_t launch_ffn_fused(const bf16_t* l3, const bf16_t* t2, const bf16_t* xi
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = launch_lin_w_fragpack(Wp, Wff, C, 5 * C, 5 * C, 0, st)) != hipSuccess) return e;
     }
-    static bool attr[RDM_MAX_DEVICES] = {};
-    const int dev = rdm_cur_device();
-    if (!attr[dev]) {
-        if ((e = hipFuncSetAttribute((const void*)ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_SMEM)) != hipSuccess) return e;
-        attr[dev] = true;
-    }
     FfnParams p{l3, t2, xin, out, W1f, b1f, Wff, bf, M};
-    ffn_fused_kernel<<<M / 128, 256, FFN_SMEM, st>>>(p);
-    return hipGetLastError();
+    static const int sks = getenv("RDM_FFN_SKS") ? atoi(getenv("RDM_FFN_SKS")) : 4;     // k-steps of GEMM 1 per LDS stage
+    auto go = [&](auto tag) -> hipError_t {
+        constexpr int SKS = decltype(tag)::value, smem = 2 * SKS * 4 * 1024 + 2 * FFN_RING2;
+        static bool attr[RDM_MAX_DEVICES] = {};
+        const int dev = rdm_cur_device();
+        if (!attr[dev]) {
+            hipError_t e2 = hipFuncSetAttribute((const void*)ffn_fused_kernel<SKS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e2 != hipSuccess) return e2;
+            attr[dev] = true;
+        }
+        ffn_fused_kernel<SKS><<<M / 128, 256, smem, st>>>(p);
+        return hipGetLastError();
+    };
+    return sks == 8 ? go(std::integral_constant<int, 8>{}) : sks == 6 ? go(std::integral_constant<int, 6>{}) : go(std::integral_constant<int, 4>{});
 }
