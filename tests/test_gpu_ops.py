@@ -550,6 +550,7 @@ def test_ffn_fused_matches_the_two_kernel_feed_forward(ctx):
     bf + x_in) (rdm/modules/attention.py:77-96; ldm GEGLU) -- and against the two-kernel path of the executors (same roundings: flips only)."""
     from rdm_amd import _lib
     from rdm_amd.packing import _geglu_perm
+    from _util import rel_l2
     d = ctx.device
     g = torch.Generator().manual_seed(9)
     M, C = 512, 384
