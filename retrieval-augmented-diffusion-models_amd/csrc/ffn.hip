@@ -26,7 +26,6 @@ struct FfnParams {
     const bf16_t* Wff;          // fragment-ordered [C / 32][5C / 16][512], hidden K groups permuted (see above)
     const float* bf;            // [C]
     int M;
-    int dbg;                    // dev-only ablation bits (RDM_FFN_DBG; wrong results): 1 no GELU, 2 no waits / barriers in the K loops, 4 no LDS stage loads, 8 no MFMAs of GEMM 2
 };
 
 constexpr int FFN_C = 384, FFN_KQ1 = FFN_C / 16, FFN_KQ2 = 5 * FFN_C / 16, FFN_NO = FFN_C / 32, FFN_CHUNKS = 4 * FFN_C / 64;
@@ -43,9 +42,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     const long long row = (long long)blockIdx.x * 128 + wave * 32 + r;
 
     // ---- stage loaders: 1 KiB fragments, one global_load_lds per wave and fragment
-    const int dbg = p.dbg;
     auto issue_w1 = [&](int t) {            // stage t = (chunk, sub-step): fragments (nb = 4 chunk + f, kq = SKS sub + ks), slot order [f][ks]
-        if (dbg & 4) return;
         const int chunk = t / NSUB, sub = t - chunk * NSUB;
         char* dst = ring1 + (t & 1) * FFN_RING1;
 #pragma unroll
@@ -56,7 +53,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
         }
     };
     auto issue_wf = [&](int kq0, int slot) {   // 4 k-steps kq0 .. kq0 + 3 of all 12 output fragments, slot order [ks][j]
-        if (dbg & 4) return;
         char* dst = ring2 + slot * FFN_RING2;
 #pragma unroll
         for (int q = 0; q < 12; q++) {
@@ -102,10 +98,14 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
                     const bf16x8 a = *(const bf16x8*)(st + (f * SKS + ks) * 1024);
                     cacc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[sub * SKS + ks], cacc[f], 0, 0, 0);
                 }
-            if (!(dbg & 2)) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
+            // issue order for this region (left alone hipcc serialises read -> wait -> MFMA: the 16-MFMA stage then takes ~4 x its matrix time): four
+            // fragment reads ahead, then one MFMA per further read
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int i = 0; i < SKS * 4 - 4; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
         // ---- bias + GELU: register 4 j + i of fragment f = weight row 8 j + 4 h + i: rows 0..15 x, 16..31 the gates of the same hidden units
         bf16x8 hb[4];
@@ -116,13 +116,13 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
             const float bx[8] = {bx0.x, bx0.y, bx0.z, bx0.w, bx1.x, bx1.y, bx1.z, bx1.w}, bg[8] = {bg0.x, bg0.y, bg0.z, bg0.w, bg1.x, bg1.y, bg1.z, bg1.w};
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = (dbg & 1) ? cacc[f][e] + bx[e] + cacc[f][8 + e] : (cacc[f][e] + bx[e]) * gelu_erf_f(cacc[f][8 + e] + bg[e]);
+            for (int e = 0; e < 8; e++) v[e] = (cacc[f][e] + bx[e]) * gelu_erf_f(cacc[f][8 + e] + bg[e]);
             union { uint4 u; bf16x8 b; } t;
             t.u = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
             hb[f] = t.b;
         }
         // ---- GEMM 2: k-step ks = hidden group 4 chunk + ks against all 12 output fragments
-        if (!(dbg & 8)) {
+        {
             const char* st = ring2 + (chunk & 1) * FFN_RING2 + lane * 16;
 #pragma unroll
             for (int ks = 0; ks < 4; ks++)
@@ -131,6 +131,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
                     const bf16x8 a = *(const bf16x8*)(st + (ks * 12 + j) * 1024);
                     oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[ks], oacc[j], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+            for (int i = 0; i < 48 - 6; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
         }
     }
     // ---- the t2 part of K: k-steps 4C/16 .. 5C/16 in 6 stages of 4 through ring 2
@@ -199,8 +203,7 @@ hipError_t launch_ffn_fused(const bf16_t* l3, const bf16_t* t2, const bf16_t* xi
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = launch_lin_w_fragpack(Wp, Wff, C, 5 * C, 5 * C, 0, st)) != hipSuccess) return e;
     }
-    static const int dbg_env = getenv("RDM_FFN_DBG") ? atoi(getenv("RDM_FFN_DBG")) : 0;
-    FfnParams p{l3, t2, xin, out, W1f, b1f, Wff, bf, M, dbg_env};
+    FfnParams p{l3, t2, xin, out, W1f, b1f, Wff, bf, M};
     static const int sks = getenv("RDM_FFN_SKS") ? atoi(getenv("RDM_FFN_SKS")) : 4;     // k-steps of GEMM 1 per LDS stage
     auto go = [&](auto tag) -> hipError_t {
         constexpr int SKS = decltype(tag)::value, smem = 2 * SKS * 4 * 1024 + 2 * FFN_RING2;
