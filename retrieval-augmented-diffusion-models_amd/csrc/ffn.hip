@@ -98,12 +98,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
                     const bf16x8 a = *(const bf16x8*)(st + (f * SKS + ks) * 1024);
                     cacc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[sub * SKS + ks], cacc[f], 0, 0, 0);
                 }
-            // issue order for this region (left alone hipcc serialises read -> wait -> MFMA: the 16-MFMA stage then takes ~4 x its matrix time): four
-            // fragment reads ahead, then one MFMA per further read
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-            for (int i = 0; i < SKS * 4 - 4; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -131,10 +125,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
                     const bf16x8 a = *(const bf16x8*)(st + (ks * 12 + j) * 1024);
                     oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[ks], oacc[j], 0, 0, 0);
                 }
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-            for (int i = 0; i < 48 - 6; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
         }
     }
     // ---- the t2 part of K: k-steps 4C/16 .. 5C/16 in 6 stages of 4 through ring 2
@@ -204,7 +194,7 @@ hipError_t launch_ffn_fused(const bf16_t* l3, const bf16_t* t2, const bf16_t* xi
         if ((e = launch_lin_w_fragpack(Wp, Wff, C, 5 * C, 5 * C, 0, st)) != hipSuccess) return e;
     }
     FfnParams p{l3, t2, xin, out, W1f, b1f, Wff, bf, M};
-    static const int sks = getenv("RDM_FFN_SKS") ? atoi(getenv("RDM_FFN_SKS")) : 4;     // k-steps of GEMM 1 per LDS stage
+    static const int sks = getenv("RDM_FFN_SKS") ? atoi(getenv("RDM_FFN_SKS")) : 6;     // k-steps of GEMM 1 per LDS stage
     auto go = [&](auto tag) -> hipError_t {
         constexpr int SKS = decltype(tag)::value, smem = 2 * SKS * 4 * 1024 + 2 * FFN_RING2;
         static bool attr[RDM_MAX_DEVICES] = {};
