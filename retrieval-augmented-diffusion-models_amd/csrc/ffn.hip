@@ -31,6 +31,12 @@ struct FfnParams {
 constexpr int FFN_C = 384, FFN_KQ1 = FFN_C / 16, FFN_KQ2 = 5 * FFN_C / 16, FFN_NO = FFN_C / 32, FFN_CHUNKS = 4 * FFN_C / 64;
 constexpr int FFN_RING2 = 48 * 1024;                                    // bytes per Wf stage (4 k-steps x 12 fragments); W1 stage: SKS k-steps x 4 fragments
 
+// fragment reads as asm statements (hipcc keeps their program order; left to itself it serialises read -> wait -> MFMA once ~450 registers are live) and
+// counted waits TIED to the fragments they cover, so that no MFMA that reads one can be scheduled above its wait
+#define FFN_LDSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define FFN_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(n))
+#define FFN_WAIT6(n, a, b, c, d, e, f) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "i"(n))
+
 template <int SKS>      // k-steps of GEMM 1 per LDS stage (4, 6 or 8: one barrier per stage)
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     constexpr int FFN_RING1 = SKS * 4 * 1024, NSUB = FFN_KQ1 / SKS;
@@ -90,14 +96,20 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
             const int t = chunk * NSUB + sub;
             if (t + 1 < FFN_CHUNKS * NSUB) issue_w1(t + 1);
             if (sub == 1 && chunk + 1 < FFN_CHUNKS) issue_wf((chunk + 1) * 4, (chunk + 1) & 1);      // (all waves are past GEMM 2 of chunk - 1: its slot is free)
-            const char* st = ring1 + (t & 1) * FFN_RING1 + lane * 16;
+            const unsigned st = (unsigned)(2 * 0 + (t & 1) * FFN_RING1 + lane * 16);       // LDS byte address (ring 1 starts at 0)
+            bf16x8 af[2][4];
 #pragma unroll
-            for (int ks = 0; ks < SKS; ks++)
+            for (int f = 0; f < 4; f++) FFN_LDSR(af[0][f], st, (f * SKS + 0) * 1024);
 #pragma unroll
-                for (int f = 0; f < 4; f++) {
-                    const bf16x8 a = *(const bf16x8*)(st + (f * SKS + ks) * 1024);
-                    cacc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[sub * SKS + ks], cacc[f], 0, 0, 0);
-                }
+            for (int ks = 0; ks < SKS; ks++) {
+                if (ks + 1 < SKS) {
+#pragma unroll
+                    for (int f = 0; f < 4; f++) FFN_LDSR(af[(ks + 1) & 1][f], st, (f * SKS + ks + 1) * 1024);
+                    FFN_WAIT4(4, af[ks & 1][0], af[ks & 1][1], af[ks & 1][2], af[ks & 1][3]);          // the four reads just issued may stay in flight
+                } else FFN_WAIT4(0, af[ks & 1][0], af[ks & 1][1], af[ks & 1][2], af[ks & 1][3]);
+#pragma unroll
+                for (int f = 0; f < 4; f++) cacc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][f], xb[sub * SKS + ks], cacc[f], 0, 0, 0);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -117,14 +129,21 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
         }
         // ---- GEMM 2: k-step ks = hidden group 4 chunk + ks against all 12 output fragments
         {
-            const char* st = ring2 + (chunk & 1) * FFN_RING2 + lane * 16;
+            // 8 half-steps of 6 fragments, read one half-step ahead
+            const unsigned st = (unsigned)(2 * FFN_RING1 + (chunk & 1) * FFN_RING2 + lane * 16);
+            bf16x8 wf6[2][6];
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++)
+            for (int j = 0; j < 6; j++) FFN_LDSR(wf6[0][j], st, j * 1024);
 #pragma unroll
-                for (int j = 0; j < FFN_NO; j++) {
-                    const bf16x8 a = *(const bf16x8*)(st + (ks * 12 + j) * 1024);
-                    oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[ks], oacc[j], 0, 0, 0);
-                }
+            for (int hs = 0; hs < 8; hs++) {
+                if (hs + 1 < 8) {
+#pragma unroll
+                    for (int j = 0; j < 6; j++) FFN_LDSR(wf6[(hs + 1) & 1][j], st, ((hs + 1) * 6 + j) * 1024);
+                    FFN_WAIT6(6, wf6[hs & 1][0], wf6[hs & 1][1], wf6[hs & 1][2], wf6[hs & 1][3], wf6[hs & 1][4], wf6[hs & 1][5]);
+                } else FFN_WAIT6(0, wf6[hs & 1][0], wf6[hs & 1][1], wf6[hs & 1][2], wf6[hs & 1][3], wf6[hs & 1][4], wf6[hs & 1][5]);
+#pragma unroll
+                for (int j = 0; j < 6; j++) oacc[(hs & 1) * 6 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf6[hs & 1][j], hb[hs >> 1], oacc[(hs & 1) * 6 + j], 0, 0, 0);
+            }
         }
     }
     // ---- the t2 part of K: k-steps 4C/16 .. 5C/16 in 6 stages of 4 through ring 2
