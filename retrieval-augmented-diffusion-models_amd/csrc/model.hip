@@ -1095,20 +1095,6 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         bf16_t* l3 = o.abf((size_t)M * C);
         if (Bx < B && !bias_fold && !o.plan)
             o.check(launch_add_bias_rows(t1 + (size_t)Mx * C, o.w<float>(s.bo2), t2 + (size_t)Mx * C, (long long)(M - Mx), C, o.c->stream), "zero-context cross attention");
-        // norm3 of the UNCONDITIONAL rows needs attn1.to_out's result only (with the bias fold those rows of t1 already hold t2), the
-        // cross-attention kernel works on the conditional rows: the two are independent -- the LayerNorm goes to the side stream beside
-        // the cross-attention launch (round 6; RDM_LN3_OVERLAP=0: after it, on the main stream)
-        bool ln3_side = false;
-        if (xfold_shape && bias_fold && M > Mx) {
-            static const int ln3_on = getenv("RDM_LN3_OVERLAP") ? atoi(getenv("RDM_LN3_OVERLAP")) : 1;
-            if (ln3_on && o.side_begin()) {
-                o.tag = "st.norm3+geglu";
-                o.layernorm(t2 + (size_t)Mx * C, 0, s.ln3g, s.ln3b, l3 + (size_t)Mx * C, 0, M - Mx, C, s.lc);
-                o.side_end();
-                o.tag = "st.norm2+attn2";
-                ln3_side = true;
-            }
-        }
         if (Mx == 0) {
         } else if (xa) {       // two skinny per-sample GEMMs (see unet_compute_xattn)
             bf16_t* P = o.abf((size_t)M * XA_NP);
@@ -1153,8 +1139,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         const int FI = 4 * s.lc;                     // GEGLU hidden width: 4 x the LOGICAL channels (a multiple of 128, never padded)
         bf16_t* ff = o.abf((size_t)M * FI);
         if (xfold_shape) {       // norm3 of the conditional rows left the cross-attention kernel; the unconditional rows' here
-            if (ln3_side) o.side_join();
-            else if (M > Mx) o.layernorm(t2 + (size_t)Mx * C, 0, s.ln3g, s.ln3b, l3 + (size_t)Mx * C, 0, M - Mx, C, s.lc);
+            if (M > Mx) o.layernorm(t2 + (size_t)Mx * C, 0, s.ln3g, s.ln3b, l3 + (size_t)Mx * C, 0, M - Mx, C, s.lc);
             o.linear(l3, nullptr, C, 0, s.wff1, s.bff1, true, M, 2 * FI, ACT_GEGLU, nullptr, ff);
         } else if (!o.linear_ln_big(t2, s.ln3g, s.ln3b, C, s.lc, s.wff1, s.bff1, true, M, 2 * FI, ACT_GEGLU, ff)) {       // norm3 folded into the GEGLU projection
             o.layernorm(t2, 0, s.ln3g, s.ln3b, l3, 0, M, C, s.lc);
