@@ -610,7 +610,7 @@ struct Ops {
     // GroupNorm -> conv1 -> GroupNorm before conv2 consumes it as the residual.  Issued on a second (non-blocking) stream at the top of the
     // block it fills the CUs the persistent conv kernels leave idle in their last, partial round of tiles (16 x 16 level: 384 tiles on
     // 256 CUs) instead of taking its own slot in the serial chain.  Same kernels, same arithmetic: only the issue order changes.
-    // RDM_SKIP_OVERLAP=0: off (resblock).  side_begin(): launches that follow go to the side stream (ordered after everything issued so far).
+    // Opt-in, RDM_SKIP_OVERLAP=1 (resblock): two same-box A/Bs disagree in sign.  side_begin(): launches that follow go to the side stream (ordered after everything issued so far).
     bool side_begin() {
         // (not while kernel classes other than the conv are bracketed with events: concurrent side work would be billed to whatever runs beside it)
         if (plan || (c->prof & ~(1u << RDM_PROF_CONV3X3))) return false;
@@ -965,7 +965,7 @@ static void unet_body(Ops& o, UNet& u, const float* x, const long long* t, const
         if (r.skip) {
             sk = o.abf((size_t)M * r.cout);
             o.tag = "res.skip";
-            static const int skip_on = getenv("RDM_SKIP_OVERLAP") ? atoi(getenv("RDM_SKIP_OVERLAP")) : 1;
+            static const int skip_on = getenv("RDM_SKIP_OVERLAP") ? atoi(getenv("RDM_SKIP_OVERLAP")) : 0;     // opt-in: + 0.45 % on one box, - 0.25 % on another (profiles/r06_skip_overlap_ab*.log)
             forked = skip_on && o.side_begin();
             o.linear(a.p, x1, C0, C1, r.wsk, r.bsk, true, M, r.cout, ACT_NONE, nullptr, sk, nullptr, nullptr, wrap_b * HW);
             if (forked) o.side_end();
